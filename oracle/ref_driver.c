@@ -1,0 +1,188 @@
+/* ref_driver.c — driver that exposes the REAL reference implementation (compiled in place from
+ * /root/reference by oracle/Makefile into oracle/_ref/libpbwtref.so) through a flat C interface
+ * so Python tests can validate the restatement in pbwt_oracle.c against it and generate the
+ * golden fixtures under tests/golden/.  TEST INFRASTRUCTURE ONLY; never shipped or called by the
+ * product.  This file is our own code: it plays the role pbwtMain.c plays in the reference
+ * (owner of the `logFile` global, caller of the library functions) and contains no reference
+ * source.  It is only compiled where /root/reference exists. */
+#include "pbwt.h"          /* the reference's own header, found via -I/root/reference */
+#include <stdint.h>
+#include <unistd.h>
+
+FILE *logFile;             /* normally defined by the reference's main program (pbwtMain.c:179) */
+
+typedef struct { int32_t ai, bi, start, end; } ref_match;
+static ref_match *g_rec; static size_t g_n, g_cap;
+
+static void capture(int ai, int bi, int start, int end)
+{
+    if (g_n == g_cap) { g_cap = g_cap ? 2 * g_cap : 4096; g_rec = realloc(g_rec, g_cap * sizeof(ref_match)); }
+    g_rec[g_n].ai = ai; g_rec[g_n].bi = bi; g_rec[g_n].start = start; g_rec[g_n].end = end; ++g_n;
+}
+
+void ref_init(void)
+{
+    static int done;
+    if (done) return;
+    logFile = fopen("/dev/null", "w");
+    pbwtInit();
+    done = 1;
+}
+
+static PBWT *make_panel(int M, int N, const uint8_t *yz, long nz, const int32_t *aFstart)
+{
+    PBWT *p = pbwtCreate(M, N);
+    if (aFstart) memcpy(p->aFstart, aFstart, sizeof(int) * M);
+    p->yz = arrayCreate(nz + 1, uchar);
+    if (nz) memcpy(arrp(p->yz, 0, uchar), yz, nz);
+    arrayMax(p->yz) = nz;
+    return p;
+}
+
+/* the pbwtReadMacs build loop (pbwtIO.c:477-483) driven from bit columns, calling the reference's
+ * cursor functions; dumps every site's state: a_all (N+1)*M, d_all (N+1)*(M+1) (with_d only) */
+long ref_build_bitcols(int M, int N, const uint32_t *bits, int wpc, int with_d,
+                       uint8_t *yz_out, long yzcap, int32_t *aFend, int32_t *a_all, int32_t *d_all)
+{
+    ref_init();
+    PBWT *p = pbwtCreate(M, 0);
+    PbwtCursor *u = pbwtCursorCreate(p, TRUE, TRUE);
+    for (int k = 0; k <= N; ++k) {
+        if (a_all) memcpy(a_all + (size_t)k * M, u->a, sizeof(int) * M);
+        if (d_all && with_d) memcpy(d_all + (size_t)k * (M + 1), u->d, sizeof(int) * (M + 1));
+        if (k == N) break;
+        const uint32_t *col = bits + (size_t)k * wpc;
+        for (int j = 0; j < M; ++j) { int h = u->a[j]; u->y[j] = (col[h >> 5] >> (h & 31)) & 1; }
+        if (with_d) pbwtCursorWriteForwardsAD(u, k); else pbwtCursorWriteForwards(u);
+        p->N++;
+    }
+    pbwtCursorToAFend(u, p);
+    long nz = arrayMax(p->yz);
+    if (nz > yzcap) nz = -1;
+    else { memcpy(yz_out, arrp(p->yz, 0, uchar), nz); memcpy(aFend, p->aFend, sizeof(int) * M); }
+    pbwtCursorDestroy(u); pbwtDestroy(p);
+    return nz;
+}
+
+/* cursor create + ForwardsReadAD loop, as matchMaximalWithin drives it; dumps k=0..N */
+void ref_sweep_dump(int M, int N, const uint8_t *yz, long nz, const int32_t *aFstart,
+                    int32_t *a_all, int32_t *d_all, uint8_t *y_all, int32_t *c_all)
+{
+    ref_init();
+    PBWT *p = make_panel(M, N, yz, nz, aFstart);
+    PbwtCursor *u = pbwtCursorCreate(p, TRUE, TRUE);
+    for (int k = 0; k <= N; ++k) {
+        memcpy(a_all + (size_t)k * M, u->a, sizeof(int) * M);
+        memcpy(d_all + (size_t)k * (M + 1), u->d, sizeof(int) * (M + 1));
+        memcpy(y_all + (size_t)k * M, u->y, M);
+        c_all[k] = u->c;
+        pbwtCursorForwardsReadAD(u, k);
+    }
+    pbwtCursorDestroy(u); pbwtDestroy(p);
+}
+
+/* matchMaximalWithin with a capturing callback: returns record count, *out = malloc'ed records */
+long ref_max_within(int M, int N, const uint8_t *yz, long nz, const int32_t *aFstart, ref_match **out)
+{
+    ref_init();
+    PBWT *p = make_panel(M, N, yz, nz, aFstart);
+    g_rec = NULL; g_n = g_cap = 0;
+    matchMaximalWithin(p, capture);
+    pbwtDestroy(p);
+    *out = g_rec;
+    return (long)g_n;
+}
+
+/* -stats -maxWithin: pbwtLongMatches prints the histogram to stdout (pbwtMatch.c:166-175);
+ * stdout is redirected into `path` for the duration of the call */
+int ref_max_within_hist_to_file(int M, int N, const uint8_t *yz, long nz, const int32_t *aFstart,
+                                const char *path, int with_check)
+{
+    ref_init();
+    PBWT *p = make_panel(M, N, yz, nz, aFstart);
+    fflush(stdout);
+    int saved = dup(1);
+    FILE *f = fopen(path, "w");
+    if (!f) return -1;
+    dup2(fileno(f), 1);
+    isStats = TRUE; isCheck = with_check ? TRUE : FALSE;
+    pbwtLongMatches(p, 0);
+    isStats = FALSE; isCheck = FALSE;
+    fflush(stdout);
+    dup2(saved, 1); close(saved); fclose(f);
+    pbwtDestroy(p);
+    return 0;
+}
+
+/* -maxWithin exactly as the CLI prints it (reportMatch, pbwtMatch.c:46-58), optional -check */
+int ref_max_within_text_to_file(int M, int N, const uint8_t *yz, long nz, const int32_t *aFstart,
+                                const char *path, int with_check)
+{
+    ref_init();
+    PBWT *p = make_panel(M, N, yz, nz, aFstart);
+    fflush(stdout);
+    int saved = dup(1);
+    FILE *f = fopen(path, "w");
+    if (!f) return -1;
+    dup2(fileno(f), 1);
+    isCheck = with_check ? TRUE : FALSE;
+    pbwtLongMatches(p, 0);
+    isCheck = FALSE;
+    fflush(stdout);
+    dup2(saved, 1); close(saved); fclose(f);
+    pbwtDestroy(p);
+    return 0;
+}
+
+long ref_match_sweep(int Mp, int N, const uint8_t *pz, long pnz, const int32_t *pStart,
+                     int Mq, const uint8_t *qz, long qnz, const int32_t *qStart, ref_match **out)
+{
+    ref_init();
+    PBWT *p = make_panel(Mp, N, pz, pnz, pStart);
+    PBWT *q = make_panel(Mq, N, qz, qnz, qStart);
+    g_rec = NULL; g_n = g_cap = 0;
+    matchSequencesSweep(p, q, capture);
+    pbwtDestroy(p); pbwtDestroy(q);
+    *out = g_rec;
+    return (long)g_n;
+}
+
+/* file-level entry points of the reference: used to make .pbwt / -haps goldens */
+int ref_macs_to_pbwt(const char *macs, const char *pbwt_out, const char *sites_out)
+{
+    ref_init();
+    FILE *fp = fopen(macs, "r"); if (!fp) return -1;
+    PBWT *p = pbwtReadMacs(fp); fclose(fp);
+    FILE *fo = fopen(pbwt_out, "w"); if (!fo) return -2;
+    pbwtWrite(p, fo); fclose(fo);
+    if (sites_out) { FILE *fs = fopen(sites_out, "w"); if (!fs) return -3; pbwtWriteSites(p, fs); fclose(fs); }
+    pbwtDestroy(p);
+    return 0;
+}
+
+int ref_vcfq_to_pbwt(const char *vcfq, const char *pbwt_out, const char *sites_out)
+{
+    ref_init();
+    FILE *fp = fopen(vcfq, "r"); if (!fp) return -1;
+    PBWT *p = pbwtReadVcfq(fp); fclose(fp);
+    FILE *fo = fopen(pbwt_out, "w"); if (!fo) return -2;
+    pbwtWrite(p, fo); fclose(fo);
+    if (sites_out) { FILE *fs = fopen(sites_out, "w"); if (!fs) return -3; pbwtWriteSites(p, fs); fclose(fs); }
+    pbwtDestroy(p);
+    return 0;
+}
+
+int ref_pbwt_to_haps(const char *pbwt_in, const char *haps_out)
+{
+    ref_init();
+    FILE *fp = fopen(pbwt_in, "r"); if (!fp) return -1;
+    PBWT *p = pbwtRead(fp); fclose(fp);
+    FILE *fo = fopen(haps_out, "w"); if (!fo) return -2;
+    pbwtWriteHaplotypes(fo, p); fclose(fo);
+    pbwtDestroy(p);
+    return 0;
+}
+
+size_t ref_pack3(uint8_t *y_with_sentinel, int M, uint8_t *out) { ref_init(); return pack3(y_with_sentinel, M, out); }
+size_t ref_unpack3(uint8_t *z, int M, uint8_t *y, int *n0) { ref_init(); return unpack3(z, M, y, n0); }
+void ref_free(void *p) { free(p); }
