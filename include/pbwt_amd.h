@@ -1,0 +1,152 @@
+/* pbwt_amd.h — C ABI of libpbwtgpu.so, the MI355X (gfx950) engine for the PBWT hot path.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  Every entry point replaces a specific
+ * whole-panel loop of the reference (richarddurbin/pbwt); the reference file:line each one stands
+ * in for is cited on the declaration.  INTEGRATION.md shows the binding a reference maintainer
+ * would add (a pbwtGpu.c that implements matchMaximalWithin() etc. on top of these calls).
+ *
+ * Conventions
+ *   - return value 0 = success; nonzero = failure, message in pbwtamd_last_error() (the host
+ *     binding turns that into the reference's die(), utils.c:31).  There is NO CPU fallback: if
+ *     no gfx950 device is usable every compute entry point fails.
+ *   - haplotype indices, site indices, a[] and d[] values are int32 like the reference's `int`
+ *     (pbwt.h:36-37,81-82); byte offsets into packed columns are int64 like its `long`.
+ *   - a "bit column" is one site's alleles, bit h of the column (little-endian 32-bit words,
+ *     bit h&31 of word h>>5) = allele of haplotype/position h; columns are `wpc` words apart,
+ *     wpc >= ceil(M/32).  "original order" columns are indexed by haplotype (x[] in
+ *     pbwtIO.c:478), "sorted order" columns by PBWT position (u->y[], pbwt.h:78).
+ *   - packed columns (`yz`) are the reference's pack3 run-length bytes (pbwtCore.c:216-225),
+ *     byte-identical to PBWT.yz / the payload of a .pbwt file (pbwtIO.c:33-57).
+ */
+#ifndef PBWT_AMD_H
+#define PBWT_AMD_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBWTAMD_ABI_VERSION 1
+
+typedef struct pbwtamd_engine pbwtamd_engine;
+
+/* one report() invocation: (ai, bi, start, end) of pbwtMatch.c:46 / pbwt.h:208 */
+typedef struct { int32_t ai, bi, start, end; } pbwtamd_match;
+
+/* callback type of matchMaximalWithin / matchSequencesSweep (pbwt.h:208,213) */
+typedef void (*pbwtamd_report_fn)(int ai, int bi, int start, int end);
+
+/* ---- library / device ---- */
+int         pbwtamd_abi_version(void);
+const char *pbwtamd_last_error(void);
+int         pbwtamd_device_count(void);            /* usable HIP devices (0 if none) */
+
+/* ---- engine: device state for one panel of M haplotypes (the role of a PbwtCursor,
+ * pbwt.h:74-87, plus its scratch, held in HBM).  batch_sites = sites processed per device
+ * batch (0 = default).  stream = a hipStream_t to enqueue on, or NULL for the engine's own. */
+int  pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, int batch_sites, void *stream);
+void pbwtamd_engine_destroy(pbwtamd_engine *e);
+int  pbwtamd_engine_M(const pbwtamd_engine *e);
+int  pbwtamd_engine_wpc(const pbwtamd_engine *e);      /* words per bit column the engine uses */
+int  pbwtamd_engine_batch(const pbwtamd_engine *e);
+
+/* ======================================================================================
+ * Host-buffer entry points: what the reference-side binding calls.  All are synchronous.
+ * ====================================================================================== */
+
+/* Build a PBWT from N bit columns in ORIGINAL haplotype order: the per-site loop of
+ * pbwtReadMacs (pbwtIO.c:477-483; same shape at pbwtIO.c:573-574) = gather y[j]=x[a[j]],
+ * pack3arrayAdd (pbwtCore.c:269-277) and pbwtCursorForwardsA (:458-470), or with with_d != 0
+ * pbwtCursorForwardsAD (:485-508).
+ *   aFstart  : initial order (PBWT.aFstart), NULL = identity (pbwtCreate, pbwtCore.c:46)
+ *   yz_out   : receives a malloc()ed buffer with the packed columns (free with pbwtamd_free)
+ *   aFend    : out, M ints = final a[] (pbwtCursorToAFend, pbwtCore.c:587-591)
+ *   dFend    : out or NULL, M+1 ints = final d[] (only meaningful with_d) */
+int pbwtamd_build(pbwtamd_engine *e, const uint32_t *bitcols, int wpc, int N, int with_d,
+                  const int32_t *aFstart, uint8_t **yz_out, int64_t *nz_out,
+                  int32_t *aFend, int32_t *dFend);
+
+/* Forward sweep of a packed panel with divergence: pbwtCursorCreate(p,TRUE,TRUE) followed by
+ * pbwtCursorForwardsReadAD(u,k) for k=0..N (pbwtCore.c:420-445,543-557), i.e. what every
+ * read-side consumer drives.  Optional outputs (NULL to skip):
+ *   csum_a/csum_d/csum_y [N+1] : order-sensitive checksums of a (M), d (M+1), y (M) at each k
+ *                                (sum_i splitmix64(i<<32 | v[i]); y is all-zero at k=N here,
+ *                                the reference leaves it stale)
+ *   dump_sites[ndump]          : sites whose full a (ndump*M), d (ndump*(M+1)) are copied out */
+int pbwtamd_sweep_AD(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart,
+                     uint64_t *csum_a, uint64_t *csum_d, uint64_t *csum_y,
+                     const int32_t *dump_sites, int ndump, int32_t *a_dump, int32_t *d_dump);
+
+/* matchMaximalWithin (pbwtMatch.c:115-142): all set-maximal matches within the panel.
+ * Exactly one of the three sinks is used:
+ *   report   : called synchronously on the calling thread, in the reference's order (k, then i,
+ *              then j; zero-length matches included — pbwtMatch.c:48 filters them itself)
+ *   recs_out : receives a malloc()ed array of all reports in that order (+ count)
+ *   hist     : the -stats histogram of pbwtMatch.c:130-131, hist[len] += 1 (histlen >= N+1) */
+int pbwtamd_max_within(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart,
+                       pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out,
+                       int64_t *hist, int histlen);
+
+/* matchSequencesSweep (pbwtMatch.c:363-443): query panel q (Mq haplotypes, packed qz) against
+ * the engine's panel (packed pz), both N sites.  Reports in the reference's order (k, query
+ * PBWT order, i); n_nomatch counts the "no match to query" events (pbwtMatch.c:405-410);
+ * tot[0]=nTot, tot[1]=totLen of pbwtMatch.c:386,435 (for the log line :438-439). */
+int pbwtamd_match_sweep(pbwtamd_engine *e, const uint8_t *pz, int64_t pnz, int N, const int32_t *pStart,
+                        int Mq, const uint8_t *qz, int64_t qnz, const int32_t *qStart,
+                        pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out,
+                        int64_t *n_nomatch, int64_t *tot);
+
+/* pack3 codec on the device (pbwtCore.c:254-305): N columns <-> packed bytes.
+ * unpack returns sorted-order bit columns (N*wpc words, caller buffer). */
+int pbwtamd_pack3(pbwtamd_engine *e, const uint32_t *sorted_bitcols, int wpc, int N,
+                  uint8_t **yz_out, int64_t *nz_out);
+int pbwtamd_unpack3(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, uint32_t *sorted_bitcols, int wpc);
+
+void pbwtamd_free(void *p);
+
+/* ======================================================================================
+ * Device-buffer entry points (inputs already resident in HBM; used by bench.py and by callers
+ * that keep panels on the device).  Pointers are device pointers on the engine's device; work is
+ * enqueued on the engine's stream and is complete when pbwtamd_sync() returns.
+ * ====================================================================================== */
+
+/* synthetic panel (SURVEY.md §8d recipe): fills ncols bit columns for sites k0..k0+ncols-1.
+ * kind 0 = founder mosaic, 1 = iid Bernoulli(1/2). */
+int pbwtamd_synth_device(pbwtamd_engine *e, void *d_bitcols, int k0, int ncols, uint64_t seed, int kind);
+
+/* start a pass at site k0: cursor state = aInit (host pointer, NULL=identity), d = 0 with the
+ * sentinels d[0]=d[M]=k0+1 (pbwtCore.c:402-418) */
+int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k0, int n_total_sites);
+
+#define PBWTAMD_OPT_WITH_D      1u   /* ForwardsAD instead of ForwardsA */
+#define PBWTAMD_OPT_SORTED      2u   /* columns are in sorted (PBWT) order, not original order */
+#define PBWTAMD_OPT_WITHIN_HIST 4u   /* fuse the maxWithin sweep, histogram sink */
+#define PBWTAMD_OPT_CHECKSUM    8u   /* per-site checksums of a/d/y */
+#define PBWTAMD_OPT_PACK3      16u   /* emit packed columns into the engine's yz buffer */
+#define PBWTAMD_OPT_WITHIN_RECS 32u  /* fuse the maxWithin sweep, record sink */
+
+/* advance the pass over `ncols` more columns held at d_bitcols (device).  The pass must see
+ * the column after the last one too unless it is the panel's last site, so callers hand
+ * ncols_avail >= ncols+1 columns except at the end.  Asynchronous. */
+int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, int wpc, int ncols, int ncols_avail,
+                         unsigned opts);
+
+/* finish: runs the k==N sweep if a WITHIN sink is active; synchronises */
+int pbwtamd_pass_end(pbwtamd_engine *e, unsigned opts);
+
+int pbwtamd_sync(pbwtamd_engine *e);
+
+/* results of the pass so far (host copies) */
+int pbwtamd_get_state(pbwtamd_engine *e, int32_t *a /*M*/, int32_t *d /*M+1 or NULL*/);
+int pbwtamd_get_hist(pbwtamd_engine *e, int64_t *hist, int histlen);
+int pbwtamd_get_checksums(pbwtamd_engine *e, int k_first, int n, uint64_t *csum_a, uint64_t *csum_d, uint64_t *csum_y);
+
+/* timing of the chain kernel (the dominant kernel) over the last pass_advance calls since
+ * pass_begin, measured with HIP events on the engine's stream: total ms and launches */
+int pbwtamd_get_chain_timing(pbwtamd_engine *e, double *ms_total, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

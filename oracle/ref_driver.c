@@ -8,6 +8,8 @@
 #include "pbwt.h"          /* the reference's own header, found via -I/root/reference */
 #include <stdint.h>
 #include <unistd.h>
+#include <sys/types.h>
+#include <sys/wait.h>
 
 FILE *logFile;             /* normally defined by the reference's main program (pbwtMain.c:179) */
 
@@ -93,25 +95,30 @@ long ref_max_within(int M, int N, const uint8_t *yz, long nz, const int32_t *aFs
     return (long)g_n;
 }
 
-/* -stats -maxWithin: pbwtLongMatches prints the histogram to stdout (pbwtMatch.c:166-175);
- * stdout is redirected into `path` for the duration of the call */
+/* -stats -maxWithin: pbwtLongMatches prints the histogram to stdout (pbwtMatch.c:166-175).
+ * Run in a forked child with stdout redirected into `path`: the reference keeps its
+ * matchLengthHist static non-NULL afterwards (pbwtMatch.c:28,158-159), which would silently switch
+ * every later matchMaximalWithin call in this process to histogram mode. */
 int ref_max_within_hist_to_file(int M, int N, const uint8_t *yz, long nz, const int32_t *aFstart,
                                 const char *path, int with_check)
 {
     ref_init();
-    PBWT *p = make_panel(M, N, yz, nz, aFstart);
-    fflush(stdout);
-    int saved = dup(1);
-    FILE *f = fopen(path, "w");
-    if (!f) return -1;
-    dup2(fileno(f), 1);
-    isStats = TRUE; isCheck = with_check ? TRUE : FALSE;
-    pbwtLongMatches(p, 0);
-    isStats = FALSE; isCheck = FALSE;
-    fflush(stdout);
-    dup2(saved, 1); close(saved); fclose(f);
-    pbwtDestroy(p);
-    return 0;
+    fflush(stdout); fflush(stderr);
+    pid_t pid = fork();
+    if (pid < 0) return -1;
+    if (pid == 0) {
+        FILE *f = fopen(path, "w");
+        if (!f) _exit(2);
+        dup2(fileno(f), 1);
+        PBWT *p = make_panel(M, N, yz, nz, aFstart);
+        isStats = TRUE; isCheck = with_check ? TRUE : FALSE;
+        pbwtLongMatches(p, 0);
+        fflush(stdout);
+        _exit(0);
+    }
+    int status = 0;
+    if (waitpid(pid, &status, 0) < 0) return -1;
+    return (WIFEXITED(status) && WEXITSTATUS(status) == 0) ? 0 : -2;
 }
 
 /* -maxWithin exactly as the CLI prints it (reportMatch, pbwtMatch.c:46-58), optional -check */

@@ -1,0 +1,195 @@
+"""ctypes binding of libpbwtgpu.so (include/pbwt_amd.h)."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+OPT_WITH_D, OPT_SORTED, OPT_WITHIN_HIST, OPT_CHECKSUM, OPT_PACK3, OPT_WITHIN_RECS = 1, 2, 4, 8, 16, 32
+MATCH_DTYPE = np.dtype([("ai", "<i4"), ("bi", "<i4"), ("start", "<i4"), ("end", "<i4")])
+REPORT_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_int, C.c_int)
+
+
+class PbwtAmdError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libpbwtgpu.so")
+
+
+_lib = None
+
+
+def load_library():
+    """load the HIP library; raises if it has not been built (no fallback)"""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise PbwtAmdError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
+        L = C.CDLL(p)
+        L.pbwtamd_last_error.restype = C.c_char_p
+        L.pbwtamd_engine_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.pbwtamd_engine_destroy.argtypes = [C.c_void_p]
+        for n in ("pbwtamd_engine_M", "pbwtamd_engine_wpc", "pbwtamd_engine_batch", "pbwtamd_sync"):
+            getattr(L, n).argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def wpc_for(M):
+    return ((M + 31) // 32 + 3) // 4 * 4
+
+
+def _p(arr, ctype):
+    return None if arr is None else arr.ctypes.data_as(C.POINTER(ctype))
+
+
+def _i32(x, M=None):
+    if x is None:
+        return None
+    return np.ascontiguousarray(x, dtype=np.int32)
+
+
+class Engine:
+    """device state for one panel of M haplotypes (the PbwtCursor of the reference, in HBM)"""
+
+    def __init__(self, M, batch_sites=0, device=0, stream=None):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.pbwtamd_engine_create(C.byref(h), int(device), int(M), int(batch_sites),
+                                           C.c_void_p(stream) if stream else None)
+        if rc:
+            raise PbwtAmdError(self._L.pbwtamd_last_error().decode())
+        self._h = h
+        self.M = int(M)
+        self.wpc = self._L.pbwtamd_engine_wpc(h)
+        self.batch = self._L.pbwtamd_engine_batch(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pbwtamd_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise PbwtAmdError(self._L.pbwtamd_last_error().decode())
+
+    # ------------------------------------------------------------ host-buffer entry points
+    def build(self, bitcols, with_d=False, aFstart=None, want_yz=True):
+        bitcols = np.ascontiguousarray(bitcols, dtype=np.uint32)
+        N, wpc = bitcols.shape
+        aF = _i32(aFstart)
+        aFend = np.zeros(self.M, np.int32)
+        dFend = np.zeros(self.M + 1, np.int32)
+        yzp = C.POINTER(C.c_uint8)()
+        nz = C.c_int64(0)
+        self._chk(self._L.pbwtamd_build(self._h, _p(bitcols, C.c_uint32), C.c_int(wpc), C.c_int(N), C.c_int(1 if with_d else 0),
+                                        _p(aF, C.c_int32), C.byref(yzp) if want_yz else None, C.byref(nz),
+                                        _p(aFend, C.c_int32), _p(dFend, C.c_int32)))
+        yz = None
+        if want_yz:
+            yz = np.ctypeslib.as_array(yzp, shape=(max(nz.value, 1),))[:nz.value].copy()
+            self._L.pbwtamd_free(yzp)
+        return dict(yz=yz, aFend=aFend, dFend=dFend if with_d else None)
+
+    def sweep_AD(self, yz, N, aFstart=None, dump_sites=(), checksums=True):
+        yz = np.ascontiguousarray(yz, dtype=np.uint8)
+        aF = _i32(aFstart)
+        ca = np.zeros(N + 1, np.uint64) if checksums else None
+        cd = np.zeros(N + 1, np.uint64) if checksums else None
+        cy = np.zeros(N + 1, np.uint64) if checksums else None
+        ds = np.asarray(list(dump_sites), dtype=np.int32)
+        a_dump = np.zeros((len(ds), self.M), np.int32)
+        d_dump = np.zeros((len(ds), self.M + 1), np.int32)
+        self._chk(self._L.pbwtamd_sweep_AD(self._h, _p(yz, C.c_uint8), C.c_int64(yz.size), C.c_int(N), _p(aF, C.c_int32),
+                                           _p(ca, C.c_uint64), _p(cd, C.c_uint64), _p(cy, C.c_uint64),
+                                           _p(ds, C.c_int32), C.c_int(len(ds)), _p(a_dump, C.c_int32), _p(d_dump, C.c_int32)))
+        return dict(csum_a=ca, csum_d=cd, csum_y=cy, a_dump=a_dump, d_dump=d_dump)
+
+    def max_within(self, yz, N, aFstart=None, mode="records", callback=None):
+        """mode 'records' -> structured array in callback order; 'hist' -> int64[N+1];
+        'callback' -> calls callback(ai,bi,start,end) per report"""
+        yz = np.ascontiguousarray(yz, dtype=np.uint8)
+        aF = _i32(aFstart)
+        if mode == "hist":
+            hist = np.zeros(N + 1, np.int64)
+            self._chk(self._L.pbwtamd_max_within(self._h, _p(yz, C.c_uint8), C.c_int64(yz.size), C.c_int(N), _p(aF, C.c_int32),
+                                                 None, None, None, _p(hist, C.c_int64), C.c_int(hist.size)))
+            return hist
+        if mode == "callback":
+            fn = REPORT_FN(callback)
+            self._chk(self._L.pbwtamd_max_within(self._h, _p(yz, C.c_uint8), C.c_int64(yz.size), C.c_int(N), _p(aF, C.c_int32),
+                                                 fn, None, None, None, C.c_int(0)))
+            return None
+        rp = C.c_void_p()
+        n = C.c_int64(0)
+        self._chk(self._L.pbwtamd_max_within(self._h, _p(yz, C.c_uint8), C.c_int64(yz.size), C.c_int(N), _p(aF, C.c_int32),
+                                             None, C.byref(rp), C.byref(n), None, C.c_int(0)))
+        out = np.zeros(n.value, MATCH_DTYPE)
+        if n.value:
+            C.memmove(out.ctypes.data, rp, n.value * MATCH_DTYPE.itemsize)
+        self._L.pbwtamd_free(rp)
+        return out
+
+    def pack3(self, sorted_bitcols):
+        sb = np.ascontiguousarray(sorted_bitcols, dtype=np.uint32)
+        N, wpc = sb.shape
+        yzp = C.POINTER(C.c_uint8)()
+        nz = C.c_int64(0)
+        self._chk(self._L.pbwtamd_pack3(self._h, _p(sb, C.c_uint32), C.c_int(wpc), C.c_int(N), C.byref(yzp), C.byref(nz)))
+        yz = np.ctypeslib.as_array(yzp, shape=(max(nz.value, 1),))[:nz.value].copy()
+        self._L.pbwtamd_free(yzp)
+        return yz
+
+    def unpack3(self, yz, N):
+        yz = np.ascontiguousarray(yz, dtype=np.uint8)
+        out = np.zeros((N, self.wpc), np.uint32)
+        self._chk(self._L.pbwtamd_unpack3(self._h, _p(yz, C.c_uint8), C.c_int64(yz.size), C.c_int(N), _p(out, C.c_uint32), C.c_int(self.wpc)))
+        return out
+
+    # ------------------------------------------------------------ device-buffer entry points
+    def synth_device(self, dptr, k0, ncols, seed=1, kind=0):
+        self._chk(self._L.pbwtamd_synth_device(self._h, C.c_void_p(dptr), C.c_int(k0), C.c_int(ncols), C.c_uint64(seed), C.c_int(kind)))
+
+    def pass_begin(self, n_total, k0=0, aInit=None):
+        a = _i32(aInit)
+        self._chk(self._L.pbwtamd_pass_begin(self._h, _p(a, C.c_int32), C.c_int(k0), C.c_int(n_total)))
+
+    def pass_advance(self, dptr, ncols, ncols_avail, opts):
+        self._chk(self._L.pbwtamd_pass_advance(self._h, C.c_void_p(dptr), C.c_int(self.wpc), C.c_int(ncols), C.c_int(ncols_avail), C.c_uint(opts)))
+
+    def pass_end(self, opts):
+        self._chk(self._L.pbwtamd_pass_end(self._h, C.c_uint(opts)))
+
+    def sync(self):
+        self._chk(self._L.pbwtamd_sync(self._h))
+
+    def get_state(self, with_d=True):
+        a = np.zeros(self.M, np.int32)
+        d = np.zeros(self.M + 1, np.int32) if with_d else None
+        self._chk(self._L.pbwtamd_get_state(self._h, _p(a, C.c_int32), _p(d, C.c_int32)))
+        return a, d
+
+    def get_hist(self, n):
+        h = np.zeros(n, np.int64)
+        self._chk(self._L.pbwtamd_get_hist(self._h, _p(h, C.c_int64), C.c_int(n)))
+        return h
+
+    def get_checksums(self, k_first, n):
+        ca = np.zeros(n, np.uint64); cd = np.zeros(n, np.uint64); cy = np.zeros(n, np.uint64)
+        self._chk(self._L.pbwtamd_get_checksums(self._h, C.c_int(k_first), C.c_int(n), _p(ca, C.c_uint64), _p(cd, C.c_uint64), _p(cy, C.c_uint64)))
+        return ca, cd, cy
+
+    def chain_timing(self):
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        self._chk(self._L.pbwtamd_get_chain_timing(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

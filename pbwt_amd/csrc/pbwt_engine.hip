@@ -1,0 +1,648 @@
+// pbwt_engine.hip — host side of libpbwtgpu.so: the C ABI of include/pbwt_amd.h over the gfx950
+// kernels in pbwt_kernels.h.  No CPU compute path lives here: every entry point fails loudly if
+// there is no usable HIP device.
+#include "../../include/pbwt_amd.h"
+#include "pbwt_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace pbwtk;
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_err = buf;
+    return 1;
+}
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));     \
+    } while (0)
+#define CHK(expr) do { int _r = (expr); if (_r) return _r; } while (0)
+
+// ------------------------------------------------------------------------------------ engine
+struct GraphKey { int with_d, sorted; hipGraphExec_t exec; };
+
+struct pbwtamd_engine {
+    int device = 0, M = 0, Mpad = 0, wpc = 0, wpc64 = 0, W = 0, wpad = 0, E = 4, T = 1024, B = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    int *A = nullptr, *D = nullptr; size_t strideA = 0, strideD = 0;      // B+1 ring slots
+    int *summ = nullptr;
+    int *ctl = nullptr;                     // [0]=kbase [1]=nsteps [2]=err
+    const uint32_t **colbase = nullptr;     // device: pointer to the current batch's columns
+    uint32_t *cols_stage = nullptr;         // (B+1) columns, for the host-buffer entry points
+    unsigned long long *ycols = nullptr;    // (B+1) sorted bit columns (wpc64 words each)
+    unsigned long long *colBytes = nullptr; // B+2
+    unsigned long long *blockCount = nullptr; size_t blockCountCap = 0;
+    unsigned long long *scal = nullptr;     // [0]=record total of the batch  [1]=yz bytes so far
+    unsigned long long *hist = nullptr; int histlen = 0;
+    unsigned long long *csum = nullptr; int csum_sites = 0;               // 3 * csum_sites
+    int4 *recs = nullptr; size_t recsCap = 0;
+    uint8_t *yz = nullptr; size_t yzCap = 0;
+    // pass state
+    int k0 = 0, k_cur = 0, n_total = 0; bool prepared = false; bool pass_open = false;
+    unsigned long long yz_bytes_host = 0;
+    std::vector<GraphKey> graphs; bool use_graph = true;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0; long long launches = 0;
+    // record sink for pass_advance (host-buffer entry points)
+    std::vector<pbwtamd_match> *rec_sink = nullptr; pbwtamd_report_fn rec_cb = nullptr;
+};
+
+extern "C" int pbwtamd_abi_version(void) { return PBWTAMD_ABI_VERSION; }
+extern "C" const char *pbwtamd_last_error(void) { return g_err.c_str(); }
+extern "C" int pbwtamd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" void pbwtamd_free(void *p) { free(p); }
+extern "C" int pbwtamd_engine_M(const pbwtamd_engine *e) { return e->M; }
+extern "C" int pbwtamd_engine_wpc(const pbwtamd_engine *e) { return e->wpc; }
+extern "C" int pbwtamd_engine_batch(const pbwtamd_engine *e) { return e->B; }
+
+static int wpc_for(int M) { return ((M + 31) / 32 + 3) / 4 * 4; }
+
+extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
+    for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->colbase, e->cols_stage, e->ycols, e->colBytes,
+                    e->blockCount, e->scal, e->hist, e->csum, e->recs, e->yz};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, int batch_sites, void *stream) {
+    *out = nullptr;
+    if (M < 2) return fail("pbwtamd_engine_create: M=%d, need at least 2 haplotypes", M);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail("pbwtamd: no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail("pbwtamd: device %d out of range (have %d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    pbwtamd_engine *e = new pbwtamd_engine();
+    e->device = device; e->M = M;
+    // tile geometry: T = 256*E positions per workgroup, at most 1024 tiles
+    e->E = 4;
+    if (M > 1024 * 256) e->E = 8;
+    if (M > 2048 * 256) e->E = 16;
+    if (const char *s = getenv("PBWTAMD_E")) { int v = atoi(s); if (v == 4 || v == 8 || v == 16) e->E = v; }
+    e->T = BLOCK * e->E;
+    e->W = (M + e->T - 1) / e->T;
+    if (e->W > 1024) { delete e; return fail("pbwtamd: M=%d too large for this build (max %d)", M, 1024 * 4096); }
+    e->Mpad = e->W * e->T;
+    e->wpad = (e->W + 63) / 64 * 64;
+    e->wpc = wpc_for(M);
+    e->wpc64 = e->wpc / 2;
+    e->B = batch_sites > 0 ? batch_sites : 512;
+    if (const char *s = getenv("PBWTAMD_NO_GRAPH")) e->use_graph = !(atoi(s) != 0);
+    if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
+    else { if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); } e->own_stream = true; }
+    e->strideA = (size_t)e->Mpad;
+    e->strideD = (size_t)e->Mpad + 64;
+    const size_t slots = (size_t)e->B + 1;
+#define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void **)&(ptr), (bytes)); if (_e != hipSuccess) { int r = fail("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(_e)); pbwtamd_engine_destroy(e); return r; } } while (0)
+    ALLOC(e->A, slots * e->strideA * sizeof(int));
+    ALLOC(e->D, slots * e->strideD * sizeof(int));
+    ALLOC(e->summ, (size_t)3 * 4 * e->wpad * sizeof(int));
+    ALLOC(e->ctl, 16 * sizeof(int));
+    ALLOC(e->colbase, sizeof(void *));
+    ALLOC(e->cols_stage, slots * e->wpc * sizeof(uint32_t));
+    ALLOC(e->ycols, slots * e->wpc64 * sizeof(unsigned long long));
+    ALLOC(e->colBytes, (slots + 1) * sizeof(unsigned long long));
+    ALLOC(e->scal, 8 * sizeof(unsigned long long));
+#undef ALLOC
+    HIPCHK(hipMemsetAsync(e->A, 0, slots * e->strideA * sizeof(int), e->stream));
+    HIPCHK(hipMemsetAsync(e->D, 0, slots * e->strideD * sizeof(int), e->stream));
+    HIPCHK(hipMemsetAsync(e->ctl, 0, 16 * sizeof(int), e->stream));
+    HIPCHK(hipMemsetAsync(e->scal, 0, 8 * sizeof(unsigned long long), e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *out = e;
+    return 0;
+}
+
+extern "C" int pbwtamd_sync(pbwtamd_engine *e) {
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int err = 0;
+    HIPCHK(hipMemcpy(&err, e->ctl + 2, sizeof(int), hipMemcpyDeviceToHost));
+    if (err) return fail("pbwtamd: device-side error flag %d (1=histogram range, 2/3=malformed packed column, 4=yz buffer overflow)", err);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ small kernels
+__global__ void set_ctl_kernel(int *ctl, int kbase, int nsteps, int n_total, const uint32_t **colbase, const uint32_t *cols) {
+    ctl[0] = kbase; ctl[1] = nsteps; ctl[3] = n_total; *colbase = cols;
+}
+__global__ void add_base_kernel(unsigned long long *v, size_t n, const unsigned long long *base) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] += *base;
+}
+__global__ void bump_kernel(unsigned long long *acc, const unsigned long long *add, unsigned long long cap, int *err) {
+    *acc += *add;
+    if (*acc > cap) atomicExch(err, 4);
+}
+
+template <int E, bool WITH_D, bool SORTED>
+static void launch_step(pbwtamd_engine *e, int j) {
+    StepArgs g;
+    g.a_in = e->A + (size_t)j * e->strideA;       g.d_in = e->D + (size_t)j * e->strideD;
+    g.a_out = e->A + (size_t)(j + 1) * e->strideA; g.d_out = e->D + (size_t)(j + 1) * e->strideD;
+    g.colbase = e->colbase; g.wpc = e->wpc; g.summ = e->summ; g.ctl = e->ctl;
+    g.j = j; g.M = e->M; g.W = e->W; g.wpad = e->wpad;
+    hipLaunchKernelGGL((step_kernel<E, WITH_D, SORTED>), dim3(e->W), dim3(BLOCK), 0, e->stream, g);
+}
+
+static void launch_step_dyn(pbwtamd_engine *e, int j, bool with_d, bool sorted) {
+#define CASE(EE)                                                                   \
+    if (e->E == EE) {                                                              \
+        if (with_d && sorted) launch_step<EE, true, true>(e, j);                   \
+        else if (with_d) launch_step<EE, true, false>(e, j);                       \
+        else if (sorted) launch_step<EE, false, true>(e, j);                       \
+        else launch_step<EE, false, false>(e, j);                                  \
+        return;                                                                    \
+    }
+    CASE(4) CASE(8) CASE(16)
+#undef CASE
+}
+
+static int get_graph(pbwtamd_engine *e, bool with_d, bool sorted, hipGraphExec_t *out) {
+    for (auto &g : e->graphs) if (g.with_d == (int)with_d && g.sorted == (int)sorted) { *out = g.exec; return 0; }
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    for (int j = 0; j < e->B; ++j) launch_step_dyn(e, j, with_d, sorted);
+    HIPCHK(hipStreamEndCapture(e->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIPCHK(hipGraphDestroy(graph));
+    e->graphs.push_back(GraphKey{(int)with_d, (int)sorted, exec});
+    *out = exec;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ pass
+extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k0, int n_total) {
+    HIPCHK(hipSetDevice(e->device));
+    if (n_total < k0) return fail("pbwtamd_pass_begin: n_total %d < k0 %d", n_total, k0);
+    e->k0 = k0; e->k_cur = k0; e->n_total = n_total; e->prepared = false; e->pass_open = true;
+    if (aInit) HIPCHK(hipMemcpyAsync(e->A, aInit, sizeof(int) * (size_t)e->M, hipMemcpyHostToDevice, e->stream));
+    const int nb = (e->Mpad + 1 + 255) / 256;
+    hipLaunchKernelGGL(init_state_kernel, dim3(nb), dim3(256), 0, e->stream, e->A, e->D, e->M, e->Mpad, k0, aInit ? 0 : 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(e->ctl, 0, 16 * sizeof(int), e->stream));
+    HIPCHK(hipMemsetAsync(e->scal, 0, 8 * sizeof(unsigned long long), e->stream));
+    const int nsites = n_total - k0 + 1;
+    if (nsites > e->csum_sites) {
+        if (e->csum) HIPCHK(hipFree(e->csum));
+        HIPCHK(hipMalloc((void **)&e->csum, (size_t)3 * nsites * sizeof(unsigned long long)));
+        e->csum_sites = nsites;
+    }
+    HIPCHK(hipMemsetAsync(e->csum, 0, (size_t)3 * e->csum_sites * sizeof(unsigned long long), e->stream));
+    const int hl = n_total + 2;
+    if (hl > e->histlen) {
+        if (e->hist) HIPCHK(hipFree(e->hist));
+        HIPCHK(hipMalloc((void **)&e->hist, (size_t)hl * sizeof(unsigned long long)));
+        e->histlen = hl;
+    }
+    HIPCHK(hipMemsetAsync(e->hist, 0, (size_t)e->histlen * sizeof(unsigned long long), e->stream));
+    e->yz_bytes_host = 0;
+    e->ev_used = 0; e->launches = 0;
+    return 0;
+}
+
+static int ensure_blockcount(pbwtamd_engine *e, size_t n) {
+    if (n <= e->blockCountCap) return 0;
+    if (e->blockCount) HIPCHK(hipFree(e->blockCount));
+    HIPCHK(hipMalloc((void **)&e->blockCount, n * sizeof(unsigned long long)));
+    e->blockCountCap = n;
+    return 0;
+}
+
+// maxWithin sweep over `nsites` ring slots starting at slot 0 (sites kbase..): histogram or records
+static int run_within(pbwtamd_engine *e, int kbase, int nsites, int final_site, unsigned opts) {
+    SweepArgs g;
+    g.A = e->A; g.D = e->D; g.strideA = e->strideA; g.strideD = e->strideD;
+    g.M = e->M; g.kbase = kbase; g.final_site = final_site;
+    g.blockCount = nullptr; g.recs = nullptr; g.hist = e->hist; g.histlen = e->histlen; g.err = e->ctl + 2;
+    const int tiles = (e->M + BLOCK - 1) / BLOCK;
+    dim3 grid(tiles, nsites);
+    if (opts & PBWTAMD_OPT_WITHIN_HIST) {
+        hipLaunchKernelGGL((sweep_within_kernel<2>), grid, dim3(BLOCK), 0, e->stream, g);
+        HIPCHK(hipGetLastError());
+    }
+    if (opts & PBWTAMD_OPT_WITHIN_RECS) {
+        const size_t nblk = (size_t)tiles * nsites;
+        CHK(ensure_blockcount(e, nblk));
+        g.blockCount = e->blockCount;
+        hipLaunchKernelGGL((sweep_within_kernel<0>), grid, dim3(BLOCK), 0, e->stream, g);
+        hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, e->stream, e->blockCount, nblk, e->scal, 0ULL);
+        HIPCHK(hipGetLastError());
+        unsigned long long total = 0;
+        HIPCHK(hipMemcpyAsync(&total, e->scal, sizeof total, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (total > e->recsCap) {
+            if (e->recs) HIPCHK(hipFree(e->recs));
+            e->recsCap = (size_t)(total + total / 4 + 1024);
+            HIPCHK(hipMalloc((void **)&e->recs, e->recsCap * sizeof(int4)));
+        }
+        if (total) {
+            g.recs = e->recs;
+            hipLaunchKernelGGL((sweep_within_kernel<1>), grid, dim3(BLOCK), 0, e->stream, g);
+            HIPCHK(hipGetLastError());
+            std::vector<pbwtamd_match> tmp;
+            std::vector<pbwtamd_match> *dst = e->rec_sink ? e->rec_sink : &tmp;
+            const size_t old = dst->size();
+            dst->resize(old + total);
+            HIPCHK(hipMemcpyAsync(dst->data() + old, e->recs, total * sizeof(int4), hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(hipStreamSynchronize(e->stream));
+            if (e->rec_cb) {
+                for (size_t r = old; r < old + total; ++r) { const pbwtamd_match &m = (*dst)[r]; e->rec_cb(m.ai, m.bi, m.start, m.end); }
+                if (dst == e->rec_sink) dst->resize(old);       // callback mode keeps nothing
+            }
+        }
+    }
+    return 0;
+}
+
+static int ensure_yz(pbwtamd_engine *e, size_t cap) {
+    if (cap <= e->yzCap) return 0;
+    uint8_t *n = nullptr;
+    HIPCHK(hipMalloc((void **)&n, cap));
+    if (e->yz) {
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpy(n, e->yz, e->yzCap, hipMemcpyDeviceToDevice));
+        HIPCHK(hipFree(e->yz));
+    }
+    e->yz = n; e->yzCap = cap;
+    return 0;
+}
+
+// pack3-encode the y columns of `nsites` ring slots (tags) and append to the engine's yz buffer
+static int run_pack3(pbwtamd_engine *e, int nsites) {
+    dim3 g1(std::min(64, (e->wpc64 + WAVES - 1) / WAVES), nsites);
+    hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, e->stream, (const int *)e->A, e->strideA, e->M, e->ycols, e->wpc64);
+    hipLaunchKernelGGL((pack3_kernel<0>), dim3(nsites), dim3(BLOCK), 0, e->stream, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
+    // exclusive offsets inside the batch; batch total -> scal[2]
+    hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, e->stream, e->colBytes, (size_t)nsites, e->scal + 2, 0ULL);
+    HIPCHK(hipGetLastError());
+    unsigned long long tot = 0;
+    HIPCHK(hipMemcpyAsync(&tot, e->scal + 2, sizeof tot, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t need = (size_t)e->yz_bytes_host + (size_t)tot;
+    if (need > e->yzCap) CHK(ensure_yz(e, std::max(need + (need >> 2) + 4096, e->yzCap * 2)));
+    hipLaunchKernelGGL(add_base_kernel, dim3((nsites + 255) / 256), dim3(256), 0, e->stream, e->colBytes, (size_t)nsites, (const unsigned long long *)(e->scal + 1));
+    hipLaunchKernelGGL((pack3_kernel<1>), dim3(nsites), dim3(BLOCK), 0, e->stream, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
+    hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, e->stream, e->scal + 1, (const unsigned long long *)(e->scal + 2), (unsigned long long)e->yzCap, e->ctl + 2);
+    HIPCHK(hipGetLastError());
+    e->yz_bytes_host += tot;
+    return 0;
+}
+
+extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, int wpc, int ncols, int ncols_avail, unsigned opts) {
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->pass_open) return fail("pbwtamd_pass_advance without pass_begin");
+    if (wpc != e->wpc) return fail("pbwtamd_pass_advance: wpc %d != engine wpc %d", wpc, e->wpc);
+    if (e->k_cur + ncols > e->n_total) return fail("pbwtamd_pass_advance: beyond n_total");
+    if (ncols_avail < ncols + 1 && e->k_cur + ncols < e->n_total)
+        return fail("pbwtamd_pass_advance: need the column after the batch (ncols_avail >= ncols+1) except at the last site");
+    const bool with_d = opts & PBWTAMD_OPT_WITH_D, sorted = opts & PBWTAMD_OPT_SORTED;
+    if ((opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) && !with_d)
+        return fail("pbwtamd: the maxWithin sweep needs OPT_WITH_D");
+    const uint32_t *cols = (const uint32_t *)d_bitcols;
+    int done = 0;
+    while (done < ncols) {
+        const int nb = std::min(e->B, ncols - done);
+        const uint32_t *bc = cols + (size_t)done * wpc;
+        if (!e->prepared) {
+            PrepArgs p;
+            p.a = e->A; p.d = e->D; p.col = bc; p.summ = e->summ; p.k = e->k_cur; p.M = e->M; p.W = e->W;
+            p.wpad = e->wpad; p.T = e->T; p.sorted = sorted; p.with_d = with_d; p.has_col = 1;
+            hipLaunchKernelGGL(prepare_kernel, dim3(e->W), dim3(BLOCK), 0, e->stream, p);
+            HIPCHK(hipGetLastError());
+            e->prepared = true;
+        }
+        hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, e->stream, e->ctl, e->k_cur, nb, e->n_total, e->colbase, bc);
+        HIPCHK(hipGetLastError());
+        // ---- the chain: one launch per site ----
+        if (e->ev_used == e->ev.size()) {
+            hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); e->ev.push_back({a, b});
+        }
+        HIPCHK(hipEventRecord(e->ev[e->ev_used].first, e->stream));
+        if (e->use_graph && nb == e->B) {
+            hipGraphExec_t exec;
+            CHK(get_graph(e, with_d, sorted, &exec));
+            HIPCHK(hipGraphLaunch(exec, e->stream));
+        } else {
+            for (int j = 0; j < nb; ++j) launch_step_dyn(e, j, with_d, sorted);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipEventRecord(e->ev[e->ev_used].second, e->stream));
+        ++e->ev_used; e->launches += nb;
+        // ---- batch consumers over slots [0, nb) = sites k_cur .. k_cur+nb-1 ----
+        if (opts & PBWTAMD_OPT_CHECKSUM) {
+            unsigned long long *ca = e->csum + (e->k_cur - e->k0), *cd = ca + e->csum_sites, *cy = cd + e->csum_sites;
+            dim3 grid(std::min(64, (e->M + BLOCK) / BLOCK), nb);
+            hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, e->stream, (const int *)e->A, (const int *)e->D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, nb);
+            HIPCHK(hipGetLastError());
+        }
+        if (opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, e->k_cur, nb, -1, opts));
+        if (opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, nb));
+        // ---- carry the cursor: slot nb -> slot 0 ----
+        HIPCHK(hipMemcpyAsync(e->A, e->A + (size_t)nb * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->stream));
+        if (with_d) HIPCHK(hipMemcpyAsync(e->D, e->D + (size_t)nb * e->strideD, sizeof(int) * e->strideD, hipMemcpyDeviceToDevice, e->stream));
+        e->k_cur += nb;
+        done += nb;
+    }
+    return 0;
+}
+
+extern "C" int pbwtamd_pass_end(pbwtamd_engine *e, unsigned opts) {
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->pass_open) return fail("pbwtamd_pass_end without pass_begin");
+    if (e->k_cur != e->n_total) return fail("pbwtamd_pass_end: at site %d of %d", e->k_cur, e->n_total);
+    const bool with_d = opts & PBWTAMD_OPT_WITH_D;
+    if (opts & PBWTAMD_OPT_CHECKSUM) {
+        unsigned long long *ca = e->csum + (e->k_cur - e->k0), *cd = ca + e->csum_sites, *cy = cd + e->csum_sites;
+        dim3 grid(std::min(64, (e->M + BLOCK) / BLOCK), 1);
+        hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, e->stream, (const int *)e->A, (const int *)e->D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, 0);
+        HIPCHK(hipGetLastError());
+    }
+    if (opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, e->n_total, 1, 0, opts));
+    e->pass_open = false;
+    return pbwtamd_sync(e);
+}
+
+extern "C" int pbwtamd_get_state(pbwtamd_engine *e, int32_t *a, int32_t *d) {
+    HIPCHK(hipSetDevice(e->device));
+    // slot 0 holds the current cursor; strip the allele tags through the ycols scratch
+    int *tmp = (int *)e->ycols;
+    static_assert(sizeof(unsigned long long) == 8, "");
+    if ((size_t)e->M * sizeof(int) > ((size_t)e->B + 1) * e->wpc64 * sizeof(unsigned long long)) {
+        std::vector<int> h(e->M);
+        HIPCHK(hipMemcpyAsync(h.data(), e->A, sizeof(int) * (size_t)e->M, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        for (int i = 0; i < e->M; ++i) a[i] = h[i] & AMASK;
+    } else {
+        hipLaunchKernelGGL(untag_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, (const int *)e->A, tmp, e->M);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(a, tmp, sizeof(int) * (size_t)e->M, hipMemcpyDeviceToHost, e->stream));
+    }
+    if (d) HIPCHK(hipMemcpyAsync(d, e->D, sizeof(int) * ((size_t)e->M + 1), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int pbwtamd_get_hist(pbwtamd_engine *e, int64_t *hist, int histlen) {
+    HIPCHK(hipSetDevice(e->device));
+    const int n = std::min(histlen, e->histlen);
+    memset(hist, 0, sizeof(int64_t) * (size_t)histlen);
+    HIPCHK(hipMemcpyAsync(hist, e->hist, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int pbwtamd_get_checksums(pbwtamd_engine *e, int k_first, int n, uint64_t *ca, uint64_t *cd, uint64_t *cy) {
+    HIPCHK(hipSetDevice(e->device));
+    const int off = k_first - e->k0;
+    if (off < 0 || off + n > e->csum_sites) return fail("pbwtamd_get_checksums: range outside the pass");
+    if (ca) HIPCHK(hipMemcpyAsync(ca, e->csum + off, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    if (cd) HIPCHK(hipMemcpyAsync(cd, e->csum + e->csum_sites + off, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    if (cy) HIPCHK(hipMemcpyAsync(cy, e->csum + 2 * (size_t)e->csum_sites + off, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" int pbwtamd_get_chain_timing(pbwtamd_engine *e, double *ms_total, int64_t *launches) {
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    double tot = 0;
+    for (size_t i = 0; i < e->ev_used; ++i) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e->ev[i].first, e->ev[i].second));
+        tot += ms;
+    }
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = e->launches;
+    return 0;
+}
+
+extern "C" int pbwtamd_synth_device(pbwtamd_engine *e, void *d_bitcols, int k0, int ncols, uint64_t seed, int kind) {
+    HIPCHK(hipSetDevice(e->device));
+    int done = 0;
+    while (done < ncols) {
+        const int nb = std::min(ncols - done, 32768);
+        dim3 grid(std::max(1, std::min(16, (e->wpc + BLOCK - 1) / BLOCK)), nb);
+        hipLaunchKernelGGL(synth_kernel, grid, dim3(BLOCK), 0, e->stream, (uint32_t *)d_bitcols + (size_t)done * e->wpc, e->M, k0 + done, nb, e->wpc, seed, kind);
+        HIPCHK(hipGetLastError());
+        done += nb;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ host-buffer API
+extern "C" int pbwtamd_build(pbwtamd_engine *e, const uint32_t *bitcols, int wpc, int N, int with_d,
+                             const int32_t *aFstart, uint8_t **yz_out, int64_t *nz_out, int32_t *aFend, int32_t *dFend) {
+    HIPCHK(hipSetDevice(e->device));
+    if (wpc < (e->M + 31) / 32) return fail("pbwtamd_build: wpc %d too small for M %d", wpc, e->M);
+    CHK(pbwtamd_pass_begin(e, aFstart, 0, N));
+    const unsigned opts = (with_d ? PBWTAMD_OPT_WITH_D : 0u) | (yz_out ? PBWTAMD_OPT_PACK3 : 0u);
+    int done = 0;
+    while (done < N) {
+        const int nb = std::min(e->B, N - done);
+        const int navail = std::min(nb + 1, N - done);
+        if (wpc == e->wpc)
+            HIPCHK(hipMemcpyAsync(e->cols_stage, bitcols + (size_t)done * wpc, (size_t)navail * wpc * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+        else {
+            HIPCHK(hipMemsetAsync(e->cols_stage, 0, (size_t)navail * e->wpc * sizeof(uint32_t), e->stream));
+            HIPCHK(hipMemcpy2DAsync(e->cols_stage, (size_t)e->wpc * 4, bitcols + (size_t)done * wpc, (size_t)wpc * 4,
+                                    (size_t)std::min(wpc, e->wpc) * 4, (size_t)navail, hipMemcpyHostToDevice, e->stream));
+        }
+        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, opts));
+        HIPCHK(hipStreamSynchronize(e->stream));           // staging buffer is reused
+        done += nb;
+    }
+    CHK(pbwtamd_pass_end(e, opts));
+    if (aFend) CHK(pbwtamd_get_state(e, aFend, with_d ? dFend : nullptr));
+    if (yz_out) {
+        const unsigned long long nz = e->yz_bytes_host;
+        uint8_t *buf = (uint8_t *)malloc(nz ? nz : 1);
+        if (!buf) return fail("pbwtamd_build: out of host memory for %llu bytes", nz);
+        if (nz) HIPCHK(hipMemcpy(buf, e->yz, nz, hipMemcpyDeviceToHost));
+        *yz_out = buf; *nz_out = (int64_t)nz;
+    }
+    return 0;
+}
+
+// decode state for packed panels on the device
+struct Packed {
+    uint8_t *z = nullptr; long long *colStart = nullptr; unsigned long long *blockSum = nullptr;
+    ~Packed() { if (z) (void)hipFree(z); if (colStart) (void)hipFree(colStart); if (blockSum) (void)hipFree(blockSum); }
+};
+
+static int packed_upload(pbwtamd_engine *e, hipStream_t st, int M, const uint8_t *yz, int64_t nz, int N, Packed &pk) {
+    if (nz <= 0 && N > 0) return fail("pbwtamd: empty packed panel for N=%d", N);
+    HIPCHK(hipMalloc((void **)&pk.z, (size_t)std::max<int64_t>(nz, 1)));
+    HIPCHK(hipMemcpyAsync(pk.z, yz, (size_t)nz, hipMemcpyHostToDevice, st));
+    const size_t nblk = ((size_t)nz + DEC_CHUNK - 1) / DEC_CHUNK;
+    HIPCHK(hipMalloc((void **)&pk.blockSum, (nblk + 1) * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&pk.colStart, ((size_t)N + 2) * sizeof(long long)));
+    HIPCHK(hipMemsetAsync(pk.colStart, 0xff, ((size_t)N + 2) * sizeof(long long), st));
+    if (nblk) {
+        hipLaunchKernelGGL(dec_sum_kernel, dim3((unsigned)nblk), dim3(BLOCK), 0, st, (const uint8_t *)pk.z, (size_t)nz, pk.blockSum);
+        hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, pk.blockSum, nblk, pk.blockSum + nblk, 0ULL);
+        hipLaunchKernelGGL(dec_colstart_kernel, dim3((unsigned)nblk), dim3(BLOCK), 0, st, (const uint8_t *)pk.z, (size_t)nz, (const unsigned long long *)pk.blockSum, M, (long long)N, pk.colStart);
+        HIPCHK(hipGetLastError());
+    }
+    unsigned long long total = 0;
+    if (nblk) HIPCHK(hipMemcpyAsync(&total, pk.blockSum + nblk, sizeof total, hipMemcpyDeviceToHost, st));
+    const long long end = nz;
+    HIPCHK(hipMemcpyAsync(pk.colStart + N, &end, sizeof end, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (total != (unsigned long long)M * (unsigned long long)N)
+        return fail("pbwtamd: packed panel decodes to %llu alleles, expected M*N = %llu", total, (unsigned long long)M * (unsigned long long)N);
+    (void)e;
+    return 0;
+}
+
+// expand columns [c0, c0+nc) of a packed panel into ycols (wpc64 words per column)
+static int packed_expand(pbwtamd_engine *e, hipStream_t st, const Packed &pk, int M, long long c0, int nc, unsigned long long *ycols, int wpc64) {
+    HIPCHK(hipMemsetAsync(ycols, 0, (size_t)nc * wpc64 * sizeof(unsigned long long), st));
+    if (nc) hipLaunchKernelGGL(dec_expand_kernel, dim3(nc), dim3(BLOCK), 0, st, (const uint8_t *)pk.z, (const long long *)pk.colStart, c0, M, ycols, wpc64, e->ctl + 2);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// drive a read-side pass over a packed panel; per batch decode -> ycols -> chain (+consumers)
+static int sweep_packed(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart, unsigned opts,
+                        const int32_t *dump_sites, int ndump, int32_t *a_dump, int32_t *d_dump) {
+    Packed pk;
+    CHK(packed_upload(e, e->stream, e->M, yz, nz, N, pk));
+    CHK(pbwtamd_pass_begin(e, aFstart, 0, N));
+    opts |= PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D;
+    std::vector<int> tmp(e->M);
+    auto dump_at = [&](int k) -> int {
+        for (int q = 0; q < ndump; ++q) if (dump_sites[q] == k) {
+            CHK(pbwtamd_get_state(e, a_dump + (size_t)q * e->M, d_dump ? d_dump + (size_t)q * (e->M + 1) : nullptr));
+        }
+        return 0;
+    };
+    int done = 0;
+    bool any_dump = ndump > 0;
+    while (done < N) {
+        int nb = std::min(e->B, N - done);
+        if (any_dump) {                                      // stop at the next dump site
+            CHK(dump_at(done));
+            int nxt = N + 1;
+            for (int q = 0; q < ndump; ++q) if (dump_sites[q] > done && dump_sites[q] < nxt) nxt = dump_sites[q];
+            nb = std::min(nb, nxt - done);
+        }
+        const int navail = std::min(nb + 1, N - done);
+        // decode straight into the column staging buffer (ycols is scratch for pack3/get_state)
+        CHK(packed_expand(e, e->stream, pk, e->M, done, navail, (unsigned long long *)e->cols_stage, e->wpc64));
+        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, opts));
+        done += nb;
+    }
+    if (any_dump) CHK(dump_at(N));
+    CHK(pbwtamd_pass_end(e, opts));
+    return 0;
+}
+
+extern "C" int pbwtamd_sweep_AD(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart,
+                                uint64_t *csum_a, uint64_t *csum_d, uint64_t *csum_y,
+                                const int32_t *dump_sites, int ndump, int32_t *a_dump, int32_t *d_dump) {
+    HIPCHK(hipSetDevice(e->device));
+    const unsigned opts = (csum_a || csum_d || csum_y) ? PBWTAMD_OPT_CHECKSUM : 0u;
+    CHK(sweep_packed(e, yz, nz, N, aFstart, opts, dump_sites, ndump, a_dump, d_dump));
+    if (opts) CHK(pbwtamd_get_checksums(e, 0, N + 1, csum_a, csum_d, csum_y));
+    return 0;
+}
+
+extern "C" int pbwtamd_max_within(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart,
+                                  pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out,
+                                  int64_t *hist, int histlen) {
+    HIPCHK(hipSetDevice(e->device));
+    const int sinks = (report ? 1 : 0) + (recs_out ? 1 : 0) + (hist ? 1 : 0);
+    if (sinks != 1) return fail("pbwtamd_max_within: exactly one of report / recs_out / hist must be given");
+    if (hist && histlen < N + 1) return fail("pbwtamd_max_within: histlen %d < N+1", histlen);
+    std::vector<pbwtamd_match> recs;
+    e->rec_sink = &recs; e->rec_cb = report;
+    const unsigned opts = hist ? PBWTAMD_OPT_WITHIN_HIST : PBWTAMD_OPT_WITHIN_RECS;
+    const int rc = sweep_packed(e, yz, nz, N, aFstart, opts, nullptr, 0, nullptr, nullptr);
+    e->rec_sink = nullptr; e->rec_cb = nullptr;
+    if (rc) return rc;
+    if (hist) CHK(pbwtamd_get_hist(e, hist, histlen));
+    if (recs_out) {
+        pbwtamd_match *buf = (pbwtamd_match *)malloc(std::max<size_t>(1, recs.size()) * sizeof(pbwtamd_match));
+        if (!buf) return fail("pbwtamd_max_within: out of host memory");
+        if (!recs.empty()) memcpy(buf, recs.data(), recs.size() * sizeof(pbwtamd_match));
+        *recs_out = buf; *nrecs_out = (int64_t)recs.size();
+    }
+    return 0;
+}
+
+extern "C" int pbwtamd_pack3(pbwtamd_engine *e, const uint32_t *sorted_bitcols, int wpc, int N, uint8_t **yz_out, int64_t *nz_out) {
+    HIPCHK(hipSetDevice(e->device));
+    if (wpc != e->wpc) return fail("pbwtamd_pack3: wpc %d != engine wpc %d", wpc, e->wpc);
+    std::vector<uint8_t> all;
+    unsigned long long *off = nullptr;
+    for (int done = 0; done < N; done += e->B) {
+        const int nb = std::min(e->B, N - done);
+        HIPCHK(hipMemcpyAsync(e->ycols, sorted_bitcols + (size_t)done * wpc, (size_t)nb * wpc * 4, hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL((pack3_kernel<0>), dim3(nb), dim3(BLOCK), 0, e->stream, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
+        hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, e->stream, e->colBytes, (size_t)nb, e->scal + 2, 0ULL);
+        HIPCHK(hipGetLastError());
+        unsigned long long tot = 0;
+        HIPCHK(hipMemcpyAsync(&tot, e->scal + 2, sizeof tot, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        CHK(ensure_yz(e, (size_t)tot + 16));
+        hipLaunchKernelGGL((pack3_kernel<1>), dim3(nb), dim3(BLOCK), 0, e->stream, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
+        HIPCHK(hipGetLastError());
+        const size_t old = all.size();
+        all.resize(old + tot);
+        if (tot) HIPCHK(hipMemcpyAsync(all.data() + old, e->yz, tot, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    (void)off;
+    uint8_t *buf = (uint8_t *)malloc(std::max<size_t>(1, all.size()));
+    if (!buf) return fail("pbwtamd_pack3: out of host memory");
+    if (!all.empty()) memcpy(buf, all.data(), all.size());
+    *yz_out = buf; *nz_out = (int64_t)all.size();
+    return 0;
+}
+
+extern "C" int pbwtamd_unpack3(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, uint32_t *sorted_bitcols, int wpc) {
+    HIPCHK(hipSetDevice(e->device));
+    if (wpc != e->wpc) return fail("pbwtamd_unpack3: wpc %d != engine wpc %d", wpc, e->wpc);
+    Packed pk;
+    CHK(packed_upload(e, e->stream, e->M, yz, nz, N, pk));
+    for (int done = 0; done < N; done += e->B) {
+        const int nb = std::min(e->B, N - done);
+        CHK(packed_expand(e, e->stream, pk, e->M, done, nb, e->ycols, e->wpc64));
+        HIPCHK(hipMemcpyAsync(sorted_bitcols + (size_t)done * wpc, e->ycols, (size_t)nb * wpc * 4, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+    }
+    return pbwtamd_sync(e);
+}
+
+extern "C" int pbwtamd_match_sweep(pbwtamd_engine *e, const uint8_t *pz, int64_t pnz, int N, const int32_t *pStart,
+                                   int Mq, const uint8_t *qz, int64_t qnz, const int32_t *qStart,
+                                   pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out,
+                                   int64_t *n_nomatch, int64_t *tot) {
+    (void)e; (void)pz; (void)pnz; (void)N; (void)pStart; (void)Mq; (void)qz; (void)qnz; (void)qStart;
+    (void)report; (void)recs_out; (void)nrecs_out; (void)n_nomatch; (void)tot;
+    return fail("pbwtamd_match_sweep: not implemented in this build");
+}

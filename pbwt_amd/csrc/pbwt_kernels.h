@@ -1,0 +1,750 @@
+// pbwt_kernels.h — hand-written gfx950 (CDNA4, wave64) kernels for the PBWT hot path.
+//
+// HBM layout:
+//   ring slot s:  A[s][Mpad] int32  — prefix array a_k, with the allele y_k[i] of the haplotype at
+//                                     position i carried in bit 31 (the "tag"); a < 2^31 always
+//                 D[s][Mpad+PADD]   — divergence d_k[0..M] (start-position form, pbwt.h:82)
+//   tile summaries S[3][4][WPAD]    — per tile of T positions of the NEXT site: cnt0, last0+1,
+//                                     last1+1, max d; built with commutative atomics by the step
+//                                     that scatters into that site, so one launch per site
+//   bit columns  C[k][wpc] uint32   — original order (gather by a) or sorted order (index by pos)
+//
+// Kernels: prepare (tags+summaries for the first site of a pass), step (one site of
+// pbwtCursorForwardsA/AD, pbwtCore.c:458-508), and the batch consumers (checksum, maxWithin sweep
+// pbwtMatch.c:115-142, pack3 encode/decode pbwtCore.c:240-305, query sweep pbwtMatch.c:363-443).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pbwtk {
+
+constexpr int BLOCK = 256;          // 4 waves of 64
+constexpr int WAVES = BLOCK / 64;
+constexpr unsigned TAG = 0x80000000u;
+constexpr int AMASK = 0x7fffffff;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ uint64_t sm64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ULL;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+
+// ---------------------------------------------------------------------------------------------
+// carry tuple of the divergence recurrence (pbwtCore.c:492-503).  For a segment of positions:
+//   c0,c1 = number of 0 / 1 alleles; all = max d over the segment;
+//   t_b   = max d over the elements after the last allele-b element (all if there is none).
+// combine(L,R) is associative; (0,0,0,0,0) is the identity (d >= 0 everywhere).
+struct Tup { int c0, c1, t0, t1, all; };
+
+__device__ __forceinline__ Tup tup_combine(const Tup &L, const Tup &R) {
+    Tup o;
+    o.c0 = L.c0 + R.c0;
+    o.c1 = L.c1 + R.c1;
+    o.all = max(L.all, R.all);
+    o.t0 = R.c0 ? R.t0 : max(L.t0, R.all);
+    o.t1 = R.c1 ? R.t1 : max(L.t1, R.all);
+    return o;
+}
+__device__ __forceinline__ Tup tup_shfl_up(const Tup &v, int o) {
+    Tup r;
+    r.c0 = __shfl_up(v.c0, o); r.c1 = __shfl_up(v.c1, o);
+    r.t0 = __shfl_up(v.t0, o); r.t1 = __shfl_up(v.t1, o); r.all = __shfl_up(v.all, o);
+    return r;
+}
+
+// block-wide exclusive scan of Tup over 256 threads; also returns the block total.
+// smem: WAVES Tups.
+template <bool WITH_D>
+__device__ __forceinline__ Tup block_scan_tup(Tup v, Tup *smem, Tup &total) {
+    const int lane = lane_id(), wv = wave_id();
+    Tup inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        Tup L = tup_shfl_up(inc, o);
+        if (lane >= o) {
+            if (WITH_D) inc = tup_combine(L, inc);
+            else { inc.c0 += L.c0; inc.c1 += L.c1; }
+        }
+    }
+    if (lane == 63) smem[wv] = inc;
+    Tup exc = tup_shfl_up(inc, 1);
+    if (lane == 0) exc = Tup{0, 0, 0, 0, 0};
+    __syncthreads();
+    Tup pre = Tup{0, 0, 0, 0, 0};
+    Tup tot = Tup{0, 0, 0, 0, 0};
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        Tup s = smem[w];
+        if (w < wv) pre = WITH_D ? tup_combine(pre, s) : Tup{pre.c0 + s.c0, pre.c1 + s.c1, 0, 0, 0};
+        tot = WITH_D ? tup_combine(tot, s) : Tup{tot.c0 + s.c0, tot.c1 + s.c1, 0, 0, 0};
+    }
+    total = tot;
+    if (WITH_D) return tup_combine(pre, exc);
+    return Tup{pre.c0 + exc.c0, pre.c1 + exc.c1, 0, 0, 0};
+}
+
+// ---------------------------------------------------------------------------------------------
+struct StepArgs {
+    const int *a_in;  const int *d_in;     // slot k
+    int *a_out;       int *d_out;          // slot k+1
+    const uint32_t *const *colbase;        // device pointer to this batch's bit columns (site kbase first)
+    int wpc;                               // 32-bit words per column
+    int *summ;                             // [3][4][wpad]
+    const int *ctl;                        // device ints: [0] kbase = site of step 0 of this batch,
+                                           // [1] live steps in the batch (j >= nsteps: no-op), [3] n_total
+    int j;                                 // step index inside the batch
+    int M, W, wpad;
+};
+
+__device__ __forceinline__ int *summ_ptr(int *summ, int wpad, int buf, int which) {
+    return summ + ((size_t)buf * 4 + which) * wpad;
+}
+
+// One site of pbwtCursorForwardsA / ForwardsAD (pbwtCore.c:458-470 / 485-508) for one tile of
+// T = 256*E consecutive positions.  grid = W tiles.
+template <int E, bool WITH_D, bool SORTED>
+__global__ __launch_bounds__(BLOCK) void step_kernel(StepArgs g) {
+    constexpr int T = BLOCK * E;
+    __shared__ int s_a[T];
+    __shared__ int s_d[WITH_D ? T : 1];
+    __shared__ Tup s_tup[WAVES];
+    __shared__ int s_red[WAVES][6];
+    __shared__ int s_acc[4][4];
+
+    const int j = g.j;
+    if (j >= g.ctl[1]) return;
+    const int k = g.ctl[0] + j;
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int w = blockIdx.x, W = g.W, M = g.M;
+    const int S = w * T;                                   // first position of the tile
+    const bool has_next = (k + 1 < g.ctl[3]);          // the panel has a site k+1
+    const uint32_t *col_next = *g.colbase + (size_t)(j + 1) * g.wpc;
+
+    int *sm_in = g.summ + (size_t)(k % 3) * 4 * g.wpad;
+    int *sm_out = g.summ + (size_t)((k + 1) % 3) * 4 * g.wpad;
+    int *sm_zero = g.summ + (size_t)((k + 2) % 3) * 4 * g.wpad;
+    const int *in_cnt0 = sm_in, *in_last0 = sm_in + g.wpad, *in_last1 = sm_in + 2 * g.wpad,
+              *in_maxd = sm_in + 3 * g.wpad;
+
+    if (t < 16) s_acc[t >> 2][t & 3] = 0;
+
+    // ---- A: own tile (blocked: thread t owns positions S + t*E .. +E) ----
+    int av[E], dv[E];
+    {
+        const int base = S + t * E;                        // arrays are padded to a multiple of T
+        const int4 *pa = reinterpret_cast<const int4 *>(g.a_in + base);
+#pragma unroll
+        for (int q = 0; q < E / 4; ++q) {
+            int4 v = pa[q];
+            av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+        }
+        if (WITH_D) {
+            const int4 *pd = reinterpret_cast<const int4 *>(g.d_in + base);
+#pragma unroll
+            for (int q = 0; q < E / 4; ++q) {
+                int4 v = pd[q];
+                dv[4 * q] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
+            }
+        }
+    }
+
+    // ---- B: tile summaries of this site -> zero offset, total zeros, carries ----
+    constexpr int SPT = 4;                                 // summaries per thread (W <= 1024)
+    int r_cnt[SPT], r_l0[SPT], r_l1[SPT], r_md[SPT];
+    int sumBefore = 0, total = 0, l0 = 0, l1 = 0;
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int jn = t + q * BLOCK;
+        r_cnt[q] = 0; r_l0[q] = 0; r_l1[q] = 0; r_md[q] = 0;
+        if (jn < W) {
+            r_cnt[q] = in_cnt0[jn];
+            if (WITH_D) { r_l0[q] = in_last0[jn]; r_l1[q] = in_last1[jn]; r_md[q] = in_maxd[jn]; }
+            total += r_cnt[q];
+            if (jn < w) { sumBefore += r_cnt[q]; l0 = max(l0, r_l0[q]); l1 = max(l1, r_l1[q]); }
+        }
+    }
+    sumBefore = wave_sum(sumBefore); total = wave_sum(total);
+    if (WITH_D) { l0 = wave_max(l0); l1 = wave_max(l1); }
+    if (lane == 0) { s_red[wv][0] = sumBefore; s_red[wv][1] = total; s_red[wv][2] = l0; s_red[wv][3] = l1; }
+    __syncthreads();
+    sumBefore = 0; total = 0; l0 = 0; l1 = 0;
+#pragma unroll
+    for (int q = 0; q < WAVES; ++q) {
+        sumBefore += s_red[q][0]; total += s_red[q][1];
+        l0 = max(l0, s_red[q][2]); l1 = max(l1, s_red[q][3]);
+    }
+    const int Zw = sumBefore;                              // zeros before this tile
+    const int C = total;                                   // zeros in the whole column (u->c)
+
+    int carry0 = 0, carry1 = 0;
+    if (WITH_D) {
+        // carry_b = max d over [l_b, S): positions after the last allele-b element before the tile.
+        // = direct reads in the tile holding l_b-1, plus whole-tile maxima in between.
+        int m0 = 0, m1 = 0;
+        const int tl0 = l0 ? (l0 - 1) / T : -1, tl1 = l1 ? (l1 - 1) / T : -1;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const int jn = t + q * BLOCK;
+            if (jn < w) {
+                if (l0 && jn > tl0) m0 = max(m0, r_md[q]);
+                if (l1 && jn > tl1) m1 = max(m1, r_md[q]);
+            }
+        }
+        if (l0) { const int hi = min((tl0 + 1) * T, S); for (int p = l0 + t; p < hi; p += BLOCK) m0 = max(m0, g.d_in[p]); }
+        if (l1) { const int hi = min((tl1 + 1) * T, S); for (int p = l1 + t; p < hi; p += BLOCK) m1 = max(m1, g.d_in[p]); }
+        m0 = wave_max(m0); m1 = wave_max(m1);
+        if (lane == 0) { s_red[wv][4] = m0; s_red[wv][5] = m1; }
+        __syncthreads();
+        m0 = 0; m1 = 0;
+#pragma unroll
+        for (int q = 0; q < WAVES; ++q) { m0 = max(m0, s_red[q][4]); m1 = max(m1, s_red[q][5]); }
+        carry0 = l0 ? m0 : k + 1;                          // nothing before: p starts at k+1 (pbwtCore.c:489)
+        carry1 = l1 ? m1 : k + 1;
+    }
+
+    // ---- C: local recurrence ----
+    const int base = S + t * E;
+    unsigned ybits = 0, vbits = 0;
+    Tup me = Tup{0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool valid = (base + e) < M;
+        const unsigned y = ((unsigned)av[e]) >> 31;
+        av[e] &= AMASK;
+        if (valid) {
+            vbits |= 1u << e;
+            ybits |= y << e;
+            if (WITH_D) {
+                const int d = dv[e];
+                me.all = max(me.all, d);
+                if (y == 0) { me.t0 = 0; me.t1 = max(me.t1, d); }
+                else        { me.t1 = 0; me.t0 = max(me.t0, d); }
+            }
+            if (y == 0) ++me.c0; else ++me.c1;
+        }
+    }
+    Tup tot;
+    const Tup pre = block_scan_tup<WITH_D>(me, s_tup, tot);
+    const int cw = tot.c0;                                 // zeros in this tile
+    const int nvalid = tot.c0 + tot.c1;
+    int p = 0, q1 = 0;
+    if (WITH_D) {
+        p = pre.c0 ? pre.t0 : max(carry0, pre.all);
+        q1 = pre.c1 ? pre.t1 : max(carry1, pre.all);
+    }
+    int zi = pre.c0, oi = cw + pre.c1;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (vbits & (1u << e)) {
+            int ldst, dn = 0;
+            if (!((ybits >> e) & 1u)) {
+                if (WITH_D) { dn = max(p, dv[e]); p = 0; q1 = max(q1, dv[e]); }
+                ldst = zi++;
+            } else {
+                if (WITH_D) { dn = max(q1, dv[e]); q1 = 0; p = max(p, dv[e]); }
+                ldst = oi++;
+            }
+            s_a[ldst] = av[e];
+            if (WITH_D) s_d[ldst] = dn;
+        }
+    }
+    __syncthreads();
+
+    // ---- D: coalesced write-out in destination order + summaries of site k+1 ----
+    const int onesBefore = S - Zw;                         // every earlier tile is full
+    const int oneBase = C + onesBefore;                    // destination of this tile's first one
+    const int tz = Zw / T, to = oneBase / T;               // first destination tile of each stream
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int l = e * BLOCK + t;
+        const bool valid = l < nvalid;
+        int P = 0, slot = 0, dn = 0;
+        unsigned tag = 0;
+        if (valid) {
+            const int a = s_a[l];
+            const bool one = l >= cw;
+            P = one ? oneBase + (l - cw) : Zw + l;
+            slot = one ? 2 + (P / T - to) : (P / T - tz);
+            if (has_next) {
+                const unsigned idx = SORTED ? (unsigned)P : (unsigned)a;
+                tag = (col_next[idx >> 5] >> (idx & 31)) & 1u;
+            }
+            g.a_out[P] = a | (int)(tag << 31);
+            if (WITH_D) {
+                dn = s_d[l];
+                if (P == 0) dn = k + 2;                    // sentinel (pbwtCore.c:507)
+                g.d_out[P] = dn;
+            }
+        }
+        if (has_next) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const unsigned long long mk = __ballot(valid && slot == s);
+                if (mk) {
+                    const unsigned long long ones = __ballot(valid && slot == s && tag);
+                    const unsigned long long zeros = mk & ~ones;
+                    int md = 0, lz = 0, lo = 0;
+                    if (WITH_D) {
+                        md = wave_max((valid && slot == s) ? dn : 0);
+                        if (zeros) lz = __shfl(P, 63 - __clzll(zeros)) + 1;
+                        if (ones) lo = __shfl(P, 63 - __clzll(ones)) + 1;
+                    }
+                    if (lane == 0) {
+                        atomicAdd(&s_acc[s][0], __popcll(zeros));
+                        if (WITH_D) {
+                            atomicMax(&s_acc[s][1], lz);
+                            atomicMax(&s_acc[s][2], lo);
+                            atomicMax(&s_acc[s][3], md);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (WITH_D && w == W - 1 && t == 0) g.d_out[M] = k + 2;
+    __syncthreads();
+    if (has_next && t < 4) {
+        const int s = t;
+        const int dt = (s < 2 ? tz : to) + (s & 1);
+        if (dt < W) {
+            const int c0 = s_acc[s][0];
+            if (c0) atomicAdd(sm_out + dt, c0);
+            if (WITH_D) {
+                if (s_acc[s][1]) atomicMax(sm_out + g.wpad + dt, s_acc[s][1]);
+                if (s_acc[s][2]) atomicMax(sm_out + 2 * g.wpad + dt, s_acc[s][2]);
+                if (s_acc[s][3]) atomicMax(sm_out + 3 * g.wpad + dt, s_acc[s][3]);
+            }
+        }
+    }
+    if (t < 4) sm_zero[t * g.wpad + w] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// prepare: first site of a pass.  Tags a[i] with y_k[i] from column k and builds that site's tile
+// summaries from scratch (plain stores), zeroing the accumulation target of the first step.
+struct PrepArgs {
+    int *a; const int *d; const uint32_t *col; int *summ;
+    int k, M, W, wpad, T, sorted, with_d, has_col;
+};
+
+__global__ __launch_bounds__(BLOCK) void prepare_kernel(PrepArgs g) {
+    __shared__ int s_red[WAVES][4];
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int w = blockIdx.x, S = w * g.T;
+    int c0 = 0, l0 = 0, l1 = 0, md = 0;
+    for (int l = t; l < g.T; l += BLOCK) {
+        const int i = S + l;
+        if (i < g.M) {
+            const int a = g.a[i] & AMASK;
+            unsigned y = 0;
+            if (g.has_col) {
+                const unsigned idx = g.sorted ? (unsigned)i : (unsigned)a;
+                y = (g.col[idx >> 5] >> (idx & 31)) & 1u;
+            }
+            g.a[i] = a | (int)(y << 31);
+            if (y == 0) { ++c0; l0 = max(l0, i + 1); } else l1 = max(l1, i + 1);
+            if (g.with_d) md = max(md, g.d[i]);
+        }
+    }
+    c0 = wave_sum(c0); l0 = wave_max(l0); l1 = wave_max(l1); md = wave_max(md);
+    if (lane == 0) { s_red[wv][0] = c0; s_red[wv][1] = l0; s_red[wv][2] = l1; s_red[wv][3] = md; }
+    __syncthreads();
+    if (t == 0) {
+        c0 = 0; l0 = 0; l1 = 0; md = 0;
+        for (int q = 0; q < WAVES; ++q) { c0 += s_red[q][0]; l0 = max(l0, s_red[q][1]); l1 = max(l1, s_red[q][2]); md = max(md, s_red[q][3]); }
+        int *cur = g.summ + (size_t)(g.k % 3) * 4 * g.wpad;
+        int *nxt = g.summ + (size_t)((g.k + 1) % 3) * 4 * g.wpad;
+        cur[w] = c0; cur[g.wpad + w] = l0; cur[2 * g.wpad + w] = l1; cur[3 * g.wpad + w] = md;
+        nxt[w] = 0; nxt[g.wpad + w] = 0; nxt[2 * g.wpad + w] = 0; nxt[3 * g.wpad + w] = 0;
+    }
+}
+
+// cursor init (pbwtNakedCursorCreate, pbwtCore.c:402-418): a = identity unless given; d = 0 with
+// sentinels d[0] = d[M] = k0+1
+__global__ void init_state_kernel(int *a, int *d, int M, int Mpad, int k0, int identity) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Mpad) {
+        if (identity) a[i] = (i < M) ? i : 0;
+        else if (i >= M) a[i] = 0;
+    }
+    if (i <= Mpad) { if (d) d[i] = (i == 0 || i == M) ? k0 + 1 : 0; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic panel generator (SURVEY.md §8d recipe in integer arithmetic; the test checker restates it)
+__device__ __forceinline__ uint64_t h2(uint64_t seed, uint64_t a, uint64_t b) {
+    return sm64(sm64(seed ^ (a * 0xD1B54A32D192ED03ULL)) + b);
+}
+
+__global__ __launch_bounds__(BLOCK) void synth_kernel(uint32_t *bits, int M, int k0, int ncols, int wpc,
+                                                     uint64_t seed, int kind) {
+    __shared__ uint64_t s_fw;
+    const int col = blockIdx.y;
+    const uint64_t k = (uint64_t)(k0 + col);
+    if (kind == 0) {
+        // founder word for this site: bit f = founder f carries the derived allele
+        if (threadIdx.x < 64) {
+            const uint64_t hk = h2(seed ^ 0xB, k, 0);
+            const uint32_t e = (uint32_t)(hk & 0xff) % 11u;
+            const uint32_t bse = 1u << (31 - e);
+            const uint32_t thr = bse / 2 + (uint32_t)((hk >> 8) % (bse / 2));
+            const bool on = (uint32_t)(h2(seed ^ 0xA, (uint64_t)threadIdx.x, k) >> 32) < thr;
+            const unsigned long long m = __ballot(on);
+            if (threadIdx.x == 0) s_fw = m;
+        }
+        __syncthreads();
+    }
+    const uint64_t fw = (kind == 0) ? s_fw : 0;
+    for (int wd = blockIdx.x * BLOCK + threadIdx.x; wd < wpc; wd += gridDim.x * BLOCK) {
+        uint32_t out = 0;
+        for (int b = 0; b < 32; ++b) {
+            const uint64_t h = (uint64_t)wd * 32 + b;
+            if (h >= (uint64_t)M) break;
+            uint32_t al;
+            if (kind == 1) al = (uint32_t)(h2(seed ^ 0xE, h, k) >> 63);
+            else {
+                const uint64_t off = h2(seed ^ 0xD, h, 0) % 2048u;
+                const uint64_t seg = (k + off) / 2048u;
+                const uint32_t F = (uint32_t)(h2(seed ^ 0xC, h, seg) & 63);
+                const uint32_t mut = ((uint32_t)(h2(seed ^ 0xE, h, k) >> 32) < 4294967u) ? 1u : 0u;
+                al = ((uint32_t)(fw >> F) & 1u) ^ mut;
+            }
+            out |= al << b;
+        }
+        bits[(size_t)col * wpc + wd] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-site checksums over ring slots: csum[site] += sum_i sm64(i<<32 | v[i]); grid (tiles, sites)
+__global__ __launch_bounds__(BLOCK) void checksum_kernel(const int *A, const int *D, size_t strideA, size_t strideD,
+                                                        int M, int with_d, unsigned long long *ca,
+                                                        unsigned long long *cd, unsigned long long *cy, int y_valid_sites) {
+    __shared__ unsigned long long s_red[WAVES][3];
+    const int site = blockIdx.y;
+    const int *a = A + (size_t)site * strideA;
+    const int *d = D + (size_t)site * strideD;
+    unsigned long long sa = 0, sd = 0, sy = 0;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i <= M; i += gridDim.x * BLOCK) {
+        if (i < M) {
+            const int v = a[i];
+            sa += sm64(((uint64_t)i << 32) | (uint32_t)(v & AMASK));
+            const uint32_t y = (site < y_valid_sites) ? ((uint32_t)v >> 31) : 0u;
+            sy += sm64(((uint64_t)i << 32) | y);
+        }
+        if (with_d) sd += sm64(((uint64_t)i << 32) | (uint32_t)d[i]);
+    }
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sd += __shfl_xor(sd, o); sy += __shfl_xor(sy, o); }
+    if (lane_id() == 0) { s_red[wave_id()][0] = sa; s_red[wave_id()][1] = sd; s_red[wave_id()][2] = sy; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sa = sd = sy = 0;
+        for (int q = 0; q < WAVES; ++q) { sa += s_red[q][0]; sd += s_red[q][1]; sy += s_red[q][2]; }
+        atomicAdd(ca + site, sa);
+        if (with_d) atomicAdd(cd + site, sd);
+        atomicAdd(cy + site, sy);
+    }
+}
+
+// strip tags: out[i] = a[i] & AMASK
+__global__ void untag_kernel(const int *a, int *out, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) out[i] = a[i] & AMASK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// matchMaximalWithin sweep (pbwtMatch.c:115-142) over ring slots holding (a_k tagged with y_k, d_k).
+// One thread per position i; grid (tiles, sites).  MODE 0: count reports per block; 1: emit
+// records at precomputed block offsets; 2: histogram (pbwtMatch.c:130-131).
+// `final_site` = index in this batch of the k == N state (all positions report, y ignored) or -1.
+struct SweepArgs {
+    const int *A; const int *D; size_t strideA, strideD;
+    int M, kbase, final_site;
+    unsigned long long *blockCount;      // [sites*tiles]   MODE 0 out / MODE 1 in (exclusive offsets)
+    int4 *recs;                          // MODE 1
+    unsigned long long *hist; int histlen;  // MODE 2
+    int *err;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
+    __shared__ unsigned long long s_w[WAVES];
+    const int site = blockIdx.y, k = g.kbase + site;
+    const bool fin = (site == g.final_site);
+    const int *a = g.A + (size_t)site * g.strideA;
+    const int *d = g.D + (size_t)site * g.strideD;
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    const int M = g.M;
+    int m = i - 1, n = i + 1, di = 0, dn = 0;
+    bool rep = false;
+    if (i < M) {
+        di = d[i]; dn = d[i + 1];
+        const unsigned yi = (unsigned)a[i] >> 31;
+        rep = true;
+        if (di <= dn) {
+            while (d[m + 1] <= di) { if (!fin && ((unsigned)a[m] >> 31) == yi) { rep = false; break; } --m; }
+        }
+        if (rep && di >= dn) {
+            while (d[n] <= dn) { if (!fin && ((unsigned)a[n] >> 31) == yi) { rep = false; break; } ++n; }
+        }
+    }
+    if (MODE == 2) {
+        if (rep) {
+            const int len = (di < dn) ? k - di : k - dn;
+            if (len >= 0 && len < g.histlen) atomicAdd(g.hist + len, 1ULL); else atomicExch(g.err, 1);
+        }
+        return;
+    }
+    const unsigned long long cnt = rep ? (unsigned long long)((i - 1 - m) + (n - 1 - i)) : 0ULL;
+    // block exclusive scan of cnt
+    unsigned long long inc = cnt;
+    for (int o = 1; o < 64; o <<= 1) { unsigned long long v = __shfl_up(inc, o); if (lane_id() >= o) inc += v; }
+    if (lane_id() == 63) s_w[wave_id()] = inc;
+    __syncthreads();
+    unsigned long long pre = 0, tot = 0;
+    for (int q = 0; q < WAVES; ++q) { if (q < wave_id()) pre += s_w[q]; tot += s_w[q]; }
+    const size_t bidx = (size_t)site * gridDim.x + blockIdx.x;
+    if (MODE == 0) { if (threadIdx.x == 0) g.blockCount[bidx] = tot; return; }
+    if (rep && cnt) {
+        int4 *out = g.recs + g.blockCount[bidx] + pre + (inc - cnt);
+        const int ai = a[i] & AMASK;
+        for (int jj = m + 1; jj < i; ++jj) *out++ = make_int4(ai, a[jj] & AMASK, di, k);
+        for (int jj = i + 1; jj < n; ++jj) *out++ = make_int4(ai, a[jj] & AMASK, dn, k);
+    }
+}
+
+// single-block exclusive scan of n 64-bit values (in place), total to *total
+__global__ __launch_bounds__(1024) void scan_u64_kernel(unsigned long long *v, size_t n, unsigned long long *total,
+                                                       unsigned long long base_in) {
+    __shared__ unsigned long long s_w[16];
+    __shared__ unsigned long long s_carry;
+    if (threadIdx.x == 0) s_carry = base_in;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (size_t b = 0; b < n; b += 1024) {
+        const size_t i = b + threadIdx.x;
+        const unsigned long long x = (i < n) ? v[i] : 0ULL;
+        unsigned long long inc = x;
+        for (int o = 1; o < 64; o <<= 1) { unsigned long long u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        unsigned long long pre = s_carry, tot = 0;
+        for (int q = 0; q < 16; ++q) { if (q < wv) pre += s_w[q]; tot += s_w[q]; }
+        if (i < n) v[i] = pre + inc - x;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = s_carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sorted bit columns out of the ring tags: ycol[site][word] (one wave per 64 positions)
+__global__ __launch_bounds__(BLOCK) void tags_to_bits_kernel(const int *A, size_t strideA, int M, unsigned long long *ycols,
+                                                            int wpc64) {
+    const int site = blockIdx.y;
+    const int *a = A + (size_t)site * strideA;
+    const int nw = (M + 63) / 64;
+    for (int wd = blockIdx.x * WAVES + wave_id(); wd < wpc64; wd += gridDim.x * WAVES) {
+        const int i = wd * 64 + lane_id();
+        const bool one = (wd < nw) && (i < M) && (a[i] < 0);
+        const unsigned long long mk = __ballot(one);
+        if (lane_id() == 0) ycols[(size_t)site * wpc64 + wd] = mk;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack3 encode (pbwtCore.c:240-267) of sorted bit columns.  One block per column; each thread
+// owns 64-position words; a run is emitted by the word in which it ENDS.
+// bytes for a run of length n (pack3Add, pbwtCore.c:240-252)
+__device__ __forceinline__ int p3_nbytes(int n) {
+    int c = n / 63488; n -= c * 63488;
+    if (n >= 2048) { ++c; n &= 0x7ff; }
+    if (n >= 64) { ++c; n &= 0x3f; }
+    if (n) ++c;
+    return c;
+}
+__device__ __forceinline__ uint8_t *p3_emit(uint8_t *o, unsigned v, int n) {
+    const uint8_t top = (uint8_t)(v << 7);
+    while (n >= 63488) { *o++ = top | 0x7f; n -= 63488; }
+    if (n >= 2048) { *o++ = top | 0x60 | (uint8_t)(n >> 11); n &= 0x7ff; }
+    if (n >= 64) { *o++ = top | 0x40 | (uint8_t)(n >> 6); n &= 0x3f; }
+    if (n) *o++ = top | (uint8_t)n;
+    return o;
+}
+
+// MODE 0: colBytes[col] = encoded size; MODE 1: write bytes at colOffset[col]
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void pack3_kernel(const unsigned long long *ycols, int wpc64, int M,
+                                                     unsigned long long *colBytes, uint8_t *out) {
+    __shared__ int s_wi[WAVES];
+    __shared__ int s_carry_start;       // start position of the run open at the chunk boundary
+    __shared__ int s_carry_bytes;       // bytes emitted so far in this column
+    const int col = blockIdx.x;
+    const unsigned long long *y = ycols + (size_t)col * wpc64;
+    const int nw = (M + 63) / 64;
+    const int lane = lane_id(), wv = wave_id();
+    if (threadIdx.x == 0) { s_carry_start = 0; s_carry_bytes = 0; }
+    __syncthreads();
+    uint8_t *obase = (MODE == 1) ? out + colBytes[col] : nullptr;
+    for (int b = 0; b < nw; b += BLOCK) {
+        const int wd = b + threadIdx.x;
+        unsigned long long cur = 0, trans = 0;
+        int nbits = 0;
+        if (wd < nw) {
+            cur = y[wd];
+            nbits = min(64, M - wd * 64);
+            const unsigned long long prevbit = (wd > 0) ? (y[wd - 1] >> 63) : 0ULL;
+            trans = cur ^ ((cur << 1) | prevbit);          // bit p set: position starts a new run
+            if (wd == 0) trans &= ~1ULL;                   // position 0 opens the first run, closes nothing
+            if (nbits < 64) trans &= (1ULL << nbits) - 1ULL;
+        }
+        // last run start at or before the beginning of this word: max-scan of last transition pos
+        int lastT = trans ? (wd * 64 + 63 - __clzll(trans)) : -1;
+        int incl = lastT;
+        for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o); if (lane >= o) incl = max(incl, v); }
+        if (lane == 63) s_wi[wv] = incl;
+        int exclT = __shfl_up(incl, 1); if (lane == 0) exclT = -1;
+        __syncthreads();
+        int preT = -1;
+        for (int q = 0; q < WAVES; ++q) if (q < wv) preT = max(preT, s_wi[q]);
+        int chunkLast = -1;
+        for (int q = 0; q < WAVES; ++q) chunkLast = max(chunkLast, s_wi[q]);
+        int open = max(max(exclT, preT), -1);
+        if (open < 0) open = s_carry_start;                // run opened in an earlier chunk (or at 0)
+        // runs closed by this word: one per transition, plus the final run if this word holds M-1
+        const bool lastWord = (wd == nw - 1);
+        int myBytes = 0;
+        {
+            unsigned long long tr = trans; int st = open;
+            while (tr) { const int pz = wd * 64 + __ffsll((long long)tr) - 1; tr &= tr - 1; myBytes += p3_nbytes(pz - st); st = pz; }
+            if (lastWord) myBytes += p3_nbytes(M - st);
+        }
+        // exclusive scan of myBytes within the chunk
+        int inc = myBytes;
+        for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+        __syncthreads();
+        if (lane == 63) s_wi[wv] = inc;
+        __syncthreads();
+        int preB = s_carry_bytes, totB = 0;
+        for (int q = 0; q < WAVES; ++q) { if (q < wv) preB += s_wi[q]; totB += s_wi[q]; }
+        if (MODE == 1 && myBytes) {
+            uint8_t *o = obase + preB + inc - myBytes;
+            unsigned long long tr = trans; int st = open;
+            while (tr) {
+                const int pz = wd * 64 + __ffsll((long long)tr) - 1; tr &= tr - 1;
+                // value of the run [st,pz) = bit at st
+                const unsigned v = (unsigned)((y[st >> 6] >> (st & 63)) & 1ULL);
+                o = p3_emit(o, v, pz - st); st = pz;
+            }
+            if (lastWord) { const unsigned v = (unsigned)((y[st >> 6] >> (st & 63)) & 1ULL); o = p3_emit(o, v, M - st); }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { s_carry_bytes += totB; if (chunkLast >= 0) s_carry_start = chunkLast; }
+        __syncthreads();
+    }
+    if (MODE == 0 && threadIdx.x == 0) colBytes[col] = (unsigned long long)s_carry_bytes;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack3 decode (unpack3, pbwtCore.c:279-305).
+__device__ __forceinline__ int p3_len(uint8_t b) {
+    b &= 0x7f;
+    return b < 64 ? b : (b < 96 ? (b - 64) << 6 : (b - 96) << 11);
+}
+// pass 1: per block of DEC_CHUNK bytes, total run length
+constexpr int DEC_CHUNK = 4096;
+__global__ __launch_bounds__(BLOCK) void dec_sum_kernel(const uint8_t *z, size_t nz, unsigned long long *blockSum) {
+    __shared__ unsigned long long s_w[WAVES];
+    const size_t b0 = (size_t)blockIdx.x * DEC_CHUNK;
+    unsigned long long s = 0;
+    for (int q = threadIdx.x; q < DEC_CHUNK; q += BLOCK) { const size_t i = b0 + q; if (i < nz) s += (unsigned)p3_len(z[i]); }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane_id() == 0) s_w[wave_id()] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { s = 0; for (int q = 0; q < WAVES; ++q) s += s_w[q]; blockSum[blockIdx.x] = s; }
+}
+// pass 2: with exclusive block offsets: colStart[c] = byte index of the first byte of column c
+// (start position divisible by M and non-empty run); colStart[N] = nz written by the host.
+__global__ __launch_bounds__(BLOCK) void dec_colstart_kernel(const uint8_t *z, size_t nz, const unsigned long long *blockOff,
+                                                            int M, long long N, long long *colStart) {
+    __shared__ unsigned long long s_w[WAVES];
+    __shared__ unsigned long long s_carry;
+    const size_t b0 = (size_t)blockIdx.x * DEC_CHUNK;
+    if (threadIdx.x == 0) s_carry = blockOff[blockIdx.x];
+    __syncthreads();
+    for (int q0 = 0; q0 < DEC_CHUNK; q0 += BLOCK) {
+        const size_t i = b0 + q0 + threadIdx.x;
+        const unsigned len = (i < nz) ? (unsigned)p3_len(z[i]) : 0u;
+        unsigned long long inc = len;
+        for (int o = 1; o < 64; o <<= 1) { unsigned long long v = __shfl_up(inc, o); if (lane_id() >= o) inc += v; }
+        if (lane_id() == 63) s_w[wave_id()] = inc;
+        __syncthreads();
+        unsigned long long pre = s_carry, tot = 0;
+        for (int q = 0; q < WAVES; ++q) { if (q < wave_id()) pre += s_w[q]; tot += s_w[q]; }
+        const unsigned long long start = pre + inc - len;
+        if (i < nz && len && start % (unsigned long long)M == 0) {
+            const unsigned long long c = start / (unsigned long long)M;
+            if ((long long)c < N) colStart[c] = (long long)i;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+}
+// pass 3: expand columns [c0, c0+nc) into sorted bit columns (zero-initialised by the caller).
+// One block per column; runs of ones set bits.
+__global__ __launch_bounds__(BLOCK) void dec_expand_kernel(const uint8_t *z, const long long *colStart, long long c0, int M,
+                                                          unsigned long long *ycols, int wpc64, int *err) {
+    __shared__ int s_w[WAVES];
+    __shared__ int s_carry;
+    const long long c = c0 + blockIdx.x;
+    const long long bs = colStart[c], be = colStart[c + 1];
+    unsigned long long *y = ycols + (size_t)blockIdx.x * wpc64;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (long long b = bs; b < be; b += BLOCK) {
+        const long long i = b + threadIdx.x;
+        const uint8_t byte = (i < be) ? z[i] : 0;
+        const int len = (i < be) ? p3_len(byte) : 0;
+        int inc = len;
+        for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o); if (lane_id() >= o) inc += v; }
+        if (lane_id() == 63) s_w[wave_id()] = inc;
+        __syncthreads();
+        int pre = s_carry, tot = 0;
+        for (int q = 0; q < WAVES; ++q) { if (q < wave_id()) pre += s_w[q]; tot += s_w[q]; }
+        const int start = pre + inc - len;
+        if (len && (byte & 0x80)) {
+            int lo = start, hi = min(start + len, M);      // [lo,hi)
+            if (start + len > M) atomicExch(err, 2);
+            while (lo < hi) {
+                const int wd = lo >> 6, bo = lo & 63;
+                const int take = min(64 - bo, hi - lo);
+                const unsigned long long mk = (take == 64) ? ~0ULL : (((1ULL << take) - 1ULL) << bo);
+                if (take == 64) y[wd] = mk; else atomicOr(&y[wd], mk);
+                lo += take;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && s_carry != M) atomicExch(err, 3);
+}
+
+}  // namespace pbwtk

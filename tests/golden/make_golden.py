@@ -1,0 +1,101 @@
+"""Generate the golden fixtures under tests/golden/ with the REAL reference (oracle/_ref, compiled
+in place from /root/reference).  Run in the build container only:  python tests/golden/make_golden.py
+
+Fixtures are data only (inputs + the reference's outputs):
+  merge1.*            the reference's own tiny test panel (test/merge.1.tab, 8 haplotypes x 10 sites):
+                      .pbwt bytes written by pbwtWrite, -haps text, per-site a/d/y dumps, MATCH records
+  mosaic_M*_N*.npz    synthetic panels (generator recipe in oracle/pbwt_oracle.c): bit columns, packed
+                      PBWT, aFend, per-site a/d, matchMaximalWithin records, -stats histogram text,
+                      matchSequencesSweep records for a held-out query split
+  macs_small.*        a MaCS-format text panel and the .pbwt/.sites the reference builds from it
+"""
+import os
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+import ctypes as C  # noqa: E402
+
+ref = oracle.ref()
+assert ref is not None, "oracle/_ref not built (needs /root/reference)"
+
+
+def parse_pbwt(path):
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"PBW3"
+    M, N = np.frombuffer(raw, "<i4", 2, 4)
+    off = 12
+    aFstart = np.frombuffer(raw, "<i4", M, off); off += 4 * M
+    aFend = np.frombuffer(raw, "<i4", M, off); off += 4 * M
+    nz = int(np.frombuffer(raw, "<i8", 1, off)[0]); off += 8 + 4
+    yz = np.frombuffer(raw, np.uint8, nz, off)
+    return int(M), int(N), aFstart.copy(), aFend.copy(), yz.copy()
+
+
+def mosaic(M, N, seed, kind, qsplit):
+    bits = oracle.synth_bitcols(M, N, seed=seed, kind=kind)
+    hap = oracle.unpack_bitcols(bits, M)
+    rb = oracle.ref_build_bitcols(bits, M, with_d=True)
+    rbA = oracle.ref_build_bitcols(bits, M, with_d=False)
+    assert np.array_equal(rb["yz"], rbA["yz"]) and np.array_equal(rb["aFend"], rbA["aFend"])
+    yz = rb["yz"]
+    sw = oracle.ref_sweep_dump(yz, M, N)
+    recs = oracle.ref_max_within(yz, M, N)
+    hist_path = os.path.join(HERE, "_tmp_hist.txt")
+    oracle.ref_max_within_file(yz, M, N, hist_path, hist=True, check=True)
+    hist_txt = open(hist_path).read(); os.remove(hist_path)
+    Mq = qsplit; Mp = M - Mq
+    pb = oracle.pack_bitcols(hap[:, :Mp]); qb = oracle.pack_bitcols(hap[:, Mp:])
+    pz = oracle.ref_build_bitcols(pb, Mp, with_d=False)["yz"]
+    qz = oracle.ref_build_bitcols(qb, Mq, with_d=False)["yz"]
+    qrecs = oracle.ref_match_sweep(pz, Mp, qz, Mq, N)
+    name = os.path.join(HERE, "mosaic_M%d_N%d_k%d.npz" % (M, N, kind))
+    np.savez_compressed(name, M=M, N=N, seed=seed, kind=kind, bits=bits, yz=yz, aFend=rb["aFend"],
+                        build_a=rb["a_all"].astype(np.int32), build_d=rb["d_all"].astype(np.int32),
+                        sweep_a=sw["a_all"], sweep_d=sw["d_all"], sweep_y=sw["y_all"], sweep_c=sw["c_all"],
+                        within=recs, hist_txt=np.frombuffer(hist_txt.encode(), np.uint8),
+                        Mq=Mq, pz=pz, qz=qz, qrecs=qrecs)
+    print("wrote", name, "within", len(recs), "qrecs", len(qrecs))
+
+
+def merge1():
+    tab = "/root/reference/test/merge.1.tab"
+    out = os.path.join(HERE, "merge1.pbwt")
+    assert ref.ref_vcfq_to_pbwt(tab.encode(), out.encode(), os.path.join(HERE, "merge1.sites").encode()) == 0
+    assert ref.ref_pbwt_to_haps(out.encode(), os.path.join(HERE, "merge1.haps").encode()) == 0
+    M, N, aFstart, aFend, yz = parse_pbwt(out)
+    sw = oracle.ref_sweep_dump(yz, M, N, aFstart)
+    recs = oracle.ref_max_within(yz, M, N, aFstart)
+    txt = os.path.join(HERE, "merge1.maxwithin.txt")
+    oracle.ref_max_within_file(yz, M, N, txt, aFstart=aFstart, check=True)
+    np.savez_compressed(os.path.join(HERE, "merge1.npz"), M=M, N=N, yz=yz, aFstart=aFstart, aFend=aFend,
+                        sweep_a=sw["a_all"], sweep_d=sw["d_all"], sweep_y=sw["y_all"], sweep_c=sw["c_all"], within=recs)
+    # the committed .haps must equal the reference's own golden for this panel
+    assert open(os.path.join(HERE, "merge1.haps")).read() == open("/root/reference/test/merge.1.out").read()
+    print("wrote merge1.*", M, N, len(recs))
+
+
+def macs_small():
+    M, N = 60, 120
+    bits = oracle.synth_bitcols(M, N, seed=99, kind=0)
+    hap = oracle.unpack_bitcols(bits, M)
+    path = os.path.join(HERE, "macs_small.macs")
+    with open(path, "w") as f:
+        f.write("COMMAND:\tmacs %d 1e6 -t 0.001 -r 0.001\nSEED:\t1\n" % M)
+        for k in range(N):
+            f.write("SITE:\t%d\t%.8f\t0.1\t%s\n" % (k, (k + 0.5) / N, "".join(map(str, hap[k]))))
+    assert ref.ref_macs_to_pbwt(path.encode(), os.path.join(HERE, "macs_small.pbwt").encode(),
+                                os.path.join(HERE, "macs_small.sites").encode()) == 0
+    print("wrote macs_small.*")
+
+
+if __name__ == "__main__":
+    merge1()
+    macs_small()
+    mosaic(8, 10, 3, 1, 2)
+    mosaic(70, 150, 11, 1, 10)       # iid, M not a multiple of 64
+    mosaic(300, 400, 5, 0, 40)       # founder mosaic
+    mosaic(1100, 260, 6, 0, 100)     # spans two 1024-position tiles

@@ -1,0 +1,166 @@
+"""GPU (-m gpu): the HIP path through the C ABI against the oracle and the committed goldens.
+Bit-exact everywhere: this is integer/index work."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_panels, parse_pbwt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd(gpu_lib):
+    assert gpu_lib.load_library().pbwtamd_device_count() > 0, "no HIP device: the GPU tests must run on the MI355X box"
+    return gpu_lib
+
+
+def test_merge1_known_answer(amd, orc):
+    M, N, aFstart, aFend, yz = parse_pbwt(os.path.join(GOLDEN, "merge1.pbwt"))
+    g = np.load(os.path.join(GOLDEN, "merge1.npz"))
+    eng = amd.Engine(M, batch_sites=4)
+    sw = eng.sweep_AD(yz, N, aFstart, dump_sites=range(N + 1))
+    assert np.array_equal(sw["a_dump"], g["sweep_a"])
+    assert np.array_equal(sw["d_dump"], g["sweep_d"])
+    recs = eng.max_within(yz, N, aFstart)
+    assert np.array_equal(recs, g["within"])
+    got = []
+    eng.max_within(yz, N, aFstart, mode="callback", callback=lambda a, b, s, e: got.append((a, b, s, e)))
+    assert got == [tuple(r) for r in g["within"].tolist()]
+    lines = ["MATCH\t%d\t%d\t%d\t%d\t%d\n" % (a, b, s, e, e - s) for (a, b, s, e) in got if s != e]
+    assert "".join(lines) == open(os.path.join(GOLDEN, "merge1.maxwithin.txt")).read()
+
+
+@pytest.mark.parametrize("path", golden_panels(), ids=os.path.basename)
+@pytest.mark.parametrize("batch", [7, 64])
+def test_golden_panel(amd, orc, path, batch):
+    g = np.load(path)
+    M, N = int(g["M"]), int(g["N"])
+    eng = amd.Engine(M, batch_sites=batch)
+    # build with and without d: packed PBWT bytes, final a, final d
+    b = eng.build(g["bits"], with_d=True)
+    assert np.array_equal(b["yz"], g["yz"])
+    assert np.array_equal(b["aFend"], g["aFend"])
+    assert np.array_equal(b["dFend"], g["build_d"][N])
+    bA = eng.build(g["bits"], with_d=False)
+    assert np.array_equal(bA["yz"], g["yz"]) and np.array_equal(bA["aFend"], g["aFend"])
+    # read-side sweep: every site's a and d
+    sites = list(range(0, N + 1, max(1, N // 25))) + [N]
+    sw = eng.sweep_AD(g["yz"], N, dump_sites=sites)
+    for q, k in enumerate(sites):
+        assert np.array_equal(sw["a_dump"][q], g["sweep_a"][k]), k
+        assert np.array_equal(sw["d_dump"][q], g["sweep_d"][k]), k
+    for k in range(N + 1):
+        assert sw["csum_a"][k] == orc.checksum_i32(g["sweep_a"][k]), k
+        assert sw["csum_d"][k] == orc.checksum_i32(g["sweep_d"][k]), k
+        if k < N:
+            assert sw["csum_y"][k] == orc.checksum_u8(g["sweep_y"][k]), k
+    # maxWithin: records in callback order, and the -stats histogram
+    assert np.array_equal(eng.max_within(g["yz"], N), g["within"])
+    hist = eng.max_within(g["yz"], N, mode="hist")
+    txt = "".join("%d\t%d\n" % (i, c) for i, c in enumerate(hist) if c)
+    assert txt == g["hist_txt"].tobytes().decode()
+
+
+@pytest.mark.parametrize("M,N,kind,batch", [(2, 9, 1, 4), (3, 50, 1, 16), (64, 64, 1, 64), (65, 33, 0, 8), (1025, 70, 0, 32),
+                                          (2500, 300, 0, 128), (5000, 200, 1, 64), (20000, 150, 0, 50)])
+def test_build_and_within_vs_oracle(amd, orc, M, N, kind, batch):
+    bits = orc.synth_bitcols(M, N, seed=1000 + M, kind=kind)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    eng = amd.Engine(M, batch_sites=batch)
+    b = eng.build(bits, with_d=True)
+    assert np.array_equal(b["yz"], o["yz"])
+    assert np.array_equal(b["aFend"], o["aFend"])
+    assert np.array_equal(b["dFend"], o["d_final"])
+    s = orc.sweep_AD(o["yz"], M, N)
+    sw = eng.sweep_AD(o["yz"], N)
+    assert np.array_equal(sw["csum_a"], s["csum_a"])
+    assert np.array_equal(sw["csum_d"], s["csum_d"])
+    assert np.array_equal(sw["csum_y"][:N], s["csum_y"][:N])
+    assert np.array_equal(eng.max_within(o["yz"], N, mode="hist"), orc.max_within_hist(o["yz"], M, N)[: N + 1])
+    if M * N <= 400000:
+        assert np.array_equal(eng.max_within(o["yz"], N), orc.max_within(o["yz"], M, N))
+
+
+def test_nonidentity_start_order(amd, orc):
+    """aFstart other than the identity (a .pbwt written after a panel transform)"""
+    M, N = 777, 90
+    rng = np.random.default_rng(5)
+    a0 = rng.permutation(M).astype(np.int32)
+    bits = orc.synth_bitcols(M, N, seed=42, kind=0)
+    o = orc.build_bitcols(bits, M, with_d=True, a0=a0)
+    eng = amd.Engine(M, batch_sites=32)
+    b = eng.build(bits, with_d=True, aFstart=a0)
+    assert np.array_equal(b["yz"], o["yz"]) and np.array_equal(b["aFend"], o["aFend"]) and np.array_equal(b["dFend"], o["d_final"])
+    assert np.array_equal(eng.max_within(o["yz"], N, a0), orc.max_within(o["yz"], M, N, a0))
+
+
+def test_degenerate_columns(amd, orc):
+    """all-zero / all-one / single-carrier columns and alternating alleles (worst case for runs)"""
+    M, N = 1500, 40
+    hap = np.zeros((N, M), np.uint8)
+    hap[1] = 1
+    hap[2, 0] = 1
+    hap[3, M - 1] = 1
+    hap[4, ::2] = 1
+    hap[5, 1::2] = 1
+    hap[6:, :] = (np.random.default_rng(3).random((N - 6, M)) < 0.002)
+    bits = orc.pack_bitcols(hap)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    eng = amd.Engine(M, batch_sites=16)
+    b = eng.build(bits, with_d=True)
+    assert np.array_equal(b["yz"], o["yz"]) and np.array_equal(b["aFend"], o["aFend"]) and np.array_equal(b["dFend"], o["d_final"])
+    assert np.array_equal(eng.max_within(o["yz"], N), orc.max_within(o["yz"], M, N))
+
+
+def test_pack3_codec_device(amd, orc):
+    rng = np.random.default_rng(9)
+    M, N = 70000, 12
+    hap = np.zeros((N, M), np.uint8)
+    hap[1] = 1
+    hap[2] = rng.random(M) < 0.5
+    hap[3] = rng.random(M) < 0.001
+    hap[4, 100:64000] = 1                      # a run longer than 63488 is split (pbwtCore.c:247)
+    hap[5, :2048] = 1
+    hap[6:] = rng.random((N - 6, M)) < 0.05
+    sb = orc.pack_bitcols(hap)
+    want = np.concatenate([orc.pack3(hap[k]) for k in range(N)])
+    eng = amd.Engine(M, batch_sites=5)
+    assert np.array_equal(eng.pack3(sb), want)
+    assert np.array_equal(eng.unpack3(want, N), sb)
+
+
+def test_synth_generator_matches_oracle(amd, orc):
+    import torch
+    M, N = 3333, 70
+    eng = amd.Engine(M, batch_sites=16)
+    for kind in (0, 1):
+        buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+        eng.synth_device(buf.data_ptr(), 5, N, seed=77, kind=kind)
+        eng.sync()
+        got = buf.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, orc.synth_bitcols(M, N, seed=77, kind=kind, k0=5))
+
+
+def test_device_pass_api_with_graph(amd, orc):
+    """device-resident columns, full-size batches (hipGraph path) + a ragged tail"""
+    import torch
+    M, N, B = 9000, 700, 256
+    eng = amd.Engine(M, batch_sites=B)
+    buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    eng.synth_device(buf.data_ptr(), 0, N, seed=3, kind=0)
+    eng.sync()
+    bits = buf.cpu().numpy().view(np.uint32)
+    opts = amd.OPT_WITH_D | amd.OPT_CHECKSUM | amd.OPT_WITHIN_HIST | amd.OPT_PACK3
+    eng.pass_begin(N)
+    eng.pass_advance(buf.data_ptr(), N, N, opts)
+    eng.pass_end(opts)
+    a, d = eng.get_state()
+    o = orc.build_bitcols(bits, M, with_d=True)
+    assert np.array_equal(a, o["aFend"]) and np.array_equal(d, o["d_final"])
+    ca, cd, _ = eng.get_checksums(0, N + 1)
+    assert np.array_equal(ca, o["csum_a"]) and np.array_equal(cd, o["csum_d"])
+    assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
+    ms, n = eng.chain_timing()
+    assert n == N and ms > 0
