@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""bench.py — PBWT build + maxWithin throughput on MI355X (sites*haplotypes/sec) with the chain
+kernel's achieved algorithmic HBM GB/s against the gfx950 roofline, beside a CPU baseline.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]): synthetic founder-mosaic panel, M = 100,000 haplotypes; one
+"step" = one batch of S = 8192 consecutive sites pushed through the hot path with the panel's bit
+columns already resident in HBM: per site pbwtCursorForwardsAD (a[], d[]) + the matchMaximalWithin
+sweep (histogram sink, the reference's -stats mode) + pack3 encoding of the PBWT column.  The
+default K = 122 steps is the whole 1M-site panel of configs[2].  Steps continue one forward pass,
+so every step works on a realistic cursor state.
+
+Multi-GPU (⑤): the site recurrence does not shard without a per-site exchange that costs more than
+the step itself, so ranks process independent panels (different chromosomes = seeds)
+with no data-path collective: weak scaling, value = total site*haps over all ranks / max time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_SITEHAP = 16.125        # r a,d + w a,d (4 B each) + 1 allele bit
+HBM_PEAK_GBPS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=122)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--haps", type=int, default=100000, help="M, haplotypes in the panel")
+    ap.add_argument("--sites-per-step", type=int, default=8192)
+    ap.add_argument("--batch", type=int, default=512, help="sites per device batch (graph length)")
+    ap.add_argument("--kind", type=int, default=0, help="0 founder mosaic, 1 iid")
+    ap.add_argument("--no-within", action="store_true")
+    ap.add_argument("--no-pack3", action="store_true")
+    ap.add_argument("--cpu-sites", type=int, default=2048, help="sites of the same panel timed on the CPU oracle")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, first_cols):
+    """the oracle (C restatement of the reference, 1 thread) on a bounded sample of the same
+    workload: build with d + pack3, then the maxWithin histogram sweep over the packed columns"""
+    import oracle
+    M = args.haps
+    n = first_cols.shape[0]
+    t0 = time.perf_counter()
+    b = oracle.build_bitcols(first_cols, M, with_d=True, want_csum=False)
+    t1 = time.perf_counter()
+    if not args.no_within:
+        oracle.max_within_hist(b["yz"], M, n)
+    t2 = time.perf_counter()
+    dt = t2 - t0
+    return {"value": M * n / dt, "unit": "site*haps/s", "cores": 1, "kind": "port",
+            "sample": "first %d sites of the same %d-haplotype panel: oracle build(AD+pack3) %.2fs + maxWithin hist %.2fs"
+                      % (n, M, t1 - t0, t2 - t1)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+    import pbwt_amd
+
+    M, S, K, Wm = args.haps, args.sites_per_step, args.steps, args.warmup
+    n_total = (K + Wm) * S
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = pbwt_amd.Engine(M, batch_sites=args.batch, device=dev.index, stream=stream)
+    wpc = eng.wpc
+    # the panel, resident in HBM before the timed region (bit-packed, original haplotype order)
+    panel = torch.empty((n_total, wpc), dtype=torch.int32, device=dev)
+    eng.synth_device(panel.data_ptr(), 0, n_total, seed=0x5EED0001 + rank, kind=args.kind)
+    eng.sync()
+    opts = pbwt_amd.OPT_WITH_D
+    if not args.no_within:
+        opts |= pbwt_amd.OPT_WITHIN_HIST
+    if not args.no_pack3:
+        opts |= pbwt_amd.OPT_PACK3
+    row_bytes = wpc * 4
+
+    def step(i):
+        k = i * S
+        avail = min(S + 1, n_total - k)
+        eng.pass_advance(panel.data_ptr() + k * row_bytes, S, avail, opts)
+
+    eng.pass_begin(n_total)
+    for i in range(Wm):
+        step(i)
+    eng.sync()
+    ms_w, n_w = eng.chain_timing()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(Wm, Wm + K):
+        step(i)
+    eng.pass_end(opts)                     # includes the k == N sweep; synchronises the stream
+    barrier()
+    dt = time.perf_counter() - t0
+    ms_all, n_all = eng.chain_timing()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    chain_ms, chain_n = ms_all - ms_w, n_all - n_w
+    us_per_launch = 1e3 * chain_ms / max(chain_n, 1)
+    achieved = ALG_BYTES_PER_SITEHAP * M / (us_per_launch * 1e-6) / 1e9
+    hist = eng.get_hist(n_total + 1)
+    out = {
+        "metric": "sites*haplotypes/sec PBWT build + maxWithin",
+        "value": world * K * S * M / dt,
+        "unit": "site*haps/s",
+        "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1e3 * dt / K,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "configs[2]: %d haplotypes x %d sites build (ForwardsAD + pack3) + maxWithin (hist sink)"
+                               % (M, K * S),
+                   "haplotypes": M, "sites_per_step": S, "sites_timed": K * S, "device_batch_sites": args.batch,
+                   "panel": "founder-mosaic" if args.kind == 0 else "iid", "within": not args.no_within,
+                   "pack3": not args.no_pack3, "units_per_rank": "independent panel per rank"},
+        "roofline": {"bound": "hbm", "kernel": "step_kernel<E,WITH_D,GATHER>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "alg_bytes_per_launch": ALG_BYTES_PER_SITEHAP * M, "us_per_launch": us_per_launch,
+                     "launches": int(chain_n),
+                     "note": "one launch = one site; duration = HIP-event time of the dependent launch chain / launches, i.e. including launch gaps"},
+        "within_reports_hist_total": int(hist.sum()),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        ncpu = min(args.cpu_sites, n_total)
+        first = panel[:ncpu].cpu().numpy().view(np.uint32)
+        out["cpu_baseline"] = cpu_baseline(args, first)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

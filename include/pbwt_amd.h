@@ -146,6 +146,11 @@ int pbwtamd_get_checksums(pbwtamd_engine *e, int k_first, int n, uint64_t *csum_
  * pass_begin, measured with HIP events on the engine's stream: total ms and launches */
 int pbwtamd_get_chain_timing(pbwtamd_engine *e, double *ms_total, int64_t *launches);
 
+/* diagnostics: with PBWTAMD_PROFILE=1 in the environment at engine creation the step kernel
+ * stamps wall_clock64() (100 MHz) at its phase boundaries for every tile of the LAST launch:
+ * out[tile*8 + phase], phases 0..6.  Returns the number of tiles copied, or < 0 on error. */
+int pbwtamd_get_phase_profile(pbwtamd_engine *e, int64_t *out, int ntiles);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,6 +21,23 @@ def lib_path():
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64; two HIP runtimes in one
+    process cannot both own the GPU.  When torch is installed, map ITS libamdhip64.so first: our
+    library's NEEDED libamdhip64.so.7 then binds to that copy (same SONAME), and a later
+    `import torch` re-uses the same file.  A plain C host without torch uses /opt/rocm's copy."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load_library():
     """load the HIP library; raises if it has not been built (no fallback)"""
     global _lib
@@ -28,6 +45,7 @@ def load_library():
         p = lib_path()
         if not os.path.exists(p):
             raise PbwtAmdError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
+        _share_hip_runtime_with_torch()
         L = C.CDLL(p)
         L.pbwtamd_last_error.restype = C.c_char_p
         L.pbwtamd_engine_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -187,6 +205,13 @@ class Engine:
         ca = np.zeros(n, np.uint64); cd = np.zeros(n, np.uint64); cy = np.zeros(n, np.uint64)
         self._chk(self._L.pbwtamd_get_checksums(self._h, C.c_int(k_first), C.c_int(n), _p(ca, C.c_uint64), _p(cd, C.c_uint64), _p(cy, C.c_uint64)))
         return ca, cd, cy
+
+    def phase_profile(self, ntiles=1024):
+        out = np.zeros((ntiles, 8), np.int64)
+        n = self._L.pbwtamd_get_phase_profile(self._h, _p(out, C.c_int64), C.c_int(ntiles))
+        if n < 0:
+            raise PbwtAmdError(self._L.pbwtamd_last_error().decode())
+        return out[:n]
 
     def chain_timing(self):
         ms = C.c_double(0)

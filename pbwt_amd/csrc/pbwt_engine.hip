@@ -32,15 +32,21 @@ static int fail(const char *fmt, ...) {
 #define CHK(expr) do { int _r = (expr); if (_r) return _r; } while (0)
 
 // ------------------------------------------------------------------------------------ engine
-struct GraphKey { int with_d, sorted; hipGraphExec_t exec; };
+struct GraphKey { int with_d, sorted, ring; hipGraphExec_t exec; };
+struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; };
 
 struct pbwtamd_engine {
     int device = 0, M = 0, Mpad = 0, wpc = 0, wpc64 = 0, W = 0, wpad = 0, E = 4, T = 1024, B = 0;
-    hipStream_t stream = nullptr; bool own_stream = false;
-    int *A = nullptr, *D = nullptr; size_t strideA = 0, strideD = 0;      // B+1 ring slots
+    hipStream_t stream = nullptr; bool own_stream = false;   // the launch chain
+    hipStream_t s2 = nullptr;                                 // batch consumers
+    hipEvent_t evChain[2] = {nullptr, nullptr}, evCons[2] = {nullptr, nullptr}; bool consRecorded[2] = {false, false};
+    int ring = 0; Pending pend;
+    int *A = nullptr, *D = nullptr; size_t strideA = 0, strideD = 0;      // 2 rings of B+1 slots
     int *summ = nullptr;
-    int *ctl = nullptr;                     // [0]=kbase [1]=nsteps [2]=err
-    const uint32_t **colbase = nullptr;     // device: pointer to the current batch's columns
+    int *ctl = nullptr;                     // [2]=device error flag
+    Ctl *ctlblk = nullptr;                  // per-batch control block read by the step kernels
+    long long *prof = nullptr;              // optional phase timestamps (PBWTAMD_PROFILE=1)
+    int summ_cur = 0;                       // summary buffer holding the current site's tiles
     uint32_t *cols_stage = nullptr;         // (B+1) columns, for the host-buffer entry points
     unsigned long long *ycols = nullptr;    // (B+1) sorted bit columns (wpc64 words each)
     unsigned long long *colBytes = nullptr; // B+2
@@ -77,9 +83,11 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->s2) { (void)hipStreamSynchronize(e->s2); (void)hipStreamDestroy(e->s2); }
+    for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->colbase, e->cols_stage, e->ycols, e->colBytes,
+    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, e->cols_stage, e->ycols, e->colBytes,
                     e->blockCount, e->scal, e->hist, e->csum, e->recs, e->yz};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -97,10 +105,10 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     pbwtamd_engine *e = new pbwtamd_engine();
     e->device = device; e->M = M;
     // tile geometry: T = 256*E positions per workgroup, at most 1024 tiles
-    e->E = 4;
-    if (M > 1024 * 256) e->E = 8;
-    if (M > 2048 * 256) e->E = 16;
-    if (const char *s = getenv("PBWTAMD_E")) { int v = atoi(s); if (v == 4 || v == 8 || v == 16) e->E = v; }
+    // (latency-bound regime: the fewer positions per thread, the shorter the launch)
+    e->E = 1;
+    while (e->E < 16 && (M + BLOCK * e->E - 1) / (BLOCK * e->E) > 1024) e->E *= 2;
+    if (const char *s = getenv("PBWTAMD_E")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->E = v; }
     e->T = BLOCK * e->E;
     e->W = (M + e->T - 1) / e->T;
     if (e->W > 1024) { delete e; return fail("pbwtamd: M=%d too large for this build (max %d)", M, 1024 * 4096); }
@@ -116,18 +124,21 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     e->strideD = (size_t)e->Mpad + 64;
     const size_t slots = (size_t)e->B + 1;
 #define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void **)&(ptr), (bytes)); if (_e != hipSuccess) { int r = fail("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(_e)); pbwtamd_engine_destroy(e); return r; } } while (0)
-    ALLOC(e->A, slots * e->strideA * sizeof(int));
-    ALLOC(e->D, slots * e->strideD * sizeof(int));
+    ALLOC(e->A, 2 * slots * e->strideA * sizeof(int));
+    ALLOC(e->D, 2 * slots * e->strideD * sizeof(int));
     ALLOC(e->summ, (size_t)3 * 4 * e->wpad * sizeof(int));
     ALLOC(e->ctl, 16 * sizeof(int));
-    ALLOC(e->colbase, sizeof(void *));
+    ALLOC(e->ctlblk, sizeof(Ctl));
+    if (const char *s = getenv("PBWTAMD_PROFILE")) if (atoi(s)) { ALLOC(e->prof, (size_t)e->W * 8 * sizeof(long long)); HIPCHK(hipMemset(e->prof, 0, (size_t)e->W * 8 * sizeof(long long))); }
     ALLOC(e->cols_stage, slots * e->wpc * sizeof(uint32_t));
     ALLOC(e->ycols, slots * e->wpc64 * sizeof(unsigned long long));
     ALLOC(e->colBytes, (slots + 1) * sizeof(unsigned long long));
     ALLOC(e->scal, 8 * sizeof(unsigned long long));
 #undef ALLOC
-    HIPCHK(hipMemsetAsync(e->A, 0, slots * e->strideA * sizeof(int), e->stream));
-    HIPCHK(hipMemsetAsync(e->D, 0, slots * e->strideD * sizeof(int), e->stream));
+    HIPCHK(hipMemsetAsync(e->A, 0, 2 * slots * e->strideA * sizeof(int), e->stream));
+    HIPCHK(hipMemsetAsync(e->D, 0, 2 * slots * e->strideD * sizeof(int), e->stream));
+    HIPCHK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&e->evChain[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->evCons[i], hipEventDisableTiming)); }
     HIPCHK(hipMemsetAsync(e->ctl, 0, 16 * sizeof(int), e->stream));
     HIPCHK(hipMemsetAsync(e->scal, 0, 8 * sizeof(unsigned long long), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -135,9 +146,13 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     return 0;
 }
 
+static int flush_pending(pbwtamd_engine *e);
+
 extern "C" int pbwtamd_sync(pbwtamd_engine *e) {
     HIPCHK(hipSetDevice(e->device));
+    CHK(flush_pending(e));
     HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipStreamSynchronize(e->s2));
     int err = 0;
     HIPCHK(hipMemcpy(&err, e->ctl + 2, sizeof(int), hipMemcpyDeviceToHost));
     if (err) return fail("pbwtamd: device-side error flag %d (1=histogram range, 2/3=malformed packed column, 4=yz buffer overflow)", err);
@@ -145,8 +160,16 @@ extern "C" int pbwtamd_sync(pbwtamd_engine *e) {
 }
 
 // ------------------------------------------------------------------------------------ small kernels
-__global__ void set_ctl_kernel(int *ctl, int kbase, int nsteps, int n_total, const uint32_t **colbase, const uint32_t *cols) {
-    ctl[0] = kbase; ctl[1] = nsteps; ctl[3] = n_total; *colbase = cols;
+// start of a batch: publish the control block and rotate the tile summaries so that the current
+// site's summaries sit in buffer 0 (step j reads buffer j%3), with buffer 1 cleared for accumulation
+__global__ __launch_bounds__(256) void set_ctl_kernel(Ctl *ctl, int kbase, int n_total, const uint32_t *cols, int *summ, int wpad, int cur) {
+    if (threadIdx.x == 0) { ctl->kbase = kbase; ctl->n_total = n_total; ctl->cols = cols; }
+    const int n = 4 * wpad;
+    if (cur != 0) {
+        for (int i = threadIdx.x; i < n; i += 256) summ[i] = summ[(size_t)cur * n + i];
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += 256) summ[(size_t)n + i] = 0;
 }
 __global__ void add_base_kernel(unsigned long long *v, size_t n, const unsigned long long *base) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -157,39 +180,43 @@ __global__ void bump_kernel(unsigned long long *acc, const unsigned long long *a
     if (*acc > cap) atomicExch(err, 4);
 }
 
+static inline int *ringA(pbwtamd_engine *e, int r) { return e->A + (size_t)r * ((size_t)e->B + 1) * e->strideA; }
+static inline int *ringD(pbwtamd_engine *e, int r) { return e->D + (size_t)r * ((size_t)e->B + 1) * e->strideD; }
+
 template <int E, bool WITH_D, bool SORTED>
-static void launch_step(pbwtamd_engine *e, int j) {
+static void launch_step(pbwtamd_engine *e, int ring, int j) {
     StepArgs g;
-    g.a_in = e->A + (size_t)j * e->strideA;       g.d_in = e->D + (size_t)j * e->strideD;
-    g.a_out = e->A + (size_t)(j + 1) * e->strideA; g.d_out = e->D + (size_t)(j + 1) * e->strideD;
-    g.colbase = e->colbase; g.wpc = e->wpc; g.summ = e->summ; g.ctl = e->ctl;
+    int *A = ringA(e, ring), *D = ringD(e, ring);
+    g.a_in = A + (size_t)j * e->strideA;        g.d_in = D + (size_t)j * e->strideD;
+    g.a_out = A + (size_t)(j + 1) * e->strideA; g.d_out = D + (size_t)(j + 1) * e->strideD;
+    g.ctl = e->ctlblk; g.summ = e->summ; g.prof = e->prof; g.wpc = e->wpc;
     g.j = j; g.M = e->M; g.W = e->W; g.wpad = e->wpad;
     hipLaunchKernelGGL((step_kernel<E, WITH_D, SORTED>), dim3(e->W), dim3(BLOCK), 0, e->stream, g);
 }
 
-static void launch_step_dyn(pbwtamd_engine *e, int j, bool with_d, bool sorted) {
+static void launch_step_dyn(pbwtamd_engine *e, int ring, int j, bool with_d, bool sorted) {
 #define CASE(EE)                                                                   \
     if (e->E == EE) {                                                              \
-        if (with_d && sorted) launch_step<EE, true, true>(e, j);                   \
-        else if (with_d) launch_step<EE, true, false>(e, j);                       \
-        else if (sorted) launch_step<EE, false, true>(e, j);                       \
-        else launch_step<EE, false, false>(e, j);                                  \
+        if (with_d && sorted) launch_step<EE, true, true>(e, ring, j);             \
+        else if (with_d) launch_step<EE, true, false>(e, ring, j);                 \
+        else if (sorted) launch_step<EE, false, true>(e, ring, j);                 \
+        else launch_step<EE, false, false>(e, ring, j);                            \
         return;                                                                    \
     }
-    CASE(4) CASE(8) CASE(16)
+    CASE(1) CASE(2) CASE(4) CASE(8) CASE(16)
 #undef CASE
 }
 
-static int get_graph(pbwtamd_engine *e, bool with_d, bool sorted, hipGraphExec_t *out) {
-    for (auto &g : e->graphs) if (g.with_d == (int)with_d && g.sorted == (int)sorted) { *out = g.exec; return 0; }
+static int get_graph(pbwtamd_engine *e, bool with_d, bool sorted, int ring, hipGraphExec_t *out) {
+    for (auto &g : e->graphs) if (g.with_d == (int)with_d && g.sorted == (int)sorted && g.ring == ring) { *out = g.exec; return 0; }
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-    for (int j = 0; j < e->B; ++j) launch_step_dyn(e, j, with_d, sorted);
+    for (int j = 0; j < e->B; ++j) launch_step_dyn(e, ring, j, with_d, sorted);
     HIPCHK(hipStreamEndCapture(e->stream, &graph));
     hipGraphExec_t exec = nullptr;
     HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     HIPCHK(hipGraphDestroy(graph));
-    e->graphs.push_back(GraphKey{(int)with_d, (int)sorted, exec});
+    e->graphs.push_back(GraphKey{(int)with_d, (int)sorted, ring, exec});
     *out = exec;
     return 0;
 }
@@ -198,7 +225,11 @@ static int get_graph(pbwtamd_engine *e, bool with_d, bool sorted, hipGraphExec_t
 extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k0, int n_total) {
     HIPCHK(hipSetDevice(e->device));
     if (n_total < k0) return fail("pbwtamd_pass_begin: n_total %d < k0 %d", n_total, k0);
+    e->pend.valid = false;
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipStreamSynchronize(e->s2));
     e->k0 = k0; e->k_cur = k0; e->n_total = n_total; e->prepared = false; e->pass_open = true;
+    e->ring = 0; e->consRecorded[0] = e->consRecorded[1] = false;
     if (aInit) HIPCHK(hipMemcpyAsync(e->A, aInit, sizeof(int) * (size_t)e->M, hipMemcpyHostToDevice, e->stream));
     const int nb = (e->Mpad + 1 + 255) / 256;
     hipLaunchKernelGGL(init_state_kernel, dim3(nb), dim3(256), 0, e->stream, e->A, e->D, e->M, e->Mpad, k0, aInit ? 0 : 1);
@@ -219,6 +250,7 @@ extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k
         e->histlen = hl;
     }
     HIPCHK(hipMemsetAsync(e->hist, 0, (size_t)e->histlen * sizeof(unsigned long long), e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
     e->yz_bytes_host = 0;
     e->ev_used = 0; e->launches = 0;
     return 0;
@@ -232,28 +264,28 @@ static int ensure_blockcount(pbwtamd_engine *e, size_t n) {
     return 0;
 }
 
-// maxWithin sweep over `nsites` ring slots starting at slot 0 (sites kbase..): histogram or records
-static int run_within(pbwtamd_engine *e, int kbase, int nsites, int final_site, unsigned opts) {
+// maxWithin sweep over `nsites` slots of (A, D) (sites kbase..) on stream st: histogram or records
+static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int *D, int kbase, int nsites, int final_site, unsigned opts) {
     SweepArgs g;
-    g.A = e->A; g.D = e->D; g.strideA = e->strideA; g.strideD = e->strideD;
+    g.A = A; g.D = D; g.strideA = e->strideA; g.strideD = e->strideD;
     g.M = e->M; g.kbase = kbase; g.final_site = final_site;
     g.blockCount = nullptr; g.recs = nullptr; g.hist = e->hist; g.histlen = e->histlen; g.err = e->ctl + 2;
     const int tiles = (e->M + BLOCK - 1) / BLOCK;
     dim3 grid(tiles, nsites);
     if (opts & PBWTAMD_OPT_WITHIN_HIST) {
-        hipLaunchKernelGGL((sweep_within_kernel<2>), grid, dim3(BLOCK), 0, e->stream, g);
+        hipLaunchKernelGGL((sweep_within_kernel<2>), grid, dim3(BLOCK), 0, st, g);
         HIPCHK(hipGetLastError());
     }
     if (opts & PBWTAMD_OPT_WITHIN_RECS) {
         const size_t nblk = (size_t)tiles * nsites;
         CHK(ensure_blockcount(e, nblk));
         g.blockCount = e->blockCount;
-        hipLaunchKernelGGL((sweep_within_kernel<0>), grid, dim3(BLOCK), 0, e->stream, g);
-        hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, e->stream, e->blockCount, nblk, e->scal, 0ULL);
+        hipLaunchKernelGGL((sweep_within_kernel<0>), grid, dim3(BLOCK), 0, st, g);
+        hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, e->blockCount, nblk, e->scal, 0ULL);
         HIPCHK(hipGetLastError());
         unsigned long long total = 0;
-        HIPCHK(hipMemcpyAsync(&total, e->scal, sizeof total, hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipMemcpyAsync(&total, e->scal, sizeof total, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
         if (total > e->recsCap) {
             if (e->recs) HIPCHK(hipFree(e->recs));
             e->recsCap = (size_t)(total + total / 4 + 1024);
@@ -261,14 +293,14 @@ static int run_within(pbwtamd_engine *e, int kbase, int nsites, int final_site, 
         }
         if (total) {
             g.recs = e->recs;
-            hipLaunchKernelGGL((sweep_within_kernel<1>), grid, dim3(BLOCK), 0, e->stream, g);
+            hipLaunchKernelGGL((sweep_within_kernel<1>), grid, dim3(BLOCK), 0, st, g);
             HIPCHK(hipGetLastError());
             std::vector<pbwtamd_match> tmp;
             std::vector<pbwtamd_match> *dst = e->rec_sink ? e->rec_sink : &tmp;
             const size_t old = dst->size();
             dst->resize(old + total);
-            HIPCHK(hipMemcpyAsync(dst->data() + old, e->recs, total * sizeof(int4), hipMemcpyDeviceToHost, e->stream));
-            HIPCHK(hipStreamSynchronize(e->stream));
+            HIPCHK(hipMemcpyAsync(dst->data() + old, e->recs, total * sizeof(int4), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
             if (e->rec_cb) {
                 for (size_t r = old; r < old + total; ++r) { const pbwtamd_match &m = (*dst)[r]; e->rec_cb(m.ai, m.bi, m.start, m.end); }
                 if (dst == e->rec_sink) dst->resize(old);       // callback mode keeps nothing
@@ -278,12 +310,12 @@ static int run_within(pbwtamd_engine *e, int kbase, int nsites, int final_site, 
     return 0;
 }
 
-static int ensure_yz(pbwtamd_engine *e, size_t cap) {
+static int ensure_yz(pbwtamd_engine *e, hipStream_t st, size_t cap) {
     if (cap <= e->yzCap) return 0;
     uint8_t *n = nullptr;
     HIPCHK(hipMalloc((void **)&n, cap));
     if (e->yz) {
-        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipMemcpy(n, e->yz, e->yzCap, hipMemcpyDeviceToDevice));
         HIPCHK(hipFree(e->yz));
     }
@@ -291,24 +323,46 @@ static int ensure_yz(pbwtamd_engine *e, size_t cap) {
     return 0;
 }
 
-// pack3-encode the y columns of `nsites` ring slots (tags) and append to the engine's yz buffer
-static int run_pack3(pbwtamd_engine *e, int nsites) {
+// pack3-encode the y columns (tags) of `nsites` slots of A and append to the engine's yz buffer
+static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites) {
     dim3 g1(std::min(64, (e->wpc64 + WAVES - 1) / WAVES), nsites);
-    hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, e->stream, (const int *)e->A, e->strideA, e->M, e->ycols, e->wpc64);
-    hipLaunchKernelGGL((pack3_kernel<0>), dim3(nsites), dim3(BLOCK), 0, e->stream, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
+    hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, st, A, e->strideA, e->M, e->ycols, e->wpc64);
+    hipLaunchKernelGGL((pack3_kernel<0>), dim3(nsites), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
     // exclusive offsets inside the batch; batch total -> scal[2]
-    hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, e->stream, e->colBytes, (size_t)nsites, e->scal + 2, 0ULL);
+    hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, e->colBytes, (size_t)nsites, e->scal + 2, 0ULL);
     HIPCHK(hipGetLastError());
     unsigned long long tot = 0;
-    HIPCHK(hipMemcpyAsync(&tot, e->scal + 2, sizeof tot, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpyAsync(&tot, e->scal + 2, sizeof tot, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     const size_t need = (size_t)e->yz_bytes_host + (size_t)tot;
-    if (need > e->yzCap) CHK(ensure_yz(e, std::max(need + (need >> 2) + 4096, e->yzCap * 2)));
-    hipLaunchKernelGGL(add_base_kernel, dim3((nsites + 255) / 256), dim3(256), 0, e->stream, e->colBytes, (size_t)nsites, (const unsigned long long *)(e->scal + 1));
-    hipLaunchKernelGGL((pack3_kernel<1>), dim3(nsites), dim3(BLOCK), 0, e->stream, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
-    hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, e->stream, e->scal + 1, (const unsigned long long *)(e->scal + 2), (unsigned long long)e->yzCap, e->ctl + 2);
+    if (need > e->yzCap) CHK(ensure_yz(e, st, std::max(need + (need >> 2) + 4096, e->yzCap * 2)));
+    hipLaunchKernelGGL(add_base_kernel, dim3((nsites + 255) / 256), dim3(256), 0, st, e->colBytes, (size_t)nsites, (const unsigned long long *)(e->scal + 1));
+    hipLaunchKernelGGL((pack3_kernel<1>), dim3(nsites), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
+    hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->scal + 1, (const unsigned long long *)(e->scal + 2), (unsigned long long)e->yzCap, e->ctl + 2);
     HIPCHK(hipGetLastError());
     e->yz_bytes_host += tot;
+    return 0;
+}
+
+// batch consumers (checksums, maxWithin sweep, pack3) of the pending batch, on the second stream so
+// they overlap the next batch's launch chain (which occupies only ~W of the 256 CUs)
+static int flush_pending(pbwtamd_engine *e) {
+    if (!e->pend.valid) return 0;
+    const Pending p = e->pend;
+    e->pend.valid = false;
+    const int *A = ringA(e, p.ring), *D = ringD(e, p.ring);
+    const bool with_d = p.opts & PBWTAMD_OPT_WITH_D;
+    HIPCHK(hipStreamWaitEvent(e->s2, e->evChain[p.ring], 0));
+    if (p.opts & PBWTAMD_OPT_CHECKSUM) {
+        unsigned long long *ca = e->csum + (p.kbase - e->k0), *cd = ca + e->csum_sites, *cy = cd + e->csum_sites;
+        dim3 grid(std::min(64, (e->M + BLOCK) / BLOCK), p.nb);
+        hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, e->s2, A, D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, p.nb);
+        HIPCHK(hipGetLastError());
+    }
+    if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, e->s2, A, D, p.kbase, p.nb, -1, p.opts));
+    if (p.opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, e->s2, A, p.nb));
+    HIPCHK(hipEventRecord(e->evCons[p.ring], e->s2));
+    e->consRecorded[p.ring] = true;
     return 0;
 }
 
@@ -327,43 +381,45 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
     while (done < ncols) {
         const int nb = std::min(e->B, ncols - done);
         const uint32_t *bc = cols + (size_t)done * wpc;
+        const int r = e->ring;
+        int *A = ringA(e, r), *D = ringD(e, r);
         if (!e->prepared) {
             PrepArgs p;
-            p.a = e->A; p.d = e->D; p.col = bc; p.summ = e->summ; p.k = e->k_cur; p.M = e->M; p.W = e->W;
+            p.a = A; p.d = D; p.col = bc; p.summ = e->summ; p.k = e->k_cur; p.M = e->M; p.W = e->W;
             p.wpad = e->wpad; p.T = e->T; p.sorted = sorted; p.with_d = with_d; p.has_col = 1;
             hipLaunchKernelGGL(prepare_kernel, dim3(e->W), dim3(BLOCK), 0, e->stream, p);
             HIPCHK(hipGetLastError());
-            e->prepared = true;
+            e->prepared = true; e->summ_cur = 0;
         }
-        hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(1), 0, e->stream, e->ctl, e->k_cur, nb, e->n_total, e->colbase, bc);
+        hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(256), 0, e->stream, e->ctlblk, e->k_cur, e->n_total, bc, e->summ, e->wpad, e->summ_cur);
+        e->summ_cur = nb % 3;
         HIPCHK(hipGetLastError());
-        // ---- the chain: one launch per site ----
+        // ---- the chain: one launch per site, slot j -> slot j+1 of ring r ----
         if (e->ev_used == e->ev.size()) {
             hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); e->ev.push_back({a, b});
         }
         HIPCHK(hipEventRecord(e->ev[e->ev_used].first, e->stream));
         if (e->use_graph && nb == e->B) {
             hipGraphExec_t exec;
-            CHK(get_graph(e, with_d, sorted, &exec));
+            CHK(get_graph(e, with_d, sorted, r, &exec));
             HIPCHK(hipGraphLaunch(exec, e->stream));
         } else {
-            for (int j = 0; j < nb; ++j) launch_step_dyn(e, j, with_d, sorted);
+            for (int j = 0; j < nb; ++j) launch_step_dyn(e, r, j, with_d, sorted);
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipEventRecord(e->ev[e->ev_used].second, e->stream));
+        HIPCHK(hipEventRecord(e->evChain[r], e->stream));
         ++e->ev_used; e->launches += nb;
-        // ---- batch consumers over slots [0, nb) = sites k_cur .. k_cur+nb-1 ----
-        if (opts & PBWTAMD_OPT_CHECKSUM) {
-            unsigned long long *ca = e->csum + (e->k_cur - e->k0), *cd = ca + e->csum_sites, *cy = cd + e->csum_sites;
-            dim3 grid(std::min(64, (e->M + BLOCK) / BLOCK), nb);
-            hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, e->stream, (const int *)e->A, (const int *)e->D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, nb);
-            HIPCHK(hipGetLastError());
+        // ---- consumers of the PREVIOUS batch (other ring) run now, beside this batch's chain ----
+        CHK(flush_pending(e));
+        // ---- carry the cursor into slot 0 of the other ring once its readers are done ----
+        if (e->consRecorded[r ^ 1]) HIPCHK(hipStreamWaitEvent(e->stream, e->evCons[r ^ 1], 0));
+        HIPCHK(hipMemcpyAsync(ringA(e, r ^ 1), A + (size_t)nb * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->stream));
+        if (with_d) HIPCHK(hipMemcpyAsync(ringD(e, r ^ 1), D + (size_t)nb * e->strideD, sizeof(int) * e->strideD, hipMemcpyDeviceToDevice, e->stream));
+        if (opts & (PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3)) {
+            e->pend.valid = true; e->pend.ring = r; e->pend.kbase = e->k_cur; e->pend.nb = nb; e->pend.opts = opts;
         }
-        if (opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, e->k_cur, nb, -1, opts));
-        if (opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, nb));
-        // ---- carry the cursor: slot nb -> slot 0 ----
-        HIPCHK(hipMemcpyAsync(e->A, e->A + (size_t)nb * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->stream));
-        if (with_d) HIPCHK(hipMemcpyAsync(e->D, e->D + (size_t)nb * e->strideD, sizeof(int) * e->strideD, hipMemcpyDeviceToDevice, e->stream));
+        e->ring = r ^ 1;
         e->k_cur += nb;
         done += nb;
     }
@@ -375,54 +431,61 @@ extern "C" int pbwtamd_pass_end(pbwtamd_engine *e, unsigned opts) {
     if (!e->pass_open) return fail("pbwtamd_pass_end without pass_begin");
     if (e->k_cur != e->n_total) return fail("pbwtamd_pass_end: at site %d of %d", e->k_cur, e->n_total);
     const bool with_d = opts & PBWTAMD_OPT_WITH_D;
+    CHK(flush_pending(e));
+    HIPCHK(hipStreamSynchronize(e->stream));               // the final state sits in slot 0 of e->ring
+    const int *A = ringA(e, e->ring), *D = ringD(e, e->ring);
     if (opts & PBWTAMD_OPT_CHECKSUM) {
         unsigned long long *ca = e->csum + (e->k_cur - e->k0), *cd = ca + e->csum_sites, *cy = cd + e->csum_sites;
         dim3 grid(std::min(64, (e->M + BLOCK) / BLOCK), 1);
-        hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, e->stream, (const int *)e->A, (const int *)e->D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, 0);
+        hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, e->s2, A, D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, 0);
         HIPCHK(hipGetLastError());
     }
-    if (opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, e->n_total, 1, 0, opts));
+    if (opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, e->s2, A, D, e->n_total, 1, 0, opts));
     e->pass_open = false;
     return pbwtamd_sync(e);
 }
 
 extern "C" int pbwtamd_get_state(pbwtamd_engine *e, int32_t *a, int32_t *d) {
     HIPCHK(hipSetDevice(e->device));
-    // slot 0 holds the current cursor; strip the allele tags through the ycols scratch
+    CHK(flush_pending(e));
+    HIPCHK(hipStreamSynchronize(e->s2));                   // ycols scratch is shared with pack3
+    // slot 0 of the current ring holds the cursor; strip the allele tags through the ycols scratch
+    const int *A = ringA(e, e->ring), *D = ringD(e, e->ring);
     int *tmp = (int *)e->ycols;
-    static_assert(sizeof(unsigned long long) == 8, "");
     if ((size_t)e->M * sizeof(int) > ((size_t)e->B + 1) * e->wpc64 * sizeof(unsigned long long)) {
         std::vector<int> h(e->M);
-        HIPCHK(hipMemcpyAsync(h.data(), e->A, sizeof(int) * (size_t)e->M, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipMemcpyAsync(h.data(), A, sizeof(int) * (size_t)e->M, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         for (int i = 0; i < e->M; ++i) a[i] = h[i] & AMASK;
     } else {
-        hipLaunchKernelGGL(untag_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, (const int *)e->A, tmp, e->M);
+        hipLaunchKernelGGL(untag_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, A, tmp, e->M);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(a, tmp, sizeof(int) * (size_t)e->M, hipMemcpyDeviceToHost, e->stream));
     }
-    if (d) HIPCHK(hipMemcpyAsync(d, e->D, sizeof(int) * ((size_t)e->M + 1), hipMemcpyDeviceToHost, e->stream));
+    if (d) HIPCHK(hipMemcpyAsync(d, D, sizeof(int) * ((size_t)e->M + 1), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
 
 extern "C" int pbwtamd_get_hist(pbwtamd_engine *e, int64_t *hist, int histlen) {
     HIPCHK(hipSetDevice(e->device));
+    CHK(flush_pending(e));
     const int n = std::min(histlen, e->histlen);
     memset(hist, 0, sizeof(int64_t) * (size_t)histlen);
-    HIPCHK(hipMemcpyAsync(hist, e->hist, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpyAsync(hist, e->hist, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, e->s2));
+    HIPCHK(hipStreamSynchronize(e->s2));
     return 0;
 }
 
 extern "C" int pbwtamd_get_checksums(pbwtamd_engine *e, int k_first, int n, uint64_t *ca, uint64_t *cd, uint64_t *cy) {
     HIPCHK(hipSetDevice(e->device));
+    CHK(flush_pending(e));
     const int off = k_first - e->k0;
     if (off < 0 || off + n > e->csum_sites) return fail("pbwtamd_get_checksums: range outside the pass");
-    if (ca) HIPCHK(hipMemcpyAsync(ca, e->csum + off, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
-    if (cd) HIPCHK(hipMemcpyAsync(cd, e->csum + e->csum_sites + off, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
-    if (cy) HIPCHK(hipMemcpyAsync(cy, e->csum + 2 * (size_t)e->csum_sites + off, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    if (ca) HIPCHK(hipMemcpyAsync(ca, e->csum + off, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, e->s2));
+    if (cd) HIPCHK(hipMemcpyAsync(cd, e->csum + e->csum_sites + off, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, e->s2));
+    if (cy) HIPCHK(hipMemcpyAsync(cy, e->csum + 2 * (size_t)e->csum_sites + off, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, e->s2));
+    HIPCHK(hipStreamSynchronize(e->s2));
     return 0;
 }
 
@@ -438,6 +501,15 @@ extern "C" int pbwtamd_get_chain_timing(pbwtamd_engine *e, double *ms_total, int
     if (ms_total) *ms_total = tot;
     if (launches) *launches = e->launches;
     return 0;
+}
+
+extern "C" int pbwtamd_get_phase_profile(pbwtamd_engine *e, int64_t *out, int ntiles) {
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->prof) return -fail("pbwtamd_get_phase_profile: engine created without PBWTAMD_PROFILE=1");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const int n = std::min(ntiles, e->W);
+    HIPCHK(hipMemcpy(out, e->prof, (size_t)n * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    return n;
 }
 
 extern "C" int pbwtamd_synth_device(pbwtamd_engine *e, void *d_bitcols, int k0, int ncols, uint64_t seed, int kind) {
@@ -608,7 +680,7 @@ extern "C" int pbwtamd_pack3(pbwtamd_engine *e, const uint32_t *sorted_bitcols, 
         unsigned long long tot = 0;
         HIPCHK(hipMemcpyAsync(&tot, e->scal + 2, sizeof tot, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
-        CHK(ensure_yz(e, (size_t)tot + 16));
+        CHK(ensure_yz(e, e->stream, (size_t)tot + 16));
         hipLaunchKernelGGL((pack3_kernel<1>), dim3(nb), dim3(BLOCK), 0, e->stream, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
         HIPCHK(hipGetLastError());
         const size_t old = all.size();

@@ -23,18 +23,36 @@ constexpr int WAVES = BLOCK / 64;
 constexpr unsigned TAG = 0x80000000u;
 constexpr int AMASK = 0x7fffffff;
 
+// workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory
+// (s_waitcnt vmcnt(0)), which would serialise every barrier behind the outstanding global loads
+// and stores this latency-bound kernel deliberately keeps in flight.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+// ---- wave64 cross-lane primitives on DPP (row_shr + row_bcast15/31): a 6-op dependent chain of
+// VALU instructions instead of 6 ds_bpermute round trips through the LDS crossbar.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_mov(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROWMASK, 0xf, false);
 }
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
+#define PBWT_DPP_SCAN(v, OP, ID)                                      \
+    v = OP(v, dpp_mov<0x111, 0xf>(ID, v)); /* row_shr:1 */            \
+    v = OP(v, dpp_mov<0x112, 0xf>(ID, v)); /* row_shr:2 */            \
+    v = OP(v, dpp_mov<0x114, 0xf>(ID, v)); /* row_shr:4 */            \
+    v = OP(v, dpp_mov<0x118, 0xf>(ID, v)); /* row_shr:8 */            \
+    v = OP(v, dpp_mov<0x142, 0xa>(ID, v)); /* row_bcast:15 */         \
+    v = OP(v, dpp_mov<0x143, 0xc>(ID, v)); /* row_bcast:31 */
+__device__ __forceinline__ int op_add(int a, int b) { return a + b; }
+__device__ __forceinline__ int op_max(int a, int b) { return max(a, b); }
+__device__ __forceinline__ int wave_iscan_sum(int v) { PBWT_DPP_SCAN(v, op_add, 0) return v; }
+__device__ __forceinline__ int wave_iscan_max(int v) { PBWT_DPP_SCAN(v, op_max, 0) return v; }   // values >= 0
+__device__ __forceinline__ int wave_sum(int v) { return __builtin_amdgcn_readlane(wave_iscan_sum(v), 63); }
+__device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlane(wave_iscan_max(v), 63); }
+// value of the previous lane (lane 0 gets `id`)
+__device__ __forceinline__ int lane_shr1(int v, int id) {
+    return __builtin_amdgcn_update_dpp(id, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
 __device__ __forceinline__ uint64_t sm64(uint64_t z) {
@@ -60,113 +78,118 @@ __device__ __forceinline__ Tup tup_combine(const Tup &L, const Tup &R) {
     o.t1 = R.c1 ? R.t1 : max(L.t1, R.all);
     return o;
 }
-__device__ __forceinline__ Tup tup_shfl_up(const Tup &v, int o) {
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ Tup tup_dpp(const Tup &v) {      // unwritten lanes get the identity
     Tup r;
-    r.c0 = __shfl_up(v.c0, o); r.c1 = __shfl_up(v.c1, o);
-    r.t0 = __shfl_up(v.t0, o); r.t1 = __shfl_up(v.t1, o); r.all = __shfl_up(v.all, o);
+    r.c0 = dpp_mov<CTRL, ROWMASK>(0, v.c0); r.c1 = dpp_mov<CTRL, ROWMASK>(0, v.c1);
+    r.t0 = dpp_mov<CTRL, ROWMASK>(0, v.t0); r.t1 = dpp_mov<CTRL, ROWMASK>(0, v.t1);
+    r.all = dpp_mov<CTRL, ROWMASK>(0, v.all);
     return r;
 }
+template <bool WITH_D>
+__device__ __forceinline__ Tup tup_op(const Tup &L, const Tup &R) {
+    if (WITH_D) return tup_combine(L, R);
+    return Tup{L.c0 + R.c0, L.c1 + R.c1, 0, 0, 0};
+}
 
-// block-wide exclusive scan of Tup over 256 threads; also returns the block total.
-// smem: WAVES Tups.
+// block-wide exclusive scan of Tup over 256 threads (lane order = position order); also returns
+// the block total.  smem: WAVES Tups.  One __syncthreads.
 template <bool WITH_D>
 __device__ __forceinline__ Tup block_scan_tup(Tup v, Tup *smem, Tup &total) {
     const int lane = lane_id(), wv = wave_id();
     Tup inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        Tup L = tup_shfl_up(inc, o);
-        if (lane >= o) {
-            if (WITH_D) inc = tup_combine(L, inc);
-            else { inc.c0 += L.c0; inc.c1 += L.c1; }
-        }
-    }
+    inc = tup_op<WITH_D>(tup_dpp<0x111, 0xf>(inc), inc);
+    inc = tup_op<WITH_D>(tup_dpp<0x112, 0xf>(inc), inc);
+    inc = tup_op<WITH_D>(tup_dpp<0x114, 0xf>(inc), inc);
+    inc = tup_op<WITH_D>(tup_dpp<0x118, 0xf>(inc), inc);
+    inc = tup_op<WITH_D>(tup_dpp<0x142, 0xa>(inc), inc);
+    inc = tup_op<WITH_D>(tup_dpp<0x143, 0xc>(inc), inc);
     if (lane == 63) smem[wv] = inc;
-    Tup exc = tup_shfl_up(inc, 1);
-    if (lane == 0) exc = Tup{0, 0, 0, 0, 0};
-    __syncthreads();
+    Tup exc;
+    exc.c0 = lane_shr1(inc.c0, 0); exc.c1 = lane_shr1(inc.c1, 0);
+    exc.t0 = lane_shr1(inc.t0, 0); exc.t1 = lane_shr1(inc.t1, 0); exc.all = lane_shr1(inc.all, 0);
+    lds_barrier();
     Tup pre = Tup{0, 0, 0, 0, 0};
     Tup tot = Tup{0, 0, 0, 0, 0};
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) {
-        Tup s = smem[w];
-        if (w < wv) pre = WITH_D ? tup_combine(pre, s) : Tup{pre.c0 + s.c0, pre.c1 + s.c1, 0, 0, 0};
-        tot = WITH_D ? tup_combine(tot, s) : Tup{tot.c0 + s.c0, tot.c1 + s.c1, 0, 0, 0};
+        const Tup sw = smem[w];
+        if (w < wv) pre = tup_op<WITH_D>(pre, sw);
+        tot = tup_op<WITH_D>(tot, sw);
     }
     total = tot;
-    if (WITH_D) return tup_combine(pre, exc);
-    return Tup{pre.c0 + exc.c0, pre.c1 + exc.c1, 0, 0, 0};
+    return tup_op<WITH_D>(pre, exc);
 }
 
 // ---------------------------------------------------------------------------------------------
+// per-batch control block in device memory, written by set_ctl_kernel before each batch so that one
+// captured graph serves every batch; read with a single scalar load at kernel start.
+struct alignas(32) Ctl {
+    int kbase;                 // site index of step 0 of this batch
+    int n_total;               // sites in the panel (has_next = k+1 < n_total)
+    int pad0, pad1;
+    const uint32_t *cols;      // bit columns of this batch: column j = site kbase+j
+    long long pad2;
+};
+
 struct StepArgs {
-    const int *a_in;  const int *d_in;     // slot k
-    int *a_out;       int *d_out;          // slot k+1
-    const uint32_t *const *colbase;        // device pointer to this batch's bit columns (site kbase first)
+    const int *a_in;  const int *d_in;     // slot j
+    int *a_out;       int *d_out;          // slot j+1
+    const Ctl *ctl;
+    int *summ;                             // [3][4][wpad]; step j reads buffer j%3, accumulates (j+1)%3, clears (j+2)%3
+    long long *prof;                       // optional phase timestamps [W][8] (NULL = off)
     int wpc;                               // 32-bit words per column
-    int *summ;                             // [3][4][wpad]
-    const int *ctl;                        // device ints: [0] kbase = site of step 0 of this batch,
-                                           // [1] live steps in the batch (j >= nsteps: no-op), [3] n_total
     int j;                                 // step index inside the batch
     int M, W, wpad;
 };
 
-__device__ __forceinline__ int *summ_ptr(int *summ, int wpad, int buf, int which) {
-    return summ + ((size_t)buf * 4 + which) * wpad;
-}
+#define PBWT_STAMP(idx) do { if (g.prof && t == 0) g.prof[(size_t)w * 8 + (idx)] = (long long)wall_clock64(); } while (0)
 
-// One site of pbwtCursorForwardsA / ForwardsAD (pbwtCore.c:458-470 / 485-508) for one tile of
-// T = 256*E consecutive positions.  grid = W tiles.
-template <int E, bool WITH_D, bool SORTED>
-__global__ __launch_bounds__(BLOCK) void step_kernel(StepArgs g) {
+// The step kernel is latency-bound, not bandwidth-bound, for M up to ~1M: one wave
+// per SIMD executes its instruction stream exactly once, so the launch time is (instructions on
+// the longest path) x (~5 cycles) + the dependent memory round trips.  Hence: one or two positions
+// per thread, no validity predication on full tiles (FULL), DPP scans, LDS-only barriers, every
+// load whose address is known at entry issued first.
+template <int E, bool WITH_D, bool SORTED, bool FULL>
+__device__ __forceinline__ void step_body(const StepArgs &g, int *s_a, int *s_d, Tup *s_tup, int (*s_red)[6], int (*s_acc)[4]) {
     constexpr int T = BLOCK * E;
-    __shared__ int s_a[T];
-    __shared__ int s_d[WITH_D ? T : 1];
-    __shared__ Tup s_tup[WAVES];
-    __shared__ int s_red[WAVES][6];
-    __shared__ int s_acc[4][4];
-
     const int j = g.j;
-    if (j >= g.ctl[1]) return;
-    const int k = g.ctl[0] + j;
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
     const int w = blockIdx.x, W = g.W, M = g.M;
     const int S = w * T;                                   // first position of the tile
-    const bool has_next = (k + 1 < g.ctl[3]);          // the panel has a site k+1
-    const uint32_t *col_next = *g.colbase + (size_t)(j + 1) * g.wpc;
+    PBWT_STAMP(0);
 
-    int *sm_in = g.summ + (size_t)(k % 3) * 4 * g.wpad;
-    int *sm_out = g.summ + (size_t)((k + 1) % 3) * 4 * g.wpad;
-    int *sm_zero = g.summ + (size_t)((k + 2) % 3) * 4 * g.wpad;
+    const int *sm_in = g.summ + (size_t)(j % 3) * 4 * g.wpad;
+    int *sm_out = g.summ + (size_t)((j + 1) % 3) * 4 * g.wpad;
+    int *sm_zero = g.summ + (size_t)((j + 2) % 3) * 4 * g.wpad;
     const int *in_cnt0 = sm_in, *in_last0 = sm_in + g.wpad, *in_last1 = sm_in + 2 * g.wpad,
               *in_maxd = sm_in + 3 * g.wpad;
 
-    if (t < 16) s_acc[t >> 2][t & 3] = 0;
-
-    // ---- A: own tile (blocked: thread t owns positions S + t*E .. +E) ----
+    // ---- issue everything whose address is known now ----
+    const Ctl ctl = *g.ctl;
     int av[E], dv[E];
-    {
-        const int base = S + t * E;                        // arrays are padded to a multiple of T
-        const int4 *pa = reinterpret_cast<const int4 *>(g.a_in + base);
+    const int base = S + t * E;                            // blocked: thread t owns E consecutive positions
+    if constexpr (E % 4 == 0) {
+        const int4 *pa = reinterpret_cast<const int4 *>(g.a_in + base);   // arrays are padded to W*T
 #pragma unroll
         for (int q = 0; q < E / 4; ++q) {
-            int4 v = pa[q];
+            const int4 v = pa[q];
             av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
         }
         if (WITH_D) {
             const int4 *pd = reinterpret_cast<const int4 *>(g.d_in + base);
 #pragma unroll
             for (int q = 0; q < E / 4; ++q) {
-                int4 v = pd[q];
+                const int4 v = pd[q];
                 dv[4 * q] = v.x; dv[4 * q + 1] = v.y; dv[4 * q + 2] = v.z; dv[4 * q + 3] = v.w;
             }
         }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { av[e] = g.a_in[base + e]; if (WITH_D) dv[e] = g.d_in[base + e]; }
     }
-
-    // ---- B: tile summaries of this site -> zero offset, total zeros, carries ----
     constexpr int SPT = 4;                                 // summaries per thread (W <= 1024)
     int r_cnt[SPT], r_l0[SPT], r_l1[SPT], r_md[SPT];
-    int sumBefore = 0, total = 0, l0 = 0, l1 = 0;
 #pragma unroll
     for (int q = 0; q < SPT; ++q) {
         const int jn = t + q * BLOCK;
@@ -174,14 +197,43 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(StepArgs g) {
         if (jn < W) {
             r_cnt[q] = in_cnt0[jn];
             if (WITH_D) { r_l0[q] = in_last0[jn]; r_l1[q] = in_last1[jn]; r_md[q] = in_maxd[jn]; }
-            total += r_cnt[q];
-            if (jn < w) { sumBefore += r_cnt[q]; l0 = max(l0, r_l0[q]); l1 = max(l1, r_l1[q]); }
         }
+    }
+    if (t < 16) s_acc[t >> 2][t & 3] = 0;
+
+    const int k = ctl.kbase + j;
+    const bool has_next = (k + 1 < ctl.n_total);           // the panel has a site k+1
+    const uint32_t *col_next = ctl.cols + (size_t)(j + 1) * g.wpc;
+
+    // ---- own alleles (tags) and, in gather mode, the next-site allele of each haplotype ----
+    unsigned ybits = 0, vbits = FULL ? ((1u << E) - 1u) : 0u, nbits = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const unsigned y = ((unsigned)av[e]) >> 31;
+        av[e] &= AMASK;
+        if (FULL) ybits |= y << e;
+        else if (base + e < M) { vbits |= 1u << e; ybits |= y << e; }
+    }
+    if (!SORTED && has_next) {
+        unsigned wd[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) wd[e] = (FULL || ((vbits >> e) & 1u)) ? col_next[(unsigned)av[e] >> 5] : 0u;
+#pragma unroll
+        for (int e = 0; e < E; ++e) nbits |= ((wd[e] >> (av[e] & 31)) & 1u) << e;
+    }
+
+    // ---- B: tile summaries of this site -> zero offset, total zeros, last-allele positions ----
+    int sumBefore = 0, total = 0, l0 = 0, l1 = 0;
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int jn = t + q * BLOCK;
+        total += r_cnt[q];
+        if (jn < w) { sumBefore += r_cnt[q]; l0 = max(l0, r_l0[q]); l1 = max(l1, r_l1[q]); }
     }
     sumBefore = wave_sum(sumBefore); total = wave_sum(total);
     if (WITH_D) { l0 = wave_max(l0); l1 = wave_max(l1); }
     if (lane == 0) { s_red[wv][0] = sumBefore; s_red[wv][1] = total; s_red[wv][2] = l0; s_red[wv][3] = l1; }
-    __syncthreads();
+    lds_barrier();
     sumBefore = 0; total = 0; l0 = 0; l1 = 0;
 #pragma unroll
     for (int q = 0; q < WAVES; ++q) {
@@ -190,13 +242,22 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(StepArgs g) {
     }
     const int Zw = sumBefore;                              // zeros before this tile
     const int C = total;                                   // zeros in the whole column (u->c)
+    PBWT_STAMP(1);
 
-    int carry0 = 0, carry1 = 0;
+    // carry_b = max d over [l_b, S): the positions after the last allele-b element before the tile
+    // = direct reads in the tile holding position l_b - 1, plus whole-tile maxima in between.
+    int cw, nvalid;                                        // zeros / valid positions in this tile
     if (WITH_D) {
-        // carry_b = max d over [l_b, S): positions after the last allele-b element before the tile.
-        // = direct reads in the tile holding l_b-1, plus whole-tile maxima in between.
         int m0 = 0, m1 = 0;
         const int tl0 = l0 ? (l0 - 1) / T : -1, tl1 = l1 ? (l1 - 1) / T : -1;
+        int pd0[E], pd1[E];
+        const int hi0 = l0 ? min((tl0 + 1) * T, S) : 0, hi1 = l1 ? min((tl1 + 1) * T, S) : 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {                      // issue the dependent loads first
+            const int p0 = l0 + t + e * BLOCK, p1 = l1 + t + e * BLOCK;
+            pd0[e] = (l0 && p0 < hi0) ? g.d_in[p0] : 0;
+            pd1[e] = (l1 && p1 < hi1) ? g.d_in[p1] : 0;
+        }
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
             const int jn = t + q * BLOCK;
@@ -205,86 +266,86 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(StepArgs g) {
                 if (l1 && jn > tl1) m1 = max(m1, r_md[q]);
             }
         }
-        if (l0) { const int hi = min((tl0 + 1) * T, S); for (int p = l0 + t; p < hi; p += BLOCK) m0 = max(m0, g.d_in[p]); }
-        if (l1) { const int hi = min((tl1 + 1) * T, S); for (int p = l1 + t; p < hi; p += BLOCK) m1 = max(m1, g.d_in[p]); }
+        // ---- C (overlaps the loads above): thread-local carry tuple ----
+        Tup me = Tup{0, 0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (FULL || (vbits & (1u << e))) {
+                const int d = dv[e];
+                me.all = max(me.all, d);
+                if (!((ybits >> e) & 1u)) { me.t0 = 0; me.t1 = max(me.t1, d); ++me.c0; }
+                else                      { me.t1 = 0; me.t0 = max(me.t0, d); ++me.c1; }
+            }
+        }
+        Tup tot;
+        const Tup pre = block_scan_tup<true>(me, s_tup, tot);
+        PBWT_STAMP(2);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { m0 = max(m0, pd0[e]); m1 = max(m1, pd1[e]); }
         m0 = wave_max(m0); m1 = wave_max(m1);
         if (lane == 0) { s_red[wv][4] = m0; s_red[wv][5] = m1; }
-        __syncthreads();
+        lds_barrier();
         m0 = 0; m1 = 0;
 #pragma unroll
         for (int q = 0; q < WAVES; ++q) { m0 = max(m0, s_red[q][4]); m1 = max(m1, s_red[q][5]); }
-        carry0 = l0 ? m0 : k + 1;                          // nothing before: p starts at k+1 (pbwtCore.c:489)
-        carry1 = l1 ? m1 : k + 1;
-    }
-
-    // ---- C: local recurrence ----
-    const int base = S + t * E;
-    unsigned ybits = 0, vbits = 0;
-    Tup me = Tup{0, 0, 0, 0, 0};
+        const int carry0 = l0 ? m0 : k + 1;                // nothing before: p starts at k+1 (pbwtCore.c:489)
+        const int carry1 = l1 ? m1 : k + 1;
+        PBWT_STAMP(3);
+        cw = tot.c0; nvalid = tot.c0 + tot.c1;
+        int p = pre.c0 ? pre.t0 : max(carry0, pre.all);
+        int q1 = pre.c1 ? pre.t1 : max(carry1, pre.all);
+        int zi = pre.c0, oi = cw + pre.c1;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const bool valid = (base + e) < M;
-        const unsigned y = ((unsigned)av[e]) >> 31;
-        av[e] &= AMASK;
-        if (valid) {
-            vbits |= 1u << e;
-            ybits |= y << e;
-            if (WITH_D) {
-                const int d = dv[e];
-                me.all = max(me.all, d);
-                if (y == 0) { me.t0 = 0; me.t1 = max(me.t1, d); }
-                else        { me.t1 = 0; me.t0 = max(me.t0, d); }
+        for (int e = 0; e < E; ++e) {
+            if (FULL || (vbits & (1u << e))) {
+                int ldst, dn;
+                if (!((ybits >> e) & 1u)) { dn = max(p, dv[e]); p = 0; q1 = max(q1, dv[e]); ldst = zi++; }
+                else                      { dn = max(q1, dv[e]); q1 = 0; p = max(p, dv[e]); ldst = oi++; }
+                s_a[ldst] = av[e] | (int)(((nbits >> e) & 1u) << 31);
+                s_d[ldst] = dn;
             }
-            if (y == 0) ++me.c0; else ++me.c1;
+        }
+    } else {
+        Tup me = Tup{0, 0, 0, 0, 0};
+        me.c0 = __popc(vbits & ~ybits); me.c1 = __popc(vbits & ybits);
+        Tup tot;
+        const Tup pre = block_scan_tup<false>(me, s_tup, tot);
+        PBWT_STAMP(2);
+        PBWT_STAMP(3);
+        cw = tot.c0; nvalid = tot.c0 + tot.c1;
+        int zi = pre.c0, oi = cw + pre.c1;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (FULL || (vbits & (1u << e))) {
+                const int ldst = ((ybits >> e) & 1u) ? oi++ : zi++;
+                s_a[ldst] = av[e] | (int)(((nbits >> e) & 1u) << 31);
+            }
         }
     }
-    Tup tot;
-    const Tup pre = block_scan_tup<WITH_D>(me, s_tup, tot);
-    const int cw = tot.c0;                                 // zeros in this tile
-    const int nvalid = tot.c0 + tot.c1;
-    int p = 0, q1 = 0;
-    if (WITH_D) {
-        p = pre.c0 ? pre.t0 : max(carry0, pre.all);
-        q1 = pre.c1 ? pre.t1 : max(carry1, pre.all);
-    }
-    int zi = pre.c0, oi = cw + pre.c1;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        if (vbits & (1u << e)) {
-            int ldst, dn = 0;
-            if (!((ybits >> e) & 1u)) {
-                if (WITH_D) { dn = max(p, dv[e]); p = 0; q1 = max(q1, dv[e]); }
-                ldst = zi++;
-            } else {
-                if (WITH_D) { dn = max(q1, dv[e]); q1 = 0; p = max(p, dv[e]); }
-                ldst = oi++;
-            }
-            s_a[ldst] = av[e];
-            if (WITH_D) s_d[ldst] = dn;
-        }
-    }
-    __syncthreads();
+    lds_barrier();
+    PBWT_STAMP(4);
 
     // ---- D: coalesced write-out in destination order + summaries of site k+1 ----
     const int onesBefore = S - Zw;                         // every earlier tile is full
     const int oneBase = C + onesBefore;                    // destination of this tile's first one
     const int tz = Zw / T, to = oneBase / T;               // first destination tile of each stream
+    int mdl[4] = {0, 0, 0, 0};                             // per-lane max d' per destination slot (E > 2)
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int l = e * BLOCK + t;
-        const bool valid = l < nvalid;
-        int P = 0, slot = 0, dn = 0;
+        const bool valid = FULL || (l < nvalid);
+        int P = 0, slot = -1, dn = 0;
         unsigned tag = 0;
         if (valid) {
-            const int a = s_a[l];
+            int a = s_a[l];
             const bool one = l >= cw;
             P = one ? oneBase + (l - cw) : Zw + l;
-            slot = one ? 2 + (P / T - to) : (P / T - tz);
-            if (has_next) {
-                const unsigned idx = SORTED ? (unsigned)P : (unsigned)a;
-                tag = (col_next[idx >> 5] >> (idx & 31)) & 1u;
-            }
-            g.a_out[P] = a | (int)(tag << 31);
+            slot = one ? 2 + (int)((unsigned)P / T - to) : (int)((unsigned)P / T - tz);
+            if (SORTED) {
+                if (has_next) tag = (col_next[(unsigned)P >> 5] >> (P & 31)) & 1u;
+                a |= (int)(tag << 31);
+            } else tag = (unsigned)a >> 31;
+            g.a_out[P] = a;
             if (WITH_D) {
                 dn = s_d[l];
                 if (P == 0) dn = k + 2;                    // sentinel (pbwtCore.c:507)
@@ -294,30 +355,40 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(StepArgs g) {
         if (has_next) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const unsigned long long mk = __ballot(valid && slot == s);
-                if (mk) {
-                    const unsigned long long ones = __ballot(valid && slot == s && tag);
+                const unsigned long long mk = __ballot(slot == s);
+                if (mk) {                                  // wave-uniform
+                    const unsigned long long ones = __ballot(slot == s && tag);
                     const unsigned long long zeros = mk & ~ones;
-                    int md = 0, lz = 0, lo = 0;
+                    int md = 0;
                     if (WITH_D) {
-                        md = wave_max((valid && slot == s) ? dn : 0);
-                        if (zeros) lz = __shfl(P, 63 - __clzll(zeros)) + 1;
-                        if (ones) lo = __shfl(P, 63 - __clzll(ones)) + 1;
+                        if (E > 2) mdl[s] = max(mdl[s], (slot == s) ? dn : 0);
+                        else md = wave_max((slot == s) ? dn : 0);
                     }
+                    // lanes of one slot are consecutive positions: P(lane) = P(first) + lane - first
+                    const int first = __ffsll((long long)mk) - 1;
+                    const int Pf = __builtin_amdgcn_readlane(P, first);
                     if (lane == 0) {
                         atomicAdd(&s_acc[s][0], __popcll(zeros));
                         if (WITH_D) {
-                            atomicMax(&s_acc[s][1], lz);
-                            atomicMax(&s_acc[s][2], lo);
-                            atomicMax(&s_acc[s][3], md);
+                            if (zeros) atomicMax(&s_acc[s][1], Pf + (63 - __clzll(zeros)) - first + 1);
+                            if (ones) atomicMax(&s_acc[s][2], Pf + (63 - __clzll(ones)) - first + 1);
+                            if (E <= 2) atomicMax(&s_acc[s][3], md);
                         }
                     }
                 }
             }
         }
     }
+    if (WITH_D && has_next && E > 2) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int m = wave_max(mdl[s]);
+            if (lane == 0 && m) atomicMax(&s_acc[s][3], m);
+        }
+    }
     if (WITH_D && w == W - 1 && t == 0) g.d_out[M] = k + 2;
-    __syncthreads();
+    lds_barrier();
+    PBWT_STAMP(5);
     if (has_next && t < 4) {
         const int s = t;
         const int dt = (s < 2 ? tz : to) + (s & 1);
@@ -332,6 +403,21 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(StepArgs g) {
         }
     }
     if (t < 4) sm_zero[t * g.wpad + w] = 0;
+    PBWT_STAMP(6);
+}
+
+// One site of pbwtCursorForwardsA / ForwardsAD (pbwtCore.c:458-470 / 485-508) for one tile of
+// T = 256*E consecutive positions.  grid = W tiles.
+template <int E, bool WITH_D, bool SORTED>
+__global__ __launch_bounds__(BLOCK) void step_kernel(StepArgs g) {
+    constexpr int T = BLOCK * E;
+    __shared__ int s_a[T];
+    __shared__ int s_d[WITH_D ? T : 1];
+    __shared__ Tup s_tup[WAVES];
+    __shared__ int s_red[WAVES][6];
+    __shared__ int s_acc[4][4];
+    if ((int)(blockIdx.x + 1) * T <= g.M) step_body<E, WITH_D, SORTED, true>(g, s_a, s_d, s_tup, s_red, s_acc);
+    else step_body<E, WITH_D, SORTED, false>(g, s_a, s_d, s_tup, s_red, s_acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -367,8 +453,8 @@ __global__ __launch_bounds__(BLOCK) void prepare_kernel(PrepArgs g) {
     if (t == 0) {
         c0 = 0; l0 = 0; l1 = 0; md = 0;
         for (int q = 0; q < WAVES; ++q) { c0 += s_red[q][0]; l0 = max(l0, s_red[q][1]); l1 = max(l1, s_red[q][2]); md = max(md, s_red[q][3]); }
-        int *cur = g.summ + (size_t)(g.k % 3) * 4 * g.wpad;
-        int *nxt = g.summ + (size_t)((g.k + 1) % 3) * 4 * g.wpad;
+        int *cur = g.summ;                                   // batch-relative: step 0 reads buffer 0
+        int *nxt = g.summ + (size_t)1 * 4 * g.wpad;
         cur[w] = c0; cur[g.wpad + w] = l0; cur[2 * g.wpad + w] = l1; cur[3 * g.wpad + w] = md;
         nxt[w] = 0; nxt[g.wpad + w] = 0; nxt[2 * g.wpad + w] = 0; nxt[3 * g.wpad + w] = 0;
     }
