@@ -129,6 +129,13 @@ def main():
     us_per_launch = 1e3 * chain_ms / max(chain_n, 1)
     achieved = ALG_BYTES_PER_SITEHAP * M / (us_per_launch * 1e-6) / 1e9
     hist = eng.get_hist(n_total + 1)
+    traffic, traffic_src = None, None
+    try:                                   # HBM-side bytes per launch measured with rocprofv3 PMC (separate run)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(str(M))
+        if tj and tj.get("with_d"):
+            traffic, traffic_src = tj["bytes_per_launch"], tj["source"]
+    except Exception:
+        pass
     out = {
         "metric": "sites*haplotypes/sec PBWT build + maxWithin",
         "value": world * K * S * M / dt,
@@ -142,7 +149,7 @@ def main():
                    "panel": "founder-mosaic" if args.kind == 0 else "iid", "within": not args.no_within,
                    "pack3": not args.no_pack3, "units_per_rank": "independent panel per rank"},
         "roofline": {"bound": "hbm", "kernel": "step_kernel<E,WITH_D,GATHER>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "alg_bytes_per_launch": ALG_BYTES_PER_SITEHAP * M, "us_per_launch": us_per_launch,
                      "launches": int(chain_n),
                      "note": "one launch = one site; duration = HIP-event time of the dependent launch chain / launches, i.e. including launch gaps"},
