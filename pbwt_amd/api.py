@@ -157,6 +157,28 @@ class Engine:
         self._L.pbwtamd_free(rp)
         return out
 
+    def match_sweep(self, pz, N, qz, Mq, pStart=None, qStart=None, callback=None):
+        """matchSequencesSweep of a packed query panel against this engine's packed panel.
+        Returns (records in callback order, n_nomatch, (nTot, totLen)); with callback, records is None"""
+        pz = np.ascontiguousarray(pz, dtype=np.uint8)
+        qz = np.ascontiguousarray(qz, dtype=np.uint8)
+        pa, qa = _i32(pStart), _i32(qStart)
+        rp = C.c_void_p()
+        n = C.c_int64(0)
+        nom = C.c_int64(0)
+        tot = (C.c_int64 * 2)()
+        fn = REPORT_FN(callback) if callback else None
+        self._chk(self._L.pbwtamd_match_sweep(self._h, _p(pz, C.c_uint8), C.c_int64(pz.size), C.c_int(N), _p(pa, C.c_int32),
+                                              C.c_int(Mq), _p(qz, C.c_uint8), C.c_int64(qz.size), _p(qa, C.c_int32),
+                                              fn, None if callback else C.byref(rp), C.byref(n), C.byref(nom), tot))
+        out = None
+        if not callback:
+            out = np.zeros(n.value, MATCH_DTYPE)
+            if n.value:
+                C.memmove(out.ctypes.data, rp, n.value * MATCH_DTYPE.itemsize)
+            self._L.pbwtamd_free(rp)
+        return out, nom.value, (tot[0], tot[1])
+
     def pack3(self, sorted_bitcols):
         sb = np.ascontiguousarray(sorted_bitcols, dtype=np.uint32)
         N, wpc = sb.shape

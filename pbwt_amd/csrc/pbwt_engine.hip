@@ -96,7 +96,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
 
 extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, int batch_sites, void *stream) {
     *out = nullptr;
-    if (M < 2) return fail("pbwtamd_engine_create: M=%d, need at least 2 haplotypes", M);
+    if (M < 1) return fail("pbwtamd_engine_create: M=%d", M);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail("pbwtamd: no HIP device available (this library has no CPU path)");
@@ -649,6 +649,7 @@ extern "C" int pbwtamd_max_within(pbwtamd_engine *e, const uint8_t *yz, int64_t 
     HIPCHK(hipSetDevice(e->device));
     const int sinks = (report ? 1 : 0) + (recs_out ? 1 : 0) + (hist ? 1 : 0);
     if (sinks != 1) return fail("pbwtamd_max_within: exactly one of report / recs_out / hist must be given");
+    if (e->M < 2) return fail("pbwtamd_max_within: needs at least 2 haplotypes (the reference reads y[-1] for M = 1)");
     if (hist && histlen < N + 1) return fail("pbwtamd_max_within: histlen %d < N+1", histlen);
     std::vector<pbwtamd_match> recs;
     e->rec_sink = &recs; e->rec_cb = report;
@@ -710,11 +711,128 @@ extern "C" int pbwtamd_unpack3(pbwtamd_engine *e, const uint8_t *yz, int64_t nz,
     return pbwtamd_sync(e);
 }
 
+// small RAII holder for temporary device buffers
+struct DevBufs {
+    std::vector<void *> v;
+    ~DevBufs() { for (void *p : v) if (p) (void)hipFree(p); }
+    template <typename T> int alloc(T **out, size_t n) {
+        void *p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return fail("hipMalloc(%zu) failed", n * sizeof(T));
+        v.push_back(p); *out = (T *)p; return 0;
+    }
+};
+
+static int deliver_records(pbwtamd_engine *e, hipStream_t st, const int4 *drecs, size_t total, std::vector<pbwtamd_match> &all, pbwtamd_report_fn report) {
+    if (!total) return 0;
+    const size_t old = all.size();
+    all.resize(old + total);
+    HIPCHK(hipMemcpyAsync(all.data() + old, drecs, total * sizeof(int4), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (report) {
+        for (size_t r = old; r < old + total; ++r) report(all[r].ai, all[r].bi, all[r].start, all[r].end);
+        all.resize(old);
+    }
+    (void)e;
+    return 0;
+}
+
 extern "C" int pbwtamd_match_sweep(pbwtamd_engine *e, const uint8_t *pz, int64_t pnz, int N, const int32_t *pStart,
                                    int Mq, const uint8_t *qz, int64_t qnz, const int32_t *qStart,
                                    pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out,
-                                   int64_t *n_nomatch, int64_t *tot) {
-    (void)e; (void)pz; (void)pnz; (void)N; (void)pStart; (void)Mq; (void)qz; (void)qnz; (void)qStart;
-    (void)report; (void)recs_out; (void)nrecs_out; (void)n_nomatch; (void)tot;
-    return fail("pbwtamd_match_sweep: not implemented in this build");
+                                   int64_t *n_nomatch, int64_t *tot_out) {
+    HIPCHK(hipSetDevice(e->device));
+    if ((report ? 1 : 0) + (recs_out ? 1 : 0) != 1) return fail("pbwtamd_match_sweep: exactly one of report / recs_out must be given");
+    pbwtamd_engine *eq = nullptr;
+    CHK(pbwtamd_engine_create(&eq, e->device, Mq, e->B, nullptr));
+    struct EngGuard { pbwtamd_engine *p; ~EngGuard() { pbwtamd_engine_destroy(p); } } guard{eq};
+    const int Mp = e->M;
+    Packed pk, qk;
+    CHK(packed_upload(e, e->stream, Mp, pz, pnz, N, pk));
+    CHK(packed_upload(eq, eq->stream, Mq, qz, qnz, N, qk));
+    CHK(pbwtamd_pass_begin(e, pStart, 0, N));
+    CHK(pbwtamd_pass_begin(eq, qStart, 0, N));
+    DevBufs bufs;
+    unsigned char *xq; int *invq, *rankdir, *fst[2], *dst[2]; unsigned long long *cnt, *tot; int4 *recs = nullptr; size_t recsCap = 0;
+    const size_t BQ = (size_t)e->B * Mq;
+    CHK(bufs.alloc(&xq, BQ)); CHK(bufs.alloc(&invq, BQ)); CHK(bufs.alloc(&cnt, std::max(BQ, (size_t)Mq)));
+    CHK(bufs.alloc(&rankdir, (size_t)e->B * (e->wpc64 + 1)));
+    for (int i = 0; i < 2; ++i) { CHK(bufs.alloc(&fst[i], (size_t)Mq)); CHK(bufs.alloc(&dst[i], (size_t)Mq)); }
+    CHK(bufs.alloc(&tot, (size_t)4));
+    hipStream_t st = e->s2;
+    HIPCHK(hipMemsetAsync(fst[0], 0, sizeof(int) * (size_t)Mq, st));      // calloc'ed f[], d[] (pbwtMatch.c:368-369)
+    HIPCHK(hipMemsetAsync(dst[0], 0, sizeof(int) * (size_t)Mq, st));
+    HIPCHK(hipMemsetAsync(tot, 0, 4 * sizeof(unsigned long long), st));
+    std::vector<pbwtamd_match> all;
+    int cur = 0;
+    const int qblocks = (Mq + BLOCK - 1) / BLOCK;
+    auto ensure_recs = [&](size_t total) -> int {
+        if (total <= recsCap) return 0;
+        recsCap = total + total / 4 + 1024;
+        return bufs.alloc(&recs, recsCap);
+    };
+    for (int done = 0; done < N;) {
+        const int nb = std::min(e->B, N - done);
+        const int navail = std::min(nb + 1, N - done);
+        CHK(packed_expand(e, e->stream, pk, Mp, done, navail, (unsigned long long *)e->cols_stage, e->wpc64));
+        CHK(packed_expand(eq, eq->stream, qk, Mq, done, navail, (unsigned long long *)eq->cols_stage, eq->wpc64));
+        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D));
+        CHK(pbwtamd_pass_advance(eq, eq->cols_stage, eq->wpc, nb, navail, PBWTAMD_OPT_SORTED));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipStreamSynchronize(eq->stream));
+        const int *A = ringA(e, e->ring ^ 1), *D = ringD(e, e->ring ^ 1), *AQ = ringA(eq, eq->ring ^ 1);
+        dim3 g1(std::min(64, (e->wpc64 + WAVES - 1) / WAVES), nb);
+        hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, st, A, e->strideA, Mp, e->ycols, e->wpc64);
+        hipLaunchKernelGGL(qs_rankdir_kernel, dim3(nb), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, Mp, rankdir);
+        hipLaunchKernelGGL(qs_unsort_kernel, dim3(std::min(qblocks, 64), nb), dim3(BLOCK), 0, st, AQ, eq->strideA, Mq, xq, invq);
+        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * (size_t)nb * Mq, st));
+        QSweepArgs g;
+        g.A = A; g.D = D; g.strideA = e->strideA; g.strideD = e->strideD; g.ycols = e->ycols; g.wpc64 = e->wpc64;
+        g.rankdir = rankdir; g.xq = xq; g.invq = invq; g.Mp = Mp; g.Mq = Mq; g.kbase = done; g.nsites = nb;
+        g.f_in = fst[cur]; g.dq_in = dst[cur]; g.f_out = fst[cur ^ 1]; g.dq_out = dst[cur ^ 1];
+        g.cnt = cnt; g.recs = nullptr; g.tot = tot;
+        hipLaunchKernelGGL((qs_sweep_kernel<0>), dim3(qblocks), dim3(BLOCK), 0, st, g);
+        hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, cnt, (size_t)nb * Mq, tot + 3, 0ULL);
+        HIPCHK(hipGetLastError());
+        unsigned long long total = 0;
+        HIPCHK(hipMemcpyAsync(&total, tot + 3, sizeof total, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (total) {
+            CHK(ensure_recs((size_t)total));
+            g.recs = recs;
+            hipLaunchKernelGGL((qs_sweep_kernel<1>), dim3(qblocks), dim3(BLOCK), 0, st, g);
+            HIPCHK(hipGetLastError());
+            CHK(deliver_records(e, st, recs, (size_t)total, all, report));
+        }
+        cur ^= 1;
+        done += nb;
+    }
+    // matches still open at the end of the panel, in final query order (pbwtMatch.c:430-436)
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipStreamSynchronize(eq->stream));
+    {
+        const int *A = ringA(e, e->ring), *D = ringD(e, e->ring), *AQ = ringA(eq, eq->ring);
+        hipLaunchKernelGGL((qs_tail_kernel<0>), dim3(qblocks), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, (const int *)fst[cur], (const int *)dst[cur], cnt, (int4 *)nullptr, tot);
+        hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, cnt, (size_t)Mq, tot + 3, 0ULL);
+        HIPCHK(hipGetLastError());
+        unsigned long long total = 0;
+        HIPCHK(hipMemcpyAsync(&total, tot + 3, sizeof total, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        CHK(ensure_recs((size_t)total));
+        hipLaunchKernelGGL((qs_tail_kernel<1>), dim3(qblocks), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, (const int *)fst[cur], (const int *)dst[cur], cnt, recs, tot);
+        HIPCHK(hipGetLastError());
+        CHK(deliver_records(e, st, recs, (size_t)total, all, report));
+    }
+    unsigned long long htot[4];
+    HIPCHK(hipMemcpy(htot, tot, sizeof htot, hipMemcpyDeviceToHost));
+    if (tot_out) { tot_out[0] = (int64_t)htot[0]; tot_out[1] = (int64_t)htot[1]; }
+    if (n_nomatch) *n_nomatch = (int64_t)htot[2];
+    CHK(pbwtamd_pass_end(e, 0));
+    CHK(pbwtamd_pass_end(eq, 0));
+    if (recs_out) {
+        pbwtamd_match *buf = (pbwtamd_match *)malloc(std::max<size_t>(1, all.size()) * sizeof(pbwtamd_match));
+        if (!buf) return fail("pbwtamd_match_sweep: out of host memory");
+        if (!all.empty()) memcpy(buf, all.data(), all.size() * sizeof(pbwtamd_match));
+        *recs_out = buf; *nrecs_out = (int64_t)all.size();
+    }
+    return 0;
 }

@@ -833,4 +833,142 @@ __global__ __launch_bounds__(BLOCK) void dec_expand_kernel(const uint8_t *z, con
     if (threadIdx.x == 0 && s_carry != M) atomicExch(err, 3);
 }
 
+// ---------------------------------------------------------------------------------------------
+// matchSequencesSweep (pbwtMatch.c:363-443): Q query haplotypes against the panel.
+// Per batch: the panel chain (SORTED, WITH_D) and the query chain (SORTED, A only) fill their ring
+// slots; then for the batch's sites
+//   qs_unsort  : query alleles back to original query order + each query's rank in the query PBWT
+//                order (the reference iterates queries in that order, which fixes the report order)
+//   qs_rankdir : zero-prefix directory of the panel column (pbwtCursorCalculateU, pbwtCore.c:510)
+//   qs_sweep   : one thread per query walks the batch's sites with its (f, d) state
+__global__ __launch_bounds__(BLOCK) void qs_unsort_kernel(const int *AQ, size_t strideAQ, int Mq, unsigned char *xq, int *invq) {
+    const int s = blockIdx.y;
+    const int *aq = AQ + (size_t)s * strideAQ;
+    for (int j = blockIdx.x * BLOCK + threadIdx.x; j < Mq; j += gridDim.x * BLOCK) {
+        const int v = aq[j];
+        const int jj = v & AMASK;
+        xq[(size_t)s * Mq + jj] = (unsigned char)((unsigned)v >> 31);
+        invq[(size_t)s * Mq + jj] = j;
+    }
+}
+
+// rankdir[s][w] = zeros in positions [0, 64 w) of the panel column; rankdir[s][wpc64] = c
+__global__ __launch_bounds__(BLOCK) void qs_rankdir_kernel(const unsigned long long *ycols, int wpc64, int M, int *rankdir) {
+    __shared__ int s_w[WAVES];
+    __shared__ int s_carry;
+    const int s = blockIdx.x;
+    const unsigned long long *y = ycols + (size_t)s * wpc64;
+    int *rd = rankdir + (size_t)s * (wpc64 + 1);
+    const int nw = (M + 63) / 64;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int b = 0; b < wpc64; b += BLOCK) {
+        const int wd = b + threadIdx.x;
+        int z = 0;
+        if (wd < nw) z = min(64, M - wd * 64) - __popcll(y[wd]);
+        const int inc = wave_iscan_sum(z);
+        if (lane_id() == 63) s_w[wave_id()] = inc;
+        __syncthreads();
+        int pre = s_carry, tot = 0;
+        for (int q = 0; q < WAVES; ++q) { if (q < wave_id()) pre += s_w[q]; tot += s_w[q]; }
+        if (wd < wpc64) rd[wd] = pre + inc - z;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rd[wpc64] = s_carry;
+}
+
+struct QSweepArgs {
+    const int *A; const int *D; size_t strideA, strideD;     // panel ring slots of the batch
+    const unsigned long long *ycols; int wpc64;              // panel sorted bit columns of the batch
+    const int *rankdir;                                      // [site][wpc64+1]
+    const unsigned char *xq; const int *invq;                // [site][Mq]
+    int Mp, Mq, kbase, nsites;
+    const int *f_in; const int *dq_in; int *f_out; int *dq_out;
+    unsigned long long *cnt;                                 // [site][Mq] in query-PBWT order: counts / exclusive offsets
+    int4 *recs;
+    unsigned long long *tot;                                 // [0] nTot [1] totLen [2] no-match events
+};
+
+// MODE 0: count reports per (site, query rank), accumulate totals, write the new state;
+// MODE 1: emit records at the scanned offsets (state is recomputed, not stored).
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void qs_sweep_kernel(QSweepArgs g) {
+    const int jj = blockIdx.x * BLOCK + threadIdx.x;
+    if (jj >= g.Mq) return;
+    const int M = g.Mp;
+    int f = g.f_in[jj], dq = g.dq_in[jj];
+    unsigned long long nTot = 0, totLen = 0, nomatch = 0;
+    for (int s = 0; s < g.nsites; ++s) {
+        const int k = g.kbase + s;
+        const int *a = g.A + (size_t)s * g.strideA;
+        const int *d = g.D + (size_t)s * g.strideD;
+        const unsigned long long *yc = g.ycols + (size_t)s * g.wpc64;
+        const unsigned x = g.xq[(size_t)s * g.Mq + jj];
+#define PY(i) ((unsigned)((yc[(i) >> 6] >> ((i) & 63)) & 1ULL))
+        if (PY(f) != x) {
+            int iPlus = f;
+            bool found = false;
+            while (++iPlus < M && d[iPlus] <= dq)                     // pbwtMatch.c:381-383
+                if (PY(iPlus) == x) { f = iPlus; found = true; break; }
+            if (!found) {
+                const int n = iPlus - f;                              // pbwtMatch.c:385-386
+                const size_t slot = (size_t)s * g.Mq + g.invq[(size_t)s * g.Mq + jj];
+                if (MODE == 0) { g.cnt[slot] = (unsigned long long)n; nTot += n; totLen += (unsigned long long)(k - dq) * n; }
+                else { int4 *o = g.recs + g.cnt[slot]; for (int i = f; i < iPlus; ++i) *o++ = make_int4(jj, a[i] & AMASK, dq, k); }
+                int iMinus = f;
+                int dPlus = (iPlus < M) ? d[iPlus] : k;
+                int dMinus = d[iMinus];
+                for (;;) {                                            // pbwtMatch.c:389-411
+                    if (dMinus <= dPlus) {
+                        int hit = -1;
+                        while (d[iMinus] <= dMinus) { --iMinus; if (PY(iMinus) == x) hit = iMinus; }
+                        if (hit >= 0) { f = hit; dq = dMinus; break; }
+                        dMinus = d[iMinus];
+                    } else {
+                        bool got = false;
+                        while (iPlus < M && d[iPlus] <= dPlus) {
+                            if (PY(iPlus) == x) { f = iPlus; dq = dPlus; got = true; break; }
+                            ++iPlus;
+                        }
+                        if (got) break;
+                        dPlus = (iPlus == M) ? k : d[iPlus];
+                        if (!iMinus && iPlus == M) { ++nomatch; dq = k + 1; break; }
+                    }
+                }
+            }
+        }
+#undef PY
+        // pbwtCursorMap (pbwt.h:130-131) with the f == M trap of pbwtMatch.c:422
+        const int *rd = g.rankdir + (size_t)s * (g.wpc64 + 1);
+        const unsigned long long wdv = yc[f >> 6];
+        const int uf = rd[f >> 6] + ((f & 63) - __popcll(wdv & ((1ULL << (f & 63)) - 1ULL)));
+        const int c = rd[g.wpc64];
+        f = x ? c + f - uf : uf;
+        if (f == M) f = 0;
+    }
+    if (MODE == 0) {
+        g.f_out[jj] = f; g.dq_out[jj] = dq;
+        if (nTot) { atomicAdd(g.tot, nTot); atomicAdd(g.tot + 1, totLen); }
+        if (nomatch) atomicAdd(g.tot + 2, nomatch);
+    }
+}
+
+// matches still running at the end of the panel (pbwtMatch.c:430-436), in final query order
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void qs_tail_kernel(const int *A, const int *D, const int *AQ, int Mp, int Mq, int N,
+                                                       const int *f, const int *dq, unsigned long long *cnt, int4 *recs,
+                                                       unsigned long long *tot) {
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= Mq) return;
+    const int jj = AQ[j] & AMASK;
+    const int f0 = f[jj], d0 = dq[jj];
+    int i = f0;
+    while (++i < Mp && D[i] <= d0) {}
+    const int n = i - f0;
+    if (MODE == 0) { cnt[j] = (unsigned long long)n; atomicAdd(tot, (unsigned long long)n); atomicAdd(tot + 1, (unsigned long long)(N - d0) * n); }
+    else { int4 *o = recs + cnt[j]; for (int q = f0; q < i; ++q) *o++ = make_int4(jj, A[q] & AMASK, d0, N); }
+}
+
 }  // namespace pbwtk

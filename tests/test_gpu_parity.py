@@ -164,3 +164,32 @@ def test_device_pass_api_with_graph(amd, orc):
     assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
     ms, n = eng.chain_timing()
     assert n == N and ms > 0
+
+
+@pytest.mark.parametrize("path", golden_panels(), ids=os.path.basename)
+def test_match_sweep_golden(amd, orc, path):
+    """matchSequencesSweep records, in the reference's callback order, for the held-out query split"""
+    g = np.load(path)
+    M, N, Mq = int(g["M"]), int(g["N"]), int(g["Mq"])
+    eng = amd.Engine(M - Mq, batch_sites=37)
+    recs, nomatch, tot = eng.match_sweep(g["pz"], N, g["qz"], Mq)
+    assert np.array_equal(recs, g["qrecs"])
+    _, o_nomatch, o_tot = orc.match_sweep(g["pz"], M - Mq, g["qz"], Mq, N)
+    assert nomatch == o_nomatch and tuple(tot) == tuple(o_tot)
+
+
+@pytest.mark.parametrize("Mp,Mq,N,kind,batch", [(1, 3, 20, 1, 8), (5, 1, 40, 1, 16), (700, 90, 300, 0, 64), (3000, 400, 500, 0, 128),
+                                               (2100, 300, 260, 1, 100)])
+def test_match_sweep_vs_oracle(amd, orc, Mp, Mq, N, kind, batch):
+    bits = orc.synth_bitcols(Mp + Mq, N, seed=31 + Mp, kind=kind)
+    hap = orc.unpack_bitcols(bits, Mp + Mq)
+    pz = orc.build_bitcols(orc.pack_bitcols(hap[:, :Mp]), Mp, with_d=False)["yz"]
+    qz = orc.build_bitcols(orc.pack_bitcols(hap[:, Mp:]), Mq, with_d=False)["yz"]
+    want, w_nomatch, w_tot = orc.match_sweep(pz, Mp, qz, Mq, N)
+    eng = amd.Engine(Mp, batch_sites=batch)
+    recs, nomatch, tot = eng.match_sweep(pz, N, qz, Mq)
+    assert np.array_equal(recs, want)
+    assert nomatch == w_nomatch and tuple(tot) == tuple(w_tot)
+    got = []
+    eng.match_sweep(pz, N, qz, Mq, callback=lambda a, b, s, e: got.append((a, b, s, e)))
+    assert got == [tuple(r) for r in want.tolist()]
