@@ -73,10 +73,16 @@ int pbwtamd_build(pbwtamd_engine *e, const uint32_t *bitcols, int wpc, int N, in
  *   csum_a/csum_d/csum_y [N+1] : order-sensitive checksums of a (M), d (M+1), y (M) at each k
  *                                (sum_i splitmix64(i<<32 | v[i]); y is all-zero at k=N here,
  *                                the reference leaves it stale)
- *   dump_sites[ndump]          : sites whose full a (ndump*M), d (ndump*(M+1)) are copied out */
+ *   dump_sites[ndump]          : sites whose full a (ndump*M), d (ndump*(M+1)) and y (ndump*M
+ *                                bytes, NULL to skip) are copied out — what exportSiteInfo
+ *                                (pbwtMain.c:82-100) prints */
 int pbwtamd_sweep_AD(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart,
                      uint64_t *csum_a, uint64_t *csum_d, uint64_t *csum_y,
-                     const int32_t *dump_sites, int ndump, int32_t *a_dump, int32_t *d_dump);
+                     const int32_t *dump_sites, int ndump, int32_t *a_dump, int32_t *d_dump, uint8_t *y_dump);
+
+/* -haps: pbwtWriteHaplotypes (pbwtIO.c:839-857) without the text formatting: out[k*M + h] = allele
+ * (0/1) of haplotype h at site k, recovered by a forward sweep of the packed panel */
+int pbwtamd_haplotypes(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart, uint8_t *out);
 
 /* matchMaximalWithin (pbwtMatch.c:115-142): all set-maximal matches within the panel.
  * Exactly one of the three sinks is used:

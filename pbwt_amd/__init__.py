@@ -8,4 +8,4 @@ library) raises.
 """
 from .api import Engine, PbwtAmdError, lib_path, load_library, wpc_for, MATCH_DTYPE  # noqa: F401
 from .api import OPT_WITH_D, OPT_SORTED, OPT_WITHIN_HIST, OPT_CHECKSUM, OPT_PACK3, OPT_WITHIN_RECS  # noqa: F401
-from .build import build_library  # noqa: F401
+from .build import build_library, build_cli  # noqa: F401

@@ -127,10 +127,19 @@ class Engine:
         ds = np.asarray(list(dump_sites), dtype=np.int32)
         a_dump = np.zeros((len(ds), self.M), np.int32)
         d_dump = np.zeros((len(ds), self.M + 1), np.int32)
+        y_dump = np.zeros((len(ds), self.M), np.uint8)
         self._chk(self._L.pbwtamd_sweep_AD(self._h, _p(yz, C.c_uint8), C.c_int64(yz.size), C.c_int(N), _p(aF, C.c_int32),
                                            _p(ca, C.c_uint64), _p(cd, C.c_uint64), _p(cy, C.c_uint64),
-                                           _p(ds, C.c_int32), C.c_int(len(ds)), _p(a_dump, C.c_int32), _p(d_dump, C.c_int32)))
-        return dict(csum_a=ca, csum_d=cd, csum_y=cy, a_dump=a_dump, d_dump=d_dump)
+                                           _p(ds, C.c_int32), C.c_int(len(ds)), _p(a_dump, C.c_int32), _p(d_dump, C.c_int32),
+                                           _p(y_dump, C.c_uint8)))
+        return dict(csum_a=ca, csum_d=cd, csum_y=cy, a_dump=a_dump, d_dump=d_dump, y_dump=y_dump)
+
+    def haplotypes(self, yz, N, aFstart=None):
+        yz = np.ascontiguousarray(yz, dtype=np.uint8)
+        aF = _i32(aFstart)
+        out = np.zeros((N, self.M), np.uint8)
+        self._chk(self._L.pbwtamd_haplotypes(self._h, _p(yz, C.c_uint8), C.c_int64(yz.size), C.c_int(N), _p(aF, C.c_int32), _p(out, C.c_uint8)))
+        return out
 
     def max_within(self, yz, N, aFstart=None, mode="records", callback=None):
         """mode 'records' -> structured array in callback order; 'hist' -> int64[N+1];

@@ -29,5 +29,25 @@ def build_library(force=False, verbose=False):
     return OUT
 
 
+CLI_OUT = os.path.join(_HERE, "pbwt")
+CLI_SRC = ["host/pbwt_cli.c", "host/pbwt_host.c"]
+
+
+def build_cli(force=False, verbose=False):
+    """the host C side: `pbwt_amd/pbwt`, the reference's CLI grammar over the C ABI (gcc, plain C)"""
+    build_library(force=False)
+    deps = CLI_SRC + ["host/pbwt_host.h", "../include/pbwt_amd.h"]
+    if not force and os.path.exists(CLI_OUT) and all(os.path.getmtime(os.path.join(_HERE, d)) <= os.path.getmtime(CLI_OUT) for d in deps) \
+            and os.path.getmtime(OUT) <= os.path.getmtime(CLI_OUT):
+        return CLI_OUT
+    cmd = ["gcc", "-O2", "-std=gnu11", "-Wall", "-o", CLI_OUT] + [os.path.join(_HERE, s) for s in CLI_SRC] + \
+          ["-L" + _HERE, "-lpbwtgpu", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CLI_OUT
+
+
 if __name__ == "__main__":
+    build_cli(force=True, verbose=True)
     build_library(force=True, verbose=True)

@@ -32,6 +32,17 @@ static int fail(const char *fmt, ...) {
 #define CHK(expr) do { int _r = (expr); if (_r) return _r; } while (0)
 
 // ------------------------------------------------------------------------------------ engine
+// small RAII holder for temporary device buffers
+struct DevBufs {
+    std::vector<void *> v;
+    ~DevBufs() { for (void *p : v) if (p) (void)hipFree(p); }
+    template <typename T> int alloc(T **out, size_t n) {
+        void *p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return fail("hipMalloc(%zu) failed", n * sizeof(T));
+        v.push_back(p); *out = (T *)p; return 0;
+    }
+};
+
 struct GraphKey { int with_d, sorted, ring; hipGraphExec_t exec; };
 struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; };
 
@@ -344,6 +355,18 @@ static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites
     return 0;
 }
 
+// first site of a pass: tag slot 0 with that site's alleles and build its tile summaries
+static int ensure_prepared(pbwtamd_engine *e, const uint32_t *col, bool sorted, bool with_d) {
+    if (e->prepared) return 0;
+    PrepArgs p;
+    p.a = ringA(e, e->ring); p.d = ringD(e, e->ring); p.col = col; p.summ = e->summ; p.k = e->k_cur; p.M = e->M; p.W = e->W;
+    p.wpad = e->wpad; p.T = e->T; p.sorted = sorted; p.with_d = with_d; p.has_col = 1;
+    hipLaunchKernelGGL(prepare_kernel, dim3(e->W), dim3(BLOCK), 0, e->stream, p);
+    HIPCHK(hipGetLastError());
+    e->prepared = true; e->summ_cur = 0;
+    return 0;
+}
+
 // batch consumers (checksums, maxWithin sweep, pack3) of the pending batch, on the second stream so
 // they overlap the next batch's launch chain (which occupies only ~W of the 256 CUs)
 static int flush_pending(pbwtamd_engine *e) {
@@ -383,14 +406,7 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         const uint32_t *bc = cols + (size_t)done * wpc;
         const int r = e->ring;
         int *A = ringA(e, r), *D = ringD(e, r);
-        if (!e->prepared) {
-            PrepArgs p;
-            p.a = A; p.d = D; p.col = bc; p.summ = e->summ; p.k = e->k_cur; p.M = e->M; p.W = e->W;
-            p.wpad = e->wpad; p.T = e->T; p.sorted = sorted; p.with_d = with_d; p.has_col = 1;
-            hipLaunchKernelGGL(prepare_kernel, dim3(e->W), dim3(BLOCK), 0, e->stream, p);
-            HIPCHK(hipGetLastError());
-            e->prepared = true; e->summ_cur = 0;
-        }
+        CHK(ensure_prepared(e, bc, sorted, with_d));
         hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(256), 0, e->stream, e->ctlblk, e->k_cur, e->n_total, bc, e->summ, e->wpad, e->summ_cur);
         e->summ_cur = nb % 3;
         HIPCHK(hipGetLastError());
@@ -599,8 +615,19 @@ static int packed_expand(pbwtamd_engine *e, hipStream_t st, const Packed &pk, in
 }
 
 // drive a read-side pass over a packed panel; per batch decode -> ycols -> chain (+consumers)
+static int get_state_y(pbwtamd_engine *e, uint8_t *y) {
+    CHK(flush_pending(e));
+    HIPCHK(hipStreamSynchronize(e->s2));
+    unsigned char *tmp = (unsigned char *)e->ycols;
+    hipLaunchKernelGGL(tags_to_bytes_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, (const int *)ringA(e, e->ring), tmp, e->M);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(y, tmp, (size_t)e->M, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
 static int sweep_packed(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart, unsigned opts,
-                        const int32_t *dump_sites, int ndump, int32_t *a_dump, int32_t *d_dump) {
+                        const int32_t *dump_sites, int ndump, int32_t *a_dump, int32_t *d_dump, uint8_t *y_dump = nullptr) {
     Packed pk;
     CHK(packed_upload(e, e->stream, e->M, yz, nz, N, pk));
     CHK(pbwtamd_pass_begin(e, aFstart, 0, N));
@@ -609,6 +636,7 @@ static int sweep_packed(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N,
     auto dump_at = [&](int k) -> int {
         for (int q = 0; q < ndump; ++q) if (dump_sites[q] == k) {
             CHK(pbwtamd_get_state(e, a_dump + (size_t)q * e->M, d_dump ? d_dump + (size_t)q * (e->M + 1) : nullptr));
+            if (y_dump) CHK(get_state_y(e, y_dump + (size_t)q * e->M));
         }
         return 0;
     };
@@ -617,7 +645,6 @@ static int sweep_packed(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N,
     while (done < N) {
         int nb = std::min(e->B, N - done);
         if (any_dump) {                                      // stop at the next dump site
-            CHK(dump_at(done));
             int nxt = N + 1;
             for (int q = 0; q < ndump; ++q) if (dump_sites[q] > done && dump_sites[q] < nxt) nxt = dump_sites[q];
             nb = std::min(nb, nxt - done);
@@ -625,6 +652,10 @@ static int sweep_packed(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N,
         const int navail = std::min(nb + 1, N - done);
         // decode straight into the column staging buffer (ycols is scratch for pack3/get_state)
         CHK(packed_expand(e, e->stream, pk, e->M, done, navail, (unsigned long long *)e->cols_stage, e->wpc64));
+        if (any_dump) {
+            CHK(ensure_prepared(e, e->cols_stage, true, true));   // tags of the first site exist before it is dumped
+            CHK(dump_at(done));
+        }
         CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, opts));
         done += nb;
     }
@@ -635,10 +666,10 @@ static int sweep_packed(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N,
 
 extern "C" int pbwtamd_sweep_AD(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart,
                                 uint64_t *csum_a, uint64_t *csum_d, uint64_t *csum_y,
-                                const int32_t *dump_sites, int ndump, int32_t *a_dump, int32_t *d_dump) {
+                                const int32_t *dump_sites, int ndump, int32_t *a_dump, int32_t *d_dump, uint8_t *y_dump) {
     HIPCHK(hipSetDevice(e->device));
     const unsigned opts = (csum_a || csum_d || csum_y) ? PBWTAMD_OPT_CHECKSUM : 0u;
-    CHK(sweep_packed(e, yz, nz, N, aFstart, opts, dump_sites, ndump, a_dump, d_dump));
+    CHK(sweep_packed(e, yz, nz, N, aFstart, opts, dump_sites, ndump, a_dump, d_dump, y_dump));
     if (opts) CHK(pbwtamd_get_checksums(e, 0, N + 1, csum_a, csum_d, csum_y));
     return 0;
 }
@@ -665,6 +696,32 @@ extern "C" int pbwtamd_max_within(pbwtamd_engine *e, const uint8_t *yz, int64_t 
         *recs_out = buf; *nrecs_out = (int64_t)recs.size();
     }
     return 0;
+}
+
+// -haps (pbwtWriteHaplotypes, pbwtIO.c:839-857): the panel's alleles in original haplotype order,
+// out[k*M + h] = 0/1, from a forward A-only sweep of the packed panel
+extern "C" int pbwtamd_haplotypes(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart, uint8_t *out) {
+    HIPCHK(hipSetDevice(e->device));
+    Packed pk;
+    CHK(packed_upload(e, e->stream, e->M, yz, nz, N, pk));
+    CHK(pbwtamd_pass_begin(e, aFstart, 0, N));
+    DevBufs bufs;
+    unsigned char *dout;
+    CHK(bufs.alloc(&dout, (size_t)e->B * e->M));
+    for (int done = 0; done < N;) {
+        const int nb = std::min(e->B, N - done);
+        const int navail = std::min(nb + 1, N - done);
+        CHK(packed_expand(e, e->stream, pk, e->M, done, navail, (unsigned long long *)e->cols_stage, e->wpc64));
+        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, PBWTAMD_OPT_SORTED));
+        const int *A = ringA(e, e->ring ^ 1);
+        dim3 grid(std::min(64, (e->M + BLOCK - 1) / BLOCK), nb);
+        hipLaunchKernelGGL(unsort_alleles_kernel, grid, dim3(BLOCK), 0, e->stream, A, e->strideA, e->M, dout);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(out + (size_t)done * e->M, dout, (size_t)nb * e->M, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        done += nb;
+    }
+    return pbwtamd_pass_end(e, PBWTAMD_OPT_SORTED);
 }
 
 extern "C" int pbwtamd_pack3(pbwtamd_engine *e, const uint32_t *sorted_bitcols, int wpc, int N, uint8_t **yz_out, int64_t *nz_out) {
@@ -710,17 +767,6 @@ extern "C" int pbwtamd_unpack3(pbwtamd_engine *e, const uint8_t *yz, int64_t nz,
     }
     return pbwtamd_sync(e);
 }
-
-// small RAII holder for temporary device buffers
-struct DevBufs {
-    std::vector<void *> v;
-    ~DevBufs() { for (void *p : v) if (p) (void)hipFree(p); }
-    template <typename T> int alloc(T **out, size_t n) {
-        void *p = nullptr;
-        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return fail("hipMalloc(%zu) failed", n * sizeof(T));
-        v.push_back(p); *out = (T *)p; return 0;
-    }
-};
 
 static int deliver_records(pbwtamd_engine *e, hipStream_t st, const int4 *drecs, size_t total, std::vector<pbwtamd_match> &all, pbwtamd_report_fn report) {
     if (!total) return 0;

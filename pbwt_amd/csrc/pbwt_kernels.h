@@ -547,6 +547,21 @@ __global__ __launch_bounds__(BLOCK) void checksum_kernel(const int *A, const int
     }
 }
 
+// alleles back to original haplotype order (pbwtWriteHaplotypes, pbwtIO.c:845: hap[a[j]] = y[j]);
+// grid (tiles, sites); out[site][hap] = 0/1
+__global__ __launch_bounds__(BLOCK) void unsort_alleles_kernel(const int *A, size_t strideA, int M, unsigned char *out) {
+    const int s = blockIdx.y;
+    const int *a = A + (size_t)s * strideA;
+    for (int j = blockIdx.x * BLOCK + threadIdx.x; j < M; j += gridDim.x * BLOCK) {
+        const int v = a[j];
+        out[(size_t)s * M + (v & AMASK)] = (unsigned char)((unsigned)v >> 31);
+    }
+}
+__global__ void tags_to_bytes_kernel(const int *a, unsigned char *out, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) out[i] = (unsigned char)((unsigned)a[i] >> 31);
+}
+
 // strip tags: out[i] = a[i] & AMASK
 __global__ void untag_kernel(const int *a, int *out, int M) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

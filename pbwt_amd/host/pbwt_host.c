@@ -1,0 +1,363 @@
+/* pbwt_host.c — see pbwt_host.h.  File formats + glue; all panel-wide computation is in libpbwtgpu. */
+#include "pbwt_host.h"
+#include <ctype.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/resource.h>
+#include <sys/time.h>
+
+FILE *logFile ;
+int isCheck = 0, isStats = 0 ;
+
+void die (const char *format, ...)
+{
+  va_list args ;
+  va_start (args, format) ;
+  fprintf (stderr, "FATAL ERROR: ") ;
+  vfprintf (stderr, format, args) ;
+  fprintf (stderr, "\n") ;
+  va_end (args) ;
+  timeUpdate (stderr) ;
+  exit (-1) ;
+}
+
+static void *xalloc (size_t n)
+{ void *p = calloc (n ? n : 1, 1) ; if (!p) die ("out of memory allocating %zu bytes", n) ; return p ; }
+
+/* user/system time and memory lines after every command (utils.c:173-198) */
+void timeUpdate (FILE *f)
+{
+  static int isFirst = 1 ;
+  static struct rusage rOld ;
+  struct rusage rNew ;
+  getrusage (RUSAGE_SELF, &rNew) ;
+  if (!isFirst)
+    { double u = (rNew.ru_utime.tv_sec - rOld.ru_utime.tv_sec) + 1e-6 * (rNew.ru_utime.tv_usec - rOld.ru_utime.tv_usec) ;
+      double s = (rNew.ru_stime.tv_sec - rOld.ru_stime.tv_sec) + 1e-6 * (rNew.ru_stime.tv_usec - rOld.ru_stime.tv_usec) ;
+      fprintf (f, "user\t%.6f\tsystem\t%.6f\tmax_RSS\t%ld\n", u, s, rNew.ru_maxrss) ;
+    }
+  else isFirst = 0 ;
+  rOld = rNew ;
+}
+
+/* one engine per panel width, created on first use; failure is fatal (no CPU fallback) */
+static pbwtamd_engine *engineFor (int M)
+{
+  static pbwtamd_engine *e = 0 ; static int Mcur = 0 ;
+  if (e && Mcur != M) { pbwtamd_engine_destroy (e) ; e = 0 ; }
+  if (!e && pbwtamd_engine_create (&e, 0, M, 0, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+  Mcur = M ;
+  return e ;
+}
+
+Panel *panelCreate (int M, int N)
+{
+  Panel *p = xalloc (sizeof (Panel)) ;
+  if (M <= 0 || N < 0) die ("pbwtCreate called with bad M %d or N %d", M, N) ;
+  p->M = M ; p->N = N ;
+  p->aFstart = xalloc (sizeof (int) * M) ;
+  for (int i = 0 ; i < M ; ++i) p->aFstart[i] = i ;
+  return p ;
+}
+
+void panelDestroy (Panel *p)
+{
+  if (!p) return ;
+  if (p->sites) { for (int i = 0 ; i < p->N ; ++i) free (p->sites[i].var) ; free (p->sites) ; }
+  free (p->chrom) ; free (p->yz) ; free (p->aFstart) ; free (p->aFend) ; free (p) ;
+}
+
+/* .pbwt: "PBW3", int M, int N, aFstart[M], aFend[M], long nz, 4 pad bytes, yz[nz] (pbwtIO.c:33-57).
+ * Reader also takes PBW2 (int nz, no pad), PBWT (no index arrays) and GBWT (pbwtIO.c:182-208). */
+void panelWrite (Panel *p, FILE *fp)
+{
+  if (!p || !p->yz) die ("pbwtWrite called without a valid pbwt") ;
+  if (!p->aFstart || !p->aFend) die ("pbwtWrite called without start and end indexes") ;
+  long n = (long) p->nz ;
+  if (fwrite ("PBW3", 1, 4, fp) != 4 || fwrite (&p->M, sizeof (int), 1, fp) != 1 || fwrite (&p->N, sizeof (int), 1, fp) != 1
+      || fwrite (p->aFstart, sizeof (int), p->M, fp) != (size_t) p->M || fwrite (p->aFend, sizeof (int), p->M, fp) != (size_t) p->M
+      || fwrite (&n, sizeof (long), 1, fp) != 1 || fwrite ("    ", 1, 4, fp) != 4
+      || fwrite (p->yz, 1, (size_t) n, fp) != (size_t) n)
+    die ("error writing PBWT in pbwtWrite") ;
+  fprintf (logFile, "written %ld chars pbwt: M, N are %d, %d\n", n, p->M, p->N) ;
+}
+
+Panel *panelRead (FILE *fp)
+{
+  char tag[5] = "test", pad[4] ;
+  int m, n, version ;
+  long nz ;
+  if (fread (tag, 1, 4, fp) != 4) die ("failed to read 4 char tag - is file readable?") ;
+  if (!strcmp (tag, "PBW3")) version = 3 ;
+  else if (!strcmp (tag, "PBW2")) version = 2 ;
+  else if (!strcmp (tag, "PBWT")) version = 1 ;
+  else if (!strcmp (tag, "GBWT")) version = 0 ;
+  else die ("failed to recognise file type %s in pbwtRead - was it written by pbwt?", tag) ;
+  if (fread (&m, sizeof (int), 1, fp) != 1) die ("error reading m in pbwtRead") ;
+  if (fread (&n, sizeof (int), 1, fp) != 1) die ("error reading n in pbwtRead") ;
+  Panel *p = panelCreate (m, n) ;
+  if (version > 1)
+    { if (fread (p->aFstart, sizeof (int), m, fp) != (size_t) m) die ("error reading aFstart in pbwtRead") ;
+      p->aFend = xalloc (sizeof (int) * m) ;
+      if (fread (p->aFend, sizeof (int), m, fp) != (size_t) m) die ("error reading aFend in pbwtRead") ;
+    }
+  if (version <= 2)
+    { int nn ; if (fread (&nn, sizeof (int), 1, fp) != 1) die ("error reading pbwt file") ; nz = nn ; }
+  else if (fread (&nz, sizeof (long), 1, fp) != 1 || fread (pad, 1, 4, fp) != 4) die ("error reading pbwt file") ;
+  p->yz = xalloc ((size_t) nz) ; p->nz = nz ;
+  if (fread (p->yz, 1, (size_t) nz, fp) != (size_t) nz) die ("error reading data in pbwt file") ;
+  fprintf (logFile, "read pbwt %s file with %ld bytes: M, N are %d, %d\n", tag, nz, p->M, p->N) ;
+  return p ;
+}
+
+/* .sites: "chrom\tpos\tvariation" per site (pbwtIO.c:59-77); glibc prints a NULL variation as
+ * "(null)", which is what the reference emits for MaCS panels (no variation dictionary entry) */
+void panelWriteSites (Panel *p, FILE *fp)
+{
+  if (!p || !p->sites) die ("pbwtWriteSites called without sites") ;
+  for (int i = 0 ; i < p->N ; ++i)
+    fprintf (fp, "%s\t%d\t%s\n", p->chrom ? p->chrom : ".", p->sites[i].x, p->sites[i].var ? p->sites[i].var : "(null)") ;
+  if (ferror (fp)) die ("error writing sites file") ;
+  fprintf (logFile, "written %d sites from %d to %d\n", p->N, p->sites[0].x, p->sites[p->N-1].x) ;
+}
+
+void panelReadSites (Panel *p, FILE *fp)
+{
+  if (!p) die ("pbwtReadSites called without a valid pbwt") ;
+  size_t cap = 4096, n = 0, len = 0 ;
+  HostSite *sites = xalloc (cap * sizeof (HostSite)) ;
+  char *line = 0 ;
+  ssize_t got ;
+  int lineNo = 1 ;
+  while ((got = getline (&line, &len, fp)) > 0)
+    { char *s = line ;
+      while (got > 0 && (s[got-1] == '\n' || s[got-1] == '\r')) s[--got] = 0 ;
+      if (!got) continue ;
+      char *tab = strchr (s, '\t') ; if (!tab) tab = strchr (s, ' ') ;
+      if (!tab) die ("bad position line %d in sites file", lineNo) ;
+      *tab = 0 ;
+      if (strcmp (s, "."))		/* readMatchChrom (pbwtIO.c:219-230): match if set, else adopt */
+	{ if (p->chrom && strcmp (p->chrom, s)) die ("failed to match chromosome in sites file: line %d", lineNo) ;
+	  if (!p->chrom) p->chrom = strdup (s) ;
+	}
+      char *q = tab + 1 ;
+      if (!isdigit ((unsigned char) *q)) die ("bad position line %d in sites file", lineNo) ;
+      if (n == cap) { cap *= 2 ; sites = realloc (sites, cap * sizeof (HostSite)) ; }
+      sites[n].x = 0 ; while (isdigit ((unsigned char) *q)) sites[n].x = sites[n].x * 10 + (*q++ - '0') ;
+      sites[n].var = 0 ;
+      if (*q) { while (*q && isspace ((unsigned char) *q)) ++q ; if (*q) sites[n].var = strdup (q) ; }
+      ++n ; ++lineNo ;
+    }
+  free (line) ;
+  if (ferror (fp)) die ("error reading sites file") ;
+  fprintf (logFile, "read %zu sites on chromosome %s from file\n", n, p->chrom ? p->chrom : "(null)") ;
+  if ((int) n != p->N) die ("sites file contains %zu sites not %d as in pbwt", n, p->N) ;
+  p->sites = sites ;
+}
+
+static FILE *fopenTag (const char *root, const char *tag, const char *mode)
+{ char *name = xalloc (strlen (root) + strlen (tag) + 2) ;
+  sprintf (name, "%s.%s", root, tag) ;
+  FILE *f = fopen (name, mode) ; free (name) ; return f ;
+}
+
+void panelWriteAll (Panel *p, const char *root)
+{
+  FILE *fp ;
+  if (!(fp = fopenTag (root, "pbwt", "w"))) die ("failed to open root.%s", "pbwt") ;
+  panelWrite (p, fp) ; fclose (fp) ;
+  if (p->sites) { if (!(fp = fopenTag (root, "sites", "w"))) die ("failed to open root.%s", "sites") ; panelWriteSites (p, fp) ; fclose (fp) ; }
+}
+
+Panel *panelReadAll (const char *root)
+{
+  FILE *fp ; Panel *p ;
+  if ((fp = fopenTag (root, "pbwt", "r"))) { p = panelRead (fp) ; fclose (fp) ; }
+  else die ("failed to open %s.pbwt", root) ;
+  if ((fp = fopenTag (root, "sites", "r"))) { panelReadSites (p, fp) ; fclose (fp) ; }
+  return p ;
+}
+
+/* MaCS text (pbwtIO.c:426-458): "COMMAND: <cmd> M L ...", "SEED: ...", then "SITE: n pos time <M chars>".
+ * The parsed alleles go straight into bit columns; the per-site gather/pack3/partition loop of
+ * pbwtIO.c:477-483 runs on the device (pbwtamd_build). */
+static char *word (FILE *fp, char *buf, int cap)
+{ int c, n = 0 ;
+  while ((c = getc (fp)) != EOF && isgraph (c)) if (n < cap - 1) buf[n++] = (char) c ;
+  while (c != EOF && c != '\n' && !isgraph (c)) c = getc (fp) ;
+  if (c != EOF) ungetc (c, fp) ;
+  buf[n] = 0 ; return buf ;
+}
+
+Panel *panelReadMacs (FILE *fp)
+{
+  char w[256] ;
+  int c ;
+  if (strcmp (word (fp, w, 256), "COMMAND:")) die ("MaCS COMMAND line not found") ;
+  word (fp, w, 256) ;
+  int M = atoi (word (fp, w, 256)) ; if (!M) die ("failed to get M") ;
+  double L = atof (word (fp, w, 256)) ; if (!L) die ("failed to get L") ;
+  while ((c = getc (fp)) != '\n' && c != EOF) ;
+  if (strcmp (word (fp, w, 256), "SEED:")) die ("SEED line not found") ;
+  while ((c = getc (fp)) != '\n' && c != EOF) ;
+
+  Panel *p = panelCreate (M, 0) ;
+  pbwtamd_engine *e = engineFor (M) ;
+  const int wpc = pbwtamd_engine_wpc (e) ;
+  size_t cap = 1024, n = 0 ;
+  uint32_t *cols = xalloc (cap * wpc * sizeof (uint32_t)) ;
+  p->sites = xalloc (cap * sizeof (HostSite)) ;
+  while (!feof (fp) && !strcmp (word (fp, w, 256), "SITE:"))
+    { if (n == cap)
+	{ cap *= 2 ; cols = realloc (cols, cap * wpc * sizeof (uint32_t)) ; p->sites = realloc (p->sites, cap * sizeof (HostSite)) ;
+	  if (!cols || !p->sites) die ("out of memory reading MaCS file") ;
+	}
+      int number = atoi (word (fp, w, 256)) ;
+      p->sites[n].x = (int) (L * atof (word (fp, w, 256))) ; p->sites[n].var = 0 ;
+      word (fp, w, 256) ;				/* the time, ignored */
+      uint32_t *col = cols + n * wpc ;
+      memset (col, 0, wpc * sizeof (uint32_t)) ;
+      for (int h = 0 ; h < M ; ++h) if (getc (fp) == '1') col[h >> 5] |= 1u << (h & 31) ;
+      if (feof (fp)) break ;
+      if (getc (fp) != '\n') die ("end of line error for MaCS SITE %d", number) ;
+      ++n ;
+    }
+  p->N = (int) n ;
+  p->aFend = xalloc (sizeof (int) * M) ;
+  if (pbwtamd_build (e, cols, wpc, p->N, 0, p->aFstart, &p->yz, &p->nz, p->aFend, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+  free (cols) ;
+  fprintf (logFile, "read MaCS file: M, N are\t%d\t%d\n", M, p->N) ;
+  return p ;
+}
+
+void panelWriteHaplotypes (FILE *fp, Panel *p)
+{
+  uint8_t *hap = xalloc ((size_t) p->N * p->M) ;
+  if (pbwtamd_haplotypes (engineFor (p->M), p->yz, p->nz, p->N, p->aFstart, hap)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+  char *line = xalloc ((size_t) p->M + 2) ;
+  for (int i = 0 ; i < p->N ; ++i)
+    { for (int j = 0 ; j < p->M ; ++j) line[j] = hap[(size_t) i * p->M + j] ? '1' : '0' ;
+      line[p->M] = '\n' ; fwrite (line, 1, (size_t) p->M + 1, fp) ;
+    }
+  free (line) ; free (hap) ;
+  fprintf (logFile, "written haplotype file: %d rows of %d\n", p->N, p->M) ;
+}
+
+/* reportMatch (pbwtMatch.c:46-58); -check (checkMatchMaximal, :33-44) against the decoded panel */
+static uint8_t *checkA, *checkB ; static int checkMA, checkMB, checkN ;
+static void reportMatch (int ai, int bi, int start, int end)
+{
+  if (start == end) return ;
+  printf ("MATCH\t%d\t%d\t%d\t%d\t%d\n", ai, bi, start, end, end - start) ;
+  if (isCheck)
+    { (void) checkMA ; (void) checkMB ;
+#define HA(k) checkA[(size_t)(k) * checkMA + ai]
+#define HB(k) checkB[(size_t)(k) * checkMB + bi]
+      if (start && HA(start-1) == HB(start-1)) die ("match not maximal - can extend backwards\n") ;
+      if (end < checkN && HA(end) == HB(end)) die ("match not maximal - can extend forwards\n") ;
+      for (int i = start ; i < end ; ++i) if (HA(i) != HB(i)) die ("match not a match at %d\n", i) ;
+    }
+}
+
+static uint8_t *decodeHaps (Panel *p)
+{ uint8_t *hap = xalloc ((size_t) p->N * p->M) ;
+  if (pbwtamd_haplotypes (engineFor (p->M), p->yz, p->nz, p->N, p->aFstart, hap)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+  return hap ;
+}
+
+void panelLongMatches (Panel *p, int L)
+{
+  if (!p || !p->yz) die ("option -longWithin called without a PBWT") ;
+  if (L != 0) die ("-longWithin L > 0 is not on the accelerated path of this build") ;
+  pbwtamd_engine *e = engineFor (p->M) ;
+  if (isCheck) { checkA = checkB = decodeHaps (p) ; checkMA = checkMB = p->M ; checkN = p->N ; }
+  if (isStats)				/* histogram instead of reports (pbwtMatch.c:130-131,158-178) */
+    { int64_t *h = xalloc (sizeof (int64_t) * ((size_t) p->N + 1)) ;
+      if (pbwtamd_max_within (e, p->yz, p->nz, p->N, p->aFstart, 0, 0, 0, h, p->N + 1)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+      long nTot = 0, hTot = 0 ;
+      for (int i = 0 ; i <= p->N ; ++i)
+	if (h[i]) { nTot += h[i] ; hTot += h[i] * i ; printf ("%d\t%ld\n", i, (long) h[i]) ; }
+      fprintf (logFile, "Average %.1f matches per sample\n", nTot / (double) p->M) ;
+      fprintf (logFile, "Average length %.1f\n", hTot / (double) nTot) ;
+      free (h) ;
+    }
+  else if (pbwtamd_max_within (e, p->yz, p->nz, p->N, p->aFstart, reportMatch, 0, 0, 0, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+  if (isCheck) { free (checkA) ; checkA = checkB = 0 ; }
+}
+
+void panelMatchDynamic (Panel *p, FILE *fp)
+{
+  Panel *q = panelRead (fp) ;
+  if (q->N != p->N) die ("query length in matchSequences %d != PBWT length %d", q->N, p->N) ;
+  if (isCheck) { checkA = decodeHaps (q) ; checkB = decodeHaps (p) ; checkMA = q->M ; checkMB = p->M ; checkN = p->N ; }
+  int64_t nomatch = 0, tot[2] = {0, 0} ;
+  if (pbwtamd_match_sweep (engineFor (p->M), p->yz, p->nz, p->N, p->aFstart, q->M, q->yz, q->nz, q->aFstart,
+			   reportMatch, 0, 0, &nomatch, tot))
+    die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+  fprintf (logFile, "Average number of best matches including alternates %.1f, Average length %.1f, Av number per position %.1f\n",
+	   tot[0] / (double) q->M, tot[1] / (double) tot[0], tot[1] / (double) ((long) q->M * q->N)) ;
+  if (isCheck) { free (checkA) ; free (checkB) ; checkA = checkB = 0 ; }
+  panelDestroy (q) ;
+}
+
+/* number of ones in each packed column: a format-level scan of the run bytes (pbwtCore.c:216-225) */
+static int *onesPerColumn (Panel *p)
+{
+  int *ones = xalloc (sizeof (int) * ((size_t) p->N + 1)) ;
+  int64_t b = 0 ;
+  for (int k = 0 ; k < p->N ; ++k)
+    { int m = 0 ;
+      while (m < p->M && b < p->nz)
+	{ uint8_t z = p->yz[b++] ; int v = z & 0x7f ;
+	  int n = v < 64 ? v : (v < 96 ? (v - 64) << 6 : (v - 96) << 11) ;
+	  if (z & 0x80) ones[k] += n ;
+	  m += n ;
+	}
+    }
+  return ones ;
+}
+
+void panelSiteInfo (Panel *p, FILE *fp, int f1, int f2)
+{
+  int *ones = onesPerColumn (p), n = 0 ;
+  int *sel = xalloc (sizeof (int) * ((size_t) p->N + 1)) ;
+  for (int i = 0 ; i < p->N ; ++i) if (f1 <= ones[i] && ones[i] < f2) sel[n++] = i ;
+  if (n)
+    { int *a = xalloc (sizeof (int) * (size_t) n * p->M), *d = xalloc (sizeof (int) * (size_t) n * (p->M + 1)) ;
+      uint8_t *y = xalloc ((size_t) n * p->M) ;
+      if (pbwtamd_sweep_AD (engineFor (p->M), p->yz, p->nz, p->N, p->aFstart, 0, 0, 0, sel, n, a, d, y)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+      for (int r = 0 ; r < n ; ++r)
+	{ for (int j = 0 ; j < p->M ; ++j) fprintf (fp, "%d %d ", y[(size_t) r * p->M + j], sel[r] - d[(size_t) r * (p->M + 1) + j]) ;
+	  fprintf (fp, "\n") ;
+	}
+      free (a) ; free (d) ; free (y) ;
+    }
+  free (ones) ; free (sel) ;
+  fprintf (logFile, "%d rows exported with allele count f, %d <= f < %d\n", n, f1, f2) ;
+}
+
+/* pbwtSubSample over a contiguous interval (pbwtSample.c:59-108): decode, keep the selected
+ * haplotypes in their original relative order, rebuild */
+Panel *panelSubSampleInterval (Panel *p, int start, int Mnew)
+{
+  if (start < 0 || Mnew <= 0 || start + Mnew > p->M) die ("bad start %d, Mnew %d in subsample", start, Mnew) ;
+  uint8_t *hap = decodeHaps (p) ;
+  Panel *q = panelCreate (Mnew, p->N) ;
+  pbwtamd_engine *e = engineFor (Mnew) ;
+  const int wpc = pbwtamd_engine_wpc (e) ;
+  uint32_t *cols = xalloc ((size_t) p->N * wpc * sizeof (uint32_t)) ;
+  for (int k = 0 ; k < p->N ; ++k)
+    for (int h = 0 ; h < Mnew ; ++h)
+      if (hap[(size_t) k * p->M + start + h]) cols[(size_t) k * wpc + (h >> 5)] |= 1u << (h & 31) ;
+  q->aFend = xalloc (sizeof (int) * Mnew) ;
+  if (pbwtamd_build (e, cols, wpc, q->N, 0, q->aFstart, &q->yz, &q->nz, q->aFend, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+  if (p->chrom) q->chrom = strdup (p->chrom) ;
+  if (p->sites)
+    { q->sites = xalloc (sizeof (HostSite) * (size_t) p->N) ;
+      for (int i = 0 ; i < p->N ; ++i) { q->sites[i].x = p->sites[i].x ; q->sites[i].var = p->sites[i].var ? strdup (p->sites[i].var) : 0 ; }
+    }
+  free (cols) ; free (hap) ;
+  panelDestroy (p) ;
+  return q ;
+}

@@ -93,8 +93,8 @@ def macs_small():
 
 
 if __name__ == "__main__":
+    macs_small()      # first: the reference's global variation dict must still be empty (fresh-process behaviour)
     merge1()
-    macs_small()
     mosaic(8, 10, 3, 1, 2)
     mosaic(70, 150, 11, 1, 10)       # iid, M not a multiple of 64
     mosaic(300, 400, 5, 0, 40)       # founder mosaic

@@ -1,0 +1,115 @@
+"""the host C side: `pbwt_amd/pbwt` speaks the reference's command grammar and file formats.
+CPU tests: format round trips (no device work).  GPU tests: the commands that run the hot path,
+byte-compared with the reference's own outputs (tests/golden) or the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, parse_pbwt
+
+
+@pytest.fixture(scope="module")
+def cli():
+    import pbwt_amd
+    return pbwt_amd.build_cli()
+
+
+def run(cli, *args, check=True):
+    r = subprocess.run([cli] + [str(a) for a in args], capture_output=True, text=True)
+    if check:
+        assert r.returncode == 0, r.stderr
+    return r
+
+
+def test_pbwt_and_sites_roundtrip(cli, tmp_path):
+    out, sites = tmp_path / "o.pbwt", tmp_path / "o.sites"
+    run(cli, "-read", os.path.join(GOLDEN, "merge1.pbwt"), "-readSites", os.path.join(GOLDEN, "merge1.sites"),
+        "-write", out, "-writeSites", sites)
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN, "merge1.pbwt"), "rb").read()
+    assert open(sites).read() == open(os.path.join(GOLDEN, "merge1.sites")).read()
+    root = tmp_path / "all"
+    run(cli, "-read", out, "-readSites", sites, "-writeAll", root)
+    run(cli, "-readAll", root, "-write", tmp_path / "again.pbwt")
+    assert open(tmp_path / "again.pbwt", "rb").read() == open(out, "rb").read()
+
+
+def test_older_pbwt_versions_are_read(cli, tmp_path):
+    """PBW2 (int byte count, no pad) and PBWT (no index arrays) headers (pbwtIO.c:182-208)"""
+    M, N, aFstart, aFend, yz = parse_pbwt(os.path.join(GOLDEN, "merge1.pbwt"))
+    v2 = b"PBW2" + np.array([M, N], "<i4").tobytes() + aFstart.tobytes() + aFend.tobytes() + np.array([len(yz)], "<i4").tobytes() + yz.tobytes()
+    open(tmp_path / "v2.pbwt", "wb").write(v2)
+    run(cli, "-read", tmp_path / "v2.pbwt", "-write", tmp_path / "v3.pbwt")
+    assert open(tmp_path / "v3.pbwt", "rb").read() == open(os.path.join(GOLDEN, "merge1.pbwt"), "rb").read()
+
+
+def test_errors_die_like_the_reference(cli, tmp_path):
+    r = run(cli, "-write", tmp_path / "x", check=False)
+    assert r.returncode != 0 and r.stderr.startswith("FATAL ERROR: ")
+    bad = tmp_path / "bad.pbwt"
+    bad.write_bytes(b"NOPE" + b"\0" * 16)
+    r = run(cli, "-read", bad, check=False)
+    assert r.returncode != 0 and "failed to recognise file type" in r.stderr
+    r = run(cli, "-read", os.path.join(GOLDEN, "merge1.pbwt"), "-readSites", os.path.join(GOLDEN, "macs_small.sites"), check=False)
+    assert r.returncode != 0 and "sites file contains" in r.stderr
+
+
+@pytest.mark.gpu
+def test_readMacs_write_matches_reference_bytes(cli, tmp_path):
+    """BASELINE configs[0] plumbing: -readMacs -write -writeSites reproduces the reference's files"""
+    out, sites = tmp_path / "m.pbwt", tmp_path / "m.sites"
+    run(cli, "-readMacs", os.path.join(GOLDEN, "macs_small.macs"), "-write", out, "-writeSites", sites)
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN, "macs_small.pbwt"), "rb").read()
+    assert open(sites).read() == open(os.path.join(GOLDEN, "macs_small.sites")).read()
+
+
+@pytest.mark.gpu
+def test_maxWithin_and_haps_text(cli, tmp_path):
+    r = run(cli, "-check", "-read", os.path.join(GOLDEN, "merge1.pbwt"), "-maxWithin")
+    assert r.stdout == open(os.path.join(GOLDEN, "merge1.maxwithin.txt")).read()
+    run(cli, "-read", os.path.join(GOLDEN, "merge1.pbwt"), "-haps", tmp_path / "h")
+    assert open(tmp_path / "h").read() == open(os.path.join(GOLDEN, "merge1.haps")).read()
+
+
+@pytest.mark.gpu
+def test_stats_histogram_text(cli, tmp_path):
+    g = np.load(os.path.join(GOLDEN, "mosaic_M300_N400_k0.npz"))
+    M, N = int(g["M"]), int(g["N"])
+    f = tmp_path / "p.pbwt"
+    f.write_bytes(b"PBW3" + np.array([M, N], "<i4").tobytes() + np.arange(M, dtype="<i4").tobytes() + g["aFend"].astype("<i4").tobytes()
+                  + np.array([len(g["yz"])], "<i8").tobytes() + b"    " + g["yz"].tobytes())
+    r = run(cli, "-stats", "-read", f, "-maxWithin")
+    assert r.stdout == g["hist_txt"].tobytes().decode()
+    assert "Average" in r.stderr
+
+
+@pytest.mark.gpu
+def test_matchDynamic_and_siteInfo_and_subsample(cli, orc, tmp_path):
+    g = np.load(os.path.join(GOLDEN, "mosaic_M300_N400_k0.npz"))
+    M, N, Mq = int(g["M"]), int(g["N"]), int(g["Mq"])
+
+    def write(path, m, yz, aFend=None):
+        path.write_bytes(b"PBW3" + np.array([m, N], "<i4").tobytes() + np.arange(m, dtype="<i4").tobytes()
+                         + (np.zeros(m, "<i4") if aFend is None else aFend.astype("<i4")).tobytes()
+                         + np.array([len(yz)], "<i8").tobytes() + b"    " + yz.tobytes())
+    write(tmp_path / "p.pbwt", M - Mq, g["pz"]); write(tmp_path / "q.pbwt", Mq, g["qz"]); write(tmp_path / "full.pbwt", M, g["yz"], g["aFend"])
+    r = run(cli, "-check", "-read", tmp_path / "p.pbwt", "-matchDynamic", tmp_path / "q.pbwt")
+    want = "".join("MATCH\t%d\t%d\t%d\t%d\t%d\n" % (a, b, s, e, e - s) for (a, b, s, e) in g["qrecs"].tolist() if s != e)
+    assert r.stdout == want
+    assert "Average number of best matches including alternates" in r.stderr
+    # -subsample start n == the reference's -subsample: the panel rebuilt from those haplotypes
+    run(cli, "-read", tmp_path / "full.pbwt", "-subsample", M - Mq, Mq, "-write", tmp_path / "sub.pbwt")
+    _, _, _, aFend, yz = parse_pbwt(str(tmp_path / "sub.pbwt"))
+    hap = orc.unpack_bitcols(g["bits"], M)
+    o = orc.build_bitcols(orc.pack_bitcols(hap[:, M - Mq:]), Mq, with_d=False)
+    assert np.array_equal(yz, o["yz"]) and np.array_equal(aFend, o["aFend"])
+    # -siteInfo f kmin kmax: "y (k - d)" pairs of the selected sites (pbwtMain.c:82-100)
+    run(cli, "-read", tmp_path / "full.pbwt", "-siteInfo", tmp_path / "si.txt", 20, 60)
+    sw = orc.sweep_AD(g["yz"], M, N, dump_sites=range(N))
+    lines = []
+    for k in range(N):
+        f1 = int(sw["y_dump"][k].sum())
+        if 20 <= f1 < 60:
+            lines.append("".join("%d %d " % (sw["y_dump"][k][j], k - sw["d_dump"][k][j]) for j in range(M)) + "\n")
+    assert len(lines) > 3 and open(tmp_path / "si.txt").read() == "".join(lines)

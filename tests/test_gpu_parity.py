@@ -193,3 +193,15 @@ def test_match_sweep_vs_oracle(amd, orc, Mp, Mq, N, kind, batch):
     got = []
     eng.match_sweep(pz, N, qz, Mq, callback=lambda a, b, s, e: got.append((a, b, s, e)))
     assert got == [tuple(r) for r in want.tolist()]
+
+
+def test_haplotypes_and_y_dump(amd, orc):
+    M, N = 1234, 77
+    bits = orc.synth_bitcols(M, N, seed=8, kind=0)
+    o = orc.build_bitcols(bits, M, with_d=False)
+    eng = amd.Engine(M, batch_sites=20)
+    assert np.array_equal(eng.haplotypes(o["yz"], N), orc.unpack_bitcols(bits, M))
+    sites = [0, 1, 19, 20, 21, 76]
+    sw = eng.sweep_AD(o["yz"], N, dump_sites=sites)
+    s = orc.sweep_AD(o["yz"], M, N, dump_sites=sites)
+    assert np.array_equal(sw["y_dump"], s["y_dump"]) and np.array_equal(sw["d_dump"], s["d_dump"]) and np.array_equal(sw["a_dump"], s["a_dump"])
