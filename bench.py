@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--kind", type=int, default=0, help="0 founder mosaic, 1 iid")
     ap.add_argument("--no-within", action="store_true")
     ap.add_argument("--no-pack3", action="store_true")
-    ap.add_argument("--cpu-sites", type=int, default=2048, help="sites of the same panel timed on the CPU oracle")
+    ap.add_argument("--cpu-sites", type=int, default=32768, help="sites of the same panel timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
 

@@ -53,7 +53,7 @@ struct pbwtamd_engine {
     hipEvent_t evChain[2] = {nullptr, nullptr}, evCons[2] = {nullptr, nullptr}; bool consRecorded[2] = {false, false};
     int ring = 0; Pending pend;
     int *A = nullptr, *D = nullptr; size_t strideA = 0, strideD = 0;      // 2 rings of B+1 slots
-    int *summ = nullptr;
+    int4 *summ = nullptr;
     int *ctl = nullptr;                     // [2]=device error flag
     Ctl *ctlblk = nullptr;                  // per-batch control block read by the step kernels
     long long *prof = nullptr;              // optional phase timestamps (PBWTAMD_PROFILE=1)
@@ -70,7 +70,7 @@ struct pbwtamd_engine {
     // pass state
     int k0 = 0, k_cur = 0, n_total = 0; bool prepared = false; bool pass_open = false;
     unsigned long long yz_bytes_host = 0;
-    std::vector<GraphKey> graphs; bool use_graph = true;
+    std::vector<GraphKey> graphs; bool use_graph = true; bool lean = true;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0; long long launches = 0;
     // record sink for pass_advance (host-buffer entry points)
     std::vector<pbwtamd_match> *rec_sink = nullptr; pbwtamd_report_fn rec_cb = nullptr;
@@ -129,6 +129,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     e->wpc64 = e->wpc / 2;
     e->B = batch_sites > 0 ? batch_sites : 512;
     if (const char *s = getenv("PBWTAMD_NO_GRAPH")) e->use_graph = !(atoi(s) != 0);
+    if (const char *s = getenv("PBWTAMD_LEAN")) e->lean = atoi(s) != 0;
     if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
     else { if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); } e->own_stream = true; }
     e->strideA = (size_t)e->Mpad;
@@ -137,7 +138,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
 #define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void **)&(ptr), (bytes)); if (_e != hipSuccess) { int r = fail("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(_e)); pbwtamd_engine_destroy(e); return r; } } while (0)
     ALLOC(e->A, 2 * slots * e->strideA * sizeof(int));
     ALLOC(e->D, 2 * slots * e->strideD * sizeof(int));
-    ALLOC(e->summ, (size_t)3 * 4 * e->wpad * sizeof(int));
+    ALLOC(e->summ, (size_t)3 * e->wpad * sizeof(int4));
     ALLOC(e->ctl, 16 * sizeof(int));
     ALLOC(e->ctlblk, sizeof(Ctl));
     if (const char *s = getenv("PBWTAMD_PROFILE")) if (atoi(s)) { ALLOC(e->prof, (size_t)e->W * 8 * sizeof(long long)); HIPCHK(hipMemset(e->prof, 0, (size_t)e->W * 8 * sizeof(long long))); }
@@ -173,14 +174,13 @@ extern "C" int pbwtamd_sync(pbwtamd_engine *e) {
 // ------------------------------------------------------------------------------------ small kernels
 // start of a batch: publish the control block and rotate the tile summaries so that the current
 // site's summaries sit in buffer 0 (step j reads buffer j%3), with buffer 1 cleared for accumulation
-__global__ __launch_bounds__(256) void set_ctl_kernel(Ctl *ctl, int kbase, int n_total, const uint32_t *cols, int *summ, int wpad, int cur) {
+__global__ __launch_bounds__(256) void set_ctl_kernel(Ctl *ctl, int kbase, int n_total, const uint32_t *cols, int4 *summ, int wpad, int cur) {
     if (threadIdx.x == 0) { ctl->kbase = kbase; ctl->n_total = n_total; ctl->cols = cols; }
-    const int n = 4 * wpad;
     if (cur != 0) {
-        for (int i = threadIdx.x; i < n; i += 256) summ[i] = summ[(size_t)cur * n + i];
+        for (int i = threadIdx.x; i < wpad; i += 256) summ[i] = summ[(size_t)cur * wpad + i];
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < n; i += 256) summ[(size_t)n + i] = 0;
+    for (int i = threadIdx.x; i < wpad; i += 256) summ[(size_t)wpad + i] = make_int4(0, 0, 0, 0);
 }
 __global__ void add_base_kernel(unsigned long long *v, size_t n, const unsigned long long *base) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -202,7 +202,12 @@ static void launch_step(pbwtamd_engine *e, int ring, int j) {
     g.a_out = A + (size_t)(j + 1) * e->strideA; g.d_out = D + (size_t)(j + 1) * e->strideD;
     g.ctl = e->ctlblk; g.summ = e->summ; g.prof = e->prof; g.wpc = e->wpc;
     g.j = j; g.M = e->M; g.W = e->W; g.wpad = e->wpad;
-    hipLaunchKernelGGL((step_kernel<E, WITH_D, SORTED>), dim3(e->W), dim3(BLOCK), 0, e->stream, g);
+    if (E == 1 && e->lean) {
+        if (e->W <= 256) hipLaunchKernelGGL((step1_kernel<WITH_D, SORTED, 1>), dim3(e->W), dim3(BLOCK), 0, e->stream, g);
+        else if (e->W <= 512) hipLaunchKernelGGL((step1_kernel<WITH_D, SORTED, 2>), dim3(e->W), dim3(BLOCK), 0, e->stream, g);
+        else hipLaunchKernelGGL((step1_kernel<WITH_D, SORTED, 4>), dim3(e->W), dim3(BLOCK), 0, e->stream, g);
+    }
+    else hipLaunchKernelGGL((step_kernel<E, WITH_D, SORTED>), dim3(e->W), dim3(BLOCK), 0, e->stream, g);
 }
 
 static void launch_step_dyn(pbwtamd_engine *e, int ring, int j, bool with_d, bool sorted) {

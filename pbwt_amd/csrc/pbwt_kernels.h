@@ -4,7 +4,7 @@
 //   ring slot s:  A[s][Mpad] int32  — prefix array a_k, with the allele y_k[i] of the haplotype at
 //                                     position i carried in bit 31 (the "tag"); a < 2^31 always
 //                 D[s][Mpad+PADD]   — divergence d_k[0..M] (start-position form, pbwt.h:82)
-//   tile summaries S[3][4][WPAD]    — per tile of T positions of the NEXT site: cnt0, last0+1,
+//   tile summaries S[3][WPAD] int4  — per tile of T positions of the NEXT site: {cnt0, last0+1,
 //                                     last1+1, max d; built with commutative atomics by the step
 //                                     that scatters into that site, so one launch per site
 //   bit columns  C[k][wpc] uint32   — original order (gather by a) or sorted order (index by pos)
@@ -136,7 +136,7 @@ struct StepArgs {
     const int *a_in;  const int *d_in;     // slot j
     int *a_out;       int *d_out;          // slot j+1
     const Ctl *ctl;
-    int *summ;                             // [3][4][wpad]; step j reads buffer j%3, accumulates (j+1)%3, clears (j+2)%3
+    int4 *summ;                            // [3][wpad] {cnt0,last0+1,last1+1,maxd}; step j reads buffer j%3, accumulates (j+1)%3, clears (j+2)%3
     long long *prof;                       // optional phase timestamps [W][8] (NULL = off)
     int wpc;                               // 32-bit words per column
     int j;                                 // step index inside the batch
@@ -159,11 +159,9 @@ __device__ __forceinline__ void step_body(const StepArgs &g, int *s_a, int *s_d,
     const int S = w * T;                                   // first position of the tile
     PBWT_STAMP(0);
 
-    const int *sm_in = g.summ + (size_t)(j % 3) * 4 * g.wpad;
-    int *sm_out = g.summ + (size_t)((j + 1) % 3) * 4 * g.wpad;
-    int *sm_zero = g.summ + (size_t)((j + 2) % 3) * 4 * g.wpad;
-    const int *in_cnt0 = sm_in, *in_last0 = sm_in + g.wpad, *in_last1 = sm_in + 2 * g.wpad,
-              *in_maxd = sm_in + 3 * g.wpad;
+    const int4 *sm_in = g.summ + (size_t)(j % 3) * g.wpad;
+    int4 *sm_out = g.summ + (size_t)((j + 1) % 3) * g.wpad;
+    int4 *sm_zero = g.summ + (size_t)((j + 2) % 3) * g.wpad;
 
     // ---- issue everything whose address is known now ----
     const Ctl ctl = *g.ctl;
@@ -194,10 +192,7 @@ __device__ __forceinline__ void step_body(const StepArgs &g, int *s_a, int *s_d,
     for (int q = 0; q < SPT; ++q) {
         const int jn = t + q * BLOCK;
         r_cnt[q] = 0; r_l0[q] = 0; r_l1[q] = 0; r_md[q] = 0;
-        if (jn < W) {
-            r_cnt[q] = in_cnt0[jn];
-            if (WITH_D) { r_l0[q] = in_last0[jn]; r_l1[q] = in_last1[jn]; r_md[q] = in_maxd[jn]; }
-        }
+        if (jn < W) { const int4 sv = sm_in[jn]; r_cnt[q] = sv.x; r_l0[q] = sv.y; r_l1[q] = sv.z; r_md[q] = sv.w; }
     }
     if (t < 16) s_acc[t >> 2][t & 3] = 0;
 
@@ -393,17 +388,186 @@ __device__ __forceinline__ void step_body(const StepArgs &g, int *s_a, int *s_d,
         const int s = t;
         const int dt = (s < 2 ? tz : to) + (s & 1);
         if (dt < W) {
+            int *so = reinterpret_cast<int *>(sm_out + dt);
             const int c0 = s_acc[s][0];
-            if (c0) atomicAdd(sm_out + dt, c0);
+            if (c0) atomicAdd(so, c0);
             if (WITH_D) {
-                if (s_acc[s][1]) atomicMax(sm_out + g.wpad + dt, s_acc[s][1]);
-                if (s_acc[s][2]) atomicMax(sm_out + 2 * g.wpad + dt, s_acc[s][2]);
-                if (s_acc[s][3]) atomicMax(sm_out + 3 * g.wpad + dt, s_acc[s][3]);
+                if (s_acc[s][1]) atomicMax(so + 1, s_acc[s][1]);
+                if (s_acc[s][2]) atomicMax(so + 2, s_acc[s][2]);
+                if (s_acc[s][3]) atomicMax(so + 3, s_acc[s][3]);
             }
         }
     }
-    if (t < 4) sm_zero[t * g.wpad + w] = 0;
+    if (t == 0) sm_zero[w] = make_int4(0, 0, 0, 0);
     PBWT_STAMP(6);
+}
+
+// ---------------------------------------------------------------------------------------------
+// step1_kernel: the E = 1 specialisation (T = 256, M <= 262144), written for the shortest
+// instruction stream: SPT = ceil(W/256) summaries per thread, results scattered straight from
+// registers (no LDS staging: the zeros of a wave go to one contiguous destination range, the ones to
+// another), every wave posts its own next-site summaries with global atomics.  Three LDS barriers.
+template <bool WITH_D, bool SORTED, bool FULL, int SPT>
+__device__ __forceinline__ void step1_body(const StepArgs &g, int *s_a, int *s_d, Tup *s_tup, int (*s_red)[6], int (*s_acc)[4]) {
+    constexpr int T = BLOCK;
+    const int j = g.j;
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int w = blockIdx.x, W = g.W, M = g.M;
+    const int S = w * T, i = S + t;
+    PBWT_STAMP(0);
+    const int4 *sm_in = g.summ + (size_t)(j % 3) * g.wpad;
+    int4 *sm_out = g.summ + (size_t)((j + 1) % 3) * g.wpad;
+    int4 *sm_zero = g.summ + (size_t)((j + 2) % 3) * g.wpad;
+
+    if (t < 16) s_acc[t >> 2][t & 3] = 0;
+    // ---- issue everything whose address is known now ----
+    const Ctl ctl = *g.ctl;
+    int a = g.a_in[i];                                     // padded to W*T
+    int d = WITH_D ? g.d_in[i] : 0;
+    int4 sv[SPT];                                          // the W tile summaries, SPT per thread
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int jn = t + q * BLOCK;
+        sv[q] = (jn < W) ? sm_in[jn] : make_int4(0, 0, 0, 0);
+    }
+    const int k = ctl.kbase + j;
+    const bool has_next = (k + 1 < ctl.n_total);
+    const uint32_t *col_next = ctl.cols + (size_t)(j + 1) * g.wpc;
+    const bool valid = FULL || (i < M);
+    const unsigned y = ((unsigned)a) >> 31;
+    a &= AMASK;
+    unsigned nbit = 0;
+    if (!SORTED && has_next && valid) nbit = (col_next[(unsigned)a >> 5] >> (a & 31)) & 1u;
+
+    // ---- fold the summaries: zeros before the tile, zeros in the column, last 0 / 1 before the tile ----
+    int sumBefore = 0, total = 0, l0 = 0, l1 = 0;
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int jn = t + q * BLOCK;
+        total += sv[q].x;
+        if (jn < w) { sumBefore += sv[q].x; if (WITH_D) { l0 = max(l0, sv[q].y); l1 = max(l1, sv[q].z); } }
+    }
+    sumBefore = wave_sum(sumBefore); total = wave_sum(total);
+    if (WITH_D) { l0 = wave_max(l0); l1 = wave_max(l1); }
+    if (lane == 0) { s_red[wv][0] = sumBefore; s_red[wv][1] = total; s_red[wv][2] = l0; s_red[wv][3] = l1; }
+    lds_barrier();
+    sumBefore = 0; total = 0; l0 = 0; l1 = 0;
+#pragma unroll
+    for (int q = 0; q < WAVES; ++q) {
+        sumBefore += s_red[q][0]; total += s_red[q][1];
+        l0 = max(l0, s_red[q][2]); l1 = max(l1, s_red[q][3]);
+    }
+    const int Zw = sumBefore;                              // zeros before this tile
+    const int C = total;                                   // zeros in the whole column (u->c)
+    int m0 = 0, m1 = 0, pd0 = 0, pd1 = 0;
+    if (WITH_D) {
+        // carry_b = max d over [l_b, S): whole-tile maxima + one partial-tile read (<= 256 positions)
+        const int tl0 = l0 ? (l0 - 1) / T : -1, tl1 = l1 ? (l1 - 1) / T : -1;
+        const int hi0 = l0 ? min((tl0 + 1) * T, S) : 0, hi1 = l1 ? min((tl1 + 1) * T, S) : 0;
+        if (l0 + t < hi0) pd0 = g.d_in[l0 + t];            // the one dependent load; consumed after the scan
+        if (l1 + t < hi1) pd1 = g.d_in[l1 + t];
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const int jn = t + q * BLOCK;
+            if (jn < w) { if (jn > tl0) m0 = max(m0, sv[q].w); if (jn > tl1) m1 = max(m1, sv[q].w); }
+        }
+    }
+    PBWT_STAMP(1);
+
+    // ---- the position's own tuple, block scan ----
+    Tup me = Tup{0, 0, 0, 0, 0};
+    if (valid) { if (y) { me.c1 = 1; me.t0 = d; } else { me.c0 = 1; me.t1 = d; } me.all = d; }
+    Tup tot;
+    const Tup pre = block_scan_tup<WITH_D>(me, s_tup, tot);
+    PBWT_STAMP(2);
+    int dn = 0;
+    if (WITH_D) {
+        m0 = wave_max(max(m0, pd0)); m1 = wave_max(max(m1, pd1));
+        if (lane == 0) { s_red[wv][4] = m0; s_red[wv][5] = m1; }
+        lds_barrier();
+        m0 = 0; m1 = 0;
+#pragma unroll
+        for (int q = 0; q < WAVES; ++q) { m0 = max(m0, s_red[q][4]); m1 = max(m1, s_red[q][5]); }
+        const int carry0 = l0 ? m0 : k + 1;                // nothing before: p starts at k+1 (pbwtCore.c:489)
+        const int carry1 = l1 ? m1 : k + 1;
+        const int pin = y ? (pre.c1 ? pre.t1 : max(carry1, pre.all)) : (pre.c0 ? pre.t0 : max(carry0, pre.all));
+        dn = max(pin, d);
+    }
+    PBWT_STAMP(3);
+    // ---- stage in LDS in destination order (coalesced stores drain faster at kernel end), then
+    //      write out + summaries of site k+1 ----
+    const int cw = tot.c0, nvalid = tot.c0 + tot.c1;
+    if (valid) {
+        const int ldst = y ? cw + pre.c1 : pre.c0;
+        s_a[ldst] = a | (int)(nbit << 31);
+        if (WITH_D) s_d[ldst] = dn;
+    }
+    lds_barrier();
+    const int oneBase = C + (S - Zw);                      // every earlier tile is full
+    const int tz = Zw / T, to = oneBase / T;
+    const bool ovalid = FULL || (t < nvalid);
+    const bool one = t >= cw;
+    const int P = one ? oneBase + (t - cw) : Zw + t;
+    const int slot = ovalid ? (one ? 2 + (P / T - to) : (P / T - tz)) : -1;
+    unsigned tag = 0;
+    if (ovalid) {
+        int ao = s_a[t];
+        if (SORTED) { if (has_next) tag = (col_next[(unsigned)P >> 5] >> (P & 31)) & 1u; ao |= (int)(tag << 31); }
+        else tag = (unsigned)ao >> 31;
+        g.a_out[P] = ao;
+        if (WITH_D) { dn = s_d[t]; if (P == 0) dn = k + 2; g.d_out[P] = dn; }      // sentinel (pbwtCore.c:507)
+    }
+    PBWT_STAMP(4);
+    if (has_next) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned long long mk = __ballot(slot == s);
+            if (mk) {                                      // wave-uniform
+                const unsigned long long ones = __ballot(slot == s && tag);
+                const unsigned long long zeros = mk & ~ones;
+                // within a stream P grows with the lane: the highest lane of a set holds its last position
+                const int pz = zeros ? __builtin_amdgcn_readlane(P, 63 - __clzll(zeros)) + 1 : 0;
+                const int po = ones ? __builtin_amdgcn_readlane(P, 63 - __clzll(ones)) + 1 : 0;
+                int md = 0;
+                if (WITH_D) md = wave_max((slot == s) ? dn : 0);
+                if (lane == 0) {                           // aggregate in LDS: 16 global atomics per tile, not per wave
+                    if (zeros) atomicAdd(&s_acc[s][0], __popcll(zeros));
+                    if (WITH_D) {
+                        if (pz) atomicMax(&s_acc[s][1], pz);
+                        if (po) atomicMax(&s_acc[s][2], po);
+                        if (md) atomicMax(&s_acc[s][3], md);
+                    }
+                }
+            }
+        }
+    }
+    if (WITH_D && w == W - 1 && t == 0) g.d_out[M] = k + 2;
+    if (t == 0) sm_zero[w] = make_int4(0, 0, 0, 0);
+    PBWT_STAMP(5);
+    if (has_next) {
+        lds_barrier();
+        if (t < 16) {
+            const int s = t >> 2, f = t & 3;
+            const int dt = (s < 2 ? tz : to) + (s & 1);
+            const int v = s_acc[s][f];
+            if (v && dt < W) {
+                int *so = reinterpret_cast<int *>(sm_out + dt) + f;
+                if (f == 0) atomicAdd(so, v); else atomicMax(so, v);
+            }
+        }
+    }
+    PBWT_STAMP(6);
+}
+
+template <bool WITH_D, bool SORTED, int SPT>
+__global__ __launch_bounds__(BLOCK) void step1_kernel(StepArgs g) {
+    __shared__ Tup s_tup[WAVES];
+    __shared__ int s_red[WAVES][6];
+    __shared__ int s_acc[4][4];
+    __shared__ int s_a[BLOCK];
+    __shared__ int s_d[WITH_D ? BLOCK : 1];
+    if ((int)(blockIdx.x + 1) * BLOCK <= g.M) step1_body<WITH_D, SORTED, true, SPT>(g, s_a, s_d, s_tup, s_red, s_acc);
+    else step1_body<WITH_D, SORTED, false, SPT>(g, s_a, s_d, s_tup, s_red, s_acc);
 }
 
 // One site of pbwtCursorForwardsA / ForwardsAD (pbwtCore.c:458-470 / 485-508) for one tile of
@@ -424,7 +588,7 @@ __global__ __launch_bounds__(BLOCK) void step_kernel(StepArgs g) {
 // prepare: first site of a pass.  Tags a[i] with y_k[i] from column k and builds that site's tile
 // summaries from scratch (plain stores), zeroing the accumulation target of the first step.
 struct PrepArgs {
-    int *a; const int *d; const uint32_t *col; int *summ;
+    int *a; const int *d; const uint32_t *col; int4 *summ;
     int k, M, W, wpad, T, sorted, with_d, has_col;
 };
 
@@ -453,10 +617,8 @@ __global__ __launch_bounds__(BLOCK) void prepare_kernel(PrepArgs g) {
     if (t == 0) {
         c0 = 0; l0 = 0; l1 = 0; md = 0;
         for (int q = 0; q < WAVES; ++q) { c0 += s_red[q][0]; l0 = max(l0, s_red[q][1]); l1 = max(l1, s_red[q][2]); md = max(md, s_red[q][3]); }
-        int *cur = g.summ;                                   // batch-relative: step 0 reads buffer 0
-        int *nxt = g.summ + (size_t)1 * 4 * g.wpad;
-        cur[w] = c0; cur[g.wpad + w] = l0; cur[2 * g.wpad + w] = l1; cur[3 * g.wpad + w] = md;
-        nxt[w] = 0; nxt[g.wpad + w] = 0; nxt[2 * g.wpad + w] = 0; nxt[3 * g.wpad + w] = 0;
+        g.summ[w] = make_int4(c0, l0, l1, md);               // batch-relative: step 0 reads buffer 0
+        g.summ[(size_t)g.wpad + w] = make_int4(0, 0, 0, 0);
     }
 }
 
