@@ -132,9 +132,10 @@ int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k0, int n_to
 #define PBWTAMD_OPT_PACK3      16u   /* emit packed columns into the engine's yz buffer */
 #define PBWTAMD_OPT_WITHIN_RECS 32u  /* fuse the maxWithin sweep, record sink */
 
-/* advance the pass over `ncols` more columns held at d_bitcols (device).  The pass must see
- * the column after the last one too unless it is the panel's last site, so callers hand
- * ncols_avail >= ncols+1 columns except at the end.  Asynchronous. */
+/* advance the pass over `ncols` more columns held at d_bitcols (device).  The pass must see the
+ * column after the last one too unless it is the panel's last site (ncols_avail >= ncols+1); with
+ * ncols_avail >= ncols+2 (or everything up to the panel's end) original-order passes run two sites
+ * per launch.  Asynchronous. */
 int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, int wpc, int ncols, int ncols_avail,
                          unsigned opts);
 
@@ -151,6 +152,7 @@ int pbwtamd_get_checksums(pbwtamd_engine *e, int k_first, int n, uint64_t *csum_
 /* timing of the chain kernel (the dominant kernel) over the last pass_advance calls since
  * pass_begin, measured with HIP events on the engine's stream: total ms and launches */
 int pbwtamd_get_chain_timing(pbwtamd_engine *e, double *ms_total, int64_t *launches);
+int pbwtamd_get_chain_sites(pbwtamd_engine *e, int64_t *sites);   /* sites those launches advanced (2 per launch on the build path) */
 
 /* diagnostics: with PBWTAMD_PROFILE=1 in the environment at engine creation the step kernel
  * stamps wall_clock64() (100 MHz) at its phase boundaries for every tile of the LAST launch:

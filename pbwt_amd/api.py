@@ -249,3 +249,8 @@ class Engine:
         n = C.c_int64(0)
         self._chk(self._L.pbwtamd_get_chain_timing(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def chain_sites(self):
+        n = C.c_int64(0)
+        self._chk(self._L.pbwtamd_get_chain_sites(self._h, C.byref(n)))
+        return n.value

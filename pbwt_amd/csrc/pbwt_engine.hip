@@ -43,7 +43,7 @@ struct DevBufs {
     }
 };
 
-struct GraphKey { int with_d, sorted, ring; hipGraphExec_t exec; };
+struct GraphKey { int with_d, sorted, ring, pair; hipGraphExec_t exec; };
 struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; };
 
 struct pbwtamd_engine {
@@ -70,7 +70,9 @@ struct pbwtamd_engine {
     // pass state
     int k0 = 0, k_cur = 0, n_total = 0; bool prepared = false; bool pass_open = false;
     unsigned long long yz_bytes_host = 0;
-    std::vector<GraphKey> graphs; bool use_graph = true; bool lean = true;
+    std::vector<GraphKey> graphs; bool use_graph = true; bool lean = true; bool pair = true;
+    bool summ_pair = false;                 // format of the current tile summaries (two-site keys or single site)
+    uint32_t *zerocol = nullptr; long long sites_done = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0; long long launches = 0;
     // record sink for pass_advance (host-buffer entry points)
     std::vector<pbwtamd_match> *rec_sink = nullptr; pbwtamd_report_fn rec_cb = nullptr;
@@ -98,7 +100,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, e->cols_stage, e->ycols, e->colBytes,
+    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, e->cols_stage, e->ycols, e->colBytes,
                     e->blockCount, e->scal, e->hist, e->csum, e->recs, e->yz};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -128,17 +130,20 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     e->wpc = wpc_for(M);
     e->wpc64 = e->wpc / 2;
     e->B = batch_sites > 0 ? batch_sites : 512;
+    if (e->B & 1) ++e->B;                                  // two-site launches: even batches
     if (const char *s = getenv("PBWTAMD_NO_GRAPH")) e->use_graph = !(atoi(s) != 0);
     if (const char *s = getenv("PBWTAMD_LEAN")) e->lean = atoi(s) != 0;
+    if (const char *s = getenv("PBWTAMD_PAIR")) e->pair = atoi(s) != 0;
     if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
     else { if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); } e->own_stream = true; }
     e->strideA = (size_t)e->Mpad;
     e->strideD = (size_t)e->Mpad + 64;
-    const size_t slots = (size_t)e->B + 1;
+    const size_t slots = (size_t)e->B + 2;
 #define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void **)&(ptr), (bytes)); if (_e != hipSuccess) { int r = fail("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(_e)); pbwtamd_engine_destroy(e); return r; } } while (0)
     ALLOC(e->A, 2 * slots * e->strideA * sizeof(int));
     ALLOC(e->D, 2 * slots * e->strideD * sizeof(int));
-    ALLOC(e->summ, (size_t)3 * e->wpad * sizeof(int4));
+    ALLOC(e->summ, (size_t)3 * e->wpad * 3 * sizeof(int4));
+    ALLOC(e->zerocol, (size_t)e->wpc * sizeof(uint32_t));
     ALLOC(e->ctl, 16 * sizeof(int));
     ALLOC(e->ctlblk, sizeof(Ctl));
     if (const char *s = getenv("PBWTAMD_PROFILE")) if (atoi(s)) { ALLOC(e->prof, (size_t)e->W * 8 * sizeof(long long)); HIPCHK(hipMemset(e->prof, 0, (size_t)e->W * 8 * sizeof(long long))); }
@@ -153,6 +158,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&e->evChain[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->evCons[i], hipEventDisableTiming)); }
     HIPCHK(hipMemsetAsync(e->ctl, 0, 16 * sizeof(int), e->stream));
     HIPCHK(hipMemsetAsync(e->scal, 0, 8 * sizeof(unsigned long long), e->stream));
+    HIPCHK(hipMemsetAsync(e->zerocol, 0, (size_t)e->wpc * sizeof(uint32_t), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     *out = e;
     return 0;
@@ -174,13 +180,14 @@ extern "C" int pbwtamd_sync(pbwtamd_engine *e) {
 // ------------------------------------------------------------------------------------ small kernels
 // start of a batch: publish the control block and rotate the tile summaries so that the current
 // site's summaries sit in buffer 0 (step j reads buffer j%3), with buffer 1 cleared for accumulation
-__global__ __launch_bounds__(256) void set_ctl_kernel(Ctl *ctl, int kbase, int n_total, const uint32_t *cols, int4 *summ, int wpad, int cur) {
-    if (threadIdx.x == 0) { ctl->kbase = kbase; ctl->n_total = n_total; ctl->cols = cols; }
+// (`n` = int4 entries per summary buffer: wpad for single-site steps, 3*wpad for two-site steps)
+__global__ __launch_bounds__(256) void set_ctl_kernel(Ctl *ctl, int kbase, int n_total, const uint32_t *cols, const uint32_t *zerocol, int4 *summ, int n, int cur) {
+    if (threadIdx.x == 0) { ctl->kbase = kbase; ctl->n_total = n_total; ctl->cols = cols; ctl->zerocol = zerocol; }
     if (cur != 0) {
-        for (int i = threadIdx.x; i < wpad; i += 256) summ[i] = summ[(size_t)cur * wpad + i];
+        for (int i = threadIdx.x; i < n; i += 256) summ[i] = summ[(size_t)cur * n + i];
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < wpad; i += 256) summ[(size_t)wpad + i] = make_int4(0, 0, 0, 0);
+    for (int i = threadIdx.x; i < n; i += 256) summ[(size_t)n + i] = make_int4(0, 0, 0, 0);
 }
 __global__ void add_base_kernel(unsigned long long *v, size_t n, const unsigned long long *base) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -191,8 +198,8 @@ __global__ void bump_kernel(unsigned long long *acc, const unsigned long long *a
     if (*acc > cap) atomicExch(err, 4);
 }
 
-static inline int *ringA(pbwtamd_engine *e, int r) { return e->A + (size_t)r * ((size_t)e->B + 1) * e->strideA; }
-static inline int *ringD(pbwtamd_engine *e, int r) { return e->D + (size_t)r * ((size_t)e->B + 1) * e->strideD; }
+static inline int *ringA(pbwtamd_engine *e, int r) { return e->A + (size_t)r * ((size_t)e->B + 2) * e->strideA; }
+static inline int *ringD(pbwtamd_engine *e, int r) { return e->D + (size_t)r * ((size_t)e->B + 2) * e->strideD; }
 
 template <int E, bool WITH_D, bool SORTED>
 static void launch_step(pbwtamd_engine *e, int ring, int j) {
@@ -223,16 +230,30 @@ static void launch_step_dyn(pbwtamd_engine *e, int ring, int j, bool with_d, boo
 #undef CASE
 }
 
-static int get_graph(pbwtamd_engine *e, bool with_d, bool sorted, int ring, hipGraphExec_t *out) {
-    for (auto &g : e->graphs) if (g.with_d == (int)with_d && g.sorted == (int)sorted && g.ring == ring) { *out = g.exec; return 0; }
+static void launch_step2(pbwtamd_engine *e, int ring, int jl, bool with_d) {
+    Step2Args g;
+    int *A = ringA(e, ring), *D = ringD(e, ring);
+    g.a_in = A + (size_t)(2 * jl) * e->strideA;      g.d_in = D + (size_t)(2 * jl) * e->strideD;
+    g.a_mid = A + (size_t)(2 * jl + 1) * e->strideA; g.d_mid = D + (size_t)(2 * jl + 1) * e->strideD;
+    g.a_out = A + (size_t)(2 * jl + 2) * e->strideA; g.d_out = D + (size_t)(2 * jl + 2) * e->strideD;
+    g.ctl = e->ctlblk; g.summ = e->summ; g.prof = e->prof; g.wpc = e->wpc; g.jl = jl; g.M = e->M; g.W = e->W; g.wpad = e->wpad;
+#define L2(WD, SP) hipLaunchKernelGGL((step2_kernel<WD, SP>), dim3(e->W), dim3(BLOCK), 0, e->stream, g)
+    if (with_d) { if (e->W <= 256) L2(true, 1); else if (e->W <= 512) L2(true, 2); else L2(true, 4); }
+    else        { if (e->W <= 256) L2(false, 1); else if (e->W <= 512) L2(false, 2); else L2(false, 4); }
+#undef L2
+}
+
+static int get_graph(pbwtamd_engine *e, bool with_d, bool sorted, int ring, bool pair, hipGraphExec_t *out) {
+    for (auto &g : e->graphs) if (g.with_d == (int)with_d && g.sorted == (int)sorted && g.ring == ring && g.pair == (int)pair) { *out = g.exec; return 0; }
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-    for (int j = 0; j < e->B; ++j) launch_step_dyn(e, ring, j, with_d, sorted);
+    if (pair) { for (int jl = 0; jl < e->B / 2; ++jl) launch_step2(e, ring, jl, with_d); }
+    else { for (int j = 0; j < e->B; ++j) launch_step_dyn(e, ring, j, with_d, sorted); }
     HIPCHK(hipStreamEndCapture(e->stream, &graph));
     hipGraphExec_t exec = nullptr;
     HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     HIPCHK(hipGraphDestroy(graph));
-    e->graphs.push_back(GraphKey{(int)with_d, (int)sorted, ring, exec});
+    e->graphs.push_back(GraphKey{(int)with_d, (int)sorted, ring, (int)pair, exec});
     *out = exec;
     return 0;
 }
@@ -268,7 +289,7 @@ extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k
     HIPCHK(hipMemsetAsync(e->hist, 0, (size_t)e->histlen * sizeof(unsigned long long), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->yz_bytes_host = 0;
-    e->ev_used = 0; e->launches = 0;
+    e->ev_used = 0; e->launches = 0; e->sites_done = 0;
     return 0;
 }
 
@@ -360,15 +381,24 @@ static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites
     return 0;
 }
 
-// first site of a pass: tag slot 0 with that site's alleles and build its tile summaries
-static int ensure_prepared(pbwtamd_engine *e, const uint32_t *col, bool sorted, bool with_d) {
-    if (e->prepared) return 0;
-    PrepArgs p;
-    p.a = ringA(e, e->ring); p.d = ringD(e, e->ring); p.col = col; p.summ = e->summ; p.k = e->k_cur; p.M = e->M; p.W = e->W;
-    p.wpad = e->wpad; p.T = e->T; p.sorted = sorted; p.with_d = with_d; p.has_col = 1;
-    hipLaunchKernelGGL(prepare_kernel, dim3(e->W), dim3(BLOCK), 0, e->stream, p);
+// first site of a pass (or after a mode switch / odd-length batch): tag slot 0 with the alleles of
+// its site(s) and build the tile summaries from scratch, in the format of the step kernel to follow
+static int ensure_prepared(pbwtamd_engine *e, const uint32_t *col, bool sorted, bool with_d, bool pair, int ncols_avail) {
+    if (e->prepared && e->summ_pair == pair) return 0;
+    if (pair) {
+        Prep2Args p;
+        p.a = ringA(e, e->ring); p.d = ringD(e, e->ring); p.col0 = col;
+        p.col1 = (e->k_cur + 1 < e->n_total && ncols_avail > 1) ? col + e->wpc : e->zerocol;
+        p.summ = e->summ; p.M = e->M; p.W = e->W; p.wpad = e->wpad; p.with_d = with_d;
+        hipLaunchKernelGGL(prepare2_kernel, dim3(e->W), dim3(BLOCK), 0, e->stream, p);
+    } else {
+        PrepArgs p;
+        p.a = ringA(e, e->ring); p.d = ringD(e, e->ring); p.col = col; p.summ = e->summ; p.k = e->k_cur; p.M = e->M; p.W = e->W;
+        p.wpad = e->wpad; p.T = e->T; p.sorted = sorted; p.with_d = with_d; p.has_col = 1;
+        hipLaunchKernelGGL(prepare_kernel, dim3(e->W), dim3(BLOCK), 0, e->stream, p);
+    }
     HIPCHK(hipGetLastError());
-    e->prepared = true; e->summ_cur = 0;
+    e->prepared = true; e->summ_cur = 0; e->summ_pair = pair;
     return 0;
 }
 
@@ -411,26 +441,36 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         const uint32_t *bc = cols + (size_t)done * wpc;
         const int r = e->ring;
         int *A = ringA(e, r), *D = ringD(e, r);
-        CHK(ensure_prepared(e, bc, sorted, with_d));
-        hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(256), 0, e->stream, e->ctlblk, e->k_cur, e->n_total, bc, e->summ, e->wpad, e->summ_cur);
-        e->summ_cur = nb % 3;
+        // two sites per launch when the columns are in original order (the keys of the next pair are
+        // gathered by haplotype) and the pair's successor columns are at hand
+        const int left = ncols_avail - done;               // columns available from bc on
+        const int remaining = e->n_total - e->k_cur;
+        const int L = (nb + 1) / 2;
+        const bool pair = e->pair && !sorted && e->E == 1 && left >= std::min(2 * L + 2, remaining);
+        CHK(ensure_prepared(e, bc, sorted, with_d, pair, left));
+        hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(256), 0, e->stream, e->ctlblk, e->k_cur, e->n_total, bc, (const uint32_t *)e->zerocol,
+                           e->summ, pair ? 3 * e->wpad : e->wpad, e->summ_cur);
+        const int nlaunch = pair ? L : nb;
+        e->summ_cur = nlaunch % 3;
         HIPCHK(hipGetLastError());
-        // ---- the chain: one launch per site, slot j -> slot j+1 of ring r ----
+        // ---- the chain: slot j -> slot j+1 (-> slot j+2) of ring r ----
         if (e->ev_used == e->ev.size()) {
             hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); e->ev.push_back({a, b});
         }
         HIPCHK(hipEventRecord(e->ev[e->ev_used].first, e->stream));
         if (e->use_graph && nb == e->B) {
             hipGraphExec_t exec;
-            CHK(get_graph(e, with_d, sorted, r, &exec));
+            CHK(get_graph(e, with_d, sorted, r, pair, &exec));
             HIPCHK(hipGraphLaunch(exec, e->stream));
         } else {
-            for (int j = 0; j < nb; ++j) launch_step_dyn(e, r, j, with_d, sorted);
+            if (pair) { for (int jl = 0; jl < L; ++jl) launch_step2(e, r, jl, with_d); }
+            else { for (int j = 0; j < nb; ++j) launch_step_dyn(e, r, j, with_d, sorted); }
             HIPCHK(hipGetLastError());
         }
+        if (pair && (nb & 1)) e->prepared = false;         // slot nb is a level-1 output: re-derive tags and summaries
         HIPCHK(hipEventRecord(e->ev[e->ev_used].second, e->stream));
         HIPCHK(hipEventRecord(e->evChain[r], e->stream));
-        ++e->ev_used; e->launches += nb;
+        ++e->ev_used; e->launches += nlaunch; e->sites_done += nb;
         // ---- consumers of the PREVIOUS batch (other ring) run now, beside this batch's chain ----
         CHK(flush_pending(e));
         // ---- carry the cursor into slot 0 of the other ring once its readers are done ----
@@ -524,6 +564,8 @@ extern "C" int pbwtamd_get_chain_timing(pbwtamd_engine *e, double *ms_total, int
     return 0;
 }
 
+extern "C" int pbwtamd_get_chain_sites(pbwtamd_engine *e, int64_t *sites) { *sites = e->sites_done; return 0; }
+
 extern "C" int pbwtamd_get_phase_profile(pbwtamd_engine *e, int64_t *out, int ntiles) {
     HIPCHK(hipSetDevice(e->device));
     if (!e->prof) return -fail("pbwtamd_get_phase_profile: engine created without PBWTAMD_PROFILE=1");
@@ -556,7 +598,7 @@ extern "C" int pbwtamd_build(pbwtamd_engine *e, const uint32_t *bitcols, int wpc
     int done = 0;
     while (done < N) {
         const int nb = std::min(e->B, N - done);
-        const int navail = std::min(nb + 1, N - done);
+        const int navail = std::min(nb + 2, N - done);
         if (wpc == e->wpc)
             HIPCHK(hipMemcpyAsync(e->cols_stage, bitcols + (size_t)done * wpc, (size_t)navail * wpc * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
         else {
@@ -658,7 +700,7 @@ static int sweep_packed(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N,
         // decode straight into the column staging buffer (ycols is scratch for pack3/get_state)
         CHK(packed_expand(e, e->stream, pk, e->M, done, navail, (unsigned long long *)e->cols_stage, e->wpc64));
         if (any_dump) {
-            CHK(ensure_prepared(e, e->cols_stage, true, true));   // tags of the first site exist before it is dumped
+            CHK(ensure_prepared(e, e->cols_stage, true, true, false, navail));   // tags of the first site exist before it is dumped
             CHK(dump_at(done));
         }
         CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, opts));

@@ -21,7 +21,7 @@ namespace pbwtk {
 constexpr int BLOCK = 256;          // 4 waves of 64
 constexpr int WAVES = BLOCK / 64;
 constexpr unsigned TAG = 0x80000000u;
-constexpr int AMASK = 0x7fffffff;
+constexpr int AMASK = 0x3fffffff;    // bits 31/30 of a ring entry carry the alleles at the slot's site / the next site
 
 // workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory
 // (s_waitcnt vmcnt(0)), which would serialise every barrier behind the outstanding global loads
@@ -129,7 +129,7 @@ struct alignas(32) Ctl {
     int n_total;               // sites in the panel (has_next = k+1 < n_total)
     int pad0, pad1;
     const uint32_t *cols;      // bit columns of this batch: column j = site kbase+j
-    long long pad2;
+    const uint32_t *zerocol;   // an all-zero column standing in for sites >= n_total (two-site steps)
 };
 
 struct StepArgs {
@@ -400,6 +400,277 @@ __device__ __forceinline__ void step_body(const StepArgs &g, int *s_a, int *s_d,
     }
     if (t == 0) sm_zero[w] = make_int4(0, 0, 0, 0);
     PBWT_STAMP(6);
+}
+
+// ---------------------------------------------------------------------------------------------
+// step2_kernel: TWO sites per launch (gather mode, E = 1).  a_{k+2} is the stable 4-way partition of
+// a_k by the key q = b0 | b1<<1 (alleles at sites k, k+1), and every divergence at both levels is a
+// static function of (keys, d_k) (tests/tile_model.py::step2_tiles):
+//   predecessor with the same key in level-0 order  -> range max of d_k over (pred, e]
+//   no such predecessor                             -> k + 1 + msb(q ^ q'), q' = nearest lower non-empty key
+//   level-1 value (same b0)                         -> the smaller of the two keys' running maxima
+// so the per-launch fixed cost (launch gap + first round trip) is paid once per two sites.
+// Tile summaries for the next PAIR of sites, per tile: c[4] (keys), last[4] (+1), maxd — 3 int4,
+// all commutative, accumulated by the launch that scatters into that order.
+struct Tup4 { int c[4]; int t[4]; int all; };
+
+__device__ __forceinline__ Tup4 tup4_id() { Tup4 r; for (int q = 0; q < 4; ++q) { r.c[q] = 0; r.t[q] = 0; } r.all = 0; return r; }
+__device__ __forceinline__ Tup4 tup4_combine(const Tup4 &L, const Tup4 &R) {
+    Tup4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { o.c[q] = L.c[q] + R.c[q]; o.t[q] = R.c[q] ? R.t[q] : max(L.t[q], R.all); }
+    o.all = max(L.all, R.all);
+    return o;
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ Tup4 tup4_dpp(const Tup4 &v) {
+    Tup4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { r.c[q] = dpp_mov<CTRL, ROWMASK>(0, v.c[q]); r.t[q] = dpp_mov<CTRL, ROWMASK>(0, v.t[q]); }
+    r.all = dpp_mov<CTRL, ROWMASK>(0, v.all);
+    return r;
+}
+__device__ __forceinline__ Tup4 block_scan_tup4(Tup4 v, Tup4 *smem, Tup4 &total) {
+    const int lane = lane_id(), wv = wave_id();
+    Tup4 inc = v;
+    inc = tup4_combine(tup4_dpp<0x111, 0xf>(inc), inc);
+    inc = tup4_combine(tup4_dpp<0x112, 0xf>(inc), inc);
+    inc = tup4_combine(tup4_dpp<0x114, 0xf>(inc), inc);
+    inc = tup4_combine(tup4_dpp<0x118, 0xf>(inc), inc);
+    inc = tup4_combine(tup4_dpp<0x142, 0xa>(inc), inc);
+    inc = tup4_combine(tup4_dpp<0x143, 0xc>(inc), inc);
+    if (lane == 63) smem[wv] = inc;
+    Tup4 exc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { exc.c[q] = lane_shr1(inc.c[q], 0); exc.t[q] = lane_shr1(inc.t[q], 0); }
+    exc.all = lane_shr1(inc.all, 0);
+    lds_barrier();
+    Tup4 pre = tup4_id(), tot = tup4_id();
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        const Tup4 sw = smem[w];
+        if (w < wv) pre = tup4_combine(pre, sw);
+        tot = tup4_combine(tot, sw);
+    }
+    total = tot;
+    return tup4_combine(pre, exc);
+}
+
+struct Step2Args {
+    const int *a_in; const int *d_in;      // slot 2*jl   (state before site k = kbase + 2*jl)
+    int *a_mid; int *d_mid;                // slot 2*jl+1 (before site k+1)
+    int *a_out; int *d_out;                // slot 2*jl+2 (before site k+2)
+    const Ctl *ctl;
+    int4 *summ;                            // [3][wpad][3] int4: {c[4]}, {last[4]}, {maxd,0,0,0}
+    long long *prof;
+    int wpc, jl, M, W, wpad;
+};
+
+template <bool WITH_D, bool FULL, int SPT>
+__device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int (*s_red)[16], int *s_acc) {
+    constexpr int T = BLOCK;
+    const int jl = g.jl;
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
+    const int w = blockIdx.x, W = g.W, M = g.M;
+    const int S = w * T, i = S + t;
+    PBWT_STAMP(0);
+    const int4 *sm_in = g.summ + (size_t)(jl % 3) * g.wpad * 3;
+    int4 *sm_out = g.summ + (size_t)((jl + 1) % 3) * g.wpad * 3;
+    int4 *sm_zero = g.summ + (size_t)((jl + 2) % 3) * g.wpad * 3;
+    if (t < 72) s_acc[t] = 0;
+
+    // ---- issue everything whose address is known now ----
+    const Ctl ctl = *g.ctl;
+    int a = g.a_in[i];
+    const int d = WITH_D ? g.d_in[i] : 0;
+    int4 sc[SPT], sl[SPT]; int smx[SPT];
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int jn = t + q * BLOCK;
+        sc[q] = make_int4(0, 0, 0, 0); sl[q] = make_int4(0, 0, 0, 0); smx[q] = 0;
+        if (jn < W) { sc[q] = sm_in[(size_t)jn * 3]; if (WITH_D) { sl[q] = sm_in[(size_t)jn * 3 + 1]; smx[q] = sm_in[(size_t)jn * 3 + 2].x; } }
+    }
+    const int k = ctl.kbase + 2 * jl;
+    const bool valid = FULL || (i < M);
+    const int key = (int)(((unsigned)a >> 31) | (((unsigned)a >> 29) & 2u));     // b0 | b1<<1
+    a &= AMASK;
+    // alleles of this haplotype at sites k+2, k+3: the tags of slot 2*jl+2 = the next launch's key
+    const uint32_t *c2 = (k + 2 < ctl.n_total) ? ctl.cols + (size_t)(2 * jl + 2) * g.wpc : ctl.zerocol;
+    const uint32_t *c3 = (k + 3 < ctl.n_total) ? ctl.cols + (size_t)(2 * jl + 3) * g.wpc : ctl.zerocol;
+    int nkey = 0;
+    if (valid) nkey = (int)(((c2[(unsigned)a >> 5] >> (a & 31)) & 1u) | (((c3[(unsigned)a >> 5] >> (a & 31)) & 1u) << 1));
+
+    // ---- fold the tile summaries ----
+    int bef[4] = {0, 0, 0, 0}, tot4[4] = {0, 0, 0, 0}, lst[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int jn = t + q * BLOCK;
+        const int cc[4] = {sc[q].x, sc[q].y, sc[q].z, sc[q].w};
+        const int ll[4] = {sl[q].x, sl[q].y, sl[q].z, sl[q].w};
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { tot4[x] += cc[x]; if (jn < w) { bef[x] += cc[x]; lst[x] = max(lst[x], ll[x]); } }
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { bef[x] = wave_sum(bef[x]); tot4[x] = wave_sum(tot4[x]); if (WITH_D) lst[x] = wave_max(lst[x]); }
+    if (lane == 0) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { s_red[wv][x] = bef[x]; s_red[wv][4 + x] = tot4[x]; s_red[wv][8 + x] = lst[x]; }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        bef[x] = 0; tot4[x] = 0; lst[x] = 0;
+#pragma unroll
+        for (int q = 0; q < WAVES; ++q) { bef[x] += s_red[q][x]; tot4[x] += s_red[q][4 + x]; lst[x] = max(lst[x], s_red[q][8 + x]); }
+    }
+    PBWT_STAMP(1);
+    // carries: max d_k over [last[x], S) = whole-tile maxima + one partial-tile read per key
+    int mx[4] = {0, 0, 0, 0}, pd[4] = {0, 0, 0, 0};
+    if (WITH_D) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int tl = lst[x] ? (lst[x] - 1) / T : -1;
+            const int hi = lst[x] ? min((tl + 1) * T, S) : 0;
+            if (lst[x] + t < hi) pd[x] = g.d_in[lst[x] + t];
+#pragma unroll
+            for (int q = 0; q < SPT; ++q) { const int jn = t + q * BLOCK; if (jn < w && jn > tl) mx[x] = max(mx[x], smx[q]); }
+        }
+    }
+
+    // ---- own tuple, block scan ----
+    Tup4 me = tup4_id();
+    if (valid) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { me.c[x] = (x == key) ? 1 : 0; me.t[x] = (x == key) ? 0 : d; }
+        me.all = d;
+    }
+    Tup4 tot;
+    const Tup4 pre = block_scan_tup4(me, s_tup, tot);
+    PBWT_STAMP(2);
+    int dd1 = 0, dd2 = 0;
+    if (WITH_D) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) mx[x] = wave_max(max(mx[x], pd[x]));
+        if (lane == 0) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) s_red[wv][12 + x] = mx[x];
+        }
+        lds_barrier();
+        int eff[4]; bool ex[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            int cr = 0;
+#pragma unroll
+            for (int q = 0; q < WAVES; ++q) cr = max(cr, s_red[q][12 + x]);
+            ex[x] = pre.c[x] || lst[x];
+            eff[x] = pre.c[x] ? pre.t[x] : max(cr, pre.all);
+        }
+        // level 2: same key
+        int e2 = 0; bool x2 = false;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) if (x == key) { e2 = eff[x]; x2 = ex[x]; }
+        if (x2) dd2 = max(e2, d);
+        else {
+            int lower = -1;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) if (x < key && tot4[x] > 0) lower = x;
+            dd2 = (lower >= 0) ? k + 1 + (31 - __clz(key ^ lower)) : 0;
+        }
+        // level 1: same allele at site k = the later of the two keys sharing b0 = the smaller maximum
+        const int b0 = key & 1;
+        const int ea = b0 ? eff[1] : eff[0], eb = b0 ? eff[3] : eff[2];
+        const bool xa = b0 ? ex[1] : ex[0], xb = b0 ? ex[3] : ex[2];
+        if (xa || xb) dd1 = max(min(xa ? ea : 0x7fffffff, xb ? eb : 0x7fffffff), d);
+        else dd1 = k + 1;
+    }
+    PBWT_STAMP(3);
+    // ---- positions at both levels, scatter ----
+    const int b0 = key & 1, b1 = key >> 1;
+    const int Zw1 = bef[0] + bef[2], C1 = tot4[0] + tot4[2];
+    const int zr = pre.c[0] + pre.c[2], orr = pre.c[1] + pre.c[3];
+    const int pos1 = b0 ? C1 + (S - Zw1) + orr : Zw1 + zr;
+    int G2[4]; G2[0] = 0; G2[1] = tot4[0]; G2[2] = tot4[0] + tot4[1]; G2[3] = tot4[0] + tot4[1] + tot4[2];
+    int base2 = 0, prk = 0;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) if (x == key) { base2 = G2[x] + bef[x]; prk = pre.c[x]; }
+    const int pos2 = base2 + prk;
+    if (valid) {
+        g.a_mid[pos1] = a | (int)((unsigned)b1 << 31);
+        g.a_out[pos2] = a | (int)(((unsigned)(nkey & 1) << 31) | ((unsigned)(nkey >> 1) << 30));
+        if (WITH_D) {
+            g.d_mid[pos1] = pos1 ? dd1 : k + 2;            // sentinels (pbwtCore.c:507)
+            if (pos2 == 0) dd2 = k + 3;
+            g.d_out[pos2] = dd2;
+        }
+    }
+    if (WITH_D && w == W - 1 && t == 0) { g.d_mid[M] = k + 2; g.d_out[M] = k + 3; }
+    PBWT_STAMP(4);
+    // ---- summaries of the next pair, per destination tile of the level-2 order ----
+    const bool has_next = (k + 2 < ctl.n_total);
+    const int ft = base2 / T;                              // first destination tile of this key's stream
+    if (has_next) {
+        if (valid) {
+            const int slot = key * 2 + (pos2 / T - ft);    // <= 2 destination tiles per key stream
+            atomicAdd(&s_acc[slot * 9 + nkey], 1);
+            if (WITH_D) { atomicMax(&s_acc[slot * 9 + 4 + nkey], pos2 + 1); atomicMax(&s_acc[slot * 9 + 8], dd2); }
+        }
+        // every thread needs the first destination tile of each of the 4 streams to address the slots
+        int ftq[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) ftq[x] = (G2[x] + bef[x]) / T;
+        lds_barrier();
+        if (t < 72) {
+            const int slot = t / 9, f = t % 9;
+            int fq = 0;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) if (x == (slot >> 1)) fq = ftq[x];
+            const int dt = fq + (slot & 1);
+            const int v = s_acc[t];
+            if (v && dt < W) {
+                int *so = reinterpret_cast<int *>(sm_out + (size_t)dt * 3) + f;
+                if (f < 4) atomicAdd(so, v); else atomicMax(so, v);
+            }
+        }
+    }
+    if (t < 3) sm_zero[(size_t)w * 3 + t] = make_int4(0, 0, 0, 0);
+    PBWT_STAMP(5);
+    PBWT_STAMP(6);
+}
+
+template <bool WITH_D, int SPT>
+__global__ __launch_bounds__(BLOCK) void step2_kernel(Step2Args g) {
+    __shared__ Tup4 s_tup[WAVES];
+    __shared__ int s_red[WAVES][16];
+    __shared__ int s_acc[72];
+    if ((int)(blockIdx.x + 1) * BLOCK <= g.M) step2_body<WITH_D, true, SPT>(g, s_tup, s_red, s_acc);
+    else step2_body<WITH_D, false, SPT>(g, s_tup, s_red, s_acc);
+}
+
+// first pair of a pass (or after an odd-length batch): both allele tags of slot 0 from columns k, k+1
+// and the pair summaries from scratch; clears the accumulation buffer of the first launch
+struct Prep2Args { int *a; const int *d; const uint32_t *col0; const uint32_t *col1; int4 *summ; int M, W, wpad, with_d; };
+__global__ __launch_bounds__(BLOCK) void prepare2_kernel(Prep2Args g) {
+    __shared__ int s_acc[9];
+    const int t = threadIdx.x, w = blockIdx.x, i = w * BLOCK + t;
+    if (t < 9) s_acc[t] = 0;
+    __syncthreads();
+    if (i < g.M) {
+        const int a = g.a[i] & AMASK;
+        const unsigned b0 = (g.col0[(unsigned)a >> 5] >> (a & 31)) & 1u, b1 = (g.col1[(unsigned)a >> 5] >> (a & 31)) & 1u;
+        g.a[i] = a | (int)((b0 << 31) | (b1 << 30));
+        const int key = (int)(b0 | (b1 << 1));
+        atomicAdd(&s_acc[key], 1);
+        atomicMax(&s_acc[4 + key], i + 1);
+        if (g.with_d) atomicMax(&s_acc[8], g.d[i]);
+    }
+    __syncthreads();
+    if (t == 0) {
+        g.summ[(size_t)w * 3] = make_int4(s_acc[0], s_acc[1], s_acc[2], s_acc[3]);
+        g.summ[(size_t)w * 3 + 1] = make_int4(s_acc[4], s_acc[5], s_acc[6], s_acc[7]);
+        g.summ[(size_t)w * 3 + 2] = make_int4(s_acc[8], 0, 0, 0);
+        int4 *nxt = g.summ + (size_t)g.wpad * 3;
+        nxt[(size_t)w * 3] = make_int4(0, 0, 0, 0); nxt[(size_t)w * 3 + 1] = make_int4(0, 0, 0, 0); nxt[(size_t)w * 3 + 2] = make_int4(0, 0, 0, 0);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -83,6 +83,33 @@ def test_build_and_within_vs_oracle(amd, orc, M, N, kind, batch):
         assert np.array_equal(eng.max_within(o["yz"], N), orc.max_within(o["yz"], M, N))
 
 
+@pytest.mark.parametrize("M,N,batch,avail_extra", [(3000, 301, 64, 2), (3000, 300, 64, 1), (700, 97, 10, 2), (300, 5, 4, 2), (1030, 64, 64, 2)])
+def test_two_site_launch_paths(amd, orc, M, N, batch, avail_extra):
+    """device pass over original-order columns: two-site launches (look-ahead of two columns), the
+    single-site fallback (look-ahead of one), odd panel lengths and ragged batches; every site's a/d"""
+    import torch
+    eng = amd.Engine(M, batch_sites=batch)
+    buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    eng.synth_device(buf.data_ptr(), 0, N, seed=5, kind=0)
+    eng.sync()
+    bits = buf.cpu().numpy().view(np.uint32)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    opts = amd.OPT_WITH_D | amd.OPT_CHECKSUM
+    eng.pass_begin(N)
+    k, step = 0, 2 * batch + 1                    # odd advance sizes exercise the re-prepare path
+    while k < N:
+        n = min(step, N - k)
+        eng.pass_advance(buf.data_ptr() + k * eng.wpc * 4, n, min(n + avail_extra, N - k), opts)
+        k += n
+    eng.pass_end(opts)
+    a, d = eng.get_state()
+    assert np.array_equal(a, o["aFend"]) and np.array_equal(d, o["d_final"])
+    ca, cd, _ = eng.get_checksums(0, N + 1)
+    assert np.array_equal(ca, o["csum_a"]) and np.array_equal(cd, o["csum_d"])
+    if avail_extra == 2:
+        assert eng.chain_timing()[1] < N          # fewer launches than sites
+
+
 def test_nonidentity_start_order(amd, orc):
     """aFstart other than the identity (a .pbwt written after a panel transform)"""
     M, N = 777, 90
@@ -163,7 +190,7 @@ def test_device_pass_api_with_graph(amd, orc):
     assert np.array_equal(ca, o["csum_a"]) and np.array_equal(cd, o["csum_d"])
     assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
     ms, n = eng.chain_timing()
-    assert n == N and ms > 0
+    assert eng.chain_sites() == N and n == N // 2 and ms > 0      # the build path runs two sites per launch
 
 
 @pytest.mark.parametrize("path", golden_panels(), ids=os.path.basename)

@@ -55,3 +55,88 @@ def step_tiles(a, d, y, k, T, summ):
                 a2[oi] = a[i]; d2[oi] = q; oi += 1; q = 0
     d2[0] = k + 2; d2[M] = k + 2
     return a2, d2
+
+
+# ------------------------------------------------------------------------------------------------
+# two sites per launch (step2_kernel): key = b0 | b1<<1 (b0 = allele at site k, b1 at site k+1).
+# Everything at both levels is a static function of (keys, d_k):
+#   same-key predecessor (level-0 order)  -> range max of d_k;  no predecessor -> k+1+msb(key^key')
+#   with key' the nearest lower non-empty bucket; level-1 value = min over the two keys sharing b0.
+def summaries2(key, d, M, T):
+    W = (M + T - 1) // T
+    c = np.zeros((W, 4), np.int64); last = np.zeros((W, 4), np.int64); maxd = np.zeros(W, np.int64)
+    for i in range(M):
+        w = i // T
+        c[w, key[i]] += 1
+        last[w, key[i]] = max(last[w, key[i]], i + 1)
+        maxd[w] = max(maxd[w], d[i])
+    return c, last, maxd
+
+
+def step2_tiles(a, d, key, k, T, summ):
+    """sites k and k+1 in one pass; returns (a1, d1) = state before site k+1, (a2, d2) = before k+2"""
+    M = len(a)
+    W = (M + T - 1) // T
+    c, last, maxd = summ
+    tot = c.sum(axis=0)
+    C1 = int(tot[0] + tot[2])                       # zeros of site k (keys with b0 == 0)
+    G2 = np.concatenate([[0], np.cumsum(tot)])[:4]  # bucket bases at level 2, order 00,01,10,11 (b1 major)
+    a1 = np.zeros(M, np.int64); d1 = np.zeros(M + 1, np.int64)
+    a2 = np.zeros(M, np.int64); d2 = np.zeros(M + 1, np.int64)
+    for w in range(W):
+        S = w * T
+        before = c[:w].sum(axis=0) if w else np.zeros(4, np.int64)
+        l = [int(last[:w, q].max()) if w else 0 for q in range(4)]
+        carry = [0] * 4
+        for q in range(4):
+            if l[q]:
+                tl = (l[q] - 1) // T
+                m = 0
+                for jn in range(tl + 1, w):
+                    m = max(m, int(maxd[jn]))
+                for p in range(l[q], min((tl + 1) * T, S)):
+                    m = max(m, int(d[p]))
+                carry[q] = m
+        # running state inside the tile: t[q] = max d since the last key-q element (INF when none yet here)
+        seen = [False] * 4
+        t = [0] * 4
+        allm = 0
+        cnt = [0] * 4
+        for i in range(S, min(S + T, M)):
+            q = int(key[i]); di = int(d[i])
+            b0 = q & 1
+            # effective "max d since last key-q' element" for every key, including earlier tiles
+            def eff(qq):
+                if seen[qq]:
+                    return t[qq], True
+                if l[qq]:
+                    return max(carry[qq], allm), True
+                return None, False
+            # level 2
+            v, ex = eff(q)
+            if ex:
+                dd2 = max(v, di)
+            else:
+                lower = [qq for qq in range(q) if tot[qq] > 0]
+                dd2 = (k + 1 + ((q ^ lower[-1]).bit_length() - 1)) if lower else 0   # pos 0 gets the sentinel
+            # level 1: the later of the two keys sharing b0 = the smaller of the two maxima
+            cand = [eff(qq) for qq in (b0, b0 + 2)]
+            vals = [vv for vv, e2 in cand if e2]
+            dd1 = max(min(vals), di) if vals else k + 1
+            zr = cnt[0] + cnt[2]; orr = cnt[1] + cnt[3]
+            Zw1 = int(before[0] + before[2])
+            pos1 = (C1 + (S - Zw1) + orr) if b0 else (Zw1 + zr)
+            pos2 = int(G2[q] + before[q] + cnt[q])
+            a1[pos1] = a[i]; d1[pos1] = dd1
+            a2[pos2] = a[i]; d2[pos2] = dd2
+            # update running state
+            allm = max(allm, di)
+            for qq in range(4):
+                if qq == q:
+                    t[qq] = 0; seen[qq] = True
+                elif seen[qq]:
+                    t[qq] = max(t[qq], di)
+            cnt[q] += 1
+    d1[0] = k + 2; d1[M] = k + 2
+    d2[0] = k + 3; d2[M] = k + 3
+    return (a1, d1), (a2, d2)

@@ -12,9 +12,9 @@ eng.synth_device(buf.data_ptr(), 0, N + 1, seed=3, kind=0); eng.sync()
 for opts in (pbwt_amd.OPT_WITH_D, 0):
     eng.pass_begin(N + 1)
     eng.pass_advance(buf.data_ptr(), N, N + 1, opts); eng.sync()
-    ms, n = eng.chain_timing()
+    ms, n = eng.chain_timing(); ns = eng.chain_sites()
     pr = eng.phase_profile()
     d = (pr[:, 1:7] - pr[:, 0:1]) * 10.0     # ns since kernel entry of that tile (100 MHz clock)
-    print("M=%d B=%d with_d=%d: %.2f us/launch over %d launches" % (M, B, bool(opts), 1e3 * ms / n, n))
+    print("M=%d B=%d with_d=%d: %.2f us/launch over %d launches, %.2f us/site" % (M, B, bool(opts), 1e3 * ms / n, n, 1e3 * ms / ns))
     print("  phase stamps (ns after tile entry), median over tiles: " + "  ".join("%d:%.0f" % (i + 1, np.median(d[:, i])) for i in range(6)))
     print("  tile entry spread: %.0f ns, last tile exit - first tile entry: %.0f ns" % ((pr[:, 0].max() - pr[:, 0].min()) * 10.0, (pr[:, 6].max() - pr[:, 0].min()) * 10.0))
