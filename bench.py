@@ -68,16 +68,11 @@ def cpu_baseline(args, first_cols):
 def main():
     args = parse()
     import torch
-    import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        torch.cuda.set_device(0)
+    from pbwt_amd import dist as pdist
+    rank, local, world = pdist.env_world()
     dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    pdist.init("nccl", device_id=dev)      # backend "nccl" is RCCL on ROCm; only barrier + max-reduce use it
     import pbwt_amd
 
     M, S, K, Wm = args.haps, args.sites_per_step, args.steps, args.warmup
@@ -87,7 +82,8 @@ def main():
     wpc = eng.wpc
     # the panel, resident in HBM before the timed region (bit-packed, original haplotype order)
     panel = torch.empty((n_total, wpc), dtype=torch.int32, device=dev)
-    eng.synth_device(panel.data_ptr(), 0, n_total, seed=0x5EED0001 + rank, kind=args.kind)
+    unit = pdist.units_for_rank(world, rank, world)[0]      # one independent panel per rank (weak scaling)
+    eng.synth_device(panel.data_ptr(), 0, n_total, seed=pdist.panel_seed(0x5EED0001, unit), kind=args.kind)
     eng.sync()
     opts = pbwt_amd.OPT_WITH_D
     if not args.no_within:
@@ -109,8 +105,7 @@ def main():
     sites_w = eng.chain_sites()
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        pdist.barrier()
         torch.cuda.synchronize()
 
     barrier()
@@ -121,10 +116,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ms_all, n_all = eng.chain_timing()
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = pdist.max_over_ranks(dt, device=dev)
 
     chain_ms, chain_n = ms_all - ms_w, n_all - n_w
     chain_sites = eng.chain_sites() - sites_w
@@ -165,8 +157,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, first)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    pdist.finish()
 
 
 if __name__ == "__main__":

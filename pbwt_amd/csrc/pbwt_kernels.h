@@ -430,6 +430,9 @@ __device__ __forceinline__ Tup4 tup4_dpp(const Tup4 &v) {
     r.all = dpp_mov<CTRL, ROWMASK>(0, v.all);
     return r;
 }
+// wave totals -> every wave redundantly scans them in its first NW lanes (NW <= 16: one DPP row),
+// so a block of up to 1024 threads needs a single barrier and no per-thread loop over the waves
+template <int NW>
 __device__ __forceinline__ Tup4 block_scan_tup4(Tup4 v, Tup4 *smem, Tup4 &total) {
     const int lane = lane_id(), wv = wave_id();
     Tup4 inc = v;
@@ -445,15 +448,36 @@ __device__ __forceinline__ Tup4 block_scan_tup4(Tup4 v, Tup4 *smem, Tup4 &total)
     for (int q = 0; q < 4; ++q) { exc.c[q] = lane_shr1(inc.c[q], 0); exc.t[q] = lane_shr1(inc.t[q], 0); }
     exc.all = lane_shr1(inc.all, 0);
     lds_barrier();
-    Tup4 pre = tup4_id(), tot = tup4_id();
+    Tup4 wt = tup4_id();
+    if (lane < NW) wt = smem[lane];
+    wt = tup4_combine(tup4_dpp<0x111, 0xf>(wt), wt);
+    wt = tup4_combine(tup4_dpp<0x112, 0xf>(wt), wt);
+    if (NW > 4) { wt = tup4_combine(tup4_dpp<0x114, 0xf>(wt), wt); wt = tup4_combine(tup4_dpp<0x118, 0xf>(wt), wt); }
+    Tup4 pre = tup4_id(), tot;
+    const int src = (wv > 0) ? wv - 1 : 0;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-        const Tup4 sw = smem[w];
-        if (w < wv) pre = tup4_combine(pre, sw);
-        tot = tup4_combine(tot, sw);
+    for (int q = 0; q < 4; ++q) {
+        const int pc = __builtin_amdgcn_readlane(wt.c[q], src), pt = __builtin_amdgcn_readlane(wt.t[q], src);
+        if (wv > 0) { pre.c[q] = pc; pre.t[q] = pt; }
+        tot.c[q] = __builtin_amdgcn_readlane(wt.c[q], NW - 1); tot.t[q] = __builtin_amdgcn_readlane(wt.t[q], NW - 1);
     }
+    { const int pa = __builtin_amdgcn_readlane(wt.all, src); if (wv > 0) pre.all = pa; tot.all = __builtin_amdgcn_readlane(wt.all, NW - 1); }
     total = tot;
     return tup4_combine(pre, exc);
+}
+
+// combine one value per wave across the block (first NW lanes of every wave reduce the NW wave values)
+template <int NW, bool IS_MAX>
+__device__ __forceinline__ int waves_combine(const int *col /* stride 16 ints per wave */, int lane) {
+    int v = (lane < NW) ? col[lane * 16] : 0;
+    if (IS_MAX) {
+        v = max(v, dpp_mov<0x111, 0xf>(0, v)); v = max(v, dpp_mov<0x112, 0xf>(0, v));
+        if (NW > 4) { v = max(v, dpp_mov<0x114, 0xf>(0, v)); v = max(v, dpp_mov<0x118, 0xf>(0, v)); }
+    } else {
+        v += dpp_mov<0x111, 0xf>(0, v); v += dpp_mov<0x112, 0xf>(0, v);
+        if (NW > 4) { v += dpp_mov<0x114, 0xf>(0, v); v += dpp_mov<0x118, 0xf>(0, v); }
+    }
+    return __builtin_amdgcn_readlane(v, NW - 1);
 }
 
 struct Step2Args {
@@ -466,9 +490,10 @@ struct Step2Args {
     int wpc, jl, M, W, wpad;
 };
 
-template <bool WITH_D, bool FULL, int SPT>
+// NT threads per workgroup = positions per tile (256 for M <= 262144, 1024 up to M = 1048576)
+template <bool WITH_D, bool FULL, int SPT, int NT>
 __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int (*s_red)[16], int *s_acc) {
-    constexpr int T = BLOCK;
+    constexpr int T = NT, NW = NT / 64;
     const int jl = g.jl;
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
     const int w = blockIdx.x, W = g.W, M = g.M;
@@ -486,7 +511,7 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
     int4 sc[SPT], sl[SPT]; int smx[SPT];
 #pragma unroll
     for (int q = 0; q < SPT; ++q) {
-        const int jn = t + q * BLOCK;
+        const int jn = t + q * NT;
         sc[q] = make_int4(0, 0, 0, 0); sl[q] = make_int4(0, 0, 0, 0); smx[q] = 0;
         if (jn < W) { sc[q] = sm_in[(size_t)jn * 3]; if (WITH_D) { sl[q] = sm_in[(size_t)jn * 3 + 1]; smx[q] = sm_in[(size_t)jn * 3 + 2].x; } }
     }
@@ -504,24 +529,24 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
     int bef[4] = {0, 0, 0, 0}, tot4[4] = {0, 0, 0, 0}, lst[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < SPT; ++q) {
-        const int jn = t + q * BLOCK;
+        const int jn = t + q * NT;
         const int cc[4] = {sc[q].x, sc[q].y, sc[q].z, sc[q].w};
         const int ll[4] = {sl[q].x, sl[q].y, sl[q].z, sl[q].w};
 #pragma unroll
         for (int x = 0; x < 4; ++x) { tot4[x] += cc[x]; if (jn < w) { bef[x] += cc[x]; lst[x] = max(lst[x], ll[x]); } }
     }
 #pragma unroll
-    for (int x = 0; x < 4; ++x) { bef[x] = wave_sum(bef[x]); tot4[x] = wave_sum(tot4[x]); if (WITH_D) lst[x] = wave_max(lst[x]); }
-    if (lane == 0) {
+    for (int x = 0; x < 4; ++x) { bef[x] = wave_iscan_sum(bef[x]); tot4[x] = wave_iscan_sum(tot4[x]); if (WITH_D) lst[x] = wave_iscan_max(lst[x]); }
+    if (lane == 63) {
 #pragma unroll
         for (int x = 0; x < 4; ++x) { s_red[wv][x] = bef[x]; s_red[wv][4 + x] = tot4[x]; s_red[wv][8 + x] = lst[x]; }
     }
     lds_barrier();
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-        bef[x] = 0; tot4[x] = 0; lst[x] = 0;
-#pragma unroll
-        for (int q = 0; q < WAVES; ++q) { bef[x] += s_red[q][x]; tot4[x] += s_red[q][4 + x]; lst[x] = max(lst[x], s_red[q][8 + x]); }
+        bef[x] = waves_combine<NW, false>(&s_red[0][x], lane);
+        tot4[x] = waves_combine<NW, false>(&s_red[0][4 + x], lane);
+        lst[x] = WITH_D ? waves_combine<NW, true>(&s_red[0][8 + x], lane) : 0;
     }
     PBWT_STAMP(1);
     // carries: max d_k over [last[x], S) = whole-tile maxima + one partial-tile read per key
@@ -533,7 +558,7 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
             const int hi = lst[x] ? min((tl + 1) * T, S) : 0;
             if (lst[x] + t < hi) pd[x] = g.d_in[lst[x] + t];
 #pragma unroll
-            for (int q = 0; q < SPT; ++q) { const int jn = t + q * BLOCK; if (jn < w && jn > tl) mx[x] = max(mx[x], smx[q]); }
+            for (int q = 0; q < SPT; ++q) { const int jn = t + q * NT; if (jn < w && jn > tl) mx[x] = max(mx[x], smx[q]); }
         }
     }
 
@@ -545,13 +570,13 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
         me.all = d;
     }
     Tup4 tot;
-    const Tup4 pre = block_scan_tup4(me, s_tup, tot);
+    const Tup4 pre = block_scan_tup4<NW>(me, s_tup, tot);
     PBWT_STAMP(2);
     int dd1 = 0, dd2 = 0;
     if (WITH_D) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) mx[x] = wave_max(max(mx[x], pd[x]));
-        if (lane == 0) {
+        for (int x = 0; x < 4; ++x) mx[x] = wave_iscan_max(max(mx[x], pd[x]));
+        if (lane == 63) {
 #pragma unroll
             for (int x = 0; x < 4; ++x) s_red[wv][12 + x] = mx[x];
         }
@@ -559,9 +584,7 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
         int eff[4]; bool ex[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            int cr = 0;
-#pragma unroll
-            for (int q = 0; q < WAVES; ++q) cr = max(cr, s_red[q][12 + x]);
+            const int cr = waves_combine<NW, true>(&s_red[0][12 + x], lane);
             ex[x] = pre.c[x] || lst[x];
             eff[x] = pre.c[x] ? pre.t[x] : max(cr, pre.all);
         }
@@ -614,16 +637,10 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
             atomicAdd(&s_acc[slot * 9 + nkey], 1);
             if (WITH_D) { atomicMax(&s_acc[slot * 9 + 4 + nkey], pos2 + 1); atomicMax(&s_acc[slot * 9 + 8], dd2); }
         }
-        // every thread needs the first destination tile of each of the 4 streams to address the slots
-        int ftq[4];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) ftq[x] = (G2[x] + bef[x]) / T;
         lds_barrier();
         if (t < 72) {
-            const int slot = t / 9, f = t % 9;
-            int fq = 0;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) if (x == (slot >> 1)) fq = ftq[x];
+            const int slot = t / 9, f = t - slot * 9, kq = slot >> 1;
+            const int fq = (G2[kq] + bef[kq]) / T;         // first destination tile of stream kq
             const int dt = fq + (slot & 1);
             const int v = s_acc[t];
             if (v && dt < W) {
@@ -637,21 +654,22 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
     PBWT_STAMP(6);
 }
 
-template <bool WITH_D, int SPT>
-__global__ __launch_bounds__(BLOCK) void step2_kernel(Step2Args g) {
-    __shared__ Tup4 s_tup[WAVES];
-    __shared__ int s_red[WAVES][16];
+template <bool WITH_D, int SPT, int NT>
+__global__ __launch_bounds__(NT) void step2_kernel(Step2Args g) {
+    __shared__ Tup4 s_tup[NT / 64];
+    __shared__ int s_red[NT / 64][16];
     __shared__ int s_acc[72];
-    if ((int)(blockIdx.x + 1) * BLOCK <= g.M) step2_body<WITH_D, true, SPT>(g, s_tup, s_red, s_acc);
-    else step2_body<WITH_D, false, SPT>(g, s_tup, s_red, s_acc);
+    if ((int)(blockIdx.x + 1) * NT <= g.M) step2_body<WITH_D, true, SPT, NT>(g, s_tup, s_red, s_acc);
+    else step2_body<WITH_D, false, SPT, NT>(g, s_tup, s_red, s_acc);
 }
 
 // first pair of a pass (or after an odd-length batch): both allele tags of slot 0 from columns k, k+1
 // and the pair summaries from scratch; clears the accumulation buffer of the first launch
 struct Prep2Args { int *a; const int *d; const uint32_t *col0; const uint32_t *col1; int4 *summ; int M, W, wpad, with_d; };
-__global__ __launch_bounds__(BLOCK) void prepare2_kernel(Prep2Args g) {
+template <int NT>
+__global__ __launch_bounds__(NT) void prepare2_kernel(Prep2Args g) {
     __shared__ int s_acc[9];
-    const int t = threadIdx.x, w = blockIdx.x, i = w * BLOCK + t;
+    const int t = threadIdx.x, w = blockIdx.x, i = w * NT + t;
     if (t < 9) s_acc[t] = 0;
     __syncthreads();
     if (i < g.M) {

@@ -1,0 +1,62 @@
+"""CPU: the N>1 path of bench.py (one process per rank, independent panels per rank, barrier +
+max-over-ranks timing) with the gloo backend and world_size 2 / 3."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from conftest import ROOT
+
+WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    from pbwt_amd import dist as pd
+    rank, world = pd.init("gloo")
+    units = pd.units_for_rank(int(os.environ["N_UNITS"]), rank, world)
+    seeds = [pd.panel_seed(1000, u) for u in units]
+    pd.barrier()
+    elapsed = 0.01 * (rank + 1)                      # rank-dependent "work"
+    worst = pd.max_over_ranks(elapsed)
+    total_units = pd.sum_over_ranks(len(units))
+    pd.barrier()
+    print(json.dumps({"rank": rank, "world": world, "units": units, "seeds": seeds, "worst": worst, "total": total_units}))
+    pd.finish()
+""") % ROOT
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("world,n_units", [(2, 2), (3, 8)])
+def test_independent_panels_per_rank_gloo(world, n_units, tmp_path):
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, N_UNITS=str(n_units))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert sorted(o["rank"] for o in outs) == list(range(world))
+    all_units = sorted(u for o in outs for u in o["units"])
+    assert all_units == list(range(n_units))                          # every panel exactly once
+    assert len({s for o in outs for s in o["seeds"]}) == n_units      # distinct panels
+    for o in outs:
+        assert o["world"] == world
+        assert abs(o["worst"] - 0.01 * world) < 1e-9                  # max over ranks, same on every rank
+        assert o["total"] == n_units
+
+
+def test_units_for_rank_partition():
+    from pbwt_amd.dist import units_for_rank
+    for world in (1, 2, 4, 8):
+        for n in (world, 22, 23):
+            got = [u for r in range(world) for u in units_for_rank(n, r, world)]
+            assert got == list(range(n))
+            sizes = [len(units_for_rank(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1

@@ -232,3 +232,21 @@ def test_haplotypes_and_y_dump(amd, orc):
     sw = eng.sweep_AD(o["yz"], N, dump_sites=sites)
     s = orc.sweep_AD(o["yz"], M, N, dump_sites=sites)
     assert np.array_equal(sw["y_dump"], s["y_dump"]) and np.array_equal(sw["d_dump"], s["d_dump"]) and np.array_equal(sw["a_dump"], s["a_dump"])
+
+
+@pytest.mark.parametrize("pair1024", ["0", "1"])
+def test_large_panel_1024_position_tiles(amd, orc, pair1024, monkeypatch):
+    """M > 262144 uses 1024-position tiles: single-site launches (4 positions per thread) by default,
+    two-site launches with 1024-thread workgroups when PBWTAMD_PAIR1024=1"""
+    import torch
+    monkeypatch.setenv("PBWTAMD_PAIR1024", pair1024)
+    M, N = 300000, 41
+    eng = amd.Engine(M, batch_sites=16)
+    buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    eng.synth_device(buf.data_ptr(), 0, N, seed=2, kind=0)
+    eng.sync()
+    bits = buf.cpu().numpy().view(np.uint32)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    b = eng.build(bits, with_d=True)
+    assert np.array_equal(b["yz"], o["yz"]) and np.array_equal(b["aFend"], o["aFend"]) and np.array_equal(b["dFend"], o["d_final"])
+    assert np.array_equal(eng.max_within(o["yz"], N, mode="hist"), orc.max_within_hist(o["yz"], M, N)[: N + 1])
