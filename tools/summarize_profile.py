@@ -31,7 +31,7 @@ cal = {}
 for p, k, c, n, m in rows:
     if k.startswith("calib_copy4"):
         cal[c] = (256 << 20) * 4 / 1024.0 / m
-step = {c: m for p, k, c, n, m in rows if "step_kernel" in k and p.startswith("pmc")}
+step = {c: m for p, k, c, n, m in rows if k.startswith("void pbwtk::step") and p.startswith("pmc")}
 print("calibration (true/reported): ", cal)
 fetch = step.get("FETCH_SIZE", 0) * cal.get("FETCH_SIZE", 1) * 1024
 write = step.get("WRITE_SIZE", 0) * cal.get("WRITE_SIZE", 1) * 1024
