@@ -1033,6 +1033,32 @@ struct SweepArgs {
     int *err;
 };
 
+// wave-cooperative walk: from position `from` in direction `dir` (-1 up, +1 down) find the first
+// position p with d[p + off] > thr (the block boundary; `stop` = p) or, unless `fin`, with allele
+// == yi (then the match extends: returns true = skip).  64 positions per step via ballot.
+// All 64 lanes call this with wave-uniform arguments.
+__device__ __forceinline__ bool coop_walk(const int *a, const int *d, int from, int dir, int thr, unsigned yi, bool fin, int M, int &stop) {
+    const int lane = lane_id();
+    for (;;) {
+        const int p = from + dir * lane;                   // candidate neighbour index (m or n of the reference loop)
+        // up:   loop test d[m+1] <= thr  with m = p  -> boundary when d[p+1] > thr ; y test on y[p]
+        // down: loop test d[n]   <= thr  with n = p  -> boundary when d[p]   > thr ; y test on y[p]
+        const int di = (dir < 0) ? p + 1 : p;
+        const bool inb = (di >= 0) && (di <= M);
+        const bool bound = inb ? (d[di] > thr) : true;
+        const bool same = (!bound && !fin && p >= 0 && p < M) ? (((unsigned)a[p] >> 31) == yi) : false;
+        const unsigned long long mb = __ballot(bound), ms = __ballot(same);
+        const unsigned long long any = mb | ms;
+        if (any) {
+            const int first = __ffsll((long long)any) - 1;
+            if ((ms >> first) & 1ULL) return true;         // same allele inside the block: i is not reported
+            stop = from + dir * first;                     // first index that fails the divergence test
+            return false;
+        }
+        from += dir * 64;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     __shared__ unsigned long long s_w[WAVES];
@@ -1042,18 +1068,60 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     const int *d = g.D + (size_t)site * g.strideD;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     const int M = g.M;
+    const int lane = lane_id();
     int m = i - 1, n = i + 1, di = 0, dn = 0;
+    unsigned yi = 0;
     bool rep = false;
+    // scalar prefix of the reference's two scans (pbwtMatch.c:124-129), a few steps per lane; the rare
+    // long walks (a rare allele beside a long run of the other one) are finished wave-cooperatively
+    constexpr int BUDGET = 4;
+    bool needUp = false, needDown = false;
     if (i < M) {
         di = d[i]; dn = d[i + 1];
-        const unsigned yi = (unsigned)a[i] >> 31;
+        yi = (unsigned)a[i] >> 31;
         rep = true;
         if (di <= dn) {
-            while (d[m + 1] <= di) { if (!fin && ((unsigned)a[m] >> 31) == yi) { rep = false; break; } --m; }
+            int steps = 0;
+            while (d[m + 1] <= di) {
+                if (!fin && ((unsigned)a[m] >> 31) == yi) { rep = false; break; }
+                --m;
+                if (++steps == BUDGET) { needUp = true; break; }
+            }
         }
-        if (rep && di >= dn) {
-            while (d[n] <= dn) { if (!fin && ((unsigned)a[n] >> 31) == yi) { rep = false; break; } ++n; }
+        if (rep && !needUp && di >= dn) {
+            int steps = 0;
+            while (d[n] <= dn) {
+                if (!fin && ((unsigned)a[n] >> 31) == yi) { rep = false; break; }
+                ++n;
+                if (++steps == BUDGET) { needDown = true; break; }
+            }
         }
+    }
+    // finish long upward walks, one lane at a time, all 64 lanes scanning
+    for (unsigned long long pend = __ballot(needUp); pend; pend &= pend - 1) {
+        const int src = __ffsll((long long)pend) - 1;
+        const int from = __builtin_amdgcn_readlane(m, src), thr = __builtin_amdgcn_readlane(di, src);
+        const unsigned yy = (unsigned)__builtin_amdgcn_readlane((int)yi, src);
+        int stop = 0;
+        const bool skip = coop_walk(a, d, from, -1, thr, yy, fin, M, stop);
+        if (lane == src) { if (skip) rep = false; else m = stop; }
+    }
+    // lanes whose upward walk was long still owe the downward scan
+    if (needUp && rep && di >= dn) {
+        int steps = 0;
+        while (d[n] <= dn) {
+            if (!fin && ((unsigned)a[n] >> 31) == yi) { rep = false; break; }
+            ++n;
+            if (++steps == BUDGET) { needDown = true; break; }
+        }
+    }
+    for (unsigned long long pend = __ballot(needDown && rep); pend; pend &= pend - 1) {
+        const int src = __ffsll((long long)pend) - 1;
+        const int from = __builtin_amdgcn_readlane(n, src), thr = __builtin_amdgcn_readlane(dn, src);
+        const unsigned yy = (unsigned)__builtin_amdgcn_readlane((int)yi, src);
+        int stop = 0;
+        const bool skip = coop_walk(a, d, from, +1, thr, yy, fin, M, stop);
+        if (lane == src) { if (skip) rep = false; else n = stop; }
     }
     if (MODE == 2) {
         if (rep) {
