@@ -69,7 +69,7 @@ struct pbwtamd_engine {
     uint8_t *yz = nullptr; size_t yzCap = 0;
     // pass state
     int k0 = 0, k_cur = 0, n_total = 0; bool prepared = false; bool pass_open = false;
-    unsigned long long yz_bytes_host = 0;
+    unsigned long long yz_bytes_host = 0; size_t yz_upper = 0;   // host-side upper bound of the packed bytes written
     std::vector<GraphKey> graphs; bool use_graph = true; bool lean = true; bool pair = true;
     bool pair1024 = false;
     bool summ_pair = false;                 // format of the current tile summaries (two-site keys or single site)
@@ -292,7 +292,7 @@ extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k
     }
     HIPCHK(hipMemsetAsync(e->hist, 0, (size_t)e->histlen * sizeof(unsigned long long), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->yz_bytes_host = 0;
+    e->yz_bytes_host = 0; e->yz_upper = 0;
     e->ev_used = 0; e->launches = 0; e->sites_done = 0;
     return 0;
 }
@@ -364,7 +364,18 @@ static int ensure_yz(pbwtamd_engine *e, hipStream_t st, size_t cap) {
     return 0;
 }
 
-// pack3-encode the y columns (tags) of `nsites` slots of A and append to the engine's yz buffer
+// pack3-encode the y columns (tags) of `nsites` slots of A and append to the engine's yz buffer.
+// No host sync in the steady state: the host tracks an upper bound of the bytes used (worst case one
+// byte per position) and only reads the true count back when that bound would exceed the capacity.
+__global__ void pack3_offsets_kernel(unsigned long long *colBytes, size_t n, const unsigned long long *base, unsigned long long *batchTotal,
+                                     unsigned long long *acc, unsigned long long cap, int *err) {
+    // colBytes holds exclusive offsets inside the batch (scan done); rebase them and bump the running total
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long b = *base;
+    if (i < n) colBytes[i] += b;
+    if (i == 0) { if (b + *batchTotal > cap) atomicExch(err, 4); }
+    (void)acc;
+}
 static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites) {
     dim3 g1(std::min(64, (e->wpc64 + WAVES - 1) / WAVES), nsites);
     hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, st, A, e->strideA, e->M, e->ycols, e->wpc64);
@@ -372,16 +383,20 @@ static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites
     // exclusive offsets inside the batch; batch total -> scal[2]
     hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, e->colBytes, (size_t)nsites, e->scal + 2, 0ULL);
     HIPCHK(hipGetLastError());
-    unsigned long long tot = 0;
-    HIPCHK(hipMemcpyAsync(&tot, e->scal + 2, sizeof tot, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const size_t need = (size_t)e->yz_bytes_host + (size_t)tot;
-    if (need > e->yzCap) CHK(ensure_yz(e, st, std::max(need + (need >> 2) + 4096, e->yzCap * 2)));
-    hipLaunchKernelGGL(add_base_kernel, dim3((nsites + 255) / 256), dim3(256), 0, st, e->colBytes, (size_t)nsites, (const unsigned long long *)(e->scal + 1));
+    const size_t worst = (size_t)nsites * (size_t)e->M;
+    if (e->yz_upper + worst > e->yzCap) {                  // refresh the bound with the true count, grow if needed
+        unsigned long long used = 0;
+        HIPCHK(hipMemcpyAsync(&used, e->scal + 1, sizeof used, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        e->yz_upper = (size_t)used;
+        if (e->yz_upper + worst > e->yzCap) CHK(ensure_yz(e, st, std::max(e->yz_upper + worst + (worst >> 1), e->yzCap * 2)));
+    }
+    hipLaunchKernelGGL(pack3_offsets_kernel, dim3((nsites + 255) / 256), dim3(256), 0, st, e->colBytes, (size_t)nsites, (const unsigned long long *)(e->scal + 1),
+                       e->scal + 2, e->scal + 1, (unsigned long long)e->yzCap, e->ctl + 2);
     hipLaunchKernelGGL((pack3_kernel<1>), dim3(nsites), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
     hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->scal + 1, (const unsigned long long *)(e->scal + 2), (unsigned long long)e->yzCap, e->ctl + 2);
     HIPCHK(hipGetLastError());
-    e->yz_bytes_host += tot;
+    e->yz_upper += worst;
     return 0;
 }
 
@@ -620,7 +635,8 @@ extern "C" int pbwtamd_build(pbwtamd_engine *e, const uint32_t *bitcols, int wpc
     CHK(pbwtamd_pass_end(e, opts));
     if (aFend) CHK(pbwtamd_get_state(e, aFend, with_d ? dFend : nullptr));
     if (yz_out) {
-        const unsigned long long nz = e->yz_bytes_host;
+        unsigned long long nz = 0;
+        HIPCHK(hipMemcpy(&nz, e->scal + 1, sizeof nz, hipMemcpyDeviceToHost));
         uint8_t *buf = (uint8_t *)malloc(nz ? nz : 1);
         if (!buf) return fail("pbwtamd_build: out of host memory for %llu bytes", nz);
         if (nz) HIPCHK(hipMemcpy(buf, e->yz, nz, hipMemcpyDeviceToHost));
