@@ -49,21 +49,27 @@ def parse():
 
 
 def cpu_baseline(args, first_cols):
-    """the oracle (C restatement of the reference, 1 thread) on a bounded sample of the same
-    workload: build with d + pack3, then the maxWithin histogram sweep over the packed columns"""
+    """CPU baseline on a bounded sample of the same workload, 1 thread (the reference is
+    single-threaded): the REAL reference (oracle/_ref, compiled in place from the reference's own
+    sources; kind "reference") when its prebuilt library travelled with the repo, else the oracle's
+    C restatement (kind "port").  Build with d + pack3, then the -stats maxWithin sweep."""
     import oracle
     M = args.haps
     n = first_cols.shape[0]
-    t0 = time.perf_counter()
-    b = oracle.build_bitcols(first_cols, M, with_d=True, want_csum=False)
-    t1 = time.perf_counter()
-    if not args.no_within:
-        oracle.max_within_hist(b["yz"], M, n)
-    t2 = time.perf_counter()
-    dt = t2 - t0
-    return {"value": M * n / dt, "unit": "site*haps/s", "cores": 1, "kind": "port",
-            "sample": "first %d sites of the same %d-haplotype panel: oracle build(AD+pack3) %.2fs + maxWithin hist %.2fs"
-                      % (n, M, t1 - t0, t2 - t1)}
+    if oracle.ref() is not None and not args.no_within:
+        tb, tw = oracle.ref_time_build_and_within(first_cols, M)
+        kind, what = "reference", "richarddurbin/pbwt compiled from its own sources (oracle/_ref)"
+    else:
+        t0 = time.perf_counter()
+        b = oracle.build_bitcols(first_cols, M, with_d=True, want_csum=False)
+        t1 = time.perf_counter()
+        if not args.no_within:
+            oracle.max_within_hist(b["yz"], M, n)
+        tb, tw = t1 - t0, time.perf_counter() - t1
+        kind, what = "port", "oracle C restatement"
+    return {"value": M * n / (tb + tw), "unit": "site*haps/s", "cores": 1, "kind": kind,
+            "sample": "first %d sites of the same %d-haplotype panel, %s: build(WriteForwardsAD + pack3) %.2fs + -stats maxWithin %.2fs"
+                      % (n, M, what, tb, tw)}
 
 
 def main():

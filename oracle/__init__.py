@@ -245,6 +245,19 @@ def ref_build_bitcols(bits, M, with_d=True):
     return dict(yz=yz[:nz].copy(), aFend=aFend, a_all=a_all, d_all=d_all)
 
 
+def ref_time_build_and_within(bits, M):
+    """the real reference timed on this host: (t_build_AD_pack3, t_maxWithin_stats) in seconds.
+    NOTE: leaves the reference's histogram static set in this process (see ref_driver.c), so call it
+    last or in a process that does not need ref_max_within afterwards."""
+    r = ref()
+    bits = np.ascontiguousarray(bits, dtype=np.uint32)
+    N, wpc = bits.shape
+    tb, tw = C.c_double(0), C.c_double(0)
+    r.ref_time_build_and_within.restype = C.c_long
+    r.ref_time_build_and_within(C.c_int(M), C.c_int(N), _p(bits, C.c_uint32), C.c_int(wpc), C.byref(tb), C.byref(tw))
+    return tb.value, tw.value
+
+
 def ref_sweep_dump(yz, M, N, aFstart=None):
     r = ref()
     yz = np.ascontiguousarray(yz, dtype=np.uint8)

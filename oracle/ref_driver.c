@@ -8,6 +8,7 @@
 #include "pbwt.h"          /* the reference's own header, found via -I/root/reference */
 #include <stdint.h>
 #include <unistd.h>
+#include <time.h>
 #include <sys/types.h>
 #include <sys/wait.h>
 
@@ -188,6 +189,44 @@ int ref_pbwt_to_haps(const char *pbwt_in, const char *haps_out)
     pbwtWriteHaplotypes(fo, p); fclose(fo);
     pbwtDestroy(p);
     return 0;
+}
+
+/* timing helper for bench.py's cpu_baseline (kind "reference"): the reference's own build loop
+ * (pbwtCursorWriteForwardsAD over bit columns, as ref_build_bitcols) followed by its -stats
+ * -maxWithin sweep, no dumps; returns the number of histogram entries as a checksum */
+long ref_time_build_and_within(int M, int N, const uint32_t *bits, int wpc, double *t_build, double *t_within)
+{
+    ref_init();
+    struct timespec t0, t1, t2;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    PBWT *p = pbwtCreate(M, 0);
+    PbwtCursor *u = pbwtCursorCreate(p, TRUE, TRUE);
+    for (int k = 0; k < N; ++k) {
+        const uint32_t *col = bits + (size_t)k * wpc;
+        for (int j = 0; j < M; ++j) { int h = u->a[j]; u->y[j] = (col[h >> 5] >> (h & 31)) & 1; }
+        pbwtCursorWriteForwardsAD(u, k);
+        p->N++;
+    }
+    pbwtCursorToAFend(u, p);
+    pbwtCursorDestroy(u);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    /* histogram mode of matchMaximalWithin needs the file-static matchLengthHist, reachable only through
+     * pbwtLongMatches with isStats: run it with stdout sent to /dev/null */
+    fflush(stdout);
+    int saved = dup(1);
+    FILE *f = fopen("/dev/null", "w");
+    dup2(fileno(f), 1);
+    isStats = TRUE;
+    pbwtLongMatches(p, 0);
+    isStats = FALSE;
+    fflush(stdout);
+    dup2(saved, 1); close(saved); fclose(f);
+    clock_gettime(CLOCK_MONOTONIC, &t2);
+    *t_build = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    *t_within = (t2.tv_sec - t1.tv_sec) + 1e-9 * (t2.tv_nsec - t1.tv_nsec);
+    long nz = arrayMax(p->yz);
+    pbwtDestroy(p);
+    return nz;
 }
 
 size_t ref_pack3(uint8_t *y_with_sentinel, int M, uint8_t *out) { ref_init(); return pack3(y_with_sentinel, M, out); }

@@ -71,7 +71,7 @@ struct pbwtamd_engine {
     int k0 = 0, k_cur = 0, n_total = 0; bool prepared = false; bool pass_open = false;
     unsigned long long yz_bytes_host = 0; size_t yz_upper = 0;   // host-side upper bound of the packed bytes written
     std::vector<GraphKey> graphs; bool use_graph = true; bool lean = true; bool pair = true;
-    bool pair1024 = false;
+    bool pair1024 = false; bool stage = false;
     bool summ_pair = false;                 // format of the current tile summaries (two-site keys or single site)
     uint32_t *zerocol = nullptr; long long sites_done = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0; long long launches = 0;
@@ -124,6 +124,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     if (M > 262144) e->E = 4;                              // T = 1024 (two-site launches use 1024-thread workgroups)
     while (e->E < 16 && (M + BLOCK * e->E - 1) / (BLOCK * e->E) > 1024) e->E *= 2;
     if (const char *s = getenv("PBWTAMD_E")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->E = v; }
+    if (const char *s = getenv("PBWTAMD_T")) { int v = atoi(s); if (v == 256 || v == 1024 || v == 4096) e->E = v / BLOCK; }
     e->T = BLOCK * e->E;
     e->W = (M + e->T - 1) / e->T;
     if (e->W > 1024) { delete e; return fail("pbwtamd: M=%d too large for this build (max %d)", M, 1024 * 4096); }
@@ -137,6 +138,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     if (const char *s = getenv("PBWTAMD_LEAN")) e->lean = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_PAIR")) e->pair = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_PAIR1024")) e->pair1024 = atoi(s) != 0;
+    if (const char *s = getenv("PBWTAMD_STAGE")) e->stage = atoi(s) != 0;
     if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
     else { if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); } e->own_stream = true; }
     e->strideA = (size_t)e->Mpad;
@@ -184,8 +186,8 @@ extern "C" int pbwtamd_sync(pbwtamd_engine *e) {
 // start of a batch: publish the control block and rotate the tile summaries so that the current
 // site's summaries sit in buffer 0 (step j reads buffer j%3), with buffer 1 cleared for accumulation
 // (`n` = int4 entries per summary buffer: wpad for single-site steps, 3*wpad for two-site steps)
-__global__ __launch_bounds__(256) void set_ctl_kernel(Ctl *ctl, int kbase, int n_total, const uint32_t *cols, const uint32_t *zerocol, int4 *summ, int n, int cur) {
-    if (threadIdx.x == 0) { ctl->kbase = kbase; ctl->n_total = n_total; ctl->cols = cols; ctl->zerocol = zerocol; }
+__global__ __launch_bounds__(256) void set_ctl_kernel(Ctl *ctl, int kbase, int n_total, const uint32_t *cols, const uint32_t *zerocol, int4 *summ, int n, int cur, int nogather) {
+    if (threadIdx.x == 0) { ctl->kbase = kbase; ctl->n_total = n_total; ctl->cols = cols; ctl->zerocol = zerocol; ctl->pad0 = nogather; ctl->pad1 = 0; }
     if (cur != 0) {
         for (int i = threadIdx.x; i < n; i += 256) summ[i] = summ[(size_t)cur * n + i];
         __syncthreads();
@@ -240,10 +242,16 @@ static void launch_step2(pbwtamd_engine *e, int ring, int jl, bool with_d) {
     g.a_mid = A + (size_t)(2 * jl + 1) * e->strideA; g.d_mid = D + (size_t)(2 * jl + 1) * e->strideD;
     g.a_out = A + (size_t)(2 * jl + 2) * e->strideA; g.d_out = D + (size_t)(2 * jl + 2) * e->strideD;
     g.ctl = e->ctlblk; g.summ = e->summ; g.prof = e->prof; g.wpc = e->wpc; g.jl = jl; g.M = e->M; g.W = e->W; g.wpad = e->wpad;
-#define L2(WD, SP, NT) hipLaunchKernelGGL((step2_kernel<WD, SP, NT>), dim3(e->W), dim3(NT), 0, e->stream, g)
-    if (e->T == 1024) { if (with_d) L2(true, 1, 1024); else L2(false, 1, 1024); }
-    else if (with_d) { if (e->W <= 256) L2(true, 1, 256); else if (e->W <= 512) L2(true, 2, 256); else L2(true, 4, 256); }
-    else             { if (e->W <= 256) L2(false, 1, 256); else if (e->W <= 512) L2(false, 2, 256); else L2(false, 4, 256); }
+#define L2(WD, SP, NT, EE) do { if (e->stage) hipLaunchKernelGGL((step2_kernel<WD, SP, NT, EE, true>), dim3(e->W), dim3(NT), 0, e->stream, g); \
+                                 else hipLaunchKernelGGL((step2_kernel<WD, SP, NT, EE, false>), dim3(e->W), dim3(NT), 0, e->stream, g); } while (0)
+    if (e->T == 1024 && e->pair1024) { if (with_d) L2(true, 1, 1024, 1); else L2(false, 1, 1024, 1); }     // 16-wave workgroups (opt-in)
+    else if (e->T == 4096) { if (with_d) L2(true, 1, 1024, 4); else L2(false, 1, 1024, 4); }              // one 16-wave workgroup per CU, 4 positions per thread
+    else if (e->T == 1024) {                               // 4 positions per thread, 4-wave workgroups
+        if (with_d) { if (e->W <= 256) L2(true, 1, 256, 4); else if (e->W <= 512) L2(true, 2, 256, 4); else L2(true, 4, 256, 4); }
+        else        { if (e->W <= 256) L2(false, 1, 256, 4); else if (e->W <= 512) L2(false, 2, 256, 4); else L2(false, 4, 256, 4); }
+    }
+    else if (with_d) { if (e->W <= 256) L2(true, 1, 256, 1); else if (e->W <= 512) L2(true, 2, 256, 1); else L2(true, 4, 256, 1); }
+    else             { if (e->W <= 256) L2(false, 1, 256, 1); else if (e->W <= 512) L2(false, 2, 256, 1); else L2(false, 4, 256, 1); }
 #undef L2
 }
 
@@ -409,8 +417,8 @@ static int ensure_prepared(pbwtamd_engine *e, const uint32_t *col, bool sorted, 
         p.a = ringA(e, e->ring); p.d = ringD(e, e->ring); p.col0 = col;
         p.col1 = (e->k_cur + 1 < e->n_total && ncols_avail > 1) ? col + e->wpc : e->zerocol;
         p.summ = e->summ; p.M = e->M; p.W = e->W; p.wpad = e->wpad; p.with_d = with_d;
-        if (e->T == 1024) hipLaunchKernelGGL((prepare2_kernel<1024>), dim3(e->W), dim3(1024), 0, e->stream, p);
-        else hipLaunchKernelGGL((prepare2_kernel<256>), dim3(e->W), dim3(256), 0, e->stream, p);
+        p.T = e->T;
+        hipLaunchKernelGGL(prepare2_kernel, dim3(e->W), dim3(BLOCK), 0, e->stream, p);
     } else {
         PrepArgs p;
         p.a = ringA(e, e->ring); p.d = ringD(e, e->ring); p.col = col; p.summ = e->summ; p.k = e->k_cur; p.M = e->M; p.W = e->W;
@@ -466,12 +474,10 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         const int left = ncols_avail - done;               // columns available from bc on
         const int remaining = e->n_total - e->k_cur;
         const int L = (nb + 1) / 2;
-        // (1024-position tiles need 16-wave workgroups: 977 of them do not fit the chip at once at M = 1M, measured
-        //  slower than single-site launches there, so that variant is opt-in: PBWTAMD_PAIR1024=1)
-        const bool pair = e->pair && !sorted && (e->T == 256 || (e->T == 1024 && e->pair1024)) && left >= std::min(2 * L + 2, remaining);
+        const bool pair = e->pair && !sorted && (e->T == 256 || e->T == 1024 || e->T == 4096) && left >= std::min(2 * L + 2, remaining);
         CHK(ensure_prepared(e, bc, sorted, with_d, pair, left));
         hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(256), 0, e->stream, e->ctlblk, e->k_cur, e->n_total, bc, (const uint32_t *)e->zerocol,
-                           e->summ, pair ? 3 * e->wpad : e->wpad, e->summ_cur);
+                           e->summ, pair ? 3 * e->wpad : e->wpad, e->summ_cur, getenv("PBWTAMD_NOGATHER") ? 1 : 0);
         const int nlaunch = pair ? L : nb;
         e->summ_cur = nlaunch % 3;
         HIPCHK(hipGetLastError());

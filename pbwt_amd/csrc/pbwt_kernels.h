@@ -490,14 +490,15 @@ struct Step2Args {
     int wpc, jl, M, W, wpad;
 };
 
-// NT threads per workgroup = positions per tile (256 for M <= 262144, 1024 up to M = 1048576)
-template <bool WITH_D, bool FULL, int SPT, int NT>
-__device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int (*s_red)[16], int *s_acc) {
-    constexpr int T = NT, NW = NT / 64;
+// NT threads per workgroup, E consecutive positions per thread: tile of T = NT*E positions
+// (NT=256,E=1 for M <= 262144; NT=256,E=4 up to M = 1048576, all tiles resident at once).
+template <bool WITH_D, bool FULL, int SPT, int NT, int E, bool STAGE>
+__device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int (*s_red)[16], int *s_acc, int *s_st) {
+    constexpr int T = NT * E, NW = NT / 64;
     const int jl = g.jl;
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
     const int w = blockIdx.x, W = g.W, M = g.M;
-    const int S = w * T, i = S + t;
+    const int S = w * T, i0 = S + t * E;
     PBWT_STAMP(0);
     const int4 *sm_in = g.summ + (size_t)(jl % 3) * g.wpad * 3;
     int4 *sm_out = g.summ + (size_t)((jl + 1) % 3) * g.wpad * 3;
@@ -506,8 +507,16 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
 
     // ---- issue everything whose address is known now ----
     const Ctl ctl = *g.ctl;
-    int a = g.a_in[i];
-    const int d = WITH_D ? g.d_in[i] : 0;
+    int a[E], d[E];
+    if constexpr (E == 4) {
+        const int4 va = *reinterpret_cast<const int4 *>(g.a_in + i0);
+        a[0] = va.x; a[1] = va.y; a[2] = va.z; a[3] = va.w;
+        if (WITH_D) { const int4 vd = *reinterpret_cast<const int4 *>(g.d_in + i0); d[0] = vd.x; d[1] = vd.y; d[2] = vd.z; d[3] = vd.w; }
+        else { d[0] = d[1] = d[2] = d[3] = 0; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { a[e] = g.a_in[i0 + e]; d[e] = WITH_D ? g.d_in[i0 + e] : 0; }
+    }
     int4 sc[SPT], sl[SPT]; int smx[SPT];
 #pragma unroll
     for (int q = 0; q < SPT; ++q) {
@@ -516,14 +525,22 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
         if (jn < W) { sc[q] = sm_in[(size_t)jn * 3]; if (WITH_D) { sl[q] = sm_in[(size_t)jn * 3 + 1]; smx[q] = sm_in[(size_t)jn * 3 + 2].x; } }
     }
     const int k = ctl.kbase + 2 * jl;
-    const bool valid = FULL || (i < M);
-    const int key = (int)(((unsigned)a >> 31) | (((unsigned)a >> 29) & 2u));     // b0 | b1<<1
-    a &= AMASK;
-    // alleles of this haplotype at sites k+2, k+3: the tags of slot 2*jl+2 = the next launch's key
+    // alleles of the owned haplotypes at sites k+2, k+3: the tags of slot 2*jl+2 = the next launch's keys
     const uint32_t *c2 = (k + 2 < ctl.n_total) ? ctl.cols + (size_t)(2 * jl + 2) * g.wpc : ctl.zerocol;
     const uint32_t *c3 = (k + 3 < ctl.n_total) ? ctl.cols + (size_t)(2 * jl + 3) * g.wpc : ctl.zerocol;
-    int nkey = 0;
-    if (valid) nkey = (int)(((c2[(unsigned)a >> 5] >> (a & 31)) & 1u) | (((c3[(unsigned)a >> 5] >> (a & 31)) & 1u) << 1));
+    int key[E], nkey[E];
+    bool valid[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        valid[e] = FULL || (i0 + e < M);
+        key[e] = (int)(((unsigned)a[e] >> 31) | (((unsigned)a[e] >> 29) & 2u));     // b0 | b1<<1
+        a[e] &= AMASK;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        nkey[e] = 0;
+        if (valid[e] && !ctl.pad0) nkey[e] = (int)(((c2[(unsigned)a[e] >> 5] >> (a[e] & 31)) & 1u) | (((c3[(unsigned)a[e] >> 5] >> (a[e] & 31)) & 1u) << 1));   // (pad0: timing experiment without the gathers)
+    }
 
     // ---- fold the tile summaries ----
     int bef[4] = {0, 0, 0, 0}, tot4[4] = {0, 0, 0, 0}, lst[4] = {0, 0, 0, 0};
@@ -549,94 +566,154 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
         lst[x] = WITH_D ? waves_combine<NW, true>(&s_red[0][8 + x], lane) : 0;
     }
     PBWT_STAMP(1);
-    // carries: max d_k over [last[x], S) = whole-tile maxima + one partial-tile read per key
-    int mx[4] = {0, 0, 0, 0}, pd[4] = {0, 0, 0, 0};
+    // carries: max d_k over [last[x], S) = whole-tile maxima + one partial-tile read (<= T positions) per key
+    int mx[4] = {0, 0, 0, 0};
+    int pd[4][E];
     if (WITH_D) {
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             const int tl = lst[x] ? (lst[x] - 1) / T : -1;
             const int hi = lst[x] ? min((tl + 1) * T, S) : 0;
-            if (lst[x] + t < hi) pd[x] = g.d_in[lst[x] + t];
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const int p = lst[x] + t + e * NT; pd[x][e] = (p < hi) ? g.d_in[p] : 0; }
 #pragma unroll
             for (int q = 0; q < SPT; ++q) { const int jn = t + q * NT; if (jn < w && jn > tl) mx[x] = max(mx[x], smx[q]); }
         }
     }
 
-    // ---- own tuple, block scan ----
+    // ---- the thread's own tuple (E positions in order), block scan ----
     Tup4 me = tup4_id();
-    if (valid) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) { me.c[x] = (x == key) ? 1 : 0; me.t[x] = (x == key) ? 0 : d; }
-        me.all = d;
+    for (int e = 0; e < E; ++e) {
+        if (valid[e]) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { if (x == key[e]) { ++me.c[x]; me.t[x] = 0; } else me.t[x] = max(me.t[x], d[e]); }
+            me.all = max(me.all, d[e]);
+        }
     }
     Tup4 tot;
-    const Tup4 pre = block_scan_tup4<NW>(me, s_tup, tot);
+    Tup4 run = block_scan_tup4<NW>(me, s_tup, tot);       // exclusive prefix of this thread's first position
     PBWT_STAMP(2);
-    int dd1 = 0, dd2 = 0;
+    int cr[4] = {0, 0, 0, 0};
     if (WITH_D) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) mx[x] = wave_iscan_max(max(mx[x], pd[x]));
+        for (int x = 0; x < 4; ++x) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) mx[x] = max(mx[x], pd[x][e]);
+            mx[x] = wave_iscan_max(mx[x]);
+        }
         if (lane == 63) {
 #pragma unroll
             for (int x = 0; x < 4; ++x) s_red[wv][12 + x] = mx[x];
         }
         lds_barrier();
-        int eff[4]; bool ex[4];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const int cr = waves_combine<NW, true>(&s_red[0][12 + x], lane);
-            ex[x] = pre.c[x] || lst[x];
-            eff[x] = pre.c[x] ? pre.t[x] : max(cr, pre.all);
-        }
-        // level 2: same key
-        int e2 = 0; bool x2 = false;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) if (x == key) { e2 = eff[x]; x2 = ex[x]; }
-        if (x2) dd2 = max(e2, d);
-        else {
-            int lower = -1;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) if (x < key && tot4[x] > 0) lower = x;
-            dd2 = (lower >= 0) ? k + 1 + (31 - __clz(key ^ lower)) : 0;
-        }
-        // level 1: same allele at site k = the later of the two keys sharing b0 = the smaller maximum
-        const int b0 = key & 1;
-        const int ea = b0 ? eff[1] : eff[0], eb = b0 ? eff[3] : eff[2];
-        const bool xa = b0 ? ex[1] : ex[0], xb = b0 ? ex[3] : ex[2];
-        if (xa || xb) dd1 = max(min(xa ? ea : 0x7fffffff, xb ? eb : 0x7fffffff), d);
-        else dd1 = k + 1;
+        for (int x = 0; x < 4; ++x) cr[x] = waves_combine<NW, true>(&s_red[0][12 + x], lane);
     }
     PBWT_STAMP(3);
-    // ---- positions at both levels, scatter ----
-    const int b0 = key & 1, b1 = key >> 1;
+    // ---- per position: divergences and destinations at both levels, scatter, next-pair summaries ----
     const int Zw1 = bef[0] + bef[2], C1 = tot4[0] + tot4[2];
-    const int zr = pre.c[0] + pre.c[2], orr = pre.c[1] + pre.c[3];
-    const int pos1 = b0 ? C1 + (S - Zw1) + orr : Zw1 + zr;
     int G2[4]; G2[0] = 0; G2[1] = tot4[0]; G2[2] = tot4[0] + tot4[1]; G2[3] = tot4[0] + tot4[1] + tot4[2];
-    int base2 = 0, prk = 0;
+    const bool has_next = (k + 2 < ctl.n_total);
+    // local (in-tile) bucket bases of the two destination orders, for the LDS-staged write-out
+    const int cw1 = tot.c[0] + tot.c[2];
+    int LG2[4]; LG2[0] = 0; LG2[1] = tot.c[0]; LG2[2] = tot.c[0] + tot.c[1]; LG2[3] = tot.c[0] + tot.c[1] + tot.c[2];
+    const int nvalid = LG2[3] + tot.c[3];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) if (x == key) { base2 = G2[x] + bef[x]; prk = pre.c[x]; }
-    const int pos2 = base2 + prk;
-    if (valid) {
-        g.a_mid[pos1] = a | (int)((unsigned)b1 << 31);
-        g.a_out[pos2] = a | (int)(((unsigned)(nkey & 1) << 31) | ((unsigned)(nkey >> 1) << 30));
-        if (WITH_D) {
-            g.d_mid[pos1] = pos1 ? dd1 : k + 2;            // sentinels (pbwtCore.c:507)
-            if (pos2 == 0) dd2 = k + 3;
-            g.d_out[pos2] = dd2;
+    for (int e = 0; e < E; ++e) {
+        if (valid[e]) {
+            const int ky = key[e], de = d[e];
+            int dd1 = 0, dd2 = 0;
+            if (WITH_D) {
+                int eff[4]; bool ex[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { ex[x] = run.c[x] || lst[x]; eff[x] = run.c[x] ? run.t[x] : max(cr[x], run.all); }
+                int e2 = 0; bool x2 = false;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) if (x == ky) { e2 = eff[x]; x2 = ex[x]; }
+                if (x2) dd2 = max(e2, de);                 // same key: range max of d_k since that predecessor
+                else {                                     // first of its key: differs from the last element of the nearest lower non-empty key
+                    int lower = -1;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) if (x < ky && tot4[x] > 0) lower = x;
+                    dd2 = (lower >= 0) ? k + 1 + (31 - __clz(ky ^ lower)) : 0;
+                }
+                // level 1: same allele at site k = the later of the two keys sharing b0 = the smaller maximum
+                const int bb = ky & 1;
+                const int ea = bb ? eff[1] : eff[0], eb = bb ? eff[3] : eff[2];
+                const bool xa = bb ? ex[1] : ex[0], xb = bb ? ex[3] : ex[2];
+                dd1 = (xa || xb) ? max(min(xa ? ea : 0x7fffffff, xb ? eb : 0x7fffffff), de) : k + 1;
+            }
+            const int b0 = ky & 1, b1 = ky >> 1;
+            const int zr = run.c[0] + run.c[2], orr = run.c[1] + run.c[3];
+            int prk = 0, lg = 0, base2 = 0;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) if (x == ky) { base2 = G2[x] + bef[x]; prk = run.c[x]; lg = LG2[x]; }
+            const int av1 = a[e] | (int)((unsigned)b1 << 31);
+            const int av2 = a[e] | (int)(((unsigned)(nkey[e] & 1) << 31) | ((unsigned)(nkey[e] >> 1) << 30));
+            if (STAGE) {                                   // destination order in LDS; written out coalesced below
+                const int l1 = b0 ? cw1 + orr : zr, l2 = lg + prk;
+                s_st[l1] = av1; s_st[T + l2] = av2;
+                if (WITH_D) { s_st[2 * T + l1] = dd1; s_st[3 * T + l2] = dd2; }
+            } else {
+                const int pos1 = b0 ? C1 + (S - Zw1) + orr : Zw1 + zr;
+                const int pos2 = base2 + prk;
+                g.a_mid[pos1] = av1;
+                g.a_out[pos2] = av2;
+                if (WITH_D) {
+                    g.d_mid[pos1] = pos1 ? dd1 : k + 2;    // sentinels (pbwtCore.c:507)
+                    if (pos2 == 0) dd2 = k + 3;
+                    g.d_out[pos2] = dd2;
+                }
+                if (has_next) {                            // <= 2 destination tiles per key stream
+                    const int slot = ky * 2 + (pos2 / T - base2 / T);
+                    atomicAdd(&s_acc[slot * 9 + nkey[e]], 1);
+                    if (WITH_D) { atomicMax(&s_acc[slot * 9 + 4 + nkey[e]], pos2 + 1); atomicMax(&s_acc[slot * 9 + 8], dd2); }
+                }
+            }
+            if (E > 1) {                                   // advance the running prefix past this position
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { if (x == ky) { ++run.c[x]; run.t[x] = 0; } else run.t[x] = max(run.t[x], de); }
+                run.all = max(run.all, de);
+            }
+        }
+    }
+    if (STAGE) {
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int l = e * NT + t;                      // destination-order index inside the tile
+            if (FULL || l < nvalid) {
+                const int pos1 = (l < cw1) ? Zw1 + l : C1 + (S - Zw1) + (l - cw1);
+                int x2 = 0;
+                if (l >= LG2[1]) x2 = 1;
+                if (l >= LG2[2]) x2 = 2;
+                if (l >= LG2[3]) x2 = 3;
+                int base2 = 0, lg = 0;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) if (x == x2) { base2 = G2[x] + bef[x]; lg = LG2[x]; }
+                const int pos2 = base2 + (l - lg);
+                const int av2 = s_st[T + l];
+                g.a_mid[pos1] = s_st[l];
+                g.a_out[pos2] = av2;
+                int dd2 = 0;
+                if (WITH_D) {
+                    g.d_mid[pos1] = pos1 ? s_st[2 * T + l] : k + 2;
+                    dd2 = pos2 ? s_st[3 * T + l] : k + 3;
+                    g.d_out[pos2] = dd2;
+                }
+                if (has_next) {
+                    const int nk = (int)(((unsigned)av2 >> 31) | (((unsigned)av2 >> 29) & 2u));
+                    const int slot = x2 * 2 + (pos2 / T - base2 / T);
+                    atomicAdd(&s_acc[slot * 9 + nk], 1);
+                    if (WITH_D) { atomicMax(&s_acc[slot * 9 + 4 + nk], pos2 + 1); atomicMax(&s_acc[slot * 9 + 8], dd2); }
+                }
+            }
         }
     }
     if (WITH_D && w == W - 1 && t == 0) { g.d_mid[M] = k + 2; g.d_out[M] = k + 3; }
     PBWT_STAMP(4);
-    // ---- summaries of the next pair, per destination tile of the level-2 order ----
-    const bool has_next = (k + 2 < ctl.n_total);
-    const int ft = base2 / T;                              // first destination tile of this key's stream
     if (has_next) {
-        if (valid) {
-            const int slot = key * 2 + (pos2 / T - ft);    // <= 2 destination tiles per key stream
-            atomicAdd(&s_acc[slot * 9 + nkey], 1);
-            if (WITH_D) { atomicMax(&s_acc[slot * 9 + 4 + nkey], pos2 + 1); atomicMax(&s_acc[slot * 9 + 8], dd2); }
-        }
         lds_barrier();
         if (t < 72) {
             const int slot = t / 9, f = t - slot * 9, kq = slot >> 1;
@@ -654,25 +731,25 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
     PBWT_STAMP(6);
 }
 
-template <bool WITH_D, int SPT, int NT>
+template <bool WITH_D, int SPT, int NT, int E, bool STAGE>
 __global__ __launch_bounds__(NT) void step2_kernel(Step2Args g) {
     __shared__ Tup4 s_tup[NT / 64];
     __shared__ int s_red[NT / 64][16];
     __shared__ int s_acc[72];
-    if ((int)(blockIdx.x + 1) * NT <= g.M) step2_body<WITH_D, true, SPT, NT>(g, s_tup, s_red, s_acc);
-    else step2_body<WITH_D, false, SPT, NT>(g, s_tup, s_red, s_acc);
+    __shared__ int s_st[STAGE ? (WITH_D ? 4 : 2) * NT * E : 1];     // staged (a1, a2, d1, d2) in destination order
+    if ((int)(blockIdx.x + 1) * NT * E <= g.M) step2_body<WITH_D, true, SPT, NT, E, STAGE>(g, s_tup, s_red, s_acc, s_st);
+    else step2_body<WITH_D, false, SPT, NT, E, STAGE>(g, s_tup, s_red, s_acc, s_st);
 }
 
 // first pair of a pass (or after an odd-length batch): both allele tags of slot 0 from columns k, k+1
 // and the pair summaries from scratch; clears the accumulation buffer of the first launch
-struct Prep2Args { int *a; const int *d; const uint32_t *col0; const uint32_t *col1; int4 *summ; int M, W, wpad, with_d; };
-template <int NT>
-__global__ __launch_bounds__(NT) void prepare2_kernel(Prep2Args g) {
+struct Prep2Args { int *a; const int *d; const uint32_t *col0; const uint32_t *col1; int4 *summ; int M, W, wpad, with_d, T; };
+__global__ __launch_bounds__(BLOCK) void prepare2_kernel(Prep2Args g) {
     __shared__ int s_acc[9];
-    const int t = threadIdx.x, w = blockIdx.x, i = w * NT + t;
+    const int t = threadIdx.x, w = blockIdx.x;
     if (t < 9) s_acc[t] = 0;
     __syncthreads();
-    if (i < g.M) {
+    for (int i = w * g.T + t; i < min((w + 1) * g.T, g.M); i += BLOCK) {
         const int a = g.a[i] & AMASK;
         const unsigned b0 = (g.col0[(unsigned)a >> 5] >> (a & 31)) & 1u, b1 = (g.col1[(unsigned)a >> 5] >> (a & 31)) & 1u;
         g.a[i] = a | (int)((b0 << 31) | (b1 << 30));
