@@ -94,6 +94,12 @@ int pbwtamd_max_within(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, 
                        pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out,
                        int64_t *hist, int histlen);
 
+/* matchLongWithin2 (pbwtMatch.c:85-113), the -longWithin L command: every pair of haplotypes
+ * whose match ending at a site is at least L sites long, reported when the block closes; report
+ * order and quirks are the reference's (see sweep_long_kernel).  L >= 1 (L == 0 is maxWithin). */
+int pbwtamd_long_within(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart, int L,
+                        pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out);
+
 /* matchSequencesSweep (pbwtMatch.c:363-443): query panel q (Mq haplotypes, packed qz) against
  * the engine's panel (packed pz), both N sites.  Reports in the reference's order (k, query
  * PBWT order, i); n_nomatch counts the "no match to query" events (pbwtMatch.c:405-410);
@@ -131,6 +137,7 @@ int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k0, int n_to
 #define PBWTAMD_OPT_CHECKSUM    8u   /* per-site checksums of a/d/y */
 #define PBWTAMD_OPT_PACK3      16u   /* emit packed columns into the engine's yz buffer */
 #define PBWTAMD_OPT_WITHIN_RECS 32u  /* fuse the maxWithin sweep, record sink */
+#define PBWTAMD_OPT_LONG_RECS   64u  /* -longWithin L consumer (host entry point pbwtamd_long_within only) */
 
 /* advance the pass over `ncols` more columns held at d_bitcols (device).  The pass must see the
  * column after the last one too unless it is the panel's last site (ncols_avail >= ncols+1); with

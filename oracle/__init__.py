@@ -205,6 +205,16 @@ def max_within_hist(yz, M, N, aFstart=None):
     return hist
 
 
+def long_within(yz, M, N, L, aFstart=None):
+    """-longWithin L (matchLongWithin2): records in callback order"""
+    yz = np.ascontiguousarray(yz, dtype=np.uint8)
+    a0 = np.arange(M, dtype=np.int32) if aFstart is None else np.ascontiguousarray(aFstart, dtype=np.int32)
+    mv = MatchVec()
+    rc = lib().orc_long_within(C.c_int(M), C.c_int(N), C.c_int(L), _p(yz, C.c_uint8), C.c_size_t(yz.size), _p(a0, C.c_int32), C.byref(mv))
+    assert rc == 0
+    return _take(mv)
+
+
 def match_sweep(pz, Mp, qz, Mq, N, pStart=None, qStart=None):
     pz = np.ascontiguousarray(pz, dtype=np.uint8)
     qz = np.ascontiguousarray(qz, dtype=np.uint8)
@@ -295,6 +305,15 @@ def ref_max_within_file(yz, M, N, path, aFstart=None, hist=False, check=False):
     fn = r.ref_max_within_hist_to_file if hist else r.ref_max_within_text_to_file
     rc = fn(C.c_int(M), C.c_int(N), _p(yz, C.c_uint8), C.c_long(yz.size), _p(a0, C.c_int32),
             C.c_char_p(path.encode()), C.c_int(1 if check else 0))
+    assert rc == 0
+
+
+def ref_long_within_file(yz, M, N, L, path, aFstart=None, check=False):
+    r = ref()
+    yz = np.ascontiguousarray(yz, dtype=np.uint8)
+    a0 = np.arange(M, dtype=np.int32) if aFstart is None else np.ascontiguousarray(aFstart, dtype=np.int32)
+    rc = r.ref_long_within_text_to_file(C.c_int(M), C.c_int(N), C.c_int(L), _p(yz, C.c_uint8), C.c_long(yz.size), _p(a0, C.c_int32),
+                                        C.c_char_p(path.encode()), C.c_int(1 if check else 0))
     assert rc == 0
 
 

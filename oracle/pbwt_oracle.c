@@ -364,6 +364,40 @@ done:
     return rc;
 }
 
+/* ------------------------------------------------------------------ matchLongWithin2 */
+/* pbwtMatch.c:85-113 (-longWithin L).  Positions are cut into blocks wherever d[i] > k-L; when a
+ * block is closed and holds both alleles, every pair ia < ib in it with different alleles is
+ * reported with start = max d over (ia, ib].  Faithful to two quirks of the reference: i0/na/nb live
+ * across sites, so the block still open at the end of a site is never reported (at the next site
+ * d[0] closes it with an empty pair loop); and at k == N the alleles are the stale column N-1. */
+int orc_long_within(int M, int N, int L, const uint8_t *yz, size_t nz, const int32_t *aFstart, orc_matchvec *out)
+{
+    ocursor u;
+    int i0 = 0, na = 0, nb = 0;
+    oc_open(&u, M, yz, nz, aFstart);
+    for (int k = 0; k <= N; ++k) {
+        const int32_t *d = u.d, *a = u.a;
+        const uint8_t *y = u.y;
+        for (int i = 0; i < M; ++i) {
+            if (d[i] > k - L) {
+                if (na && nb)
+                    for (int ia = i0; ia < i; ++ia) {
+                        int dmin = 0;
+                        for (int ib = ia + 1; ib < i; ++ib) {
+                            if (d[ib] > dmin) dmin = d[ib];
+                            if (y[ib] != y[ia]) mv_push(out, a[ia], a[ib], dmin, k);
+                        }
+                    }
+                na = 0; nb = 0; i0 = i;
+            }
+            if (y[i] == 0) na++; else nb++;
+        }
+        oc_forwards_read_AD(&u, k);
+    }
+    oc_close(&u);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ matchSequencesSweep */
 /* pbwtMatch.c:363-443 */
 int orc_match_sweep(int Mp, int N, const uint8_t *pz, size_t pnz, const int32_t *pStart,

@@ -5,7 +5,7 @@
  * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  * The product library (pbwt_amd/csrc -> libpbwtgpu.so) never links or calls anything here.
  *
- * Parity status: PINNED.  Every function below is checked (tests/test_oracle_vs_ref.py and the
+ * Parity status: PINNED.  Every function below is checked (tests/test_oracle_golden.py and the
  * committed fixtures under tests/golden/) against outputs of the reference itself, compiled in
  * place from /root/reference into oracle/_ref/ by oracle/Makefile.
  *
@@ -75,6 +75,9 @@ int orc_sweep_AD(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aFst
  * hist[0..histlen) (counts beyond histlen-1 are an error -> returns -2). */
 int orc_max_within(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aFstart,
                    int mode, orc_matchvec *out, int64_t *hist, int histlen);
+
+/* ---- matchLongWithin2 (pbwtMatch.c:85-113), the -longWithin L command: records in callback order */
+int orc_long_within(int M, int N, int L, const uint8_t *yz, size_t nz, const int32_t *aFstart, orc_matchvec *out);
 
 /* ---- matchSequencesSweep (pbwtMatch.c:363-443): panel p vs query panel q, both packed.
  * Appends report() calls in callback order; *n_nomatch counts the "no match to query" log

@@ -142,6 +142,25 @@ int ref_max_within_text_to_file(int M, int N, const uint8_t *yz, long nz, const 
     return 0;
 }
 
+/* -longWithin L exactly as the CLI prints it (pbwtLongMatches -> matchLongWithin2 -> reportMatch) */
+int ref_long_within_text_to_file(int M, int N, int L, const uint8_t *yz, long nz, const int32_t *aFstart, const char *path, int with_check)
+{
+    ref_init();
+    PBWT *p = make_panel(M, N, yz, nz, aFstart);
+    fflush(stdout);
+    int saved = dup(1);
+    FILE *f = fopen(path, "w");
+    if (!f) return -1;
+    dup2(fileno(f), 1);
+    isCheck = with_check ? TRUE : FALSE;
+    pbwtLongMatches(p, L);
+    isCheck = FALSE;
+    fflush(stdout);
+    dup2(saved, 1); close(saved); fclose(f);
+    pbwtDestroy(p);
+    return 0;
+}
+
 long ref_match_sweep(int Mp, int N, const uint8_t *pz, long pnz, const int32_t *pStart,
                      int Mq, const uint8_t *qz, long qnz, const int32_t *qStart, ref_match **out)
 {

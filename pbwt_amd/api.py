@@ -188,6 +188,23 @@ class Engine:
             self._L.pbwtamd_free(rp)
         return out, nom.value, (tot[0], tot[1])
 
+    def long_within(self, yz, N, L, aFstart=None, callback=None):
+        """-longWithin L: records in callback order (or calls callback per report)"""
+        yz = np.ascontiguousarray(yz, dtype=np.uint8)
+        aF = _i32(aFstart)
+        rp = C.c_void_p()
+        n = C.c_int64(0)
+        fn = REPORT_FN(callback) if callback else None
+        self._chk(self._L.pbwtamd_long_within(self._h, _p(yz, C.c_uint8), C.c_int64(yz.size), C.c_int(N), _p(aF, C.c_int32), C.c_int(L),
+                                              fn, None if callback else C.byref(rp), C.byref(n)))
+        if callback:
+            return None
+        out = np.zeros(n.value, MATCH_DTYPE)
+        if n.value:
+            C.memmove(out.ctypes.data, rp, n.value * MATCH_DTYPE.itemsize)
+        self._L.pbwtamd_free(rp)
+        return out
+
     def pack3(self, sorted_bitcols):
         sb = np.ascontiguousarray(sorted_bitcols, dtype=np.uint32)
         N, wpc = sb.shape

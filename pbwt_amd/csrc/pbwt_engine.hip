@@ -77,6 +77,8 @@ struct pbwtamd_engine {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0; long long launches = 0;
     // record sink for pass_advance (host-buffer entry points)
     std::vector<pbwtamd_match> *rec_sink = nullptr; pbwtamd_report_fn rec_cb = nullptr;
+    int longL = 0;                          // L of the -longWithin consumer (PBWTAMD_OPT_LONG_RECS)
+    int *ystale = nullptr;                  // copy of the previous state's tagged a, for the k == N quirk of -longWithin
 };
 
 extern "C" int pbwtamd_abi_version(void) { return PBWTAMD_ABI_VERSION; }
@@ -101,7 +103,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, e->cols_stage, e->ycols, e->colBytes,
+    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, e->cols_stage, e->ycols, e->colBytes,
                     e->blockCount, e->scal, e->hist, e->csum, e->recs, e->yz};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -359,6 +361,45 @@ static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int
     return 0;
 }
 
+// -longWithin L over `nsites` slots (records only)
+static int run_long(pbwtamd_engine *e, hipStream_t st, const int *A, const int *D, const int *Ystale, int kbase, int nsites, int final_site) {
+    LongArgs g;
+    g.A = A; g.D = D; g.strideA = e->strideA; g.strideD = e->strideD; g.Ystale = Ystale ? Ystale : A;
+    g.M = e->M; g.kbase = kbase; g.final_site = final_site; g.L = e->longL;
+    const int tiles = (e->M + BLOCK - 1) / BLOCK;
+    dim3 grid(tiles, nsites);
+    const size_t nblk = (size_t)tiles * nsites;
+    CHK(ensure_blockcount(e, nblk));
+    g.blockCount = e->blockCount; g.recs = nullptr;
+    hipLaunchKernelGGL((sweep_long_kernel<0>), grid, dim3(BLOCK), 0, st, g);
+    hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, e->blockCount, nblk, e->scal, 0ULL);
+    HIPCHK(hipGetLastError());
+    unsigned long long total = 0;
+    HIPCHK(hipMemcpyAsync(&total, e->scal, sizeof total, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (total > e->recsCap) {
+        if (e->recs) HIPCHK(hipFree(e->recs));
+        e->recsCap = (size_t)(total + total / 4 + 1024);
+        HIPCHK(hipMalloc((void **)&e->recs, e->recsCap * sizeof(int4)));
+    }
+    if (total) {
+        g.recs = e->recs;
+        hipLaunchKernelGGL((sweep_long_kernel<1>), grid, dim3(BLOCK), 0, st, g);
+        HIPCHK(hipGetLastError());
+        std::vector<pbwtamd_match> tmp;
+        std::vector<pbwtamd_match> *dst = e->rec_sink ? e->rec_sink : &tmp;
+        const size_t old = dst->size();
+        dst->resize(old + total);
+        HIPCHK(hipMemcpyAsync(dst->data() + old, e->recs, total * sizeof(int4), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (e->rec_cb) {
+            for (size_t r = old; r < old + total; ++r) { const pbwtamd_match &m = (*dst)[r]; e->rec_cb(m.ai, m.bi, m.start, m.end); }
+            if (dst == e->rec_sink) dst->resize(old);
+        }
+    }
+    return 0;
+}
+
 static int ensure_yz(pbwtamd_engine *e, hipStream_t st, size_t cap) {
     if (cap <= e->yzCap) return 0;
     uint8_t *n = nullptr;
@@ -446,6 +487,12 @@ static int flush_pending(pbwtamd_engine *e) {
         HIPCHK(hipGetLastError());
     }
     if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, e->s2, A, D, p.kbase, p.nb, -1, p.opts));
+    if (p.opts & PBWTAMD_OPT_LONG_RECS) {
+        CHK(run_long(e, e->s2, A, D, nullptr, p.kbase, p.nb, -1));
+        // keep the batch's last state (before site kbase+nb-1): it is the stale allele column if the panel ends here
+        if (!e->ystale) HIPCHK(hipMalloc((void **)&e->ystale, sizeof(int) * e->strideA));
+        HIPCHK(hipMemcpyAsync(e->ystale, A + (size_t)(p.nb - 1) * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->s2));
+    }
     if (p.opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, e->s2, A, p.nb));
     HIPCHK(hipEventRecord(e->evCons[p.ring], e->s2));
     e->consRecorded[p.ring] = true;
@@ -460,7 +507,7 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
     if (ncols_avail < ncols + 1 && e->k_cur + ncols < e->n_total)
         return fail("pbwtamd_pass_advance: need the column after the batch (ncols_avail >= ncols+1) except at the last site");
     const bool with_d = opts & PBWTAMD_OPT_WITH_D, sorted = opts & PBWTAMD_OPT_SORTED;
-    if ((opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) && !with_d)
+    if ((opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_LONG_RECS)) && !with_d)
         return fail("pbwtamd: the maxWithin sweep needs OPT_WITH_D");
     const uint32_t *cols = (const uint32_t *)d_bitcols;
     int done = 0;
@@ -505,7 +552,7 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         if (e->consRecorded[r ^ 1]) HIPCHK(hipStreamWaitEvent(e->stream, e->evCons[r ^ 1], 0));
         HIPCHK(hipMemcpyAsync(ringA(e, r ^ 1), A + (size_t)nb * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->stream));
         if (with_d) HIPCHK(hipMemcpyAsync(ringD(e, r ^ 1), D + (size_t)nb * e->strideD, sizeof(int) * e->strideD, hipMemcpyDeviceToDevice, e->stream));
-        if (opts & (PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3)) {
+        if (opts & (PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS)) {
             e->pend.valid = true; e->pend.ring = r; e->pend.kbase = e->k_cur; e->pend.nb = nb; e->pend.opts = opts;
         }
         e->ring = r ^ 1;
@@ -530,6 +577,7 @@ extern "C" int pbwtamd_pass_end(pbwtamd_engine *e, unsigned opts) {
         HIPCHK(hipGetLastError());
     }
     if (opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, e->s2, A, D, e->n_total, 1, 0, opts));
+    if (opts & PBWTAMD_OPT_LONG_RECS) CHK(run_long(e, e->s2, A, D, e->ystale, e->n_total, 1, 0));
     e->pass_open = false;
     return pbwtamd_sync(e);
 }
@@ -798,6 +846,26 @@ extern "C" int pbwtamd_haplotypes(pbwtamd_engine *e, const uint8_t *yz, int64_t 
         done += nb;
     }
     return pbwtamd_pass_end(e, PBWTAMD_OPT_SORTED);
+}
+
+// -longWithin L: matchLongWithin2 (pbwtMatch.c:85-113) over a packed panel
+extern "C" int pbwtamd_long_within(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart, int L,
+                                   pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out) {
+    HIPCHK(hipSetDevice(e->device));
+    if ((report ? 1 : 0) + (recs_out ? 1 : 0) != 1) return fail("pbwtamd_long_within: exactly one of report / recs_out must be given");
+    if (L < 0) return fail("L %d for longWithin must be >= 0", L);
+    std::vector<pbwtamd_match> recs;
+    e->rec_sink = &recs; e->rec_cb = report; e->longL = L;
+    const int rc = sweep_packed(e, yz, nz, N, aFstart, PBWTAMD_OPT_LONG_RECS, nullptr, 0, nullptr, nullptr);
+    e->rec_sink = nullptr; e->rec_cb = nullptr;
+    if (rc) return rc;
+    if (recs_out) {
+        pbwtamd_match *buf = (pbwtamd_match *)malloc(std::max<size_t>(1, recs.size()) * sizeof(pbwtamd_match));
+        if (!buf) return fail("pbwtamd_long_within: out of host memory");
+        if (!recs.empty()) memcpy(buf, recs.data(), recs.size() * sizeof(pbwtamd_match));
+        *recs_out = buf; *nrecs_out = (int64_t)recs.size();
+    }
+    return 0;
 }
 
 extern "C" int pbwtamd_pack3(pbwtamd_engine *e, const uint32_t *sorted_bitcols, int wpc, int N, uint8_t **yz_out, int64_t *nz_out) {

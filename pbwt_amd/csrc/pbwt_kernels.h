@@ -1225,6 +1225,57 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     }
 }
 
+// matchLongWithin2 (pbwtMatch.c:85-113, -longWithin L) over ring slots: positions are cut into
+// blocks wherever d[i] > k-L; every pair ia < ib inside a CLOSED block with different alleles is
+// reported with start = max d over (ia, ib].  One thread per ia walks to the end of its block.
+// Reference quirks kept: the block still open at position M-1 is never reported (its i0/na/nb live
+// across sites and the next site's d[0] closes it with an empty loop), and at the final site k == N
+// the alleles are the stale column N-1 (`Ystale` = tags of the previous slot, by position).
+// MODE 0 counts per block, MODE 1 emits at the scanned offsets.
+struct LongArgs {
+    const int *A; const int *D; size_t strideA, strideD;
+    const int *Ystale;                   // tagged a of state N-1 (only used for final_site)
+    int M, kbase, final_site, L;
+    unsigned long long *blockCount; int4 *recs;
+};
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void sweep_long_kernel(LongArgs g) {
+    __shared__ unsigned long long s_w[WAVES];
+    const int site = blockIdx.y, k = g.kbase + site;
+    const int *a = g.A + (size_t)site * g.strideA;
+    const int *d = g.D + (size_t)site * g.strideD;
+    const int *ysrc = (site == g.final_site) ? g.Ystale : a;
+    const int ia = blockIdx.x * BLOCK + threadIdx.x;
+    const int M = g.M, thr = k - g.L;
+    unsigned long long cnt = 0;
+    int end = 0;
+    unsigned ya = 0;
+    if (ia < M) {
+        ya = (unsigned)ysrc[ia] >> 31;
+        int ib = ia + 1;
+        while (ib < M && d[ib] <= thr) { if (((unsigned)ysrc[ib] >> 31) != ya) ++cnt; ++ib; }
+        end = ib;
+        if (ib >= M) cnt = 0;                             // block never closed at this site: not reported
+    }
+    unsigned long long inc = cnt;
+    for (int o = 1; o < 64; o <<= 1) { unsigned long long v = __shfl_up(inc, o); if (lane_id() >= o) inc += v; }
+    if (lane_id() == 63) s_w[wave_id()] = inc;
+    __syncthreads();
+    unsigned long long pre = 0, tot = 0;
+    for (int q = 0; q < WAVES; ++q) { if (q < wave_id()) pre += s_w[q]; tot += s_w[q]; }
+    const size_t bidx = (size_t)site * gridDim.x + blockIdx.x;
+    if (MODE == 0) { if (threadIdx.x == 0) g.blockCount[bidx] = tot; return; }
+    if (cnt) {
+        int4 *out = g.recs + g.blockCount[bidx] + pre + (inc - cnt);
+        const int ai = a[ia] & AMASK;
+        int dmin = 0;
+        for (int ib = ia + 1; ib < end; ++ib) {
+            dmin = max(dmin, d[ib]);
+            if (((unsigned)ysrc[ib] >> 31) != ya) *out++ = make_int4(ai, a[ib] & AMASK, dmin, k);
+        }
+    }
+}
+
 // single-block exclusive scan of n 64-bit values (in place), total to *total
 __global__ __launch_bounds__(1024) void scan_u64_kernel(unsigned long long *v, size_t n, unsigned long long *total,
                                                        unsigned long long base_in) {

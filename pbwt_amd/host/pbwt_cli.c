@@ -1,7 +1,7 @@
 /* pbwt_cli.c — `pbwt` command interpreter for the hot-path subset of the reference's CLI
  * (pbwtMain.c:276-494): a sequence of "-command args" applied in order to one current panel.
  * Supported: -check -stats -log -read -readSites -readAll -readMacs -write -writeSites -writeAll
- * -haps -maxWithin -matchDynamic -siteInfo -subsample.  Everything else: "not on the accelerated
+ * -haps -maxWithin -longWithin -matchDynamic -siteInfo -subsample.  Everything else: "not on the accelerated
  * path of this build". */
 #include "pbwt_host.h"
 #include <stdlib.h>
@@ -22,7 +22,7 @@ int main (int argc, char *argv[])
   if (!argc)
     { fprintf (stderr, "Program: pbwt (MI355X hot-path build, pbwt_amd)\nUsage: pbwt [ -<command> [options]* ]+\n"
 	       "Commands: -check -stats -log <file> -read <file> -readSites <file> -readAll <root> -readMacs <file>\n"
-	       "          -write <file> -writeSites <file> -writeAll <root> -haps <file> -maxWithin\n"
+	       "          -write <file> -writeSites <file> -writeAll <root> -haps <file> -maxWithin -longWithin <L>\n"
 	       "          -matchDynamic <file> -siteInfo <file> <kmin> <kmax> -subsample <start> <n>\n") ;
       return 0 ;
     }
@@ -52,6 +52,8 @@ int main (int argc, char *argv[])
 	{ NEEDP ; fp = openOrDie (argv[1], "haps", "w") ; panelWriteHaplotypes (fp, p) ; fclose (fp) ; argc -= 2 ; argv += 2 ; }
       else if (!strcmp (argv[0], "-maxWithin"))
 	{ NEEDP ; panelLongMatches (p, 0) ; argc -= 1 ; argv += 1 ; }
+      else if (!strcmp (argv[0], "-longWithin") && argc > 1)
+	{ NEEDP ; panelLongMatches (p, atoi (argv[1])) ; argc -= 2 ; argv += 2 ; }
       else if (!strcmp (argv[0], "-matchDynamic") && argc > 1)
 	{ NEEDP ; fp = openOrDie (argv[1], "matchDynamic", "r") ; panelMatchDynamic (p, fp) ; fclose (fp) ; argc -= 2 ; argv += 2 ; }
       else if (!strcmp (argv[0], "-siteInfo") && argc > 3)

@@ -269,9 +269,14 @@ static uint8_t *decodeHaps (Panel *p)
 void panelLongMatches (Panel *p, int L)
 {
   if (!p || !p->yz) die ("option -longWithin called without a PBWT") ;
-  if (L != 0) die ("-longWithin L > 0 is not on the accelerated path of this build") ;
+  if (L < 0) die ("L %d for longWithin must be >= 0", L) ;
   pbwtamd_engine *e = engineFor (p->M) ;
   if (isCheck) { checkA = checkB = decodeHaps (p) ; checkMA = checkMB = p->M ; checkN = p->N ; }
+  if (L)				/* matchLongWithin2 (pbwtMatch.c:85-113) */
+    { if (pbwtamd_long_within (e, p->yz, p->nz, p->N, p->aFstart, L, reportMatch, 0, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+      if (isCheck) { free (checkA) ; checkA = checkB = 0 ; }
+      return ;
+    }
   if (isStats)				/* histogram instead of reports (pbwtMatch.c:130-131,158-178) */
     { int64_t *h = xalloc (sizeof (int64_t) * ((size_t) p->N + 1)) ;
       if (pbwtamd_max_within (e, p->yz, p->nz, p->N, p->aFstart, 0, 0, 0, h, p->N + 1)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;

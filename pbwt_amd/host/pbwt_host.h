@@ -36,7 +36,7 @@ Panel *panelReadAll (const char *root) ;	/* pbwtReadAll, pbwtIO.c:408-422 (.pbwt
 void panelWriteAll (Panel *p, const char *root) ;	/* pbwtWriteAll, pbwtIO.c:134-144 */
 Panel *panelReadMacs (FILE *fp) ;		/* pbwtReadMacs, pbwtIO.c:426-492 */
 void panelWriteHaplotypes (FILE *fp, Panel *p) ;	/* pbwtWriteHaplotypes, pbwtIO.c:839-857 */
-void panelLongMatches (Panel *p, int L) ;	/* pbwtLongMatches with L == 0, pbwtMatch.c:148-183 */
+void panelLongMatches (Panel *p, int L) ;	/* pbwtLongMatches, pbwtMatch.c:148-183 (L == 0: maximal) */
 void panelMatchDynamic (Panel *p, FILE *fp) ;	/* matchSequencesDynamic, pbwtMatch.c:352-357 */
 void panelSiteInfo (Panel *p, FILE *fp, int f1, int f2) ;	/* exportSiteInfo, pbwtMain.c:82-100 */
 Panel *panelSubSampleInterval (Panel *p, int start, int Mnew) ;	/* pbwtSubSampleInterval, pbwtSample.c:95-108 */

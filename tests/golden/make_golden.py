@@ -52,6 +52,8 @@ def mosaic(M, N, seed, kind, qsplit):
     pz = oracle.ref_build_bitcols(pb, Mp, with_d=False)["yz"]
     qz = oracle.ref_build_bitcols(qb, Mq, with_d=False)["yz"]
     qrecs = oracle.ref_match_sweep(pz, Mp, qz, Mq, N)
+    if M == 300:      # -longWithin 100 text exactly as the reference CLI prints it (with -check)
+        oracle.ref_long_within_file(yz, M, N, 100, os.path.join(HERE, "longwithin_M300_L100.txt"), check=True)
     name = os.path.join(HERE, "mosaic_M%d_N%d_k%d.npz" % (M, N, kind))
     np.savez_compressed(name, M=M, N=N, seed=seed, kind=kind, bits=bits, yz=yz, aFend=rb["aFend"],
                         build_a=rb["a_all"].astype(np.int32), build_d=rb["d_all"].astype(np.int32),

@@ -113,3 +113,14 @@ def test_matchDynamic_and_siteInfo_and_subsample(cli, orc, tmp_path):
         if 20 <= f1 < 60:
             lines.append("".join("%d %d " % (sw["y_dump"][k][j], k - sw["d_dump"][k][j]) for j in range(M)) + "\n")
     assert len(lines) > 3 and open(tmp_path / "si.txt").read() == "".join(lines)
+
+
+@pytest.mark.gpu
+def test_longWithin_text(cli, tmp_path):
+    g = np.load(os.path.join(GOLDEN, "mosaic_M300_N400_k0.npz"))
+    M, N = int(g["M"]), int(g["N"])
+    f = tmp_path / "p.pbwt"
+    f.write_bytes(b"PBW3" + np.array([M, N], "<i4").tobytes() + np.arange(M, dtype="<i4").tobytes() + g["aFend"].astype("<i4").tobytes()
+                  + np.array([len(g["yz"])], "<i8").tobytes() + b"    " + g["yz"].tobytes())
+    r = run(cli, "-check", "-read", f, "-longWithin", 100)
+    assert r.stdout == open(os.path.join(GOLDEN, "longwithin_M300_L100.txt")).read()

@@ -22,7 +22,8 @@ WORKER = textwrap.dedent("""
     worst = pd.max_over_ranks(elapsed)
     total_units = pd.sum_over_ranks(len(units))
     pd.barrier()
-    print(json.dumps({"rank": rank, "world": world, "units": units, "seeds": seeds, "worst": worst, "total": total_units}))
+    with open(os.path.join(os.environ["OUT_DIR"], "rank%d.json" % rank), "w") as f:      # per-rank file: stdout lines of ranks can interleave
+        json.dump({"rank": rank, "world": world, "units": units, "seeds": seeds, "worst": worst, "total": total_units}, f)
     pd.finish()
 """) % ROOT
 
@@ -36,12 +37,12 @@ def test_independent_panels_per_rank_gloo(world, n_units, tmp_path):
     import json
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, N_UNITS=str(n_units))
+    env = dict(os.environ, N_UNITS=str(n_units), OUT_DIR=str(tmp_path))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
-    outs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    outs = [json.load(open(tmp_path / ("rank%d.json" % rk))) for rk in range(world)]
     assert sorted(o["rank"] for o in outs) == list(range(world))
     all_units = sorted(u for o in outs for u in o["units"])
     assert all_units == list(range(n_units))                          # every panel exactly once

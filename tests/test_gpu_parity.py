@@ -250,3 +250,11 @@ def test_large_panel_1024_position_tiles(amd, orc, pair1024, monkeypatch):
     b = eng.build(bits, with_d=True)
     assert np.array_equal(b["yz"], o["yz"]) and np.array_equal(b["aFend"], o["aFend"]) and np.array_equal(b["dFend"], o["d_final"])
     assert np.array_equal(eng.max_within(o["yz"], N, mode="hist"), orc.max_within_hist(o["yz"], M, N)[: N + 1])
+
+
+@pytest.mark.parametrize("M,N,kind,L,batch", [(8, 10, 1, 2, 4), (70, 150, 1, 5, 16), (300, 400, 0, 30, 64), (300, 400, 0, 100, 33), (2500, 300, 0, 80, 128)])
+def test_long_within_vs_oracle(amd, orc, M, N, kind, L, batch):
+    bits = orc.synth_bitcols(M, N, seed=77 + M, kind=kind)
+    yz = orc.build_bitcols(bits, M, with_d=False)["yz"]
+    eng = amd.Engine(M, batch_sites=batch)
+    assert np.array_equal(eng.long_within(yz, N, L), orc.long_within(yz, M, N, L))

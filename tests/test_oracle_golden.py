@@ -97,3 +97,11 @@ def test_oracle_vs_real_reference_random(orc):
         r = orc.ref_build_bitcols(bits, M, with_d=True)
         assert np.array_equal(o["yz"], r["yz"]) and np.array_equal(o["a_dump"], r["a_all"]) and np.array_equal(o["d_dump"], r["d_all"])
         assert np.array_equal(orc.max_within(o["yz"], M, N), orc.ref_max_within(o["yz"], M, N))
+
+
+def test_long_within_oracle_vs_reference_text(orc):
+    """-longWithin 100 on the 300-haplotype golden panel: the oracle's records print to the reference's text"""
+    g = np.load(os.path.join(GOLDEN, "mosaic_M300_N400_k0.npz"))
+    recs = orc.long_within(g["yz"], int(g["M"]), int(g["N"]), 100)
+    txt = "".join("MATCH\t%d\t%d\t%d\t%d\t%d\n" % (r["ai"], r["bi"], r["start"], r["end"], r["end"] - r["start"]) for r in recs if r["start"] != r["end"])
+    assert txt == open(os.path.join(GOLDEN, "longwithin_M300_L100.txt")).read()
