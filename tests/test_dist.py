@@ -22,7 +22,7 @@ WORKER = textwrap.dedent("""
     worst = pd.max_over_ranks(elapsed)
     total_units = pd.sum_over_ranks(len(units))
     pd.barrier()
-    with open(os.path.join(os.environ["OUT_DIR"], "rank%d.json" % rank), "w") as f:      # per-rank file: stdout lines of ranks can interleave
+    with open(os.path.join(os.environ["OUT_DIR"], "rank" + str(rank) + ".json"), "w") as f:      # per-rank file: stdout lines of ranks can interleave
         json.dump({"rank": rank, "world": world, "units": units, "seeds": seeds, "worst": worst, "total": total_units}, f)
     pd.finish()
 """) % ROOT
