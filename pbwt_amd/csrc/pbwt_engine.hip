@@ -188,8 +188,8 @@ extern "C" int pbwtamd_sync(pbwtamd_engine *e) {
 // start of a batch: publish the control block and rotate the tile summaries so that the current
 // site's summaries sit in buffer 0 (step j reads buffer j%3), with buffer 1 cleared for accumulation
 // (`n` = int4 entries per summary buffer: wpad for single-site steps, 3*wpad for two-site steps)
-__global__ __launch_bounds__(256) void set_ctl_kernel(Ctl *ctl, int kbase, int n_total, const uint32_t *cols, const uint32_t *zerocol, int4 *summ, int n, int cur, int nogather) {
-    if (threadIdx.x == 0) { ctl->kbase = kbase; ctl->n_total = n_total; ctl->cols = cols; ctl->zerocol = zerocol; ctl->pad0 = nogather; ctl->pad1 = 0; }
+__global__ __launch_bounds__(256) void set_ctl_kernel(Ctl *ctl, int kbase, int n_total, const uint32_t *cols, const uint32_t *zerocol, int4 *summ, int n, int cur) {
+    if (threadIdx.x == 0) { ctl->kbase = kbase; ctl->n_total = n_total; ctl->cols = cols; ctl->zerocol = zerocol; ctl->pad0 = 0; ctl->pad1 = 0; }
     if (cur != 0) {
         for (int i = threadIdx.x; i < n; i += 256) summ[i] = summ[(size_t)cur * n + i];
         __syncthreads();
@@ -524,7 +524,7 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         const bool pair = e->pair && !sorted && (e->T == 256 || e->T == 1024 || e->T == 4096) && left >= std::min(2 * L + 2, remaining);
         CHK(ensure_prepared(e, bc, sorted, with_d, pair, left));
         hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(256), 0, e->stream, e->ctlblk, e->k_cur, e->n_total, bc, (const uint32_t *)e->zerocol,
-                           e->summ, pair ? 3 * e->wpad : e->wpad, e->summ_cur, getenv("PBWTAMD_NOGATHER") ? 1 : 0);
+                           e->summ, pair ? 3 * e->wpad : e->wpad, e->summ_cur);
         const int nlaunch = pair ? L : nb;
         e->summ_cur = nlaunch % 3;
         HIPCHK(hipGetLastError());

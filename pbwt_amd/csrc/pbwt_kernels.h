@@ -1,17 +1,19 @@
 // pbwt_kernels.h — hand-written gfx950 (CDNA4, wave64) kernels for the PBWT hot path.
 //
-// HBM layout (see DESIGN.md §3):
-//   ring slot s:  A[s][Mpad] int32  — prefix array a_k, with the allele y_k[i] of the haplotype at
-//                                     position i carried in bit 31 (the "tag"); a < 2^31 always
-//                 D[s][Mpad+PADD]   — divergence d_k[0..M] (start-position form, pbwt.h:82)
-//   tile summaries S[3][WPAD] int4  — per tile of T positions of the NEXT site: {cnt0, last0+1,
-//                                     last1+1, max d; built with commutative atomics by the step
-//                                     that scatters into that site, so one launch per site
-//   bit columns  C[k][wpc] uint32   — original order (gather by a) or sorted order (index by pos)
+// HBM layout (DESIGN.md §3):
+//   ring slot s:  A[s][Mpad] int32  — prefix array a_k; bits 31/30 carry the alleles of the haplotype at
+//                                     that position at the slot's site / the following site ("tags"), a < 2^30
+//                 D[s][Mpad+64]     — divergence d_k[0..M] (start-position form, pbwt.h:82, with sentinels)
+//   tile summaries                  — per tile of T positions of the NEXT launch's input order, built with
+//                                     commutative atomics by the launch that scatters into that order:
+//                                     single-site steps: int4 {cnt0, last0+1, last1+1, maxd};
+//                                     two-site steps: 3 int4 {c[4]}, {last[4]+1}, {maxd} over the 2-bit keys
+//   bit columns  C[k][wpc] uint32   — original order (gather by a) or sorted order (index by position)
 //
-// Kernels: prepare (tags+summaries for the first site of a pass), step (one site of
-// pbwtCursorForwardsA/AD, pbwtCore.c:458-508), and the batch consumers (checksum, maxWithin sweep
-// pbwtMatch.c:115-142, pack3 encode/decode pbwtCore.c:240-305, query sweep pbwtMatch.c:363-443).
+// Kernels: prepare/prepare2 (tags + summaries of the first site(s) of a pass), step2 (two sites of
+// pbwtCursorForwardsA/AD per launch, build side), step1/step (one site per launch: read side, large M),
+// and the batch consumers (checksum, maxWithin / longWithin sweeps pbwtMatch.c:85-142, pack3
+// encode/decode pbwtCore.c:240-305, query sweep pbwtMatch.c:363-443).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -539,7 +541,7 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         nkey[e] = 0;
-        if (valid[e] && !ctl.pad0) nkey[e] = (int)(((c2[(unsigned)a[e] >> 5] >> (a[e] & 31)) & 1u) | (((c3[(unsigned)a[e] >> 5] >> (a[e] & 31)) & 1u) << 1));   // (pad0: timing experiment without the gathers)
+        if (valid[e]) nkey[e] = (int)(((c2[(unsigned)a[e] >> 5] >> (a[e] & 31)) & 1u) | (((c3[(unsigned)a[e] >> 5] >> (a[e] & 31)) & 1u) << 1));
     }
 
     // ---- fold the tile summaries ----
