@@ -71,7 +71,7 @@ struct pbwtamd_engine {
     int k0 = 0, k_cur = 0, n_total = 0; bool prepared = false; bool pass_open = false;
     unsigned long long yz_bytes_host = 0; size_t yz_upper = 0;   // host-side upper bound of the packed bytes written
     std::vector<GraphKey> graphs; bool use_graph = true; bool lean = true; bool pair = true;
-    bool pair1024 = false; bool stage = false;
+    bool pair1024 = false;
     bool summ_pair = false;                 // format of the current tile summaries (two-site keys or single site)
     uint32_t *zerocol = nullptr; long long sites_done = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0; long long launches = 0;
@@ -140,7 +140,6 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     if (const char *s = getenv("PBWTAMD_LEAN")) e->lean = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_PAIR")) e->pair = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_PAIR1024")) e->pair1024 = atoi(s) != 0;
-    if (const char *s = getenv("PBWTAMD_STAGE")) e->stage = atoi(s) != 0;
     if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
     else { if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); } e->own_stream = true; }
     e->strideA = (size_t)e->Mpad;
@@ -244,8 +243,7 @@ static void launch_step2(pbwtamd_engine *e, int ring, int jl, bool with_d) {
     g.a_mid = A + (size_t)(2 * jl + 1) * e->strideA; g.d_mid = D + (size_t)(2 * jl + 1) * e->strideD;
     g.a_out = A + (size_t)(2 * jl + 2) * e->strideA; g.d_out = D + (size_t)(2 * jl + 2) * e->strideD;
     g.ctl = e->ctlblk; g.summ = e->summ; g.prof = e->prof; g.wpc = e->wpc; g.jl = jl; g.M = e->M; g.W = e->W; g.wpad = e->wpad;
-#define L2(WD, SP, NT, EE) do { if (e->stage) hipLaunchKernelGGL((step2_kernel<WD, SP, NT, EE, true>), dim3(e->W), dim3(NT), 0, e->stream, g); \
-                                 else hipLaunchKernelGGL((step2_kernel<WD, SP, NT, EE, false>), dim3(e->W), dim3(NT), 0, e->stream, g); } while (0)
+#define L2(WD, SP, NT, EE) hipLaunchKernelGGL((step2_kernel<WD, SP, NT, EE>), dim3(e->W), dim3(NT), 0, e->stream, g)
     if (e->T == 1024 && e->pair1024) { if (with_d) L2(true, 1, 1024, 1); else L2(false, 1, 1024, 1); }     // 16-wave workgroups (opt-in)
     else if (e->T == 4096) { if (with_d) L2(true, 1, 1024, 4); else L2(false, 1, 1024, 4); }              // one 16-wave workgroup per CU, 4 positions per thread
     else if (e->T == 1024) {                               // 4 positions per thread, 4-wave workgroups

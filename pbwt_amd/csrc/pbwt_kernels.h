@@ -494,8 +494,8 @@ struct Step2Args {
 
 // NT threads per workgroup, E consecutive positions per thread: tile of T = NT*E positions
 // (NT=256,E=1 for M <= 262144; NT=256,E=4 up to M = 1048576, all tiles resident at once).
-template <bool WITH_D, bool FULL, int SPT, int NT, int E, bool STAGE>
-__device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int (*s_red)[16], int *s_acc, int *s_st) {
+template <bool WITH_D, bool FULL, int SPT, int NT, int E>
+__device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int (*s_red)[16], int *s_acc) {
     constexpr int T = NT * E, NW = NT / 64;
     const int jl = g.jl;
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
@@ -617,10 +617,6 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
     const int Zw1 = bef[0] + bef[2], C1 = tot4[0] + tot4[2];
     int G2[4]; G2[0] = 0; G2[1] = tot4[0]; G2[2] = tot4[0] + tot4[1]; G2[3] = tot4[0] + tot4[1] + tot4[2];
     const bool has_next = (k + 2 < ctl.n_total);
-    // local (in-tile) bucket bases of the two destination orders, for the LDS-staged write-out
-    const int cw1 = tot.c[0] + tot.c[2];
-    int LG2[4]; LG2[0] = 0; LG2[1] = tot.c[0]; LG2[2] = tot.c[0] + tot.c[1]; LG2[3] = tot.c[0] + tot.c[1] + tot.c[2];
-    const int nvalid = LG2[3] + tot.c[3];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         if (valid[e]) {
@@ -648,16 +644,12 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
             }
             const int b0 = ky & 1, b1 = ky >> 1;
             const int zr = run.c[0] + run.c[2], orr = run.c[1] + run.c[3];
-            int prk = 0, lg = 0, base2 = 0;
+            int prk = 0, base2 = 0;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) if (x == ky) { base2 = G2[x] + bef[x]; prk = run.c[x]; lg = LG2[x]; }
+            for (int x = 0; x < 4; ++x) if (x == ky) { base2 = G2[x] + bef[x]; prk = run.c[x]; }
             const int av1 = a[e] | (int)((unsigned)b1 << 31);
             const int av2 = a[e] | (int)(((unsigned)(nkey[e] & 1) << 31) | ((unsigned)(nkey[e] >> 1) << 30));
-            if (STAGE) {                                   // destination order in LDS; written out coalesced below
-                const int l1 = b0 ? cw1 + orr : zr, l2 = lg + prk;
-                s_st[l1] = av1; s_st[T + l2] = av2;
-                if (WITH_D) { s_st[2 * T + l1] = dd1; s_st[3 * T + l2] = dd2; }
-            } else {
+            {
                 const int pos1 = b0 ? C1 + (S - Zw1) + orr : Zw1 + zr;
                 const int pos2 = base2 + prk;
                 g.a_mid[pos1] = av1;
@@ -677,39 +669,6 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
 #pragma unroll
                 for (int x = 0; x < 4; ++x) { if (x == ky) { ++run.c[x]; run.t[x] = 0; } else run.t[x] = max(run.t[x], de); }
                 run.all = max(run.all, de);
-            }
-        }
-    }
-    if (STAGE) {
-        lds_barrier();
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int l = e * NT + t;                      // destination-order index inside the tile
-            if (FULL || l < nvalid) {
-                const int pos1 = (l < cw1) ? Zw1 + l : C1 + (S - Zw1) + (l - cw1);
-                int x2 = 0;
-                if (l >= LG2[1]) x2 = 1;
-                if (l >= LG2[2]) x2 = 2;
-                if (l >= LG2[3]) x2 = 3;
-                int base2 = 0, lg = 0;
-#pragma unroll
-                for (int x = 0; x < 4; ++x) if (x == x2) { base2 = G2[x] + bef[x]; lg = LG2[x]; }
-                const int pos2 = base2 + (l - lg);
-                const int av2 = s_st[T + l];
-                g.a_mid[pos1] = s_st[l];
-                g.a_out[pos2] = av2;
-                int dd2 = 0;
-                if (WITH_D) {
-                    g.d_mid[pos1] = pos1 ? s_st[2 * T + l] : k + 2;
-                    dd2 = pos2 ? s_st[3 * T + l] : k + 3;
-                    g.d_out[pos2] = dd2;
-                }
-                if (has_next) {
-                    const int nk = (int)(((unsigned)av2 >> 31) | (((unsigned)av2 >> 29) & 2u));
-                    const int slot = x2 * 2 + (pos2 / T - base2 / T);
-                    atomicAdd(&s_acc[slot * 9 + nk], 1);
-                    if (WITH_D) { atomicMax(&s_acc[slot * 9 + 4 + nk], pos2 + 1); atomicMax(&s_acc[slot * 9 + 8], dd2); }
-                }
             }
         }
     }
@@ -733,14 +692,13 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
     PBWT_STAMP(6);
 }
 
-template <bool WITH_D, int SPT, int NT, int E, bool STAGE>
+template <bool WITH_D, int SPT, int NT, int E>
 __global__ __launch_bounds__(NT) void step2_kernel(Step2Args g) {
     __shared__ Tup4 s_tup[NT / 64];
     __shared__ int s_red[NT / 64][16];
     __shared__ int s_acc[72];
-    __shared__ int s_st[STAGE ? (WITH_D ? 4 : 2) * NT * E : 1];     // staged (a1, a2, d1, d2) in destination order
-    if ((int)(blockIdx.x + 1) * NT * E <= g.M) step2_body<WITH_D, true, SPT, NT, E, STAGE>(g, s_tup, s_red, s_acc, s_st);
-    else step2_body<WITH_D, false, SPT, NT, E, STAGE>(g, s_tup, s_red, s_acc, s_st);
+    if ((int)(blockIdx.x + 1) * NT * E <= g.M) step2_body<WITH_D, true, SPT, NT, E>(g, s_tup, s_red, s_acc);
+    else step2_body<WITH_D, false, SPT, NT, E>(g, s_tup, s_red, s_acc);
 }
 
 // first pair of a pass (or after an odd-length batch): both allele tags of slot 0 from columns k, k+1
