@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-pack3", action="store_true")
     ap.add_argument("--cpu-sites", type=int, default=32768, help="sites of the same panel timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-1m", action="store_true", help="skip the secondary measurement at the north-star width (1M haplotypes)")
     ap.add_argument("--panels", type=int, default=1, help="independent panels run concurrently on this GPU (throughput mode; default 1 = the named config)")
     return ap.parse_args()
 
@@ -70,6 +71,33 @@ def cpu_baseline(args, first_cols):
     return {"value": M * n / (tb + tw), "unit": "site*haps/s", "cores": 1, "kind": kind,
             "sample": "first %d sites of the same %d-haplotype panel, %s: build(WriteForwardsAD + pack3) %.2fs + -stats maxWithin %.2fs"
                       % (n, M, what, tb, tw)}
+
+
+def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=2048, batch=128):
+    """secondary measurement at the north-star width (1M haplotypes), same hot path, short panel:
+    reported next to the headline, not part of `value`"""
+    eng = pbwt_amd.Engine(M, batch_sites=batch, device=dev.index)
+    panel = torch.empty((sites + batch, eng.wpc), dtype=torch.int32, device=dev)
+    eng.synth_device(panel.data_ptr(), 0, sites + batch, seed=0x1A2B3C, kind=kind)
+    eng.sync()
+    n_total = sites + batch
+    eng.pass_begin(n_total)
+    eng.pass_advance(panel.data_ptr(), batch, batch + 2, opts)          # warm-up batch (graph capture)
+    eng.sync()
+    ms0, n0 = eng.chain_timing(); s0 = eng.chain_sites()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.pass_advance(panel.data_ptr() + batch * eng.wpc * 4, sites, sites, opts)
+    eng.pass_end(opts)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms1, n1 = eng.chain_timing(); s1 = eng.chain_sites()
+    us = 1e3 * (ms1 - ms0) / max(n1 - n0, 1)
+    spl = (s1 - s0) / max(n1 - n0, 1)
+    ach = ALG_BYTES_PER_SITEHAP * M * spl / (us * 1e-6) / 1e9
+    eng.close()
+    return {"haplotypes": M, "sites_timed": sites, "value": M * sites / dt, "unit": "site*haps/s", "us_per_launch": us,
+            "sites_per_launch": spl, "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS}
 
 
 def main():
@@ -145,6 +173,7 @@ def main():
     alg_bytes_per_launch = ALG_BYTES_PER_SITEHAP * M * sites_per_launch
     achieved = alg_bytes_per_launch / (us_per_launch * 1e-6) / 1e9
     hist = eng.get_hist(n_total + 1)
+    first = panel[:min(args.cpu_sites, n_total)].cpu().numpy().view(np.uint32) if (rank == 0 and world == 1 and not args.no_cpu) else None
     traffic, traffic_src = None, None
     try:                                   # HBM-side bytes per launch measured with rocprofv3 PMC (separate run)
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(str(M))
@@ -171,9 +200,11 @@ def main():
                      "note": "one launch = sites_per_launch sites; duration = HIP-event time of the dependent launch chain / launches, i.e. including launch gaps"},
         "within_reports_hist_total": int(hist.sum()),
     }
+    if rank == 0 and world == 1 and not args.no_1m:
+        del panel
+        torch.cuda.empty_cache()
+        out["north_star_width"] = north_star_width(torch, pbwt_amd, dev, opts, args.kind)
     if rank == 0 and world == 1 and not args.no_cpu:
-        ncpu = min(args.cpu_sites, n_total)
-        first = panel[:ncpu].cpu().numpy().view(np.uint32)
         out["cpu_baseline"] = cpu_baseline(args, first)
     if rank == 0:
         print(json.dumps(out))

