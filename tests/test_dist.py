@@ -61,3 +61,49 @@ def test_units_for_rank_partition():
             assert got == list(range(n))
             sizes = [len(units_for_rank(n, r, world)) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
+
+
+SHARD_WORKER = textwrap.dedent("""
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    import torch.distributed as dist
+    from pbwt_amd import dist as pd
+    from pbwt_amd.sharded import sharded_step_AD, owner_ranges
+    import oracle
+    rank, world = pd.init("gloo")
+    M, N, kind = int(os.environ["SH_M"]), int(os.environ["SH_N"]), int(os.environ["SH_KIND"])
+    bits = oracle.synth_bitcols(M, N, seed=4242, kind=kind)
+    hap = oracle.unpack_bitcols(bits, M)
+    want = oracle.build_bitcols(bits, M, with_d=True, dump_sites=range(N + 1))
+    b = owner_ranges(M, world)
+    lo, hi = b[rank], b[rank + 1]
+    a = np.arange(lo, hi, dtype=np.int64)
+    d = np.zeros(hi - lo, dtype=np.int64)
+    if rank == 0 and hi > lo:
+        d[0] = 1
+    ok = True
+    for k in range(N):
+        y = hap[k][a]
+        a, d = sharded_step_AD(a, d, y, k, M)
+        ok &= bool(np.array_equal(a, want["a_dump"][k + 1][lo:hi])) and bool(np.array_equal(d, want["d_dump"][k + 1][lo:hi]))
+    with open(os.path.join(os.environ["OUT_DIR"], "shard" + str(rank) + ".json"), "w") as f:
+        json.dump({"rank": rank, "ok": ok, "n": int(hi - lo)}, f)
+    pd.finish()
+""") % ROOT
+
+
+@pytest.mark.parametrize("world,M,N,kind", [(2, 101, 60, 1), (3, 400, 80, 0), (2, 64, 40, 0)])
+def test_position_sharded_step_protocol_gloo(world, M, N, kind, tmp_path):
+    """all-gather of carry tuples + all-to-all of (pos, a, d') reproduces the oracle's
+    a[] and d[] at every site on every rank's shard"""
+    import json
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER)
+    env = dict(os.environ, OUT_DIR=str(tmp_path), SH_M=str(M), SH_N=str(N), SH_KIND=str(kind))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    outs = [json.load(open(tmp_path / ("shard%d.json" % rk))) for rk in range(world)]
+    assert all(o["ok"] for o in outs) and sum(o["n"] for o in outs) == M
