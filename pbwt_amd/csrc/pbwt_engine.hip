@@ -261,10 +261,12 @@ static int get_graph(pbwtamd_engine *e, bool with_d, bool sorted, int ring, bool
     HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
     if (pair) { for (int jl = 0; jl < e->B / 2; ++jl) launch_step2(e, ring, jl, with_d); }
     else { for (int j = 0; j < e->B; ++j) launch_step_dyn(e, ring, j, with_d, sorted); }
-    HIPCHK(hipStreamEndCapture(e->stream, &graph));
+    const hipError_t ec = hipStreamEndCapture(e->stream, &graph);      // always leave capture mode
+    if (ec != hipSuccess || !graph) return fail("hipStreamEndCapture: %s", hipGetErrorString(ec));
     hipGraphExec_t exec = nullptr;
-    HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    HIPCHK(hipGraphDestroy(graph));
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) return fail("hipGraphInstantiate: %s", hipGetErrorString(ei));
     e->graphs.push_back(GraphKey{(int)with_d, (int)sorted, ring, (int)pair, exec});
     *out = exec;
     return 0;
@@ -531,11 +533,17 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
             hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); e->ev.push_back({a, b});
         }
         HIPCHK(hipEventRecord(e->ev[e->ev_used].first, e->stream));
+        bool launched = false;
         if (e->use_graph && nb == e->B) {
             hipGraphExec_t exec;
-            CHK(get_graph(e, with_d, sorted, r, pair, &exec));
-            HIPCHK(hipGraphLaunch(exec, e->stream));
-        } else {
+            if (get_graph(e, with_d, sorted, r, pair, &exec) == 0 && hipGraphLaunch(exec, e->stream) == hipSuccess) launched = true;
+            else {                                         // capture / instantiate / launch refused: fall back to eager launches for good
+                (void)hipGetLastError();
+                e->use_graph = false;
+                fprintf(stderr, "pbwt_amd: hipGraph path unavailable (%s); using eager launches\n", g_err.c_str());
+            }
+        }
+        if (!launched) {
             if (pair) { for (int jl = 0; jl < L; ++jl) launch_step2(e, r, jl, with_d); }
             else { for (int j = 0; j < nb; ++j) launch_step_dyn(e, r, j, with_d, sorted); }
             HIPCHK(hipGetLastError());

@@ -434,8 +434,9 @@ __device__ __forceinline__ Tup4 tup4_dpp(const Tup4 &v) {
 }
 // wave totals -> every wave redundantly scans them in its first NW lanes (NW <= 16: one DPP row),
 // so a block of up to 1024 threads needs a single barrier and no per-thread loop over the waves
-template <int NW>
-__device__ __forceinline__ Tup4 block_scan_tup4(Tup4 v, Tup4 *smem, Tup4 &total) {
+// part 1 (before the barrier): per-wave inclusive scan, wave total to LDS; part 2 (after the barrier)
+// finishes.  Split so that a caller can post other per-wave results under the same barrier.
+__device__ __forceinline__ Tup4 wave_scan_tup4(Tup4 v, Tup4 *smem, Tup4 &exc) {
     const int lane = lane_id(), wv = wave_id();
     Tup4 inc = v;
     inc = tup4_combine(tup4_dpp<0x111, 0xf>(inc), inc);
@@ -445,11 +446,14 @@ __device__ __forceinline__ Tup4 block_scan_tup4(Tup4 v, Tup4 *smem, Tup4 &total)
     inc = tup4_combine(tup4_dpp<0x142, 0xa>(inc), inc);
     inc = tup4_combine(tup4_dpp<0x143, 0xc>(inc), inc);
     if (lane == 63) smem[wv] = inc;
-    Tup4 exc;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { exc.c[q] = lane_shr1(inc.c[q], 0); exc.t[q] = lane_shr1(inc.t[q], 0); }
     exc.all = lane_shr1(inc.all, 0);
-    lds_barrier();
+    return inc;
+}
+template <int NW>
+__device__ __forceinline__ Tup4 block_scan_finish_tup4(const Tup4 &exc, const Tup4 *smem, Tup4 &total) {
+    const int lane = lane_id(), wv = wave_id();
     Tup4 wt = tup4_id();
     if (lane < NW) wt = smem[lane];
     wt = tup4_combine(tup4_dpp<0x111, 0xf>(wt), wt);
@@ -593,9 +597,10 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
             me.all = max(me.all, d[e]);
         }
     }
-    Tup4 tot;
-    Tup4 run = block_scan_tup4<NW>(me, s_tup, tot);       // exclusive prefix of this thread's first position
+    Tup4 tot, exc;
+    wave_scan_tup4(me, s_tup, exc);
     PBWT_STAMP(2);
+    // the carries' per-wave maxima ride on the scan's barrier (the partial-tile loads had the scan to land)
     int cr[4] = {0, 0, 0, 0};
     if (WITH_D) {
 #pragma unroll
@@ -608,7 +613,10 @@ __device__ __forceinline__ void step2_body(const Step2Args &g, Tup4 *s_tup, int 
 #pragma unroll
             for (int x = 0; x < 4; ++x) s_red[wv][12 + x] = mx[x];
         }
-        lds_barrier();
+    }
+    lds_barrier();
+    Tup4 run = block_scan_finish_tup4<NW>(exc, s_tup, tot);   // exclusive prefix of this thread's first position
+    if (WITH_D) {
 #pragma unroll
         for (int x = 0; x < 4; ++x) cr[x] = waves_combine<NW, true>(&s_red[0][12 + x], lane);
     }
