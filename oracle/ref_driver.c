@@ -248,6 +248,19 @@ long ref_time_build_and_within(int M, int N, const uint32_t *bits, int wpc, doub
     return nz;
 }
 
+/* -read x.pbwt -buildReverse -writeReverse y.pbwt (pbwtCore.c:151-191, pbwtIO.c:121-132) */
+int ref_build_reverse(const char *pbwt_in, const char *rev_out)
+{
+    ref_init();
+    FILE *fp = fopen(pbwt_in, "r"); if (!fp) return -1;
+    PBWT *p = pbwtRead(fp); fclose(fp);
+    pbwtBuildReverse(p);
+    FILE *fo = fopen(rev_out, "w"); if (!fo) return -2;
+    pbwtWriteReverse(p, fo); fclose(fo);
+    pbwtDestroy(p);
+    return 0;
+}
+
 size_t ref_pack3(uint8_t *y_with_sentinel, int M, uint8_t *out) { ref_init(); return pack3(y_with_sentinel, M, out); }
 size_t ref_unpack3(uint8_t *z, int M, uint8_t *y, int *n0) { ref_init(); return unpack3(z, M, y, n0); }
 void ref_free(void *p) { free(p); }

@@ -1,7 +1,7 @@
 /* pbwt_cli.c — `pbwt` command interpreter for the hot-path subset of the reference's CLI
  * (pbwtMain.c:276-494): a sequence of "-command args" applied in order to one current panel.
  * Supported: -check -stats -log -read -readSites -readAll -readMacs -write -writeSites -writeAll
- * -haps -maxWithin -longWithin -matchDynamic -siteInfo -subsample.  Everything else: "not on the accelerated
+ * -haps -maxWithin -longWithin -matchDynamic -siteInfo -subsample -buildReverse -writeReverse -readReverse.  Everything else: "not on the accelerated
  * path of this build". */
 #include "pbwt_host.h"
 #include <stdlib.h>
@@ -23,7 +23,8 @@ int main (int argc, char *argv[])
     { fprintf (stderr, "Program: pbwt (MI355X hot-path build, pbwt_amd)\nUsage: pbwt [ -<command> [options]* ]+\n"
 	       "Commands: -check -stats -log <file> -read <file> -readSites <file> -readAll <root> -readMacs <file>\n"
 	       "          -write <file> -writeSites <file> -writeAll <root> -haps <file> -maxWithin -longWithin <L>\n"
-	       "          -matchDynamic <file> -siteInfo <file> <kmin> <kmax> -subsample <start> <n>\n") ;
+	       "          -matchDynamic <file> -siteInfo <file> <kmin> <kmax> -subsample <start> <n>\n"
+	       "          -buildReverse -writeReverse <file> -readReverse <file>\n") ;
       return 0 ;
     }
   timeUpdate (logFile) ;
@@ -50,6 +51,12 @@ int main (int argc, char *argv[])
 	{ NEEDP ; panelWriteAll (p, argv[1]) ; argc -= 2 ; argv += 2 ; }
       else if (!strcmp (argv[0], "-haps") && argc > 1)
 	{ NEEDP ; fp = openOrDie (argv[1], "haps", "w") ; panelWriteHaplotypes (fp, p) ; fclose (fp) ; argc -= 2 ; argv += 2 ; }
+      else if (!strcmp (argv[0], "-buildReverse"))
+	{ NEEDP ; panelBuildReverse (p) ; argc -= 1 ; argv += 1 ; }
+      else if (!strcmp (argv[0], "-writeReverse") && argc > 1)
+	{ NEEDP ; fp = openOrDie (argv[1], "writeReverse", "w") ; panelWriteReverse (p, fp) ; fclose (fp) ; argc -= 2 ; argv += 2 ; }
+      else if (!strcmp (argv[0], "-readReverse") && argc > 1)
+	{ NEEDP ; fp = openOrDie (argv[1], "readReverse", "r") ; panelReadReverse (p, fp) ; fclose (fp) ; argc -= 2 ; argv += 2 ; }
       else if (!strcmp (argv[0], "-maxWithin"))
 	{ NEEDP ; panelLongMatches (p, 0) ; argc -= 1 ; argv += 1 ; }
       else if (!strcmp (argv[0], "-longWithin") && argc > 1)

@@ -65,7 +65,7 @@ void panelDestroy (Panel *p)
 {
   if (!p) return ;
   if (p->sites) { for (int i = 0 ; i < p->N ; ++i) free (p->sites[i].var) ; free (p->sites) ; }
-  free (p->chrom) ; free (p->yz) ; free (p->aFstart) ; free (p->aFend) ; free (p) ;
+  free (p->chrom) ; free (p->yz) ; free (p->aFstart) ; free (p->aFend) ; free (p->zz) ; free (p->aRstart) ; free (p->aRend) ; free (p) ;
 }
 
 /* .pbwt: "PBW3", int M, int N, aFstart[M], aFend[M], long nz, 4 pad bytes, yz[nz] (pbwtIO.c:33-57).
@@ -303,6 +303,50 @@ void panelMatchDynamic (Panel *p, FILE *fp)
   fprintf (logFile, "Average number of best matches including alternates %.1f, Average length %.1f, Av number per position %.1f\n",
 	   tot[0] / (double) q->M, tot[1] / (double) tot[0], tot[1] / (double) ((long) q->M * q->N)) ;
   if (isCheck) { free (checkA) ; free (checkB) ; checkA = checkB = 0 ; }
+  panelDestroy (q) ;
+}
+
+/* reverse PBWT (pbwtCore.c:151-191): the same build loop over the sites in reverse order, started
+ * from the forward pass's final order aFend (computed by a forward sweep when the file lacks it) */
+void panelBuildReverse (Panel *p)
+{
+  uint8_t *hap = decodeHaps (p) ;
+  pbwtamd_engine *e = engineFor (p->M) ;
+  const int wpc = pbwtamd_engine_wpc (e) ;
+  if (!p->aFend)			/* run forwards to the end first (pbwtCore.c:160-165) */
+    { p->aFend = xalloc (sizeof (int) * p->M) ;
+      int last = p->N ;
+      if (pbwtamd_sweep_AD (e, p->yz, p->nz, p->N, p->aFstart, 0, 0, 0, &last, 1, p->aFend, 0, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+    }
+  uint32_t *cols = xalloc ((size_t) p->N * wpc * sizeof (uint32_t)) ;
+  for (int k = 0 ; k < p->N ; ++k)		/* column k of the reverse panel = site N-1-k */
+    for (int h = 0 ; h < p->M ; ++h)
+      if (hap[(size_t) (p->N - 1 - k) * p->M + h]) cols[(size_t) k * wpc + (h >> 5)] |= 1u << (h & 31) ;
+  free (p->zz) ; free (p->aRstart) ; free (p->aRend) ;
+  p->aRstart = xalloc (sizeof (int) * p->M) ; memcpy (p->aRstart, p->aFend, sizeof (int) * p->M) ;
+  p->aRend = xalloc (sizeof (int) * p->M) ;
+  if (pbwtamd_build (e, cols, wpc, p->N, 0, p->aRstart, &p->zz, &p->nzz, p->aRend, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+  free (cols) ; free (hap) ;
+  fprintf (logFile, "built reverse PBWT - size %ld\n", (long) p->nzz) ;
+}
+
+void panelWriteReverse (Panel *p, FILE *fp)
+{
+  if (!p || !p->zz) die ("pbwtWriteReverse called without reverse pbwt") ;
+  Panel q = *p ;
+  q.yz = p->zz ; q.nz = p->nzz ; q.aFstart = p->aRstart ; q.aFend = p->aRend ;
+  fprintf (logFile, "reverse: ") ; panelWrite (&q, fp) ;
+}
+
+void panelReadReverse (Panel *p, FILE *fp)
+{
+  if (!p) die ("pbwtReadReverse called without a valid pbwt") ;
+  Panel *q = panelRead (fp) ;
+  if (q->M != p->M || q->N != p->N) die ("M %d or N %d in reverse don't match %d, %d in forward", q->M, q->N, p->M, p->N) ;
+  free (p->zz) ; free (p->aRstart) ; free (p->aRend) ;
+  p->zz = q->yz ; p->nzz = q->nz ; q->yz = 0 ;
+  p->aRstart = q->aFstart ; q->aFstart = 0 ;
+  p->aRend = q->aFend ; q->aFend = 0 ;
   panelDestroy (q) ;
 }
 

@@ -20,6 +20,8 @@ typedef struct {		/* the fields of PBWT (pbwt.h:35-53) the hot path touches */
   HostSite *sites ;		/* N entries or NULL */
   uint8_t *yz ; int64_t nz ;	/* packed columns (PBWT.yz) */
   int *aFstart, *aFend ;
+  uint8_t *zz ; int64_t nzz ;	/* packed reverse PBWT (PBWT.zz) and its index arrays, or NULL */
+  int *aRstart, *aRend ;
 } Panel ;
 
 extern FILE *logFile ;
@@ -40,5 +42,8 @@ void panelLongMatches (Panel *p, int L) ;	/* pbwtLongMatches, pbwtMatch.c:148-18
 void panelMatchDynamic (Panel *p, FILE *fp) ;	/* matchSequencesDynamic, pbwtMatch.c:352-357 */
 void panelSiteInfo (Panel *p, FILE *fp, int f1, int f2) ;	/* exportSiteInfo, pbwtMain.c:82-100 */
 Panel *panelSubSampleInterval (Panel *p, int start, int Mnew) ;	/* pbwtSubSampleInterval, pbwtSample.c:95-108 */
+void panelBuildReverse (Panel *p) ;		/* pbwtBuildReverse, pbwtCore.c:151-191 */
+void panelWriteReverse (Panel *p, FILE *fp) ;	/* pbwtWriteReverse, pbwtIO.c:121-132 */
+void panelReadReverse (Panel *p, FILE *fp) ;	/* pbwtReadReverse, pbwtIO.c:392-404 */
 void timeUpdate (FILE *f) ;			/* utils.c:173-198 */
 #endif

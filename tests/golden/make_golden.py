@@ -91,6 +91,7 @@ def macs_small():
             f.write("SITE:\t%d\t%.8f\t0.1\t%s\n" % (k, (k + 0.5) / N, "".join(map(str, hap[k]))))
     assert ref.ref_macs_to_pbwt(path.encode(), os.path.join(HERE, "macs_small.pbwt").encode(),
                                 os.path.join(HERE, "macs_small.sites").encode()) == 0
+    assert ref.ref_build_reverse(os.path.join(HERE, "macs_small.pbwt").encode(), os.path.join(HERE, "macs_small.reverse.pbwt").encode()) == 0
     print("wrote macs_small.*")
 
 

@@ -124,3 +124,13 @@ def test_longWithin_text(cli, tmp_path):
                   + np.array([len(g["yz"])], "<i8").tobytes() + b"    " + g["yz"].tobytes())
     r = run(cli, "-check", "-read", f, "-longWithin", 100)
     assert r.stdout == open(os.path.join(GOLDEN, "longwithin_M300_L100.txt")).read()
+
+
+@pytest.mark.gpu
+def test_buildReverse_matches_reference_bytes(cli, tmp_path):
+    """-read x -buildReverse -writeReverse y == the reference's reverse PBWT (zz, aRstart, aRend)"""
+    run(cli, "-read", os.path.join(GOLDEN, "macs_small.pbwt"), "-buildReverse", "-writeReverse", tmp_path / "rev.pbwt")
+    assert open(tmp_path / "rev.pbwt", "rb").read() == open(os.path.join(GOLDEN, "macs_small.reverse.pbwt"), "rb").read()
+    # and it reads back as the reverse of the same panel
+    run(cli, "-read", os.path.join(GOLDEN, "macs_small.pbwt"), "-readReverse", tmp_path / "rev.pbwt", "-writeReverse", tmp_path / "rev2.pbwt")
+    assert open(tmp_path / "rev2.pbwt", "rb").read() == open(tmp_path / "rev.pbwt", "rb").read()
