@@ -258,3 +258,30 @@ def test_long_within_vs_oracle(amd, orc, M, N, kind, L, batch):
     yz = orc.build_bitcols(bits, M, with_d=False)["yz"]
     eng = amd.Engine(M, batch_sites=batch)
     assert np.array_equal(eng.long_within(yz, N, L), orc.long_within(yz, M, N, L))
+
+
+def test_mode_switches_inside_a_pass(amd, orc):
+    """alternate look-ahead of one / two columns between advances: the pass switches between
+    single-site and two-site launches (re-deriving tags and summaries at each switch)"""
+    import torch
+    M, N = 2000, 300
+    eng = amd.Engine(M, batch_sites=32)
+    buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    eng.synth_device(buf.data_ptr(), 0, N, seed=21, kind=0)
+    eng.sync()
+    bits = buf.cpu().numpy().view(np.uint32)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    opts = amd.OPT_WITH_D | amd.OPT_CHECKSUM | amd.OPT_WITHIN_HIST
+    eng.pass_begin(N)
+    k, i = 0, 0
+    for n in [40, 7, 64, 33, 1, 2, 90, 63]:
+        n = min(n, N - k)
+        eng.pass_advance(buf.data_ptr() + k * eng.wpc * 4, n, min(n + 1 + (i & 1), N - k), opts)
+        k += n; i += 1
+    assert k == N
+    eng.pass_end(opts)
+    a, d = eng.get_state()
+    assert np.array_equal(a, o["aFend"]) and np.array_equal(d, o["d_final"])
+    ca, cd, _ = eng.get_checksums(0, N + 1)
+    assert np.array_equal(ca, o["csum_a"]) and np.array_equal(cd, o["csum_d"])
+    assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
