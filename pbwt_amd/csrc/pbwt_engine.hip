@@ -126,7 +126,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     if (M > 262144) e->E = 4;                              // T = 1024 (two-site launches use 1024-thread workgroups)
     while (e->E < 16 && (M + BLOCK * e->E - 1) / (BLOCK * e->E) > 1024) e->E *= 2;
     if (const char *s = getenv("PBWTAMD_E")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->E = v; }
-    if (const char *s = getenv("PBWTAMD_T")) { int v = atoi(s); if (v == 256 || v == 1024 || v == 4096) e->E = v / BLOCK; }
+    if (const char *s = getenv("PBWTAMD_T")) { int v = atoi(s); if (v == 256 || v == 1024 || v == 2048 || v == 4096) e->E = v / BLOCK; }
     e->T = BLOCK * e->E;
     e->W = (M + e->T - 1) / e->T;
     if (e->W > 1024) { delete e; return fail("pbwtamd: M=%d too large for this build (max %d)", M, 1024 * 4096); }
@@ -246,6 +246,7 @@ static void launch_step2(pbwtamd_engine *e, int ring, int jl, bool with_d) {
 #define L2(WD, SP, NT, EE) hipLaunchKernelGGL((step2_kernel<WD, SP, NT, EE>), dim3(e->W), dim3(NT), 0, e->stream, g)
     if (e->T == 1024 && e->pair1024) { if (with_d) L2(true, 1, 1024, 1); else L2(false, 1, 1024, 1); }     // 16-wave workgroups (opt-in)
     else if (e->T == 4096) { if (with_d) L2(true, 1, 1024, 4); else L2(false, 1, 1024, 4); }              // one 16-wave workgroup per CU, 4 positions per thread
+    else if (e->T == 2048) { if (with_d) L2(true, 1, 512, 4); else L2(false, 1, 512, 4); }                // 8-wave workgroups, 4 positions per thread
     else if (e->T == 1024) {                               // 4 positions per thread, 4-wave workgroups
         if (with_d) { if (e->W <= 256) L2(true, 1, 256, 4); else if (e->W <= 512) L2(true, 2, 256, 4); else L2(true, 4, 256, 4); }
         else        { if (e->W <= 256) L2(false, 1, 256, 4); else if (e->W <= 512) L2(false, 2, 256, 4); else L2(false, 4, 256, 4); }
@@ -521,7 +522,7 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         const int left = ncols_avail - done;               // columns available from bc on
         const int remaining = e->n_total - e->k_cur;
         const int L = (nb + 1) / 2;
-        const bool pair = e->pair && !sorted && (e->T == 256 || e->T == 1024 || e->T == 4096) && left >= std::min(2 * L + 2, remaining);
+        const bool pair = e->pair && !sorted && (e->T == 256 || e->T == 1024 || e->T == 2048 || e->T == 4096) && left >= std::min(2 * L + 2, remaining);
         CHK(ensure_prepared(e, bc, sorted, with_d, pair, left));
         hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(256), 0, e->stream, e->ctlblk, e->k_cur, e->n_total, bc, (const uint32_t *)e->zerocol,
                            e->summ, pair ? 3 * e->wpad : e->wpad, e->summ_cur);

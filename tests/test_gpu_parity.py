@@ -285,3 +285,38 @@ def test_mode_switches_inside_a_pass(amd, orc):
     ca, cd, _ = eng.get_checksums(0, N + 1)
     assert np.array_equal(ca, o["csum_a"]) and np.array_equal(cd, o["csum_d"])
     assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
+
+
+def test_degenerate_shapes(amd, orc):
+    """empty panel (N = 0), a single site, a single haplotype, width not a multiple of 32/64/256"""
+    # N = 0: nothing to build; the cursor stays at its start order with the initial sentinels
+    eng = amd.Engine(5, batch_sites=4)
+    b = eng.build(np.zeros((0, eng.wpc), np.uint32), with_d=True)
+    assert len(b["yz"]) == 0 and b["aFend"].tolist() == [0, 1, 2, 3, 4] and b["dFend"].tolist() == [1, 0, 0, 0, 0, 1]
+    sw = eng.sweep_AD(np.zeros(0, np.uint8), 0)
+    assert sw["csum_a"][0] == orc.checksum_i32(np.arange(5)) and sw["csum_d"][0] == orc.checksum_i32(np.array([1, 0, 0, 0, 0, 1]))
+    # N = 1 and M = 1
+    for M, N in [(5, 1), (1, 7), (1, 1), (33, 3), (257, 2)]:
+        bits = orc.synth_bitcols(M, N, seed=M * 10 + N, kind=1)
+        o = orc.build_bitcols(bits, M, with_d=True)
+        eng = amd.Engine(M, batch_sites=4)
+        b = eng.build(bits, with_d=True)
+        assert np.array_equal(b["yz"], o["yz"]) and np.array_equal(b["aFend"], o["aFend"]) and np.array_equal(b["dFend"], o["d_final"]), (M, N)
+        assert np.array_equal(eng.haplotypes(o["yz"], N), orc.unpack_bitcols(bits, M))
+        if M >= 2:
+            assert np.array_equal(eng.max_within(o["yz"], N), orc.max_within(o["yz"], M, N))
+    # maxWithin refuses a single haplotype (the reference would read y[-1])
+    eng1 = amd.Engine(1, batch_sites=4)
+    with pytest.raises(amd.PbwtAmdError, match="at least 2 haplotypes"):
+        eng1.max_within(orc.pack3(np.zeros(1, np.uint8)), 1)
+
+
+def test_malformed_packed_panel_is_rejected(amd, orc):
+    M, N = 100, 10
+    bits = orc.synth_bitcols(M, N, seed=1, kind=1)
+    yz = orc.build_bitcols(bits, M, with_d=False)["yz"]
+    eng = amd.Engine(M, batch_sites=4)
+    with pytest.raises(amd.PbwtAmdError, match="decodes to"):
+        eng.max_within(yz[:-3], N, mode="hist")          # truncated
+    with pytest.raises(amd.PbwtAmdError, match="decodes to"):
+        eng.max_within(yz, N + 1, mode="hist")           # wrong N
