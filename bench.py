@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--cpu-sites", type=int, default=32768, help="sites of the same panel timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-1m", action="store_true", help="skip the secondary measurement at the north-star width (1M haplotypes)")
+    ap.add_argument("--own-stream", action="store_true", help="let the engine create its own (high-priority) chain stream instead of torch's current stream")
     ap.add_argument("--panels", type=int, default=1, help="independent panels run concurrently on this GPU (throughput mode; default 1 = the named config)")
     return ap.parse_args()
 
@@ -113,7 +114,7 @@ def main():
     M, S, K, Wm = args.haps, args.sites_per_step, args.steps, args.warmup
     n_total = (K + Wm) * S
     stream = torch.cuda.current_stream().cuda_stream
-    eng = pbwt_amd.Engine(M, batch_sites=args.batch, device=dev.index, stream=stream)
+    eng = pbwt_amd.Engine(M, batch_sites=args.batch, device=dev.index, stream=None if args.own_stream else stream)
     wpc = eng.wpc
     # the panel, resident in HBM before the timed region (bit-packed, original haplotype order)
     panel = torch.empty((n_total, wpc), dtype=torch.int32, device=dev)
@@ -136,7 +137,7 @@ def main():
 
     def step(i):
         k = i * S
-        avail = min(S + 2, n_total - k)    # one look-ahead pair: the build path runs two sites per launch
+        avail = min(S + 8, n_total - k)    # look-ahead columns: the chain's radix step spans 8 sites (2 for the two-site path)
         eng.pass_advance(panel.data_ptr() + k * row_bytes, S, avail, opts)
         for e2, p2 in extra:
             e2.pass_advance(p2.data_ptr() + k * row_bytes, S, avail, opts)
@@ -193,7 +194,8 @@ def main():
                    "haplotypes": M, "sites_per_step": S, "sites_timed": K * S, "device_batch_sites": args.batch,
                    "panel": "founder-mosaic" if args.kind == 0 else "iid", "within": not args.no_within,
                    "pack3": not args.no_pack3, "units_per_rank": "independent panel per rank", "panels_per_gpu": args.panels},
-        "roofline": {"bound": "hbm", "kernel": "step2_kernel<WITH_D> (two sites per launch)" if sites_per_launch > 1.5 else "step1_kernel<WITH_D,GATHER>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+        "roofline": {"bound": "hbm", "kernel": ("skeleton chain: skel_k1/k2/k3_kernel, 3 launches per 8 sites" if sites_per_launch > 2.5 else
+                                "step2_kernel<WITH_D> (two sites per launch)" if sites_per_launch > 1.5 else "step1_kernel<WITH_D,GATHER>"), "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "alg_bytes_per_launch": alg_bytes_per_launch, "us_per_launch": us_per_launch,
                      "launches": int(chain_n), "sites_per_launch": sites_per_launch,

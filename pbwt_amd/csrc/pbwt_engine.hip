@@ -44,7 +44,7 @@ struct DevBufs {
 };
 
 struct GraphKey { int with_d, sorted, ring, pair; hipGraphExec_t exec; };
-struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; };
+struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; bool skel = false; };
 
 struct pbwtamd_engine {
     int device = 0, M = 0, Mpad = 0, wpc = 0, wpc64 = 0, W = 0, wpad = 0, E = 4, T = 1024, B = 0;
@@ -72,6 +72,12 @@ struct pbwtamd_engine {
     unsigned long long yz_bytes_host = 0; size_t yz_upper = 0;   // host-side upper bound of the packed bytes written
     std::vector<GraphKey> graphs; bool use_graph = true; bool lean = true; bool pair = true;
     bool pair1024 = false;
+    bool skel = true;                       // skeleton + fill (8 sites per round of K1/K2/K3 on the chain, the 7 states between filled beside it); PBWTAMD_SKEL=0: two-site chain
+    uint32_t *xT = nullptr; size_t strideX = 0; int xTblocks = 0;   // transposed panel of the batch in flight (= xTr[ring])
+    uint32_t *xTr[2] = {nullptr, nullptr}; // one per ring: the fill of batch n reads it while the chain transposes batch n+1
+    int4 *summF = nullptr; int wpadF = 0;  // fill: tile summaries [B/8][wpadF]
+    unsigned char *keys8 = nullptr; int *skT = nullptr;   // K1/K2 tables: cnt, tail, before, carry [W1024][256], then G[256], lower[256]
+    int W1k = 0;
     bool summ_pair = false;                 // format of the current tile summaries (two-site keys or single site)
     uint32_t *zerocol = nullptr; long long sites_done = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0; long long launches = 0;
@@ -103,7 +109,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, e->cols_stage, e->ycols, e->colBytes,
+    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->summF, (void *)e->keys8, (void *)e->skT, e->cols_stage, e->ycols, e->colBytes,
                     e->blockCount, e->scal, e->hist, e->csum, e->recs, e->yz};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -130,7 +136,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     e->T = BLOCK * e->E;
     e->W = (M + e->T - 1) / e->T;
     if (e->W > 1024) { delete e; return fail("pbwtamd: M=%d too large for this build (max %d)", M, 1024 * 4096); }
-    e->Mpad = e->W * e->T;
+    e->Mpad = (M + 4095) / 4096 * 4096;                    // every tile geometry (256 / 1024 / 4096 positions) stays inside the padding
     e->wpad = (e->W + 63) / 64 * 64;
     e->wpc = wpc_for(M);
     e->wpc64 = e->wpc / 2;
@@ -140,8 +146,13 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     if (const char *s = getenv("PBWTAMD_LEAN")) e->lean = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_PAIR")) e->pair = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_PAIR1024")) e->pair1024 = atoi(s) != 0;
+    if (const char *s = getenv("PBWTAMD_SKEL")) e->skel = atoi(s) != 0;
+    if (M > (1 << 20)) e->skel = false;                    // skeleton tables: <= 1024 tiles of 1024; fill: <= 4096 tile summaries per thread block
+    int prLow = 0, prHigh = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);  // numerically: low >= high
+    if (const char *s = getenv("PBWTAMD_NO_PRIO")) { if (atoi(s)) prLow = prHigh = 0; }
     if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
-    else { if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); } e->own_stream = true; }
+    else { if (hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prHigh) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); } e->own_stream = true; }
     e->strideA = (size_t)e->Mpad;
     e->strideD = (size_t)e->Mpad + 64;
     const size_t slots = (size_t)e->B + 2;
@@ -157,10 +168,20 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     ALLOC(e->ycols, slots * e->wpc64 * sizeof(unsigned long long));
     ALLOC(e->colBytes, (slots + 1) * sizeof(unsigned long long));
     ALLOC(e->scal, 8 * sizeof(unsigned long long));
+    if (e->skel) {
+        e->W1k = (M + SKT - 1) / SKT;
+        e->strideX = (size_t)e->Mpad; e->xTblocks = (e->B + 8 + 31) / 32 + 1;
+        ALLOC(e->xTr[0], (size_t)e->xTblocks * e->strideX * sizeof(uint32_t));
+        ALLOC(e->xTr[1], (size_t)e->xTblocks * e->strideX * sizeof(uint32_t));
+        e->wpadF = ((M + BLOCK - 1) / BLOCK + 63) / 64 * 64;
+        ALLOC(e->summF, (size_t)(e->B / 8 + 1) * e->wpadF * sizeof(int4));
+        ALLOC(e->keys8, (size_t)e->Mpad);
+        ALLOC(e->skT, ((size_t)4 * (e->W1k + 64) * SKK + 2 * SKK) * sizeof(int));
+    }
 #undef ALLOC
     HIPCHK(hipMemsetAsync(e->A, 0, 2 * slots * e->strideA * sizeof(int), e->stream));
     HIPCHK(hipMemsetAsync(e->D, 0, 2 * slots * e->strideD * sizeof(int), e->stream));
-    HIPCHK(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithPriority(&e->s2, hipStreamNonBlocking, prLow));   // consumers yield to the dependent chain
     for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&e->evChain[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->evCons[i], hipEventDisableTiming)); }
     HIPCHK(hipMemsetAsync(e->ctl, 0, 16 * sizeof(int), e->stream));
     HIPCHK(hipMemsetAsync(e->scal, 0, 8 * sizeof(unsigned long long), e->stream));
@@ -481,6 +502,22 @@ static int flush_pending(pbwtamd_engine *e) {
     const int *A = ringA(e, p.ring), *D = ringD(e, p.ring);
     const bool with_d = p.opts & PBWTAMD_OPT_WITH_D;
     HIPCHK(hipStreamWaitEvent(e->s2, e->evChain[p.ring], 0));
+    if (p.skel) {                                          // fill the 7 states between consecutive skeleton states, all blocks at once
+        FillArgs f;
+        f.A = ringA(e, p.ring); f.D = ringD(e, p.ring); f.strideA = e->strideA; f.strideD = e->strideD;
+        f.xT = e->xTr[p.ring]; f.strideX = e->strideX; f.summ = e->summF; f.M = e->M;
+        f.W = (e->M + BLOCK - 1) / BLOCK; f.wpad = e->wpadF; f.kbase = p.kbase; f.n_total = e->n_total;
+        dim3 grid(f.W, p.nb / 8);
+        for (int j = 1; j < 8; ++j) {
+            f.j = j;
+            hipLaunchKernelGGL(fill_count_kernel, grid, dim3(BLOCK), 0, e->s2, f);
+            if (f.W <= 256) hipLaunchKernelGGL((fill_step_kernel<1>), grid, dim3(BLOCK), 0, e->s2, f);
+            else if (f.W <= 512) hipLaunchKernelGGL((fill_step_kernel<2>), grid, dim3(BLOCK), 0, e->s2, f);
+            else if (f.W <= 1024) hipLaunchKernelGGL((fill_step_kernel<4>), grid, dim3(BLOCK), 0, e->s2, f);
+            else hipLaunchKernelGGL((fill_step_kernel<16>), grid, dim3(BLOCK), 0, e->s2, f);
+        }
+        HIPCHK(hipGetLastError());
+    }
     if (p.opts & PBWTAMD_OPT_CHECKSUM) {
         unsigned long long *ca = e->csum + (p.kbase - e->k0), *cd = ca + e->csum_sites, *cy = cd + e->csum_sites;
         dim3 grid(std::min(64, (e->M + BLOCK) / BLOCK), p.nb);
@@ -500,6 +537,40 @@ static int flush_pending(pbwtamd_engine *e) {
     return 0;
 }
 
+// one batch of the skeleton chain: nb (multiple of 8) sites from slot 0 of ring r, writing slots 8, 16, ..., nb.
+// cols: the batch's bit columns (navail of them, original order)
+static int run_skeleton(pbwtamd_engine *e, int r, const uint32_t *cols, int nb, int navail) {
+    int *A = ringA(e, r), *D = ringD(e, r);
+    const int nvalid = std::min(navail, e->n_total - e->k_cur);
+    const int nblk = (std::min(nb + 8, nvalid) + 31) / 32;
+    dim3 gt((e->wpc + BLOCK - 1) / BLOCK, nblk);
+    hipLaunchKernelGGL(transpose32_kernel, gt, dim3(BLOCK), 0, e->stream, cols, e->wpc, nvalid, e->xT, e->strideX, e->Mpad);
+    hipLaunchKernelGGL(skel_tag_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, A, (const uint32_t *)e->xT, 0, e->M);
+    const int Wp = (e->W1k + 63) / 64 * 64;                 // tables are [key][Wp]
+    int *cntT = e->skT, *tailT = cntT + (size_t)Wp * SKK, *beforeT = tailT + (size_t)Wp * SKK, *carryT = beforeT + (size_t)Wp * SKK;
+    int *total = carryT + (size_t)Wp * SKK;
+    for (int s8 = 0; s8 < nb / 8; ++s8) {
+        const int site = 8 * s8;                           // relative to the batch
+        Sk1Args k1; k1.a = A + (size_t)site * e->strideA; k1.d = D + (size_t)site * e->strideD;
+        k1.xT = e->xT + (size_t)(site / 32) * e->strideX; k1.keys = e->keys8; k1.cntT = cntT; k1.tailT = tailT; k1.M = e->M; k1.shift = site % 32; k1.Wp = Wp;
+        hipLaunchKernelGGL(skel_k1_kernel, dim3(e->W1k), dim3(BLOCK), 0, e->stream, k1);
+        Sk2Args k2; k2.cntT = cntT; k2.tailT = tailT; k2.beforeT = beforeT; k2.carryT = carryT; k2.total = total; k2.W = e->W1k; k2.Wp = Wp;
+        if (e->W1k <= 64) hipLaunchKernelGGL((skel_k2_kernel<1>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
+        else if (e->W1k <= 128) hipLaunchKernelGGL((skel_k2_kernel<2>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
+        else if (e->W1k <= 256) hipLaunchKernelGGL((skel_k2_kernel<4>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
+        else hipLaunchKernelGGL((skel_k2_kernel<16>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
+        Sk3Args k3; k3.a = k1.a; k3.d = k1.d; k3.keys = e->keys8;
+        k3.a_out = A + (size_t)(site + 8) * e->strideA; k3.d_out = D + (size_t)(site + 8) * e->strideD;
+        k3.beforeT = beforeT; k3.carryT = carryT; k3.total = total;
+        k3.has_next = (e->k_cur + site + 8 < e->n_total) && (site + 8 < nvalid);
+        k3.xTnext = e->xT + (size_t)((site + 8) / 32) * e->strideX; k3.shift_next = (site + 8) % 32;
+        k3.M = e->M; k3.W = e->W1k; k3.Wp = Wp; k3.k = e->k_cur + site;
+        hipLaunchKernelGGL(skel_k3_kernel, dim3(e->W1k), dim3(BLOCK), 0, e->stream, k3);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, int wpc, int ncols, int ncols_avail, unsigned opts) {
     HIPCHK(hipSetDevice(e->device));
     if (!e->pass_open) return fail("pbwtamd_pass_advance without pass_begin");
@@ -510,6 +581,8 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
     const bool with_d = opts & PBWTAMD_OPT_WITH_D, sorted = opts & PBWTAMD_OPT_SORTED;
     if ((opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_LONG_RECS)) && !with_d)
         return fail("pbwtamd: the maxWithin sweep needs OPT_WITH_D");
+    if ((opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) && e->M < 2)
+        return fail("pbwtamd: the maxWithin sweep needs at least 2 haplotypes (the reference reads y[-1] for M = 1)");
     const uint32_t *cols = (const uint32_t *)d_bitcols;
     int done = 0;
     while (done < ncols) {
@@ -522,11 +595,12 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         const int left = ncols_avail - done;               // columns available from bc on
         const int remaining = e->n_total - e->k_cur;
         const int L = (nb + 1) / 2;
-        const bool pair = e->pair && !sorted && (e->T == 256 || e->T == 1024 || e->T == 2048 || e->T == 4096) && left >= std::min(2 * L + 2, remaining);
-        CHK(ensure_prepared(e, bc, sorted, with_d, pair, left));
+        const bool skel = e->skel && !sorted && with_d && (nb % 8 == 0) && left >= std::min(nb + 8, remaining);
+        const bool pair = !skel && e->pair && !sorted && (e->T == 256 || e->T == 1024 || e->T == 2048 || e->T == 4096) && left >= std::min(2 * L + 2, remaining);
+        if (!skel) CHK(ensure_prepared(e, bc, sorted, with_d, pair, left));
         hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(256), 0, e->stream, e->ctlblk, e->k_cur, e->n_total, bc, (const uint32_t *)e->zerocol,
                            e->summ, pair ? 3 * e->wpad : e->wpad, e->summ_cur);
-        const int nlaunch = pair ? L : nb;
+        const int nlaunch = skel ? 3 * (nb / 8) : (pair ? L : nb);
         e->summ_cur = nlaunch % 3;
         HIPCHK(hipGetLastError());
         // ---- the chain: slot j -> slot j+1 (-> slot j+2) of ring r ----
@@ -535,7 +609,12 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         }
         HIPCHK(hipEventRecord(e->ev[e->ev_used].first, e->stream));
         bool launched = false;
-        if (e->use_graph && nb == e->B) {
+        if (skel) {
+            // ring r's consumers (incl. the fill that read xTr[r]) were waited for before slot 0 of ring r was written
+            e->xT = e->xTr[r];
+            CHK(run_skeleton(e, r, bc, nb, left)); launched = true; e->prepared = false;
+        }
+        else if (e->use_graph && nb == e->B) {
             hipGraphExec_t exec;
             if (get_graph(e, with_d, sorted, r, pair, &exec) == 0 && hipGraphLaunch(exec, e->stream) == hipSuccess) launched = true;
             else {                                         // capture / instantiate / launch refused: fall back to eager launches for good
@@ -559,8 +638,8 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         if (e->consRecorded[r ^ 1]) HIPCHK(hipStreamWaitEvent(e->stream, e->evCons[r ^ 1], 0));
         HIPCHK(hipMemcpyAsync(ringA(e, r ^ 1), A + (size_t)nb * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->stream));
         if (with_d) HIPCHK(hipMemcpyAsync(ringD(e, r ^ 1), D + (size_t)nb * e->strideD, sizeof(int) * e->strideD, hipMemcpyDeviceToDevice, e->stream));
-        if (opts & (PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS)) {
-            e->pend.valid = true; e->pend.ring = r; e->pend.kbase = e->k_cur; e->pend.nb = nb; e->pend.opts = opts;
+        if (skel || (opts & (PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS))) {
+            e->pend.valid = true; e->pend.ring = r; e->pend.kbase = e->k_cur; e->pend.nb = nb; e->pend.opts = opts; e->pend.skel = skel;
         }
         e->ring = r ^ 1;
         e->k_cur += nb;

@@ -709,6 +709,325 @@ __global__ __launch_bounds__(NT) void step2_kernel(Step2Args g) {
     else step2_body<WITH_D, false, SPT, NT, E>(g, s_tup, s_red, s_acc);
 }
 
+// =============================================================================================
+// SKELETON + FILL.  The critical chain advances EIGHT sites per round with three
+// launches (K1, K2, K3) and produces only every 8th state; the seven states in between are filled
+// in afterwards by batched single-site kernels that run over all blocks of a batch at once.
+//   a_{k+8} = stable sort of a_k by the 8-bit key (bit j = allele at site k+j);
+//   d_{k+8}[e] = range max of d_k since the previous element with the same key (level-0 order), or
+//                k+1+msb(key ^ key') with key' the nearest lower non-empty key when there is none
+//   (tests/tile_model.py::stepB_tiles).  Tiles of 1024 positions, 256 threads.
+// ---------------------------------------------------------------------------------------------
+constexpr int SKB = 8, SKK = 1 << SKB, SKT = 1024;
+
+// 32 sites x 32 haplotypes bit transpose: xT[blk][h] bit j = allele of haplotype h at site 32*blk + j
+// (sites at or beyond n_valid read as 0).  grid (ceil(wpc/256), nblk).
+__global__ __launch_bounds__(BLOCK) void transpose32_kernel(const uint32_t *cols, int wpc, int n_valid, uint32_t *xT, size_t strideX, int Mpad) {
+    const int wd = blockIdx.x * BLOCK + threadIdx.x, blk = blockIdx.y;
+    if (wd >= wpc) return;
+    uint32_t r[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { const int site = blk * 32 + j; r[j] = (site < n_valid) ? cols[(size_t)site * wpc + wd] : 0u; }
+    // r[j] bit i = hap 32*wd+i at site j  ->  out[i] bit j
+    uint32_t o[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v |= ((r[j] >> i) & 1u) << j;
+        o[i] = v;
+    }
+    uint32_t *dst = xT + (size_t)blk * strideX + (size_t)wd * 32;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) if (wd * 32 + i < Mpad) dst[i] = o[i];
+}
+
+// K1: per tile — gather the 8-bit keys, count them, and the max of d_k after each key's last
+// occurrence (whole-tile max for absent keys).  Threads own positions in REVERSE blocked order so
+// that a forward scan over threads is a suffix scan over positions.
+struct Sk1Args { const int *a; const int *d; const uint32_t *xT; unsigned char *keys; int *cntT; int *tailT; int M, shift, Wp; };   // tables are [key][Wp]
+__global__ __launch_bounds__(BLOCK) void skel_k1_kernel(Sk1Args g) {
+    __shared__ int h_cnt[SKK], h_last[SKK];
+    __shared__ int s_suf[SKT];
+    __shared__ int s_w[WAVES];
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x;
+    const int rb = BLOCK - 1 - t;                          // this thread's block of 4 positions, counted from the end
+    const int l0 = rb * 4, i0 = w * SKT + l0;
+    h_cnt[t] = 0; h_last[t] = -1;
+    const int4 va = *reinterpret_cast<const int4 *>(g.a + i0);
+    const int4 vd = *reinterpret_cast<const int4 *>(g.d + i0);
+    const int av[4] = {va.x & AMASK, va.y & AMASK, va.z & AMASK, va.w & AMASK};
+    int dv[4] = {vd.x, vd.y, vd.z, vd.w};
+    int key[4];
+    unsigned packed = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bool valid = i0 + e < g.M;
+        key[e] = valid ? (int)((g.xT[av[e]] >> g.shift) & 0xffu) : -1;
+        if (!valid) dv[e] = 0;
+        packed |= (unsigned)(key[e] & 0xff) << (8 * e);
+    }
+    *reinterpret_cast<unsigned *>(g.keys + i0) = packed;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (key[e] >= 0) { atomicAdd(&h_cnt[key[e]], 1); atomicMax(&h_last[key[e]], l0 + e); }
+    // suffix maxima: s_suf[l] = max d over positions > l of the tile
+    const int own = max(max(dv[0], dv[1]), max(dv[2], dv[3]));
+    int inc = wave_iscan_max(own);                         // lanes before me = positions after mine
+    if (lane == 63) s_w[wv] = inc;
+    const int excl_lane = lane_shr1(inc, 0);
+    __syncthreads();
+    int later = excl_lane;
+    for (int q = 0; q < wv; ++q) later = max(later, s_w[q]);
+    s_suf[l0 + 3] = later;
+    s_suf[l0 + 2] = max(later, dv[3]);
+    s_suf[l0 + 1] = max(max(later, dv[3]), dv[2]);
+    s_suf[l0] = max(max(max(later, dv[3]), dv[2]), dv[1]);
+    int tilemax = 0;
+    for (int q = 0; q < WAVES; ++q) tilemax = max(tilemax, s_w[q]);
+    __syncthreads();
+    // one key per thread
+    const int c = h_cnt[t];
+    g.cntT[(size_t)t * g.Wp + w] = c;
+    g.tailT[(size_t)t * g.Wp + w] = c ? s_suf[h_last[t]] : tilemax;
+}
+
+// K2: one WAVE per key — exclusive scan over the W tiles (lanes own TPL consecutive tiles) of the pair
+// (count, max d since the key's last occurrence) with combine(L,R) = (L.c+R.c, R.c ? R.t : max(L.t,R.t))
+// (for a tile without the key, t is the tile's max).  Outputs, [key][Wp]: keys before the tile, the
+// carry (-1: no earlier occurrence); and total[key].  grid = 256 keys / 4 waves.
+struct Sk2Args { const int *cntT; const int *tailT; int *beforeT; int *carryT; int *total; int W, Wp; };
+template <int TPL>
+__global__ __launch_bounds__(BLOCK) void skel_k2_kernel(Sk2Args g) {
+    const int lane = lane_id(), q = blockIdx.x * WAVES + wave_id();
+    const int *cn = g.cntT + (size_t)q * g.Wp, *tl = g.tailT + (size_t)q * g.Wp;
+    int c[TPL], tt[TPL];
+    int sc = 0, st = 0;                                    // this lane's tiles combined
+#pragma unroll
+    for (int x = 0; x < TPL; ++x) {
+        const int w = lane * TPL + x;
+        c[x] = (w < g.W) ? cn[w] : 0; tt[x] = (w < g.W) ? tl[w] : 0;
+        st = c[x] ? tt[x] : max(st, tt[x]); sc += c[x];
+    }
+    // inclusive wave scan of (sc, st)
+    int ic = sc, it = st;
+#define SK2_STEP(CTRL, RM) { const int lc = dpp_mov<CTRL, RM>(0, ic), lt2 = dpp_mov<CTRL, RM>(0, it); it = ic ? it : max(lt2, it); /* uses OLD ic = R.c */ ic += lc; }
+    // careful: combine(L,R).t = R.c ? R.t : max(L.t, R.t) with R = current (before adding L.c)
+    SK2_STEP(0x111, 0xf) SK2_STEP(0x112, 0xf) SK2_STEP(0x114, 0xf) SK2_STEP(0x118, 0xf) SK2_STEP(0x142, 0xa) SK2_STEP(0x143, 0xc)
+#undef SK2_STEP
+    int ec = lane_shr1(ic, 0), et = lane_shr1(it, 0);      // exclusive prefix of this lane's first tile
+#pragma unroll
+    for (int x = 0; x < TPL; ++x) {
+        const int w = lane * TPL + x;
+        if (w < g.W) { g.beforeT[(size_t)q * g.Wp + w] = ec; g.carryT[(size_t)q * g.Wp + w] = ec ? et : -1; }
+        et = c[x] ? tt[x] : max(et, tt[x]); ec += c[x];
+    }
+    if (lane == 63) g.total[q] = ic;
+}
+
+// K3: per tile — stable rank of every position among its key (ballot refinement inside 64-position
+// chunks + a per-key scan over the 16 chunks), previous same-key position, range max of d_k through a
+// sparse table in LDS, scatter of (a | next allele tag, d').
+struct Sk3Args {
+    const int *a; const int *d; const unsigned char *keys; int *a_out; int *d_out;
+    const int *beforeT; const int *carryT; const int *total;   // [key][Wp], [key]
+    const uint32_t *xTnext; int shift_next; int has_next;
+    int M, W, Wp, k;                                        // k = site of the input state
+};
+__global__ __launch_bounds__(BLOCK) void skel_k3_kernel(Sk3Args g) {
+    __shared__ int s_cnt[16][SKK];                          // per chunk: count -> base (exclusive over chunks)
+    __shared__ int s_lastp[16][SKK];                        // per chunk: last local position of the key -> previous one before the chunk
+    __shared__ int s_tbl[10][SKT];                          // sparse table: s_tbl[l][i] = max d over (i-2^l, i]
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x;
+    const int S = w * SKT;
+    for (int x = t; x < 16 * SKK; x += BLOCK) { (&s_cnt[0][0])[x] = 0; (&s_lastp[0][0])[x] = -1; }
+    int av[4], dv[4], key[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                           // striped: chunk r*4+wv = 64 consecutive positions
+        const int l = r * BLOCK + t, i = S + l;
+        const bool valid = i < g.M;
+        av[r] = g.a[i] & AMASK; dv[r] = valid ? g.d[i] : 0; key[r] = valid ? (int)g.keys[i] : -1;
+        s_tbl[0][l] = dv[r];
+    }
+    const int bq = g.beforeT[(size_t)t * g.Wp + w], cq = g.carryT[(size_t)t * g.Wp + w];
+    // bucket bases G (exclusive prefix of the key totals) and the nearest lower non-empty key
+    __shared__ int s_gw[WAVES], s_lw[WAVES];
+    const int tq = g.total[t];
+    const int ginc = wave_iscan_sum(tq), linc = wave_iscan_max(tq ? t + 1 : 0);
+    if (lane == 63) { s_gw[wv] = ginc; s_lw[wv] = linc; }
+    const int lexc = lane_shr1(linc, 0);
+    __syncthreads();
+    int Gq = ginc - tq, lq = lexc;
+    for (int x = 0; x < wv; ++x) { Gq += s_gw[x]; lq = max(lq, s_lw[x]); }
+    lq -= 1;
+    int rk[4], pl[4];
+    const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        unsigned long long same = __ballot(key[r] >= 0);
+#pragma unroll
+        for (int b = 0; b < SKB; ++b) { const unsigned long long bal = __ballot((key[r] >> b) & 1); same &= ((key[r] >> b) & 1) ? bal : ~bal; }
+        const unsigned long long before = same & lt;
+        rk[r] = __popcll(before);
+        pl[r] = before ? (r * 4 + wv) * 64 + (63 - __clzll(before)) : -1;
+        if (key[r] >= 0 && !before) {                       // leader of its key in this chunk
+            s_cnt[r * 4 + wv][key[r]] = __popcll(same);
+            s_lastp[r * 4 + wv][key[r]] = (r * 4 + wv) * 64 + (63 - __clzll(same));
+        }
+    }
+    __syncthreads();
+    {   // thread q = key: exclusive scan over the chunks
+        int base = 0, last = -1;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int cn = s_cnt[c][t], lp = s_lastp[c][t];
+            s_cnt[c][t] = base; s_lastp[c][t] = last;
+            base += cn; if (cn) last = lp;
+        }
+    }
+    // sparse table of d over the tile (levels 1..9)
+#pragma unroll
+    for (int l = 1; l < 10; ++l) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = r * BLOCK + t, j = i - (1 << (l - 1));
+            s_tbl[l][i] = (j >= 0) ? max(s_tbl[l - 1][i], s_tbl[l - 1][j]) : s_tbl[l - 1][i];
+        }
+    }
+    // per-key rows of the tile go through LDS too (reuse level-0..? no: keep separate small arrays)
+    __shared__ int s_before[SKK], s_carry[SKK], s_G[SKK], s_lower[SKK];
+    s_before[t] = bq; s_carry[t] = cq; s_G[t] = Gq; s_lower[t] = lq;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (key[r] < 0) continue;
+        const int l = r * BLOCK + t, c = r * 4 + wv, ky = key[r];
+        const int rank = s_cnt[c][ky] + rk[r];
+        const int p = (pl[r] >= 0) ? pl[r] : s_lastp[c][ky];        // previous same-key position in the tile, or -1
+        // range max of d over (p, l]  (p = -1: the whole prefix)
+        const int len = l - p, lv = min(31 - __clz(len), 9);     // two windows of 2^lv >= len/2 cover (p, l]; len <= 1024
+        const int rm = max(s_tbl[lv][l], s_tbl[lv][p + (1 << lv)]);
+        int dd;
+        if (p >= 0) dd = rm;
+        else if (s_carry[ky] >= 0) dd = max(s_carry[ky], rm);
+        else if (s_lower[ky] >= 0) dd = g.k + 1 + (31 - __clz(ky ^ s_lower[ky]));
+        else dd = 0;
+        const int pos = s_G[ky] + s_before[ky] + rank;
+        if (pos == 0) dd = g.k + SKB + 1;                  // sentinel (pbwtCore.c:507 after the 8th site)
+        unsigned tag = 0;
+        if (g.has_next) tag = (g.xTnext[av[r]] >> g.shift_next) & 1u;
+        g.a_out[pos] = av[r] | (int)(tag << 31);
+        g.d_out[pos] = dd;
+    }
+    if (w == g.W - 1 && t == 0) g.d_out[g.M] = g.k + SKB + 1;
+}
+
+// tag a state's entries with the allele of their haplotype at the state's site (bit `shift` of xT)
+__global__ void skel_tag_kernel(int *a, const uint32_t *xT, int shift, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) { const int v = a[i] & AMASK; a[i] = v | (int)(((xT[v] >> shift) & 1u) << 31); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FILL: the seven states between two skeleton states, for ALL blocks of a batch at once.  Launch j
+// (1..7) turns slot 8b+j-1 into slot 8b+j for every block b: grid (tiles of 256, blocks).  Same
+// single-site step as step1_kernel (fold of tile summaries, carry tuple scan, scatter), but the
+// summaries come from a count kernel over the same batch (two launches per level instead of one:
+// this runs beside the chain, throughput matters here, not latency).
+struct FillArgs {
+    int *A; int *D; size_t strideA, strideD;               // ring base (slot 0 of the batch)
+    const uint32_t *xT; size_t strideX;                     // transposed panel blocks of the batch
+    int4 *summ;                                             // [blocks][wpad] {cnt0, last0+1, last1+1, maxd}
+    int j, M, W, wpad, kbase, n_total;
+};
+
+__global__ __launch_bounds__(BLOCK) void fill_count_kernel(FillArgs g) {
+    __shared__ int s_red[WAVES][4];
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x, b = blockIdx.y;
+    const int slot = 8 * b + g.j - 1, i = w * BLOCK + t;
+    int c0 = 0, l0 = 0, l1 = 0, md = 0;
+    if (i < g.M) {
+        const int a = g.A[(size_t)slot * g.strideA + i];
+        if (a < 0) l1 = i + 1; else { c0 = 1; l0 = i + 1; }
+        md = g.D[(size_t)slot * g.strideD + i];
+    }
+    c0 = wave_sum(c0); l0 = wave_max(l0); l1 = wave_max(l1); md = wave_max(md);
+    if (lane == 0) { s_red[wv][0] = c0; s_red[wv][1] = l0; s_red[wv][2] = l1; s_red[wv][3] = md; }
+    __syncthreads();
+    if (t == 0) {
+        c0 = 0; l0 = 0; l1 = 0; md = 0;
+        for (int q = 0; q < WAVES; ++q) { c0 += s_red[q][0]; l0 = max(l0, s_red[q][1]); l1 = max(l1, s_red[q][2]); md = max(md, s_red[q][3]); }
+        g.summ[(size_t)b * g.wpad + w] = make_int4(c0, l0, l1, md);
+    }
+}
+
+template <int SPT>
+__global__ __launch_bounds__(BLOCK) void fill_step_kernel(FillArgs g) {
+    constexpr int T = BLOCK;
+    __shared__ Tup s_tup[WAVES];
+    __shared__ int s_red[WAVES][6];
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x, b = blockIdx.y;
+    const int slot = 8 * b + g.j - 1, S = w * T, i = S + t, M = g.M, W = g.W;
+    const int k = g.kbase + slot;                          // site of the input state
+    const int *a_in = g.A + (size_t)slot * g.strideA, *d_in = g.D + (size_t)slot * g.strideD;
+    int *a_out = g.A + (size_t)(slot + 1) * g.strideA, *d_out = g.D + (size_t)(slot + 1) * g.strideD;
+    const int4 *sm = g.summ + (size_t)b * g.wpad;
+    int a = a_in[i];
+    const int d = d_in[i];
+    int4 sv[SPT];
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) { const int jn = t + q * BLOCK; sv[q] = (jn < W) ? sm[jn] : make_int4(0, 0, 0, 0); }
+    const bool valid = i < M;
+    const unsigned y = ((unsigned)a) >> 31;
+    a &= AMASK;
+    // allele of this haplotype at the next site = the tag of the output state
+    unsigned tag = 0;
+    if (valid && k + 1 < g.n_total) { const int rel = slot + 1; tag = (g.xT[(size_t)(rel / 32) * g.strideX + a] >> (rel % 32)) & 1u; }
+    int sumBefore = 0, total = 0, l0 = 0, l1 = 0;
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        const int jn = t + q * BLOCK;
+        total += sv[q].x;
+        if (jn < w) { sumBefore += sv[q].x; l0 = max(l0, sv[q].y); l1 = max(l1, sv[q].z); }
+    }
+    sumBefore = wave_sum(sumBefore); total = wave_sum(total); l0 = wave_max(l0); l1 = wave_max(l1);
+    if (lane == 0) { s_red[wv][0] = sumBefore; s_red[wv][1] = total; s_red[wv][2] = l0; s_red[wv][3] = l1; }
+    __syncthreads();
+    sumBefore = 0; total = 0; l0 = 0; l1 = 0;
+#pragma unroll
+    for (int q = 0; q < WAVES; ++q) { sumBefore += s_red[q][0]; total += s_red[q][1]; l0 = max(l0, s_red[q][2]); l1 = max(l1, s_red[q][3]); }
+    const int Zw = sumBefore, C = total;
+    int m0 = 0, m1 = 0;
+    {
+        const int tl0 = l0 ? (l0 - 1) / T : -1, tl1 = l1 ? (l1 - 1) / T : -1;
+        const int hi0 = l0 ? min((tl0 + 1) * T, S) : 0, hi1 = l1 ? min((tl1 + 1) * T, S) : 0;
+        if (l0 + t < hi0) m0 = d_in[l0 + t];
+        if (l1 + t < hi1) m1 = d_in[l1 + t];
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) { const int jn = t + q * BLOCK; if (jn < w) { if (jn > tl0) m0 = max(m0, sv[q].w); if (jn > tl1) m1 = max(m1, sv[q].w); } }
+    }
+    Tup me = Tup{0, 0, 0, 0, 0};
+    if (valid) { if (y) { me.c1 = 1; me.t0 = d; } else { me.c0 = 1; me.t1 = d; } me.all = d; }
+    m0 = wave_max(m0); m1 = wave_max(m1);
+    if (lane == 0) { s_red[wv][4] = m0; s_red[wv][5] = m1; }
+    Tup tot;
+    const Tup pre = block_scan_tup<true>(me, s_tup, tot);  // (its barrier also publishes s_red[.][4..5])
+    m0 = 0; m1 = 0;
+#pragma unroll
+    for (int q = 0; q < WAVES; ++q) { m0 = max(m0, s_red[q][4]); m1 = max(m1, s_red[q][5]); }
+    const int carry0 = l0 ? m0 : k + 1, carry1 = l1 ? m1 : k + 1;
+    if (valid) {
+        const int pin = y ? (pre.c1 ? pre.t1 : max(carry1, pre.all)) : (pre.c0 ? pre.t0 : max(carry0, pre.all));
+        int dn = max(pin, d);
+        const int P = y ? C + (S - Zw) + pre.c1 : Zw + pre.c0;
+        if (P == 0) dn = k + 2;
+        a_out[P] = a | (int)(tag << 31);
+        d_out[P] = dn;
+    }
+    if (w == W - 1 && t == 0) d_out[M] = k + 2;
+}
+
 // first pair of a pass (or after an odd-length batch): both allele tags of slot 0 from columns k, k+1
 // and the pair summaries from scratch; clears the accumulation buffer of the first launch
 struct Prep2Args { int *a; const int *d; const uint32_t *col0; const uint32_t *col1; int4 *summ; int M, W, wpad, with_d, T; };

@@ -190,7 +190,11 @@ def test_device_pass_api_with_graph(amd, orc):
     assert np.array_equal(ca, o["csum_a"]) and np.array_equal(cd, o["csum_d"])
     assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
     ms, n = eng.chain_timing()
-    assert eng.chain_sites() == N and n == N // 2 and ms > 0      # the build path runs two sites per launch
+    assert eng.chain_sites() == N and ms > 0
+    if os.environ.get("PBWTAMD_SKEL", "1") == "0":
+        assert n == N // 2                                        # the two-site chain
+    else:
+        assert n < N // 2                                         # 3 launches per 8 sites where the skeleton applies
 
 
 @pytest.mark.parametrize("path", golden_panels(), ids=os.path.basename)
@@ -320,3 +324,42 @@ def test_malformed_packed_panel_is_rejected(amd, orc):
         eng.max_within(yz[:-3], N, mode="hist")          # truncated
     with pytest.raises(amd.PbwtAmdError, match="decodes to"):
         eng.max_within(yz, N + 1, mode="hist")           # wrong N
+
+
+@pytest.mark.parametrize("skel", ["1", "0"])
+@pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1024, 130, 32, 1), (1025, 96, 24, 0), (70001, 80, 40, 0),
+                                            (300000, 40, 16, 0), (1500, 41, 8, 1), (5, 64, 16, 1), (1, 16, 8, 0)])
+def test_both_chains_every_site(amd, orc, skel, M, N, batch, kind, monkeypatch):
+    """the two chain implementations — skeleton (8-bit radix step every 8 sites, K1/K2/K3, with the
+    seven states between filled by batched single-site kernels) and the two-site chain — against the
+    oracle at EVERY site (checksums of a and d), plus the consumers fed from those states (hist, pack3)"""
+    import torch
+    monkeypatch.setenv("PBWTAMD_SKEL", skel)
+    eng = amd.Engine(M, batch_sites=batch)
+    buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    eng.synth_device(buf.data_ptr(), 0, N, seed=1000 + M, kind=kind)
+    eng.sync()
+    bits = buf.cpu().numpy().view(np.uint32)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    opts = amd.OPT_WITH_D | amd.OPT_CHECKSUM | (amd.OPT_WITHIN_HIST if M > 1 else 0)
+    if M == 1:                                 # the reference's maxWithin reads y[-1] for a single haplotype: refused
+        eng.pass_begin(N)
+        with pytest.raises(amd.PbwtAmdError):
+            eng.pass_advance(buf.data_ptr(), N, N, opts | amd.OPT_WITHIN_HIST)
+    eng.pass_begin(N)
+    eng.pass_advance(buf.data_ptr(), N, N, opts)
+    eng.pass_end(opts)
+    a, d = eng.get_state()
+    ca, cd, _ = eng.get_checksums(0, N + 1)
+    assert np.array_equal(ca, o["csum_a"]), "a[] differs first at site %d" % int(np.argmax(ca != o["csum_a"]))
+    assert np.array_equal(cd, o["csum_d"]), "d[] differs first at site %d" % int(np.argmax(cd != o["csum_d"]))
+    assert np.array_equal(a, o["aFend"]) and np.array_equal(d, o["d_final"])
+    if M > 1:
+        assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
+    n = eng.chain_timing()[1]
+    if skel == "1" and N >= batch and batch % 8 == 0:
+        assert n < (N + 1) // 2                # at least one batch went through the skeleton (3 launches per 8 sites)
+    b = eng.build(bits, with_d=True)           # host entry point: pack3 stream + records sink
+    assert np.array_equal(b["yz"], o["yz"]) and np.array_equal(b["dFend"], o["d_final"])
+    if 1 < M <= 3000:
+        assert np.array_equal(eng.max_within(o["yz"], N, mode="records"), orc.max_within(o["yz"], M, N))

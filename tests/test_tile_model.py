@@ -19,3 +19,37 @@ def test_tile_model_matches_oracle(orc, M, N, kind, T):
         y = hap[k][a]
         a, d = step_tiles(a, d, y, k, T, summaries(y, d, M, T))
     assert np.array_equal(a, o["a_dump"][N]) and np.array_equal(d, o["d_dump"][N])
+
+
+@pytest.mark.parametrize("M,N,kind,T", [(37, 60, 1, 8), (100, 121, 0, 8), (257, 90, 0, 32), (500, 41, 1, 64)])
+def test_two_site_tile_model_matches_oracle(orc, M, N, kind, T):
+    """two sites per launch (step2_kernel's formulation): both output levels against the oracle"""
+    from tile_model import step2_tiles, summaries2
+    bits = orc.synth_bitcols(M, N, seed=3 * M + N, kind=kind)
+    hap = orc.unpack_bitcols(bits, M)
+    o = orc.build_bitcols(bits, M, with_d=True, dump_sites=range(N + 1))
+    a, d = o["a_dump"][0].astype(np.int64), o["d_dump"][0].astype(np.int64)
+    for k in range(0, N - 1, 2):
+        key = hap[k][a] | (hap[k + 1][a] << 1)
+        (a1, d1), (a, d) = step2_tiles(a, d, key, k, T, summaries2(key, d, M, T))
+        assert np.array_equal(a1, o["a_dump"][k + 1]) and np.array_equal(d1, o["d_dump"][k + 1])
+        assert np.array_equal(a, o["a_dump"][k + 2]) and np.array_equal(d, o["d_dump"][k + 2])
+
+
+@pytest.mark.parametrize("M,N,kind,T,B", [(37, 64, 1, 8, 8), (100, 120, 0, 8, 8), (257, 96, 0, 32, 8), (300, 60, 0, 16, 3),
+                                         (1000, 40, 0, 64, 8), (64, 35, 1, 16, 5)])
+def test_skeleton_tile_model_matches_oracle(orc, M, N, kind, T, B):
+    """B sites per step (the skeleton chain K1/K2/K3: per-tile key histograms and tails, per-key scan
+    over tiles, ranks + range maxima): the state every B sites against the oracle"""
+    from tile_model import stepB_tiles
+    bits = orc.synth_bitcols(M, N, seed=5 * M + N, kind=kind)
+    hap = orc.unpack_bitcols(bits, M).astype(np.int64)
+    o = orc.build_bitcols(bits, M, with_d=True, dump_sites=range(N + 1))
+    a, d = o["a_dump"][0].astype(np.int64), o["d_dump"][0].astype(np.int64)
+    for k in range(0, N - B + 1, B):
+        key = np.zeros(M, np.int64)
+        for j in range(B):
+            key |= hap[k + j][a] << j
+        a, d = stepB_tiles(a, d, key, k, B, T)
+        assert np.array_equal(a, o["a_dump"][k + B]), "a at site %d" % (k + B)
+        assert np.array_equal(d, o["d_dump"][k + B]), "d at site %d" % (k + B)

@@ -140,3 +140,64 @@ def step2_tiles(a, d, key, k, T, summ):
     d1[0] = k + 2; d1[M] = k + 2
     d2[0] = k + 3; d2[M] = k + 3
     return (a1, d1), (a2, d2)
+
+
+# ------------------------------------------------------------------------------------------------
+# B sites per step, level-B output only ("skeleton" step; stepB kernels K1/K2/K3):
+#   key = alleles at sites k..k+B-1 (bit j = site k+j); a_{k+B} = stable sort of a_k by key;
+#   same-key predecessor (level-0 order) -> range max of d_k; none -> k+1+msb(key ^ lower non-empty key).
+def stepB_tiles(a, d, key, k, B, T):
+    M = len(a)
+    W = (M + T - 1) // T
+    K = 1 << B
+    # K1: per tile, per key: count and the max of d_k after the key's last occurrence (whole-tile max if absent)
+    cnt = np.zeros((W, K), np.int64); tail = np.zeros((W, K), np.int64)
+    for w in range(W):
+        lo, hi = w * T, min((w + 1) * T, M)
+        kk = key[lo:hi]; dd = d[lo:hi]
+        for q in range(K):
+            idx = np.nonzero(kk == q)[0]
+            cnt[w, q] = len(idx)
+            tail[w, q] = (dd[idx[-1] + 1:].max() if len(idx) and idx[-1] + 1 < len(dd) else 0) if len(idx) else dd.max()
+    # K2: per key, scan over tiles
+    before = np.zeros((W, K), np.int64); carry = -np.ones((W, K), np.int64)
+    for q in range(K):
+        run, ex, c = 0, False, 0
+        for w in range(W):
+            before[w, q] = run
+            carry[w, q] = c if ex else -1
+            if cnt[w, q]:
+                ex = True; c = tail[w, q]
+            elif ex:
+                c = max(c, tail[w, q])
+            run += cnt[w, q]
+    total = cnt.sum(axis=0)
+    G = np.concatenate([[0], np.cumsum(total)])[:K]
+    lower = -np.ones(K, np.int64)
+    last = -1
+    for q in range(K):
+        lower[q] = last
+        if total[q]:
+            last = q
+    # K3: per tile
+    a2 = np.zeros(M, np.int64); d2 = np.zeros(M + 1, np.int64)
+    for w in range(W):
+        lo, hi = w * T, min((w + 1) * T, M)
+        seen_at = {}
+        rank = {}
+        for i in range(lo, hi):
+            q = int(key[i])
+            r = rank.get(q, 0)
+            if q in seen_at:
+                dd = int(d[seen_at[q] + 1: i + 1].max())
+            elif carry[w, q] >= 0:
+                dd = max(int(carry[w, q]), int(d[lo: i + 1].max()))
+            elif lower[q] >= 0:
+                dd = k + 1 + ((q ^ int(lower[q])).bit_length() - 1)
+            else:
+                dd = 0
+            pos = int(G[q] + before[w, q] + r)
+            a2[pos] = a[i]; d2[pos] = dd
+            seen_at[q] = i; rank[q] = r + 1
+    d2[0] = k + B + 1; d2[M] = k + B + 1
+    return a2, d2
