@@ -72,12 +72,17 @@ struct pbwtamd_engine {
     unsigned long long yz_bytes_host = 0; size_t yz_upper = 0;   // host-side upper bound of the packed bytes written
     std::vector<GraphKey> graphs; bool use_graph = true; bool lean = true; bool pair = true;
     bool pair1024 = false;
+    bool skn = true;                        // skeleton rounds of two launches (hist, rank) when the panel has <= 128 tiles of 1024; PBWTAMD_SKN=0: K1/K2/K3
     bool skel = true;                       // skeleton + fill (8 sites per round of K1/K2/K3 on the chain, the 7 states between filled beside it); PBWTAMD_SKEL=0: two-site chain
     uint32_t *xT = nullptr; size_t strideX = 0; int xTblocks = 0;   // transposed panel of the batch in flight (= xTr[ring])
     uint32_t *xTr[2] = {nullptr, nullptr}; // one per ring: the fill of batch n reads it while the chain transposes batch n+1
     int4 *summF = nullptr; int wpadF = 0;  // fill: tile summaries [B/8][wpadF]
-    unsigned char *keys8 = nullptr; int *skT = nullptr;   // K1/K2 tables: cnt, tail, before, carry [W1024][256], then G[256], lower[256]
-    int W1k = 0;
+    unsigned char *keys8 = nullptr; int *skT = nullptr;   // skT: hist tables of the round in flight (cnt, tail [256][Wp], or [W][256] {cnt, tail})
+    unsigned char *keysR[2] = {nullptr, nullptr};         // per ring: the keys of states 0, 8, 16, ... of the batch ([B/8+1][Mpad]), kept for the fill
+    int *saveR[2] = {nullptr, nullptr}; size_t strideS = 0;   // per ring and round: before[256][Wp], carry[256][Wp], total[256]
+    bool fill_steps = false;                // PBWTAMD_FILL_STEPS=1: fill with 14 batched single-site launches instead of skel_fill_kernel
+    int Wt = 0, skEPT = 4;                  // skeleton tiles: 256*skEPT positions, Wt of them; PBWTAMD_SKT=512|1024
+    int skn_maxw = 16;                      // two-launch round (rank scans the tile table itself) up to this many tiles; PBWTAMD_SKN_MAXW
     bool summ_pair = false;                 // format of the current tile summaries (two-site keys or single site)
     uint32_t *zerocol = nullptr; long long sites_done = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0; long long launches = 0;
@@ -109,7 +114,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->summF, (void *)e->keys8, (void *)e->skT, e->cols_stage, e->ycols, e->colBytes,
+    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->summF, (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->skT, e->cols_stage, e->ycols, e->colBytes,
                     e->blockCount, e->scal, e->hist, e->csum, e->recs, e->yz};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -147,6 +152,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     if (const char *s = getenv("PBWTAMD_PAIR")) e->pair = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_PAIR1024")) e->pair1024 = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_SKEL")) e->skel = atoi(s) != 0;
+    if (const char *s = getenv("PBWTAMD_SKN")) e->skn = atoi(s) != 0;
     if (M > (1 << 20)) e->skel = false;                    // skeleton tables: <= 1024 tiles of 1024; fill: <= 4096 tile summaries per thread block
     int prLow = 0, prHigh = 0;
     (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);  // numerically: low >= high
@@ -169,19 +175,40 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     ALLOC(e->colBytes, (slots + 1) * sizeof(unsigned long long));
     ALLOC(e->scal, 8 * sizeof(unsigned long long));
     if (e->skel) {
-        e->W1k = (M + SKT - 1) / SKT;
+        e->skEPT = (M <= 40000) ? 1 : (M <= 300000) ? 2 : 4;   // measured: smaller tiles = shorter per-workgroup latency chains, until the per-key tile scan grows
+        if (const char *sv = getenv("PBWTAMD_SKT")) e->skEPT = (atoi(sv) == 256) ? 1 : (atoi(sv) == 512) ? 2 : 4;
+        if (M > 256 * e->skEPT * 2048) e->skEPT = 4;           // skel_k2_kernel scans at most 2048 tiles per key
+        if (const char *sv = getenv("PBWTAMD_SKN_MAXW")) e->skn_maxw = std::min(atoi(sv), SKN_MAXW);
+        e->Wt = (M + 256 * e->skEPT - 1) / (256 * e->skEPT);
         e->strideX = (size_t)e->Mpad; e->xTblocks = (e->B + 8 + 31) / 32 + 1;
         ALLOC(e->xTr[0], (size_t)e->xTblocks * e->strideX * sizeof(uint32_t));
         ALLOC(e->xTr[1], (size_t)e->xTblocks * e->strideX * sizeof(uint32_t));
         e->wpadF = ((M + BLOCK - 1) / BLOCK + 63) / 64 * 64;
         ALLOC(e->summF, (size_t)(e->B / 8 + 1) * e->wpadF * sizeof(int4));
-        ALLOC(e->keys8, (size_t)e->Mpad);
-        ALLOC(e->skT, ((size_t)4 * (e->W1k + 64) * SKK + 2 * SKK) * sizeof(int));
+        if (const char *sv = getenv("PBWTAMD_FILL_STEPS")) e->fill_steps = atoi(sv) != 0;
+        {
+            const int Wp = (e->Wt + 63) / 64 * 64, rounds = e->B / 8 + 1;
+            e->strideS = (size_t)2 * SKK * Wp + SKK;
+            for (int i = 0; i < 2; ++i) {
+                ALLOC(e->keysR[i], (size_t)(rounds + 1) * e->Mpad);
+                ALLOC(e->saveR[i], (size_t)rounds * e->strideS * sizeof(int));
+            }
+        }
+        ALLOC(e->skT, ((size_t)4 * (e->Wt + 64) * SKK + 2 * SKK) * sizeof(int));
     }
 #undef ALLOC
     HIPCHK(hipMemsetAsync(e->A, 0, 2 * slots * e->strideA * sizeof(int), e->stream));
     HIPCHK(hipMemsetAsync(e->D, 0, 2 * slots * e->strideD * sizeof(int), e->stream));
-    HIPCHK(hipStreamCreateWithPriority(&e->s2, hipStreamNonBlocking, prLow));   // consumers yield to the dependent chain
+    {   // consumers yield to the dependent chain: low priority, and (PBWTAMD_S2_CUS=n) only n of the CUs
+        int ncus = 0; const char *pat = getenv("PBWTAMD_S2_PATTERN");
+        if (const char *s = getenv("PBWTAMD_S2_CUS")) ncus = atoi(s);
+        if (ncus > 0) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (pat && atoi(pat) == 1) { for (int i = 0; i < 256; ++i) if ((i / 8) < ncus / 8) mask[i / 32] |= 1u << (i % 32); }   // low bits
+            else { for (int i = 0; i < 256; ++i) if ((i % 32) < ncus / 8) mask[i / 32] |= 1u << (i % 32); }                       // per 32-bit word
+            HIPCHK(hipExtStreamCreateWithCUMask(&e->s2, 8, mask));
+        } else HIPCHK(hipStreamCreateWithPriority(&e->s2, hipStreamNonBlocking, prLow));
+    }
     for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&e->evChain[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->evCons[i], hipEventDisableTiming)); }
     HIPCHK(hipMemsetAsync(e->ctl, 0, 16 * sizeof(int), e->stream));
     HIPCHK(hipMemsetAsync(e->scal, 0, 8 * sizeof(unsigned long long), e->stream));
@@ -502,7 +529,19 @@ static int flush_pending(pbwtamd_engine *e) {
     const int *A = ringA(e, p.ring), *D = ringD(e, p.ring);
     const bool with_d = p.opts & PBWTAMD_OPT_WITH_D;
     HIPCHK(hipStreamWaitEvent(e->s2, e->evChain[p.ring], 0));
-    if (p.skel) {                                          // fill the 7 states between consecutive skeleton states, all blocks at once
+    static const bool nofill = getenv("PBWTAMD_NOFILL") && atoi(getenv("PBWTAMD_NOFILL"));   // measurement only: results are wrong
+    if (p.skel && !nofill && !e->fill_steps) {             // the 7 states between consecutive skeleton states: all blocks and tiles in one launch
+        SkFillArgs f;
+        f.A = ringA(e, p.ring); f.D = ringD(e, p.ring); f.strideA = e->strideA; f.strideD = e->strideD;
+        f.keys = e->keysR[p.ring]; f.strideK = e->Mpad; f.save = e->saveR[p.ring]; f.strideS = e->strideS;
+        f.M = e->M; f.W = e->Wt; f.Wp = (e->Wt + 63) / 64 * 64; f.kbase = p.kbase;
+        dim3 grid(e->Wt, p.nb / 8);
+        if (e->skEPT == 1) hipLaunchKernelGGL((skel_fill_kernel<1>), grid, dim3(BLOCK), 0, e->s2, f);
+        else if (e->skEPT == 2) hipLaunchKernelGGL((skel_fill_kernel<2>), grid, dim3(BLOCK), 0, e->s2, f);
+        else hipLaunchKernelGGL((skel_fill_kernel<4>), grid, dim3(BLOCK), 0, e->s2, f);
+        HIPCHK(hipGetLastError());
+    }
+    if (p.skel && !nofill && e->fill_steps) {                               // fill the 7 states between consecutive skeleton states, all blocks at once
         FillArgs f;
         f.A = ringA(e, p.ring); f.D = ringD(e, p.ring); f.strideA = e->strideA; f.strideD = e->strideD;
         f.xT = e->xTr[p.ring]; f.strideX = e->strideX; f.summ = e->summF; f.M = e->M;
@@ -539,33 +578,57 @@ static int flush_pending(pbwtamd_engine *e) {
 
 // one batch of the skeleton chain: nb (multiple of 8) sites from slot 0 of ring r, writing slots 8, 16, ..., nb.
 // cols: the batch's bit columns (navail of them, original order)
+static inline bool skel_two_launch(const pbwtamd_engine *e) { return e->skn && e->Wt <= e->skn_maxw; }
+
+// launch helpers for the skeleton kernels: EPT = positions per thread (tile = 256*EPT)
+template <int EPT>
+static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
+    const int W = g.W;
+    if (two_launch) {
+        hipLaunchKernelGGL((skel_hist_kernel<EPT, true>), dim3(W), dim3(BLOCK), 0, e->stream, g);
+        if (W <= 16) hipLaunchKernelGGL((skel_rank_kernel<EPT, 16>), dim3(W), dim3(BLOCK), 0, e->stream, g);
+        else if (W <= 32) hipLaunchKernelGGL((skel_rank_kernel<EPT, 32>), dim3(W), dim3(BLOCK), 0, e->stream, g);
+        else if (W <= 64) hipLaunchKernelGGL((skel_rank_kernel<EPT, 64>), dim3(W), dim3(BLOCK), 0, e->stream, g);
+        else hipLaunchKernelGGL((skel_rank_kernel<EPT, SKN_MAXW>), dim3(W), dim3(BLOCK), 0, e->stream, g);
+        return;
+    }
+    hipLaunchKernelGGL((skel_hist_kernel<EPT, false>), dim3(W), dim3(BLOCK), 0, e->stream, g);
+    Sk2Args k2; k2.cntT = g.cntT; k2.tailT = g.tailT; k2.beforeT = (int *)g.beforeT; k2.carryT = (int *)g.carryT; k2.total = (int *)g.total; k2.W = W; k2.Wp = g.Wp;
+    if (W <= 64) hipLaunchKernelGGL((skel_k2_kernel<1>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
+    else if (W <= 128) hipLaunchKernelGGL((skel_k2_kernel<2>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
+    else if (W <= 256) hipLaunchKernelGGL((skel_k2_kernel<4>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
+    else if (W <= 1024) hipLaunchKernelGGL((skel_k2_kernel<16>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
+    else hipLaunchKernelGGL((skel_k2_kernel<32>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
+    hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
+}
+
+// the skeleton chain of one batch: slot 8s -> slot 8s+8 with an 8-bit radix step (keys = the alleles
+// at the 8 sites, gathered through the transposed panel and carried along with the state)
 static int run_skeleton(pbwtamd_engine *e, int r, const uint32_t *cols, int nb, int navail) {
     int *A = ringA(e, r), *D = ringD(e, r);
     const int nvalid = std::min(navail, e->n_total - e->k_cur);
     const int nblk = (std::min(nb + 8, nvalid) + 31) / 32;
     dim3 gt((e->wpc + BLOCK - 1) / BLOCK, nblk);
     hipLaunchKernelGGL(transpose32_kernel, gt, dim3(BLOCK), 0, e->stream, cols, e->wpc, nvalid, e->xT, e->strideX, e->Mpad);
-    hipLaunchKernelGGL(skel_tag_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, A, (const uint32_t *)e->xT, 0, e->M);
-    const int Wp = (e->W1k + 63) / 64 * 64;                 // tables are [key][Wp]
-    int *cntT = e->skT, *tailT = cntT + (size_t)Wp * SKK, *beforeT = tailT + (size_t)Wp * SKK, *carryT = beforeT + (size_t)Wp * SKK;
-    int *total = carryT + (size_t)Wp * SKK;
+    unsigned char *kb = e->keysR[r];
+    hipLaunchKernelGGL(skel_keys_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, A, (const uint32_t *)e->xT, 0, e->M, kb);
+    const int W = e->Wt, Wp = (W + 63) / 64 * 64;           // tables of the three-launch round are [key][Wp]
+    const bool two = skel_two_launch(e);
+    SkArgs g;
+    g.tbl = (int2 *)e->skT;
+    g.cntT = e->skT; g.tailT = g.cntT + (size_t)Wp * SKK;
+    g.M = e->M; g.W = W; g.Wp = Wp;
     for (int s8 = 0; s8 < nb / 8; ++s8) {
         const int site = 8 * s8;                           // relative to the batch
-        Sk1Args k1; k1.a = A + (size_t)site * e->strideA; k1.d = D + (size_t)site * e->strideD;
-        k1.xT = e->xT + (size_t)(site / 32) * e->strideX; k1.keys = e->keys8; k1.cntT = cntT; k1.tailT = tailT; k1.M = e->M; k1.shift = site % 32; k1.Wp = Wp;
-        hipLaunchKernelGGL(skel_k1_kernel, dim3(e->W1k), dim3(BLOCK), 0, e->stream, k1);
-        Sk2Args k2; k2.cntT = cntT; k2.tailT = tailT; k2.beforeT = beforeT; k2.carryT = carryT; k2.total = total; k2.W = e->W1k; k2.Wp = Wp;
-        if (e->W1k <= 64) hipLaunchKernelGGL((skel_k2_kernel<1>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
-        else if (e->W1k <= 128) hipLaunchKernelGGL((skel_k2_kernel<2>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
-        else if (e->W1k <= 256) hipLaunchKernelGGL((skel_k2_kernel<4>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
-        else hipLaunchKernelGGL((skel_k2_kernel<16>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
-        Sk3Args k3; k3.a = k1.a; k3.d = k1.d; k3.keys = e->keys8;
-        k3.a_out = A + (size_t)(site + 8) * e->strideA; k3.d_out = D + (size_t)(site + 8) * e->strideD;
-        k3.beforeT = beforeT; k3.carryT = carryT; k3.total = total;
-        k3.has_next = (e->k_cur + site + 8 < e->n_total) && (site + 8 < nvalid);
-        k3.xTnext = e->xT + (size_t)((site + 8) / 32) * e->strideX; k3.shift_next = (site + 8) % 32;
-        k3.M = e->M; k3.W = e->W1k; k3.Wp = Wp; k3.k = e->k_cur + site;
-        hipLaunchKernelGGL(skel_k3_kernel, dim3(e->W1k), dim3(BLOCK), 0, e->stream, k3);
+        g.a = A + (size_t)site * e->strideA; g.d = D + (size_t)site * e->strideD; g.keys = kb + (size_t)s8 * e->Mpad;
+        g.a_out = A + (size_t)(site + 8) * e->strideA; g.d_out = D + (size_t)(site + 8) * e->strideD; g.keys_out = kb + (size_t)(s8 + 1) * e->Mpad;
+        int *sv = e->saveR[r] + (size_t)s8 * e->strideS;   // this round's per-key scan over the tiles, kept for the fill
+        g.beforeS = sv; g.carryS = sv + (size_t)SKK * Wp; g.totalS = sv + (size_t)2 * SKK * Wp;
+        g.beforeT = g.beforeS; g.carryT = g.carryS; g.total = g.totalS;
+        g.has_next = (e->k_cur + site + 8 < e->n_total) && (site + 8 < nvalid);
+        g.xTnext = e->xT + (size_t)((site + 8) / 32) * e->strideX; g.shift_next = (site + 8) % 32;
+        g.k = e->k_cur + site;
+        if (e->skEPT == 1) launch_skel_round<1>(e, g, two); else if (e->skEPT == 2) launch_skel_round<2>(e, g, two); else launch_skel_round<4>(e, g, two);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -600,7 +663,7 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         if (!skel) CHK(ensure_prepared(e, bc, sorted, with_d, pair, left));
         hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(256), 0, e->stream, e->ctlblk, e->k_cur, e->n_total, bc, (const uint32_t *)e->zerocol,
                            e->summ, pair ? 3 * e->wpad : e->wpad, e->summ_cur);
-        const int nlaunch = skel ? 3 * (nb / 8) : (pair ? L : nb);
+        const int nlaunch = skel ? (skel_two_launch(e) ? 2 : 3) * (nb / 8) : (pair ? L : nb);
         e->summ_cur = nlaunch % 3;
         HIPCHK(hipGetLastError());
         // ---- the chain: slot j -> slot j+1 (-> slot j+2) of ring r ----

@@ -718,7 +718,7 @@ __global__ __launch_bounds__(NT) void step2_kernel(Step2Args g) {
 //                k+1+msb(key ^ key') with key' the nearest lower non-empty key when there is none
 //   (tests/tile_model.py::stepB_tiles).  Tiles of 1024 positions, 256 threads.
 // ---------------------------------------------------------------------------------------------
-constexpr int SKB = 8, SKK = 1 << SKB, SKT = 1024;
+constexpr int SKB = 8, SKK = 1 << SKB;
 
 // 32 sites x 32 haplotypes bit transpose: xT[blk][h] bit j = allele of haplotype h at site 32*blk + j
 // (sites at or beyond n_valid read as 0).  grid (ceil(wpc/256), nblk).
@@ -742,54 +742,71 @@ __global__ __launch_bounds__(BLOCK) void transpose32_kernel(const uint32_t *cols
     for (int i = 0; i < 32; ++i) if (wd * 32 + i < Mpad) dst[i] = o[i];
 }
 
-// K1: per tile — gather the 8-bit keys, count them, and the max of d_k after each key's last
-// occurrence (whole-tile max for absent keys).  Threads own positions in REVERSE blocked order so
-// that a forward scan over threads is a suffix scan over positions.
-struct Sk1Args { const int *a; const int *d; const uint32_t *xT; unsigned char *keys; int *cntT; int *tailT; int M, shift, Wp; };   // tables are [key][Wp]
-__global__ __launch_bounds__(BLOCK) void skel_k1_kernel(Sk1Args g) {
+// HIST (K1): per tile of T = 256*EPT positions — count the 8-bit keys, and the max of d_k after each
+// key's last occurrence (whole-tile max for absent keys).  The keys travel with the state (the rank
+// kernel of the previous round scattered them), so this reads 1 + 4 bytes per position.  Threads own
+// positions in REVERSE blocked order so that a forward scan over threads is a suffix scan over
+// positions.  Tables: ROWMAJOR ? tbl[tile][key] {count, tail} : cntT/tailT[key][Wp].
+struct SkArgs {
+    const int *a; const int *d; const unsigned char *keys;     // input state and its 8-bit keys
+    int *a_out; int *d_out; unsigned char *keys_out;
+    int2 *tbl;                                                  // [W][256] {count, tail}                (two-launch round)
+    int *cntT; int *tailT; const int *beforeT; const int *carryT; const int *total;   // [key][Wp], [key]  (three-launch round)
+    int *beforeS; int *carryS; int *totalS;                     // where the two-launch round keeps its per-key scan for the fill
+    const uint32_t *xTnext; int shift_next; int has_next;
+    int M, W, Wp, k;                                            // k = site of the input state
+};
+
+template <int EPT, bool ROWMAJOR>
+__global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
+    constexpr int T = BLOCK * EPT;
     __shared__ int h_cnt[SKK], h_last[SKK];
-    __shared__ int s_suf[SKT];
+    __shared__ int s_suf[T];
     __shared__ int s_w[WAVES];
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x;
-    const int rb = BLOCK - 1 - t;                          // this thread's block of 4 positions, counted from the end
-    const int l0 = rb * 4, i0 = w * SKT + l0;
-    h_cnt[t] = 0; h_last[t] = -1;
-    const int4 va = *reinterpret_cast<const int4 *>(g.a + i0);
-    const int4 vd = *reinterpret_cast<const int4 *>(g.d + i0);
-    const int av[4] = {va.x & AMASK, va.y & AMASK, va.z & AMASK, va.w & AMASK};
-    int dv[4] = {vd.x, vd.y, vd.z, vd.w};
-    int key[4];
-    unsigned packed = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const bool valid = i0 + e < g.M;
-        key[e] = valid ? (int)((g.xT[av[e]] >> g.shift) & 0xffu) : -1;
-        if (!valid) dv[e] = 0;
-        packed |= (unsigned)(key[e] & 0xff) << (8 * e);
+    const int rb = BLOCK - 1 - t;
+    const int l0 = rb * EPT, i0 = w * T + l0;
+    unsigned packed;
+    int dv[EPT];
+    if constexpr (EPT == 4) {
+        packed = *reinterpret_cast<const unsigned *>(g.keys + i0);
+        const int4 vd = *reinterpret_cast<const int4 *>(g.d + i0);
+        dv[0] = vd.x; dv[1] = vd.y; dv[2] = vd.z; dv[3] = vd.w;
+    } else if constexpr (EPT == 2) {
+        packed = *reinterpret_cast<const unsigned short *>(g.keys + i0);
+        const int2 vd = *reinterpret_cast<const int2 *>(g.d + i0);
+        dv[0] = vd.x; dv[1] = vd.y;
+    } else {
+        packed = g.keys[i0]; dv[0] = g.d[i0];
     }
-    *reinterpret_cast<unsigned *>(g.keys + i0) = packed;
-    __syncthreads();
+    h_cnt[t] = 0; h_last[t] = -1;
+    int key[EPT];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) if (key[e] >= 0) { atomicAdd(&h_cnt[key[e]], 1); atomicMax(&h_last[key[e]], l0 + e); }
-    // suffix maxima: s_suf[l] = max d over positions > l of the tile
-    const int own = max(max(dv[0], dv[1]), max(dv[2], dv[3]));
+    for (int e = 0; e < EPT; ++e) {
+        const bool valid = i0 + e < g.M;
+        key[e] = valid ? (int)((packed >> (8 * e)) & 0xffu) : -1;
+        if (!valid) dv[e] = 0;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) if (key[e] >= 0) { atomicAdd(&h_cnt[key[e]], 1); atomicMax(&h_last[key[e]], l0 + e); }
+    int own = dv[0];
+#pragma unroll
+    for (int e = 1; e < EPT; ++e) own = max(own, dv[e]);
     int inc = wave_iscan_max(own);                         // lanes before me = positions after mine
     if (lane == 63) s_w[wv] = inc;
     const int excl_lane = lane_shr1(inc, 0);
-    __syncthreads();
+    lds_barrier();
     int later = excl_lane;
     for (int q = 0; q < wv; ++q) later = max(later, s_w[q]);
-    s_suf[l0 + 3] = later;
-    s_suf[l0 + 2] = max(later, dv[3]);
-    s_suf[l0 + 1] = max(max(later, dv[3]), dv[2]);
-    s_suf[l0] = max(max(max(later, dv[3]), dv[2]), dv[1]);
+#pragma unroll
+    for (int e = EPT - 1; e >= 0; --e) { s_suf[l0 + e] = later; later = max(later, dv[e]); }   // s_suf[l] = max d over positions > l
     int tilemax = 0;
     for (int q = 0; q < WAVES; ++q) tilemax = max(tilemax, s_w[q]);
-    __syncthreads();
-    // one key per thread
-    const int c = h_cnt[t];
-    g.cntT[(size_t)t * g.Wp + w] = c;
-    g.tailT[(size_t)t * g.Wp + w] = c ? s_suf[h_last[t]] : tilemax;
+    lds_barrier();
+    const int c = h_cnt[t], tl = c ? s_suf[h_last[t]] : tilemax;
+    if constexpr (ROWMAJOR) g.tbl[(size_t)w * SKK + t] = make_int2(c, tl);
+    else { g.cntT[(size_t)t * g.Wp + w] = c; g.tailT[(size_t)t * g.Wp + w] = tl; }
 }
 
 // K2: one WAVE per key — exclusive scan over the W tiles (lanes own TPL consecutive tiles) of the pair
@@ -825,45 +842,53 @@ __global__ __launch_bounds__(BLOCK) void skel_k2_kernel(Sk2Args g) {
     if (lane == 63) g.total[q] = ic;
 }
 
-// K3: per tile — stable rank of every position among its key (ballot refinement inside 64-position
-// chunks + a per-key scan over the 16 chunks), previous same-key position, range max of d_k through a
-// sparse table in LDS, scatter of (a | next allele tag, d').
-struct Sk3Args {
-    const int *a; const int *d; const unsigned char *keys; int *a_out; int *d_out;
-    const int *beforeT; const int *carryT; const int *total;   // [key][Wp], [key]
-    const uint32_t *xTnext; int shift_next; int has_next;
-    int M, W, Wp, k;                                        // k = site of the input state
-};
-__global__ __launch_bounds__(BLOCK) void skel_k3_kernel(Sk3Args g) {
-    __shared__ int s_cnt[16][SKK];                          // per chunk: count -> base (exclusive over chunks)
-    __shared__ int s_lastp[16][SKK];                        // per chunk: last local position of the key -> previous one before the chunk
-    __shared__ int s_tbl[10][SKT];                          // sparse table: s_tbl[l][i] = max d over (i-2^l, i]
-    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x;
-    const int S = w * SKT;
-    for (int x = t; x < 16 * SKK; x += BLOCK) { (&s_cnt[0][0])[x] = 0; (&s_lastp[0][0])[x] = -1; }
-    int av[4], dv[4], key[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {                           // striped: chunk r*4+wv = 64 consecutive positions
-        const int l = r * BLOCK + t, i = S + l;
-        const bool valid = i < g.M;
-        av[r] = g.a[i] & AMASK; dv[r] = valid ? g.d[i] : 0; key[r] = valid ? (int)g.keys[i] : -1;
-        s_tbl[0][l] = dv[r];
-    }
-    const int bq = g.beforeT[(size_t)t * g.Wp + w], cq = g.carryT[(size_t)t * g.Wp + w];
-    // bucket bases G (exclusive prefix of the key totals) and the nearest lower non-empty key
+// RANK (K3): per tile — stable rank of every position among its key (ballot refinement inside
+// 64-position chunks + a per-key scan over the chunks), previous same-key position, range max of d_k
+// through a sparse table in LDS, scatter of (a | next allele tag, d', next key).
+// TR > 0 (two-launch round, W <= TR tiles): the per-key scan over the tiles is done here, from the
+// row-major table: W coalesced 8-byte loads per thread, issued first and consumed last, behind the
+// ballot refinement and the sparse table.  TR == 0: before/carry/total come from skel_k2_kernel.
+constexpr int SKN_MAXW = 128;
+template <int EPT, int TR>
+__global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
+    constexpr int T = BLOCK * EPT, NC = EPT * WAVES;        // positions per tile, 64-position chunks per tile
+    constexpr int NL = (EPT == 4) ? 10 : (EPT == 2) ? 9 : 8;   // sparse table levels: windows 1 .. T/2
+    __shared__ int s_cnt[NC][SKK];                          // per chunk: count -> base (exclusive over chunks)
+    __shared__ int s_lastp[NC][SKK];                        // per chunk: last local position of the key -> previous one before the chunk
+    __shared__ int s_tbl[NL][T];                            // s_tbl[l][i] = max d over (i-2^l, i]
+    __shared__ int s_before[SKK], s_carry[SKK], s_G[SKK], s_lower[SKK];
     __shared__ int s_gw[WAVES], s_lw[WAVES];
-    const int tq = g.total[t];
-    const int ginc = wave_iscan_sum(tq), linc = wave_iscan_max(tq ? t + 1 : 0);
-    if (lane == 63) { s_gw[wv] = ginc; s_lw[wv] = linc; }
-    const int lexc = lane_shr1(linc, 0);
-    __syncthreads();
-    int Gq = ginc - tq, lq = lexc;
-    for (int x = 0; x < wv; ++x) { Gq += s_gw[x]; lq = max(lq, s_lw[x]); }
-    lq -= 1;
-    int rk[4], pl[4];
-    const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x;
+    const int S = w * T;
+    int av[EPT], dv[EPT], key[EPT];
+    unsigned nk[EPT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < EPT; ++r) {                         // striped: chunk r*4+wv = 64 consecutive positions
+        const int i = S + r * BLOCK + t;
+        av[r] = g.a[i]; dv[r] = g.d[i]; key[r] = (int)g.keys[i];
+    }
+    int2 row[TR > 0 ? TR : 1];
+    int bq = 0, cq = -1, tq = 0;
+    if constexpr (TR > 0) {
+#pragma unroll
+        for (int r = 0; r < TR; ++r) row[r] = (r < g.W) ? g.tbl[(size_t)r * SKK + t] : make_int2(0, 0);
+    } else {
+        bq = g.beforeT[(size_t)t * g.Wp + w]; cq = g.carryT[(size_t)t * g.Wp + w]; tq = g.total[t];
+    }
+    for (int x = t; x < NC * SKK; x += BLOCK) { (&s_cnt[0][0])[x] = 0; (&s_lastp[0][0])[x] = -1; }
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        const int l = r * BLOCK + t;
+        const bool valid = S + l < g.M;
+        av[r] &= AMASK; if (!valid) { dv[r] = 0; key[r] = -1; }
+        s_tbl[0][l] = dv[r];
+        nk[r] = (g.has_next && valid) ? ((g.xTnext[av[r]] >> g.shift_next) & 0xffu) : 0u;   // next round's key (bit 0 = the output state's tag)
+    }
+    int rk[EPT], pl[EPT];
+    const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+    lds_barrier();                                          // zeroed tables visible
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
         unsigned long long same = __ballot(key[r] >= 0);
 #pragma unroll
         for (int b = 0; b < SKB; ++b) { const unsigned long long bal = __ballot((key[r] >> b) & 1); same &= ((key[r] >> b) & 1) ? bal : ~bal; }
@@ -875,38 +900,53 @@ __global__ __launch_bounds__(BLOCK) void skel_k3_kernel(Sk3Args g) {
             s_lastp[r * 4 + wv][key[r]] = (r * 4 + wv) * 64 + (63 - __clzll(same));
         }
     }
-    __syncthreads();
+    lds_barrier();
     {   // thread q = key: exclusive scan over the chunks
         int base = 0, last = -1;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
+        for (int c = 0; c < NC; ++c) {
             const int cn = s_cnt[c][t], lp = s_lastp[c][t];
             s_cnt[c][t] = base; s_lastp[c][t] = last;
             base += cn; if (cn) last = lp;
         }
     }
-    // sparse table of d over the tile (levels 1..9)
 #pragma unroll
-    for (int l = 1; l < 10; ++l) {
-        __syncthreads();
+    for (int l = 1; l < NL; ++l) {
+        lds_barrier();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < EPT; ++r) {
             const int i = r * BLOCK + t, j = i - (1 << (l - 1));
             s_tbl[l][i] = (j >= 0) ? max(s_tbl[l - 1][i], s_tbl[l - 1][j]) : s_tbl[l - 1][i];
         }
     }
-    // per-key rows of the tile go through LDS too (reuse level-0..? no: keep separate small arrays)
-    __shared__ int s_before[SKK], s_carry[SKK], s_G[SKK], s_lower[SKK];
-    s_before[t] = bq; s_carry[t] = cq; s_G[t] = Gq; s_lower[t] = lq;
-    __syncthreads();
+    if constexpr (TR > 0) {   // thread q = key: scan of the tiles (keys before this tile, carry = max d since the key's last earlier occurrence, total)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < TR; ++r) {
+            const int c = row[r].x, tl = row[r].y;
+            if (r < w) { cq = c ? tl : (cq >= 0 ? max(cq, tl) : -1); bq += c; }
+            tq += c;
+        }
+        g.beforeS[(size_t)t * g.Wp + w] = bq; g.carryS[(size_t)t * g.Wp + w] = cq;   // kept for the fill kernel
+        if (w == 0) g.totalS[t] = tq;
+    }
+    // bucket bases G (exclusive prefix of the key totals) and the nearest lower non-empty key
+    const int ginc = wave_iscan_sum(tq), linc = wave_iscan_max(tq ? t + 1 : 0);
+    if (lane == 63) { s_gw[wv] = ginc; s_lw[wv] = linc; }
+    const int lexc = lane_shr1(linc, 0);
+    lds_barrier();
+    int Gq = ginc - tq, lq = lexc;
+    for (int x = 0; x < wv; ++x) { Gq += s_gw[x]; lq = max(lq, s_lw[x]); }
+    lq -= 1;
+    s_before[t] = bq; s_carry[t] = cq; s_G[t] = Gq; s_lower[t] = lq;
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
         if (key[r] < 0) continue;
         const int l = r * BLOCK + t, c = r * 4 + wv, ky = key[r];
         const int rank = s_cnt[c][ky] + rk[r];
         const int p = (pl[r] >= 0) ? pl[r] : s_lastp[c][ky];        // previous same-key position in the tile, or -1
-        // range max of d over (p, l]  (p = -1: the whole prefix)
-        const int len = l - p, lv = min(31 - __clz(len), 9);     // two windows of 2^lv >= len/2 cover (p, l]; len <= 1024
+        // range max of d over (p, l]  (p = -1: the whole prefix): two windows of 2^lv >= len/2
+        const int len = l - p, lv = min(31 - __clz(len), NL - 1);
         const int rm = max(s_tbl[lv][l], s_tbl[lv][p + (1 << lv)]);
         int dd;
         if (p >= 0) dd = rm;
@@ -915,18 +955,131 @@ __global__ __launch_bounds__(BLOCK) void skel_k3_kernel(Sk3Args g) {
         else dd = 0;
         const int pos = s_G[ky] + s_before[ky] + rank;
         if (pos == 0) dd = g.k + SKB + 1;                  // sentinel (pbwtCore.c:507 after the 8th site)
-        unsigned tag = 0;
-        if (g.has_next) tag = (g.xTnext[av[r]] >> g.shift_next) & 1u;
-        g.a_out[pos] = av[r] | (int)(tag << 31);
+        g.a_out[pos] = av[r] | (int)((nk[r] & 1u) << 31);
         g.d_out[pos] = dd;
+        g.keys_out[pos] = (unsigned char)nk[r];
     }
     if (w == g.W - 1 && t == 0) g.d_out[g.M] = g.k + SKB + 1;
 }
 
-// tag a state's entries with the allele of their haplotype at the state's site (bit `shift` of xT)
-__global__ void skel_tag_kernel(int *a, const uint32_t *xT, int shift, int M) {
+// keys (and tags) of a state from the transposed panel: start of a batch
+__global__ void skel_keys_kernel(int *a, const uint32_t *xT, int shift, int M, unsigned char *keys) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M) { const int v = a[i] & AMASK; a[i] = v | (int)(((xT[v] >> shift) & 1u) << 31); }
+    if (i < M) { const int v = a[i] & AMASK; const unsigned kk = (xT[v] >> shift) & 0xffu; a[i] = v | (int)((kk & 1u) << 31); keys[i] = (unsigned char)kk; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FILL, one launch per batch: the seven states between two skeleton states, for every 8-site block b
+// and every tile w of the block's input state (grid (W, blocks)).  State 8b+j is the stable sort of
+// state 8b by the low j bits of the same 8-bit keys, so everything the rank kernel derived for j = 8
+// folds down: counts / last positions per chunk, keys before the tile, carries and totals of a j-bit
+// key are sums / maxima / minima over the 8-bit keys sharing its low bits (a later last occurrence has
+// the smaller suffix maximum, hence min over the carries).  Reads a, d, keys once, writes 7 x (a, d).
+struct SkFillArgs {
+    int *A; int *D; size_t strideA, strideD;               // ring base (slot 0 of the batch)
+    const unsigned char *keys; size_t strideK;              // keys of state 8b at keys + b*strideK
+    const int *save; size_t strideS;                        // per block: beforeT[256][Wp], carryT[256][Wp], total[256]
+    int M, W, Wp, kbase;
+};
+
+template <int EPT>
+__global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
+    constexpr int T = BLOCK * EPT, NC = EPT * WAVES;
+    constexpr int NL = (EPT == 4) ? 10 : (EPT == 2) ? 9 : 8;
+    __shared__ short s_raw[NC][SKK], s_lastraw[NC][SKK];    // per chunk and key: count, last local position (-1: none); folded in place level by level
+    __shared__ short s_base[NC][SKK / 2], s_prev[NC][SKK / 2];   // per level: exclusive over the chunks
+    __shared__ int s_tbl[NL][T];
+    __shared__ int s_b[SKK], s_c[SKK], s_t[SKK], s_G[SKK], s_lower[SKK];
+    __shared__ int s_gw[WAVES], s_lw[WAVES];
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x, b = blockIdx.y;
+    const int S = w * T, k = g.kbase + 8 * b;
+    const int *a_in = g.A + (size_t)(8 * b) * g.strideA, *d_in = g.D + (size_t)(8 * b) * g.strideD;
+    const unsigned char *keys = g.keys + (size_t)b * g.strideK;
+    const int *sv = g.save + (size_t)b * g.strideS;
+    int av[EPT], key[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        const int l = r * BLOCK + t, i = S + l;
+        const bool valid = i < g.M;
+        av[r] = a_in[i] & AMASK; key[r] = valid ? (int)keys[i] : -1;
+        s_tbl[0][l] = valid ? d_in[i] : 0;
+    }
+    s_b[t] = sv[(size_t)t * g.Wp + w]; s_c[t] = sv[(size_t)(SKK + t) * g.Wp + w]; s_t[t] = sv[(size_t)2 * SKK * g.Wp + t];
+    for (int x = t; x < NC * SKK; x += BLOCK) { (&s_raw[0][0])[x] = 0; (&s_lastraw[0][0])[x] = -1; }
+    __syncthreads();
+    // ballot refinement bit by bit: after bit j-1 the mask of same-j-key lanes
+    short rk[EPT][8], pl[EPT][8];                           // [.][j]: rank inside the chunk, previous same-j-key position in the chunk (-1)
+    const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        const int c = r * 4 + wv;
+        unsigned long long same = __ballot(key[r] >= 0);
+#pragma unroll
+        for (int bb = 0; bb < SKB; ++bb) {
+            const unsigned long long bal = __ballot((key[r] >> bb) & 1);
+            same &= ((key[r] >> bb) & 1) ? bal : ~bal;
+            const unsigned long long before = same & lt;
+            if (bb < SKB - 1) { rk[r][bb + 1] = (short)__popcll(before); pl[r][bb + 1] = before ? (short)(c * 64 + (63 - __clzll(before))) : (short)-1; }
+            else if (key[r] >= 0 && !before) { s_raw[c][key[r]] = (short)__popcll(same); s_lastraw[c][key[r]] = (short)(c * 64 + (63 - __clzll(same))); }
+        }
+    }
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const int i = r * BLOCK + t, j = i - (1 << (l - 1));
+            s_tbl[l][i] = (j >= 0) ? max(s_tbl[l - 1][i], s_tbl[l - 1][j]) : s_tbl[l - 1][i];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = SKB - 1; j >= 1; --j) {
+        const int K = 1 << j;
+        int tq = 0;
+        if (t < K) {                                        // fold bit j away, then the exclusive scan over the chunks
+            int base = 0, last = -1;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int cn = s_raw[c][t] + s_raw[c][t + K], lp = max((int)s_lastraw[c][t], (int)s_lastraw[c][t + K]);
+                s_raw[c][t] = (short)cn; s_lastraw[c][t] = (short)lp;
+                s_base[c][t] = (short)base; s_prev[c][t] = (short)last;
+                base += cn; if (cn) last = lp;
+            }
+            const int c0 = s_c[t], c1 = s_c[t + K];
+            s_b[t] += s_b[t + K]; tq = s_t[t] + s_t[t + K]; s_t[t] = tq;
+            s_c[t] = (c0 < 0) ? c1 : (c1 < 0) ? c0 : min(c0, c1);
+        }
+        const int ginc = wave_iscan_sum(tq), linc = wave_iscan_max(tq ? t + 1 : 0);
+        if (lane == 63) { s_gw[wv] = ginc; s_lw[wv] = linc; }
+        const int lexc = lane_shr1(linc, 0);
+        __syncthreads();
+        int Gq = ginc - tq, lq = lexc;
+        for (int x = 0; x < wv; ++x) { Gq += s_gw[x]; lq = max(lq, s_lw[x]); }
+        s_G[t] = Gq; s_lower[t] = lq - 1;
+        __syncthreads();
+        int *a_out = g.A + (size_t)(8 * b + j) * g.strideA, *d_out = g.D + (size_t)(8 * b + j) * g.strideD;
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            if (key[r] < 0) continue;
+            const int l = r * BLOCK + t, c = r * 4 + wv, kj = key[r] & (K - 1);
+            const int rank = s_base[c][kj] + rk[r][j];
+            const int p = (pl[r][j] >= 0) ? pl[r][j] : s_prev[c][kj];
+            const int len = l - p, lv = min(31 - __clz(len), NL - 1);
+            const int rm = max(s_tbl[lv][l], s_tbl[lv][p + (1 << lv)]);
+            int dd;
+            if (p >= 0) dd = rm;
+            else if (s_c[kj] >= 0) dd = max(s_c[kj], rm);
+            else if (s_lower[kj] >= 0) dd = k + 1 + (31 - __clz(kj ^ s_lower[kj]));
+            else dd = 0;
+            const int pos = s_G[kj] + s_b[kj] + rank;
+            if (pos == 0) dd = k + j + 1;
+            a_out[pos] = av[r] | (int)(((unsigned)(key[r] >> j) & 1u) << 31);
+            d_out[pos] = dd;
+        }
+        if (w == g.W - 1 && t == 0) d_out[g.M] = k + j + 1;
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -2,7 +2,7 @@ import os, sys
 os.environ["PBWTAMD_SKEL"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, pbwt_amd, oracle
-for (M, N, B) in [(3000, 64, 32), (100000, 128, 64), (1500, 40, 8), (70000, 256, 256), (100000, 2048, 512), (1024, 64, 64), (1025, 72, 24), (10000, 512, 512)]:
+for (M, N, B) in [(3000, 64, 32), (100000, 128, 64), (1500, 40, 8), (70000, 256, 256), (100000, 2048, 512), (1024, 64, 64), (1025, 72, 24), (10000, 512, 512), (33000, 512, 512), (1000000, 64, 32)]:
     eng = pbwt_amd.Engine(M, batch_sites=B)
     buf = torch.zeros((N + 8, eng.wpc), dtype=torch.int32, device="cuda")
     eng.synth_device(buf.data_ptr(), 0, N, seed=9, kind=0); eng.sync()
