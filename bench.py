@@ -135,12 +135,18 @@ def main():
         opts |= pbwt_amd.OPT_PACK3
     row_bytes = wpc * 4
 
+    pool = None
+    if extra:                              # one host thread per panel: launches are enqueued concurrently (ctypes drops the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=len(extra))
+
     def step(i):
         k = i * S
         avail = min(S + 8, n_total - k)    # look-ahead columns: the chain's radix step spans 8 sites (2 for the two-site path)
+        futs = [pool.submit(e2.pass_advance, p2.data_ptr() + k * row_bytes, S, avail, opts) for e2, p2 in extra]
         eng.pass_advance(panel.data_ptr() + k * row_bytes, S, avail, opts)
-        for e2, p2 in extra:
-            e2.pass_advance(p2.data_ptr() + k * row_bytes, S, avail, opts)
+        for f in futs:
+            f.result()
 
     eng.pass_begin(n_total)
     for e2, _ in extra:

@@ -15,7 +15,8 @@ class PbwtAmdError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libpbwtgpu.so")
+    # PBWTAMD_LIB: another build of the same C ABI (A/B measurements of two builds on one GPU box)
+    return os.environ.get("PBWTAMD_LIB") or os.path.join(_HERE, "libpbwtgpu.so")
 
 
 _lib = None

@@ -50,7 +50,7 @@ struct pbwtamd_engine {
     int device = 0, M = 0, Mpad = 0, wpc = 0, wpc64 = 0, W = 0, wpad = 0, E = 4, T = 1024, B = 0;
     hipStream_t stream = nullptr; bool own_stream = false;   // the launch chain
     hipStream_t s2 = nullptr;                                 // batch consumers
-    hipEvent_t evChain[2] = {nullptr, nullptr}, evCons[2] = {nullptr, nullptr}; bool consRecorded[2] = {false, false};
+    hipEvent_t evChain[2] = {nullptr, nullptr}, evCons[2] = {nullptr, nullptr}; bool consRecorded[2] = {false, false}, chainRecorded[2] = {false, false};
     int ring = 0; Pending pend;
     int *A = nullptr, *D = nullptr; size_t strideA = 0, strideD = 0;      // 2 rings of B+1 slots
     int4 *summ = nullptr;
@@ -70,6 +70,9 @@ struct pbwtamd_engine {
     // pass state
     int k0 = 0, k_cur = 0, n_total = 0; bool prepared = false; bool pass_open = false;
     unsigned long long yz_bytes_host = 0; size_t yz_upper = 0;   // host-side upper bound of the packed bytes written
+    // the true byte count travels back asynchronously (pinned ring + events): the bound is refreshed from the newest reading
+    // that has landed, so the host never waits for the consumer stream unless the buffer really has to grow
+    unsigned long long *h_used = nullptr; hipEvent_t evUsed[8] = {}; size_t usedWorstAfter[8] = {}; long long used_n = 0;
     std::vector<GraphKey> graphs; bool use_graph = true; bool lean = true; bool pair = true;
     bool pair1024 = false;
     bool skn = true;                        // skeleton rounds of two launches (hist, rank) when the panel has <= 128 tiles of 1024; PBWTAMD_SKN=0: K1/K2/K3
@@ -80,6 +83,8 @@ struct pbwtamd_engine {
     unsigned char *keys8 = nullptr; int *skT = nullptr;   // skT: hist tables of the round in flight (cnt, tail [256][Wp], or [W][256] {cnt, tail})
     unsigned char *keysR[2] = {nullptr, nullptr};         // per ring: the keys of states 0, 8, 16, ... of the batch ([B/8+1][Mpad]), kept for the fill
     int *saveR[2] = {nullptr, nullptr}; size_t strideS = 0;   // per ring and round: before[256][Wp], carry[256][Wp], total[256]
+    hipEvent_t tev[16] = {}; long long tev_n = 0; int thr_rounds = 32, thr_depth = 2;   // host throttle: an event every thr_rounds rounds, host at most thr_depth events ahead
+    bool keys_ready[2] = {false, false};     // slot-0 keys of the ring delivered by the previous batch's last round
     bool fill_steps = false;                // PBWTAMD_FILL_STEPS=1: fill with 14 batched single-site launches instead of skel_fill_kernel
     int Wt = 0, skEPT = 4;                  // skeleton tiles: 256*skEPT positions, Wt of them; PBWTAMD_SKT=512|1024
     int skn_maxw = 16;                      // two-launch round (rank scans the tile table itself) up to this many tiles; PBWTAMD_SKN_MAXW
@@ -111,6 +116,9 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->s2) { (void)hipStreamSynchronize(e->s2); (void)hipStreamDestroy(e->s2); }
+    for (int i = 0; i < 16; ++i) if (e->tev[i]) (void)hipEventDestroy(e->tev[i]);
+    for (int i = 0; i < 8; ++i) if (e->evUsed[i]) (void)hipEventDestroy(e->evUsed[i]);
+    if (e->h_used) (void)hipHostFree(e->h_used);
     for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -186,6 +194,9 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         e->wpadF = ((M + BLOCK - 1) / BLOCK + 63) / 64 * 64;
         ALLOC(e->summF, (size_t)(e->B / 8 + 1) * e->wpadF * sizeof(int4));
         if (const char *sv = getenv("PBWTAMD_FILL_STEPS")) e->fill_steps = atoi(sv) != 0;
+        if (const char *sv = getenv("PBWTAMD_THR_ROUNDS")) e->thr_rounds = atoi(sv);
+        if (const char *sv = getenv("PBWTAMD_THR_DEPTH")) e->thr_depth = std::max(1, std::min(atoi(sv), 15));
+        for (int i = 0; i < 16; ++i) HIPCHK(hipEventCreateWithFlags(&e->tev[i], hipEventDisableTiming));
         {
             const int Wp = (e->Wt + 63) / 64 * 64, rounds = e->B / 8 + 1;
             e->strideS = (size_t)2 * SKK * Wp + SKK;
@@ -329,7 +340,8 @@ extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipStreamSynchronize(e->s2));
     e->k0 = k0; e->k_cur = k0; e->n_total = n_total; e->prepared = false; e->pass_open = true;
-    e->ring = 0; e->consRecorded[0] = e->consRecorded[1] = false;
+    e->ring = 0; e->consRecorded[0] = e->consRecorded[1] = false; e->chainRecorded[0] = e->chainRecorded[1] = false;
+    e->keys_ready[0] = e->keys_ready[1] = false;
     if (aInit) HIPCHK(hipMemcpyAsync(e->A, aInit, sizeof(int) * (size_t)e->M, hipMemcpyHostToDevice, e->stream));
     const int nb = (e->Mpad + 1 + 255) / 256;
     hipLaunchKernelGGL(init_state_kernel, dim3(nb), dim3(256), 0, e->stream, e->A, e->D, e->M, e->Mpad, k0, aInit ? 0 : 1);
@@ -351,7 +363,7 @@ extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k
     }
     HIPCHK(hipMemsetAsync(e->hist, 0, (size_t)e->histlen * sizeof(unsigned long long), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->yz_bytes_host = 0; e->yz_upper = 0;
+    e->yz_bytes_host = 0; e->yz_upper = 0; e->used_n = 0;
     e->ev_used = 0; e->launches = 0; e->sites_done = 0;
     return 0;
 }
@@ -370,6 +382,8 @@ static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int
     g.A = A; g.D = D; g.strideA = e->strideA; g.strideD = e->strideD;
     g.M = e->M; g.kbase = kbase; g.final_site = final_site;
     g.blockCount = nullptr; g.recs = nullptr; g.hist = e->hist; g.histlen = e->histlen; g.err = e->ctl + 2;
+    static const bool no_fuse = getenv("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
+    g.ycols = (!no_fuse && final_site < 0 && (opts & PBWTAMD_OPT_PACK3) && (opts & PBWTAMD_OPT_WITHIN_HIST)) ? e->ycols : nullptr; g.wpc64 = e->wpc64;
     const int tiles = (e->M + BLOCK - 1) / BLOCK;
     dim3 grid(tiles, nsites);
     if (opts & PBWTAMD_OPT_WITHIN_HIST) {
@@ -474,20 +488,30 @@ __global__ void pack3_offsets_kernel(unsigned long long *colBytes, size_t n, con
     if (i == 0) { if (b + *batchTotal > cap) atomicExch(err, 4); }
     (void)acc;
 }
-static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites) {
+static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites, bool have_ycols) {
     dim3 g1(std::min(64, (e->wpc64 + WAVES - 1) / WAVES), nsites);
-    hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, st, A, e->strideA, e->M, e->ycols, e->wpc64);
+    if (!have_ycols) hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, st, A, e->strideA, e->M, e->ycols, e->wpc64);   // else: emitted by the maxWithin sweep
     hipLaunchKernelGGL((pack3_kernel<0>), dim3(nsites), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
     // exclusive offsets inside the batch; batch total -> scal[2]
     hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, e->colBytes, (size_t)nsites, e->scal + 2, 0ULL);
     HIPCHK(hipGetLastError());
     const size_t worst = (size_t)nsites * (size_t)e->M;
+    if (e->h_used) {                                       // newest asynchronous reading of the true count that has landed
+        for (long long j = e->used_n - 1; j >= 0 && j >= e->used_n - 8; --j) {
+            if (hipEventQuery(e->evUsed[j % 8]) != hipSuccess) continue;
+            size_t later = 0;
+            for (long long q = j + 1; q < e->used_n; ++q) later += e->usedWorstAfter[q % 8];
+            e->yz_upper = std::min(e->yz_upper, (size_t)e->h_used[j % 8] + later);
+            break;
+        }
+        (void)hipGetLastError();
+    }
     if (e->yz_upper + worst > e->yzCap) {                  // refresh the bound with the true count, grow if needed
         unsigned long long used = 0;
         HIPCHK(hipMemcpyAsync(&used, e->scal + 1, sizeof used, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         e->yz_upper = (size_t)used;
-        if (e->yz_upper + worst > e->yzCap) CHK(ensure_yz(e, st, std::max(e->yz_upper + worst + (worst >> 1), e->yzCap * 2)));
+        if (e->yz_upper + 8 * worst > e->yzCap) CHK(ensure_yz(e, st, std::max(e->yz_upper + 16 * worst, e->yzCap * 2)));
     }
     hipLaunchKernelGGL(pack3_offsets_kernel, dim3((nsites + 255) / 256), dim3(256), 0, st, e->colBytes, (size_t)nsites, (const unsigned long long *)(e->scal + 1),
                        e->scal + 2, e->scal + 1, (unsigned long long)e->yzCap, e->ctl + 2);
@@ -495,6 +519,17 @@ static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites
     hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->scal + 1, (const unsigned long long *)(e->scal + 2), (unsigned long long)e->yzCap, e->ctl + 2);
     HIPCHK(hipGetLastError());
     e->yz_upper += worst;
+    if (!e->h_used) {
+        HIPCHK(hipHostMalloc((void **)&e->h_used, 8 * sizeof(unsigned long long), hipHostMallocDefault));
+        for (int i = 0; i < 8; ++i) HIPCHK(hipEventCreateWithFlags(&e->evUsed[i], hipEventDisableTiming));
+    }
+    {   // this batch's true running total, read back without waiting for it
+        const int slot = (int)(e->used_n % 8);
+        HIPCHK(hipMemcpyAsync(e->h_used + slot, e->scal + 1, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(e->evUsed[slot], st));
+        e->usedWorstAfter[slot] = worst;                   // bytes this batch may have added (for readings older than it)
+        ++e->used_n;
+    }
     return 0;
 }
 
@@ -535,10 +570,12 @@ static int flush_pending(pbwtamd_engine *e) {
         f.A = ringA(e, p.ring); f.D = ringD(e, p.ring); f.strideA = e->strideA; f.strideD = e->strideD;
         f.keys = e->keysR[p.ring]; f.strideK = e->Mpad; f.save = e->saveR[p.ring]; f.strideS = e->strideS;
         f.M = e->M; f.W = e->Wt; f.Wp = (e->Wt + 63) / 64 * 64; f.kbase = p.kbase;
+        static const int dbg_nowrite = getenv("PBWTAMD_DEBUG_FILL_NOWRITE") ? 1 : 0; f.dbg_nowrite = dbg_nowrite;
         dim3 grid(e->Wt, p.nb / 8);
-        if (e->skEPT == 1) hipLaunchKernelGGL((skel_fill_kernel<1>), grid, dim3(BLOCK), 0, e->s2, f);
-        else if (e->skEPT == 2) hipLaunchKernelGGL((skel_fill_kernel<2>), grid, dim3(BLOCK), 0, e->s2, f);
-        else hipLaunchKernelGGL((skel_fill_kernel<4>), grid, dim3(BLOCK), 0, e->s2, f);
+        const size_t dyn = 0;
+        if (e->skEPT == 1) hipLaunchKernelGGL((skel_fill_kernel<1>), grid, dim3(BLOCK), dyn, e->s2, f);
+        else if (e->skEPT == 2) hipLaunchKernelGGL((skel_fill_kernel<2>), grid, dim3(BLOCK), dyn, e->s2, f);
+        else hipLaunchKernelGGL((skel_fill_kernel<4>), grid, dim3(BLOCK), dyn, e->s2, f);
         HIPCHK(hipGetLastError());
     }
     if (p.skel && !nofill && e->fill_steps) {                               // fill the 7 states between consecutive skeleton states, all blocks at once
@@ -570,7 +607,8 @@ static int flush_pending(pbwtamd_engine *e) {
         if (!e->ystale) HIPCHK(hipMalloc((void **)&e->ystale, sizeof(int) * e->strideA));
         HIPCHK(hipMemcpyAsync(e->ystale, A + (size_t)(p.nb - 1) * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->s2));
     }
-    if (p.opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, e->s2, A, p.nb));
+    static const bool no_fuse = getenv("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
+    if (p.opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, e->s2, A, p.nb, !no_fuse && (p.opts & PBWTAMD_OPT_WITHIN_HIST) != 0));
     HIPCHK(hipEventRecord(e->evCons[p.ring], e->s2));
     e->consRecorded[p.ring] = true;
     return 0;
@@ -603,32 +641,58 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
 }
 
 // the skeleton chain of one batch: slot 8s -> slot 8s+8 with an 8-bit radix step (keys = the alleles
-// at the 8 sites, gathered through the transposed panel and carried along with the state)
-static int run_skeleton(pbwtamd_engine *e, int r, const uint32_t *cols, int nb, int navail) {
-    int *A = ringA(e, r), *D = ringD(e, r);
-    const int nvalid = std::min(navail, e->n_total - e->k_cur);
+// at the 8 sites, gathered through the transposed panel and carried along with the state).
+// skel_prepare: transposed panel of the batch and the keys of slot 0 (unless the previous batch's last round delivered them).
+static void skel_transpose(pbwtamd_engine *e, hipStream_t st, uint32_t *xT, const uint32_t *cols, int nb, int nvalid) {
     const int nblk = (std::min(nb + 8, nvalid) + 31) / 32;
     dim3 gt((e->wpc + BLOCK - 1) / BLOCK, nblk);
-    hipLaunchKernelGGL(transpose32_kernel, gt, dim3(BLOCK), 0, e->stream, cols, e->wpc, nvalid, e->xT, e->strideX, e->Mpad);
+    hipLaunchKernelGGL(transpose32_kernel, gt, dim3(BLOCK), 0, st, cols, e->wpc, nvalid, xT, e->strideX, e->Mpad);
+}
+
+static int skel_prepare(pbwtamd_engine *e, int r, const uint32_t *cols, int nb, int navail) {
+    const int nvalid = std::min(navail, e->n_total - e->k_cur);
+    skel_transpose(e, e->stream, e->xTr[r], cols, nb, nvalid);
+    if (!e->keys_ready[r])
+        hipLaunchKernelGGL(skel_keys_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, ringA(e, r), (const uint32_t *)e->xTr[r], 0, e->M, e->keysR[r]);
+    e->keys_ready[r] = false;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// rounds [s_from, s_to) of the batch; `direct`: the batch's last round scatters straight into slot 0
+// (and the slot-0 keys) of the other ring, where the next batch starts
+static int skel_rounds(pbwtamd_engine *e, int r, int nb, int navail, int s_from, int s_to, bool direct) {
+    int *A = ringA(e, r), *D = ringD(e, r);
+    const int nvalid = std::min(navail, e->n_total - e->k_cur);
     unsigned char *kb = e->keysR[r];
-    hipLaunchKernelGGL(skel_keys_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, A, (const uint32_t *)e->xT, 0, e->M, kb);
+    const uint32_t *xT = e->xTr[r];
     const int W = e->Wt, Wp = (W + 63) / 64 * 64;           // tables of the three-launch round are [key][Wp]
     const bool two = skel_two_launch(e);
     SkArgs g;
     g.tbl = (int2 *)e->skT;
     g.cntT = e->skT; g.tailT = g.cntT + (size_t)Wp * SKK;
     g.M = e->M; g.W = W; g.Wp = Wp;
-    for (int s8 = 0; s8 < nb / 8; ++s8) {
+    for (int s8 = s_from; s8 < s_to; ++s8) {
         const int site = 8 * s8;                           // relative to the batch
+        const bool last = direct && s8 == nb / 8 - 1;
         g.a = A + (size_t)site * e->strideA; g.d = D + (size_t)site * e->strideD; g.keys = kb + (size_t)s8 * e->Mpad;
-        g.a_out = A + (size_t)(site + 8) * e->strideA; g.d_out = D + (size_t)(site + 8) * e->strideD; g.keys_out = kb + (size_t)(s8 + 1) * e->Mpad;
-        int *sv = e->saveR[r] + (size_t)s8 * e->strideS;   // this round's per-key scan over the tiles, kept for the fill
+        g.a_out = last ? ringA(e, r ^ 1) : A + (size_t)(site + 8) * e->strideA;
+        g.d_out = last ? ringD(e, r ^ 1) : D + (size_t)(site + 8) * e->strideD;
+        g.keys_out = last ? e->keysR[r ^ 1] : kb + (size_t)(s8 + 1) * e->Mpad;
+        static const bool nosave = getenv("PBWTAMD_DEBUG_NOSAVE") != nullptr;   // measurement only (breaks the fill)
+        int *sv = e->saveR[r] + (nosave ? 0 : (size_t)s8 * e->strideS);   // this round's per-key scan over the tiles, kept for the fill
         g.beforeS = sv; g.carryS = sv + (size_t)SKK * Wp; g.totalS = sv + (size_t)2 * SKK * Wp;
         g.beforeT = g.beforeS; g.carryT = g.carryS; g.total = g.totalS;
         g.has_next = (e->k_cur + site + 8 < e->n_total) && (site + 8 < nvalid);
-        g.xTnext = e->xT + (size_t)((site + 8) / 32) * e->strideX; g.shift_next = (site + 8) % 32;
+        g.xTnext = xT + (size_t)((site + 8) / 32) * e->strideX; g.shift_next = (site + 8) % 32;
         g.k = e->k_cur + site;
         if (e->skEPT == 1) launch_skel_round<1>(e, g, two); else if (e->skEPT == 2) launch_skel_round<2>(e, g, two); else launch_skel_round<4>(e, g, two);
+        if (last) e->keys_ready[r ^ 1] = g.has_next != 0;
+        if (e->thr_rounds > 0 && (s8 + 1) % e->thr_rounds == 0) {   // a deep command queue slows the dependent chain down (measured): stay just ahead
+            HIPCHK(hipEventRecord(e->tev[e->tev_n % 16], e->stream));
+            if (e->tev_n >= e->thr_depth) HIPCHK(hipEventSynchronize(e->tev[(e->tev_n - e->thr_depth) % 16]));
+            ++e->tev_n;
+        }
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -653,6 +717,8 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         const uint32_t *bc = cols + (size_t)done * wpc;
         const int r = e->ring;
         int *A = ringA(e, r), *D = ringD(e, r);
+        static const int throttle = getenv("PBWTAMD_THROTTLE") ? atoi(getenv("PBWTAMD_THROTTLE")) : 0;
+        if (throttle && e->chainRecorded[r]) HIPCHK(hipEventSynchronize(e->evChain[r]));   // host at most one batch ahead of the chain
         // two sites per launch when the columns are in original order (the keys of the next pair are
         // gathered by haplotype) and the pair's successor columns are at hand
         const int left = ncols_avail - done;               // columns available from bc on
@@ -660,11 +726,14 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         const int L = (nb + 1) / 2;
         const bool skel = e->skel && !sorted && with_d && (nb % 8 == 0) && left >= std::min(nb + 8, remaining);
         const bool pair = !skel && e->pair && !sorted && (e->T == 256 || e->T == 1024 || e->T == 2048 || e->T == 4096) && left >= std::min(2 * L + 2, remaining);
-        if (!skel) CHK(ensure_prepared(e, bc, sorted, with_d, pair, left));
-        hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(256), 0, e->stream, e->ctlblk, e->k_cur, e->n_total, bc, (const uint32_t *)e->zerocol,
-                           e->summ, pair ? 3 * e->wpad : e->wpad, e->summ_cur);
+        if (!skel) {
+            CHK(ensure_prepared(e, bc, sorted, with_d, pair, left));
+            hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(256), 0, e->stream, e->ctlblk, e->k_cur, e->n_total, bc, (const uint32_t *)e->zerocol,
+                               e->summ, pair ? 3 * e->wpad : e->wpad, e->summ_cur);
+            e->keys_ready[r] = false;
+        }
         const int nlaunch = skel ? (skel_two_launch(e) ? 2 : 3) * (nb / 8) : (pair ? L : nb);
-        e->summ_cur = nlaunch % 3;
+        if (!skel) e->summ_cur = nlaunch % 3;
         HIPCHK(hipGetLastError());
         // ---- the chain: slot j -> slot j+1 (-> slot j+2) of ring r ----
         if (e->ev_used == e->ev.size()) {
@@ -673,9 +742,25 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         HIPCHK(hipEventRecord(e->ev[e->ev_used].first, e->stream));
         bool launched = false;
         if (skel) {
-            // ring r's consumers (incl. the fill that read xTr[r]) were waited for before slot 0 of ring r was written
+            // ring r's consumers (incl. the fill that read xTr[r], keysR[r], saveR[r]) were waited for before slot 0 of ring r was written
             e->xT = e->xTr[r];
-            CHK(run_skeleton(e, r, bc, nb, left)); launched = true; e->prepared = false;
+            CHK(skel_prepare(e, r, bc, nb, left));
+            // the other stream's work is enqueued once all but the last round of this batch are (measured: better than right away)
+            static const bool early_flush = getenv("PBWTAMD_EARLY_FLUSH") != nullptr;
+            const int nr = nb / 8, head = early_flush ? std::min(4, nr - 1) : nr - 1;
+            CHK(skel_rounds(e, r, nb, left, 0, head, true));
+            // consumers of the PREVIOUS batch (other ring) are enqueued now, beside this batch's chain
+            CHK(flush_pending(e));
+            // the last round scatters straight into slot 0 of the other ring, once its readers are done
+            static const bool no_direct = getenv("PBWTAMD_NO_DIRECT") != nullptr;
+            CHK(skel_rounds(e, r, nb, left, head, nr - 1, !no_direct));
+            if (e->consRecorded[r ^ 1]) HIPCHK(hipStreamWaitEvent(e->stream, e->evCons[r ^ 1], 0));
+            CHK(skel_rounds(e, r, nb, left, nr - 1, nr, !no_direct));
+            if (no_direct) {
+                HIPCHK(hipMemcpyAsync(ringA(e, r ^ 1), A + (size_t)nb * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->stream));
+                HIPCHK(hipMemcpyAsync(ringD(e, r ^ 1), D + (size_t)nb * e->strideD, sizeof(int) * e->strideD, hipMemcpyDeviceToDevice, e->stream));
+            }
+            launched = true; e->prepared = false;
         }
         else if (e->use_graph && nb == e->B) {
             hipGraphExec_t exec;
@@ -693,14 +778,16 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         }
         if (pair && (nb & 1)) e->prepared = false;         // slot nb is a level-1 output: re-derive tags and summaries
         HIPCHK(hipEventRecord(e->ev[e->ev_used].second, e->stream));
-        HIPCHK(hipEventRecord(e->evChain[r], e->stream));
+        HIPCHK(hipEventRecord(e->evChain[r], e->stream)); e->chainRecorded[r] = true;
         ++e->ev_used; e->launches += nlaunch; e->sites_done += nb;
-        // ---- consumers of the PREVIOUS batch (other ring) run now, beside this batch's chain ----
-        CHK(flush_pending(e));
-        // ---- carry the cursor into slot 0 of the other ring once its readers are done ----
-        if (e->consRecorded[r ^ 1]) HIPCHK(hipStreamWaitEvent(e->stream, e->evCons[r ^ 1], 0));
-        HIPCHK(hipMemcpyAsync(ringA(e, r ^ 1), A + (size_t)nb * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->stream));
-        if (with_d) HIPCHK(hipMemcpyAsync(ringD(e, r ^ 1), D + (size_t)nb * e->strideD, sizeof(int) * e->strideD, hipMemcpyDeviceToDevice, e->stream));
+        if (!skel) {
+            // ---- consumers of the PREVIOUS batch (other ring) run now, beside this batch's chain ----
+            CHK(flush_pending(e));
+            // ---- carry the cursor into slot 0 of the other ring once its readers are done ----
+            if (e->consRecorded[r ^ 1]) HIPCHK(hipStreamWaitEvent(e->stream, e->evCons[r ^ 1], 0));
+            HIPCHK(hipMemcpyAsync(ringA(e, r ^ 1), A + (size_t)nb * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->stream));
+            if (with_d) HIPCHK(hipMemcpyAsync(ringD(e, r ^ 1), D + (size_t)nb * e->strideD, sizeof(int) * e->strideD, hipMemcpyDeviceToDevice, e->stream));
+        }
         if (skel || (opts & (PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS))) {
             e->pend.valid = true; e->pend.ring = r; e->pend.kbase = e->k_cur; e->pend.nb = nb; e->pend.opts = opts; e->pend.skel = skel;
         }

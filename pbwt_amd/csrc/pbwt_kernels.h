@@ -759,6 +759,9 @@ struct SkArgs {
 
 template <int EPT, bool ROWMAJOR>
 __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
+#endif
     constexpr int T = BLOCK * EPT;
     __shared__ int h_cnt[SKK], h_last[SKK];
     __shared__ int s_suf[T];
@@ -816,6 +819,9 @@ __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
 struct Sk2Args { const int *cntT; const int *tailT; int *beforeT; int *carryT; int *total; int W, Wp; };
 template <int TPL>
 __global__ __launch_bounds__(BLOCK) void skel_k2_kernel(Sk2Args g) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
+#endif
     const int lane = lane_id(), q = blockIdx.x * WAVES + wave_id();
     const int *cn = g.cntT + (size_t)q * g.Wp, *tl = g.tailT + (size_t)q * g.Wp;
     int c[TPL], tt[TPL];
@@ -851,10 +857,13 @@ __global__ __launch_bounds__(BLOCK) void skel_k2_kernel(Sk2Args g) {
 constexpr int SKN_MAXW = 128;
 template <int EPT, int TR>
 __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
+#endif
     constexpr int T = BLOCK * EPT, NC = EPT * WAVES;        // positions per tile, 64-position chunks per tile
     constexpr int NL = (EPT == 4) ? 10 : (EPT == 2) ? 9 : 8;   // sparse table levels: windows 1 .. T/2
-    __shared__ int s_cnt[NC][SKK];                          // per chunk: count -> base (exclusive over chunks)
-    __shared__ int s_lastp[NC][SKK];                        // per chunk: last local position of the key -> previous one before the chunk
+    __shared__ short s_cnt[NC][SKK];                        // per chunk: count -> base (exclusive over chunks)
+    __shared__ short s_lastp[NC][SKK];                      // per chunk: last local position of the key -> previous one before the chunk
     __shared__ int s_tbl[NL][T];                            // s_tbl[l][i] = max d over (i-2^l, i]
     __shared__ int s_before[SKK], s_carry[SKK], s_G[SKK], s_lower[SKK];
     __shared__ int s_gw[WAVES], s_lw[WAVES];
@@ -875,7 +884,7 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
     } else {
         bq = g.beforeT[(size_t)t * g.Wp + w]; cq = g.carryT[(size_t)t * g.Wp + w]; tq = g.total[t];
     }
-    for (int x = t; x < NC * SKK; x += BLOCK) { (&s_cnt[0][0])[x] = 0; (&s_lastp[0][0])[x] = -1; }
+    for (int x = t; x < NC * SKK / 2; x += BLOCK) { reinterpret_cast<int *>(&s_cnt[0][0])[x] = 0; reinterpret_cast<int *>(&s_lastp[0][0])[x] = -1; }
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
         const int l = r * BLOCK + t;
@@ -896,8 +905,8 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
         rk[r] = __popcll(before);
         pl[r] = before ? (r * 4 + wv) * 64 + (63 - __clzll(before)) : -1;
         if (key[r] >= 0 && !before) {                       // leader of its key in this chunk
-            s_cnt[r * 4 + wv][key[r]] = __popcll(same);
-            s_lastp[r * 4 + wv][key[r]] = (r * 4 + wv) * 64 + (63 - __clzll(same));
+            s_cnt[r * 4 + wv][key[r]] = (short)__popcll(same);
+            s_lastp[r * 4 + wv][key[r]] = (short)((r * 4 + wv) * 64 + (63 - __clzll(same)));
         }
     }
     lds_barrier();
@@ -906,7 +915,7 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int cn = s_cnt[c][t], lp = s_lastp[c][t];
-            s_cnt[c][t] = base; s_lastp[c][t] = last;
+            s_cnt[c][t] = (short)base; s_lastp[c][t] = (short)last;
             base += cn; if (cn) last = lp;
         }
     }
@@ -980,6 +989,7 @@ struct SkFillArgs {
     const unsigned char *keys; size_t strideK;              // keys of state 8b at keys + b*strideK
     const int *save; size_t strideS;                        // per block: beforeT[256][Wp], carryT[256][Wp], total[256]
     int M, W, Wp, kbase;
+    int dbg_nowrite;                                        // measurement only
 };
 
 template <int EPT>
@@ -1074,6 +1084,7 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
             else dd = 0;
             const int pos = s_G[kj] + s_b[kj] + rank;
             if (pos == 0) dd = k + j + 1;
+            if (g.dbg_nowrite && pos >= 0) continue;
             a_out[pos] = av[r] | (int)(((unsigned)(key[r] >> j) & 1u) << 31);
             d_out[pos] = dd;
         }
@@ -1548,6 +1559,7 @@ struct SweepArgs {
     int4 *recs;                          // MODE 1
     unsigned long long *hist; int histlen;  // MODE 2
     int *err;
+    unsigned long long *ycols; int wpc64;   // MODE 2, optional: also emit the sorted bit column of each site (what pack3 encodes)
 };
 
 // wave-cooperative walk: from position `from` in direction `dir` (-1 up, +1 down) find the first
@@ -1612,6 +1624,15 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
                 ++n;
                 if (++steps == BUDGET) { needDown = true; break; }
             }
+        }
+    }
+    if constexpr (MODE == 2) {
+        if (g.ycols) {                                      // the tags of this site as a sorted bit column (saves pack3 a pass over A)
+            const unsigned long long mk = __ballot(i < M && yi);
+            const int wd = blockIdx.x * WAVES + wave_id();
+            unsigned long long *yc = g.ycols + (size_t)site * g.wpc64;
+            if (lane == 0 && wd < g.wpc64) yc[wd] = mk;
+            if (blockIdx.x == gridDim.x - 1) for (int x = gridDim.x * WAVES + threadIdx.x; x < g.wpc64; x += BLOCK) yc[x] = 0ULL;
         }
     }
     // finish long upward walks, one lane at a time, all 64 lanes scanning
