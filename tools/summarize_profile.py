@@ -33,25 +33,49 @@ cal = {}
 for p, k, c, n, m in rows:
     if k.startswith("calib_copy4"):
         cal[c] = (256 << 20) * 4 / 1024.0 / m
-step = {c: m for p, k, c, n, m in rows if k.startswith("void pbwtk::step") and p.startswith("pmc")}
+import json
+CHAIN = ("void pbwtk::skel_hist_kernel", "void pbwtk::skel_k2_kernel", "void pbwtk::skel_rank_kernel")
+
+
+def chain_counter(counter, passname):
+    """mean per dispatch of each chain kernel (hist, k2, rank) for one counter"""
+    out = {}
+    for p, k, c, n, m in rows:
+        if p == passname and c == counter:
+            for ck in CHAIN:
+                if k.startswith(ck):
+                    out[ck.split("::")[1]] = m
+    return out
+
+
+fetch_k, write_k = chain_counter("FETCH_SIZE", "pmc_fetch"), chain_counter("WRITE_SIZE", "pmc_write")
 print("calibration (true/reported): ", cal)
-fetch = step.get("FETCH_SIZE", 0) * cal.get("FETCH_SIZE", 1) * 1024
-write = step.get("WRITE_SIZE", 0) * cal.get("WRITE_SIZE", 1) * 1024
-print("step_kernel HBM-side traffic per launch: fetch %.0f B + write %.0f B = %.0f B" % (fetch, write, fetch + write))
-sq = {c: m for p, k, c, n, m in rows if k.startswith("void pbwtk::step") and p == "pmc_sq"}
-if sq:
-    with open(os.path.join("profiles", tag + "_sq.txt"), "w") as f:
-        f.write("rocprofv3 PMC (SQ block), chain kernel, mean per dispatch:\n")
-        for c in sorted(sq):
-            f.write("  %-20s %.1f\n" % (c, sq[c]))
-        if sq.get("SQ_WAVES"):
-            w = sq["SQ_WAVES"]
-            f.write("per wave: VALU %.0f  SALU %.0f  LDS %.0f instructions; wave-cycles (quad-cycle units) %.0f, of which waiting %.0f (%.0f%%), issuing %.0f\n"
-                    % (sq.get("SQ_INSTS_VALU", 0) / w, sq.get("SQ_INSTS_SALU", 0) / w, sq.get("SQ_INSTS_LDS", 0) / w, sq.get("SQ_WAVE_CYCLES", 0) / w,
-                       sq.get("SQ_WAIT_ANY", 0) / w, 100.0 * sq.get("SQ_WAIT_ANY", 0) / max(sq.get("SQ_WAVE_CYCLES", 1), 1), sq.get("SQ_ACTIVE_INST_ANY", 0) / w))
-    print(open(os.path.join("profiles", tag + "_sq.txt")).read())
+cf, cw = cal.get("FETCH_SIZE", 1), cal.get("WRITE_SIZE", 1)
+per_round = sum(fetch_k.values()) * cf * 1024 + sum(write_k.values()) * cw * 1024
+per_launch = per_round / max(len(fetch_k), 1)
 with open(os.path.join("profiles", tag + "_traffic.txt"), "w") as f:
     f.write("rocprofv3 PMC, separate passes (FETCH_SIZE, WRITE_SIZE), units KiB; calibration on tools/pmc_calib.hip\n")
-    f.write("(1 GiB copy with 4 B/lane coalesced accesses, the step kernel's pattern): true/reported = %s\n" % cal)
-    f.write("step_kernel per launch: FETCH_SIZE %.1f KiB x %.3f, WRITE_SIZE %.1f KiB x %.3f => %.0f bytes HBM-side traffic\n"
-            % (step.get("FETCH_SIZE", 0), cal.get("FETCH_SIZE", 1), step.get("WRITE_SIZE", 0), cal.get("WRITE_SIZE", 1), fetch + write))
+    f.write("(1 GiB copy with 4 B/lane coalesced accesses): true/reported = %s\n" % cal)
+    f.write("skeleton chain, one round = 8 sites = %d launches (M = 100000):\n" % len(fetch_k))
+    for kname in fetch_k:
+        f.write("  %-20s FETCH_SIZE %9.1f KiB x %.3f   WRITE_SIZE %9.1f KiB x %.3f\n" % (kname, fetch_k[kname], cf, write_k.get(kname, 0), cw))
+    f.write("=> %.0f bytes HBM-side traffic per round, %.0f per launch (algorithmic: 16.125 B x M x 8 sites = %.0f per round)\n"
+            % (per_round, per_launch, 16.125 * 100000 * 8))
+print(open(os.path.join("profiles", tag + "_traffic.txt")).read())
+json.dump({"100000": {"with_d": True, "kernel": "skeleton chain (skel_hist/k2/rank), mean over the launches of a round",
+                      "bytes_per_launch": int(per_launch),
+                      "source": "profiles/%s_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x%.1f per the calibration kernel tools/pmc_calib.hip)" % (tag, cf)}},
+          open(os.path.join("profiles", "traffic.json"), "w"), indent=1)
+sq_rows = [(k, c, m) for p, k, c, n, m in rows if p == "pmc_sq" and any(k.startswith(ck) for ck in CHAIN)]
+if sq_rows:
+    with open(os.path.join("profiles", tag + "_sq.txt"), "w") as f:
+        f.write("rocprofv3 PMC (SQ block), chain kernels, mean per dispatch:\n")
+        for ck in CHAIN:
+            sq = {c: m for k, c, m in sq_rows if k.startswith(ck)}
+            if not sq.get("SQ_WAVES"):
+                continue
+            w = sq["SQ_WAVES"]
+            f.write("%s: waves %.0f; per wave: VALU %.0f  SALU %.0f  LDS %.0f instructions; wave-cycles (quad-cycle units) %.0f, of which waiting %.0f (%.0f%%), issuing %.0f\n"
+                    % (ck.split("::")[1], w, sq.get("SQ_INSTS_VALU", 0) / w, sq.get("SQ_INSTS_SALU", 0) / w, sq.get("SQ_INSTS_LDS", 0) / w, sq.get("SQ_WAVE_CYCLES", 0) / w,
+                       sq.get("SQ_WAIT_ANY", 0) / w, 100.0 * sq.get("SQ_WAIT_ANY", 0) / max(sq.get("SQ_WAVE_CYCLES", 1), 1), sq.get("SQ_ACTIVE_INST_ANY", 0) / w))
+    print(open(os.path.join("profiles", tag + "_sq.txt")).read())
