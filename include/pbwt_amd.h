@@ -155,6 +155,9 @@ int pbwtamd_sync(pbwtamd_engine *e);
 int pbwtamd_get_state(pbwtamd_engine *e, int32_t *a /*M*/, int32_t *d /*M+1 or NULL*/);
 int pbwtamd_get_hist(pbwtamd_engine *e, int64_t *hist, int histlen);
 int pbwtamd_get_checksums(pbwtamd_engine *e, int k_first, int n, uint64_t *csum_a, uint64_t *csum_d, uint64_t *csum_y);
+/* the pack3 bytes (PBWTAMD_OPT_PACK3) written since pass_begin = the p->yz array of pbwtCore.c:254-267; malloc'd, free with
+ * pbwtamd_free */
+int pbwtamd_get_packed(pbwtamd_engine *e, uint8_t **yz_out, int64_t *nz_out);
 
 /* timing of the chain kernel (the dominant kernel) over the last pass_advance calls since
  * pass_begin, measured with HIP events on the engine's stream: total ms and launches */

@@ -250,6 +250,14 @@ class Engine:
         self._chk(self._L.pbwtamd_get_hist(self._h, _p(h, C.c_int64), C.c_int(n)))
         return h
 
+    def get_packed(self):
+        """pack3 bytes written since pass_begin (OPT_PACK3)"""
+        yz = C.POINTER(C.c_uint8)(); nz = C.c_int64(0)
+        self._chk(self._L.pbwtamd_get_packed(self._h, C.byref(yz), C.byref(nz)))
+        out = np.ctypeslib.as_array(yz, shape=(max(nz.value, 1),))[: nz.value].copy()
+        self._L.pbwtamd_free(yz)
+        return out
+
     def get_checksums(self, k_first, n):
         ca = np.zeros(n, np.uint64); cd = np.zeros(n, np.uint64); cy = np.zeros(n, np.uint64)
         self._chk(self._L.pbwtamd_get_checksums(self._h, C.c_int(k_first), C.c_int(n), _p(ca, C.c_uint64), _p(cd, C.c_uint64), _p(cy, C.c_uint64)))

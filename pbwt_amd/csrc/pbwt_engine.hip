@@ -46,6 +46,14 @@ struct DevBufs {
 struct GraphKey { int with_d, sorted, ring, pair; hipGraphExec_t exec; };
 struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; bool skel = false; };
 
+// skeleton batches whose consumers need (d, y) of every site but not the haplotype ids (histogram sweep, pack3 through the
+// sweep's bit columns): the fill writes d | y << 31 and no a — half the consumer stream's bytes (they are what slows the chain)
+static inline bool packed_fill(const Pending &p) {
+    static const bool off = getenv("PBWTAMD_NO_PACKED_FILL") != nullptr, no_fuse = getenv("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
+    const unsigned ids = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_LONG_RECS;
+    return !off && !no_fuse && p.skel && (p.opts & PBWTAMD_OPT_WITHIN_HIST) && !(p.opts & ids);
+}
+
 struct pbwtamd_engine {
     int device = 0, M = 0, Mpad = 0, wpc = 0, wpc64 = 0, W = 0, wpad = 0, E = 4, T = 1024, B = 0;
     hipStream_t stream = nullptr; bool own_stream = false;   // the launch chain
@@ -80,9 +88,9 @@ struct pbwtamd_engine {
     uint32_t *xT = nullptr; size_t strideX = 0; int xTblocks = 0;   // transposed panel of the batch in flight (= xTr[ring])
     uint32_t *xTr[2] = {nullptr, nullptr}; // one per ring: the fill of batch n reads it while the chain transposes batch n+1
     int4 *summF = nullptr; int wpadF = 0;  // fill: tile summaries [B/8][wpadF]
-    unsigned char *keys8 = nullptr; int *skT = nullptr;   // skT: hist tables of the round in flight (cnt, tail [256][Wp], or [W][256] {cnt, tail})
+    unsigned char *keys8 = nullptr; int *skT = nullptr;   // skT: hist table of the round in flight, [W][256] {cnt, tail}
     unsigned char *keysR[2] = {nullptr, nullptr};         // per ring: the keys of states 0, 8, 16, ... of the batch ([B/8+1][Mpad]), kept for the fill
-    int *saveR[2] = {nullptr, nullptr}; size_t strideS = 0;   // per ring and round: before[256][Wp], carry[256][Wp], total[256]
+    int2 *saveR[2] = {nullptr, nullptr}; size_t strideS = 0;  // per ring and round: scan[W][256] {before, carry}, total[256] (stride in int2)
     hipEvent_t tev[16] = {}; long long tev_n = 0; int thr_rounds = 32, thr_depth = 2;   // host throttle: an event every thr_rounds rounds, host at most thr_depth events ahead
     bool keys_ready[2] = {false, false};     // slot-0 keys of the ring delivered by the previous batch's last round
     bool fill_steps = false;                // PBWTAMD_FILL_STEPS=1: fill with 14 batched single-site launches instead of skel_fill_kernel
@@ -185,7 +193,8 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     if (e->skel) {
         e->skEPT = (M <= 40000) ? 1 : (M <= 300000) ? 2 : 4;   // measured: smaller tiles = shorter per-workgroup latency chains, until the per-key tile scan grows
         if (const char *sv = getenv("PBWTAMD_SKT")) e->skEPT = (atoi(sv) == 256) ? 1 : (atoi(sv) == 512) ? 2 : 4;
-        if (M > 256 * e->skEPT * 2048) e->skEPT = 4;           // skel_k2_kernel scans at most 2048 tiles per key
+
+        if (M > 256 * e->skEPT * 1024) e->skEPT = 4;           // skel_k2_kernel scans at most 1024 tiles per key
         if (const char *sv = getenv("PBWTAMD_SKN_MAXW")) e->skn_maxw = std::min(atoi(sv), SKN_MAXW);
         e->Wt = (M + 256 * e->skEPT - 1) / (256 * e->skEPT);
         e->strideX = (size_t)e->Mpad; e->xTblocks = (e->B + 8 + 31) / 32 + 1;
@@ -198,14 +207,14 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         if (const char *sv = getenv("PBWTAMD_THR_DEPTH")) e->thr_depth = std::max(1, std::min(atoi(sv), 15));
         for (int i = 0; i < 16; ++i) HIPCHK(hipEventCreateWithFlags(&e->tev[i], hipEventDisableTiming));
         {
-            const int Wp = (e->Wt + 63) / 64 * 64, rounds = e->B / 8 + 1;
-            e->strideS = (size_t)2 * SKK * Wp + SKK;
+            const int rounds = e->B / 8 + 1;
+            e->strideS = (size_t)SKK * e->Wt + SKK / 2;
             for (int i = 0; i < 2; ++i) {
                 ALLOC(e->keysR[i], (size_t)(rounds + 1) * e->Mpad);
-                ALLOC(e->saveR[i], (size_t)rounds * e->strideS * sizeof(int));
+                ALLOC(e->saveR[i], (size_t)rounds * e->strideS * sizeof(int2));
             }
         }
-        ALLOC(e->skT, ((size_t)4 * (e->Wt + 64) * SKK + 2 * SKK) * sizeof(int));
+        ALLOC(e->skT, (size_t)(e->Wt + 1) * SKK * sizeof(int2));
     }
 #undef ALLOC
     HIPCHK(hipMemsetAsync(e->A, 0, 2 * slots * e->strideA * sizeof(int), e->stream));
@@ -377,7 +386,7 @@ static int ensure_blockcount(pbwtamd_engine *e, size_t n) {
 }
 
 // maxWithin sweep over `nsites` slots of (A, D) (sites kbase..) on stream st: histogram or records
-static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int *D, int kbase, int nsites, int final_site, unsigned opts) {
+static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int *D, int kbase, int nsites, int final_site, unsigned opts, bool packed = false) {
     SweepArgs g;
     g.A = A; g.D = D; g.strideA = e->strideA; g.strideD = e->strideD;
     g.M = e->M; g.kbase = kbase; g.final_site = final_site;
@@ -387,7 +396,8 @@ static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int
     const int tiles = (e->M + BLOCK - 1) / BLOCK;
     dim3 grid(tiles, nsites);
     if (opts & PBWTAMD_OPT_WITHIN_HIST) {
-        hipLaunchKernelGGL((sweep_within_kernel<2>), grid, dim3(BLOCK), 0, st, g);
+        if (packed) hipLaunchKernelGGL((sweep_within_kernel<2, true>), grid, dim3(BLOCK), 0, st, g);
+        else hipLaunchKernelGGL((sweep_within_kernel<2>), grid, dim3(BLOCK), 0, st, g);
         HIPCHK(hipGetLastError());
     }
     if (opts & PBWTAMD_OPT_WITHIN_RECS) {
@@ -565,12 +575,15 @@ static int flush_pending(pbwtamd_engine *e) {
     const bool with_d = p.opts & PBWTAMD_OPT_WITH_D;
     HIPCHK(hipStreamWaitEvent(e->s2, e->evChain[p.ring], 0));
     static const bool nofill = getenv("PBWTAMD_NOFILL") && atoi(getenv("PBWTAMD_NOFILL"));   // measurement only: results are wrong
-    if (p.skel && !nofill && !e->fill_steps) {             // the 7 states between consecutive skeleton states: all blocks and tiles in one launch
+    const unsigned consumers = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS;
+    const bool packed = packed_fill(p) && !e->fill_steps;
+    if (p.skel && !nofill && !e->fill_steps && (p.opts & consumers)) {   // the 7 states between consecutive skeleton states: all blocks and tiles in one launch
         SkFillArgs f;
         f.A = ringA(e, p.ring); f.D = ringD(e, p.ring); f.strideA = e->strideA; f.strideD = e->strideD;
-        f.keys = e->keysR[p.ring]; f.strideK = e->Mpad; f.save = e->saveR[p.ring]; f.strideS = e->strideS;
-        f.M = e->M; f.W = e->Wt; f.Wp = (e->Wt + 63) / 64 * 64; f.kbase = p.kbase;
+        f.keys = e->keysR[p.ring]; f.strideK = e->Mpad; f.scan = e->saveR[p.ring]; f.strideS = e->strideS;
+        f.M = e->M; f.W = e->Wt; f.kbase = p.kbase;
         static const int dbg_nowrite = getenv("PBWTAMD_DEBUG_FILL_NOWRITE") ? 1 : 0; f.dbg_nowrite = dbg_nowrite;
+        f.pack_y = packed ? 1 : 0;
         dim3 grid(e->Wt, p.nb / 8);
         const size_t dyn = 0;
         if (e->skEPT == 1) hipLaunchKernelGGL((skel_fill_kernel<1>), grid, dim3(BLOCK), dyn, e->s2, f);
@@ -600,7 +613,7 @@ static int flush_pending(pbwtamd_engine *e) {
         hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, e->s2, A, D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, p.nb);
         HIPCHK(hipGetLastError());
     }
-    if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, e->s2, A, D, p.kbase, p.nb, -1, p.opts));
+    if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, e->s2, A, D, p.kbase, p.nb, -1, p.opts, packed));
     if (p.opts & PBWTAMD_OPT_LONG_RECS) {
         CHK(run_long(e, e->s2, A, D, nullptr, p.kbase, p.nb, -1));
         // keep the batch's last state (before site kbase+nb-1): it is the stale allele column if the panel ends here
@@ -622,21 +635,17 @@ static inline bool skel_two_launch(const pbwtamd_engine *e) { return e->skn && e
 template <int EPT>
 static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
     const int W = g.W;
+    hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, e->stream, g);
     if (two_launch) {
-        hipLaunchKernelGGL((skel_hist_kernel<EPT, true>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         if (W <= 16) hipLaunchKernelGGL((skel_rank_kernel<EPT, 16>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         else if (W <= 32) hipLaunchKernelGGL((skel_rank_kernel<EPT, 32>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         else if (W <= 64) hipLaunchKernelGGL((skel_rank_kernel<EPT, 64>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         else hipLaunchKernelGGL((skel_rank_kernel<EPT, SKN_MAXW>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         return;
     }
-    hipLaunchKernelGGL((skel_hist_kernel<EPT, false>), dim3(W), dim3(BLOCK), 0, e->stream, g);
-    Sk2Args k2; k2.cntT = g.cntT; k2.tailT = g.tailT; k2.beforeT = (int *)g.beforeT; k2.carryT = (int *)g.carryT; k2.total = (int *)g.total; k2.W = W; k2.Wp = g.Wp;
-    if (W <= 64) hipLaunchKernelGGL((skel_k2_kernel<1>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
-    else if (W <= 128) hipLaunchKernelGGL((skel_k2_kernel<2>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
-    else if (W <= 256) hipLaunchKernelGGL((skel_k2_kernel<4>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
-    else if (W <= 1024) hipLaunchKernelGGL((skel_k2_kernel<16>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
-    else hipLaunchKernelGGL((skel_k2_kernel<32>), dim3(SKK / WAVES), dim3(BLOCK), 0, e->stream, k2);
+    Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = W;
+    if (W <= 256) hipLaunchKernelGGL((skel_k2_kernel<16, 4>), dim3(SKK / 16), dim3(BLOCK), 0, e->stream, k2);
+    else hipLaunchKernelGGL((skel_k2_kernel<4, 16>), dim3(SKK / 4), dim3(BLOCK), 0, e->stream, k2);
     hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
 }
 
@@ -666,12 +675,11 @@ static int skel_rounds(pbwtamd_engine *e, int r, int nb, int navail, int s_from,
     const int nvalid = std::min(navail, e->n_total - e->k_cur);
     unsigned char *kb = e->keysR[r];
     const uint32_t *xT = e->xTr[r];
-    const int W = e->Wt, Wp = (W + 63) / 64 * 64;           // tables of the three-launch round are [key][Wp]
+    const int W = e->Wt;
     const bool two = skel_two_launch(e);
     SkArgs g;
     g.tbl = (int2 *)e->skT;
-    g.cntT = e->skT; g.tailT = g.cntT + (size_t)Wp * SKK;
-    g.M = e->M; g.W = W; g.Wp = Wp;
+    g.M = e->M; g.W = W;
     for (int s8 = s_from; s8 < s_to; ++s8) {
         const int site = 8 * s8;                           // relative to the batch
         const bool last = direct && s8 == nb / 8 - 1;
@@ -679,10 +687,8 @@ static int skel_rounds(pbwtamd_engine *e, int r, int nb, int navail, int s_from,
         g.a_out = last ? ringA(e, r ^ 1) : A + (size_t)(site + 8) * e->strideA;
         g.d_out = last ? ringD(e, r ^ 1) : D + (size_t)(site + 8) * e->strideD;
         g.keys_out = last ? e->keysR[r ^ 1] : kb + (size_t)(s8 + 1) * e->Mpad;
-        static const bool nosave = getenv("PBWTAMD_DEBUG_NOSAVE") != nullptr;   // measurement only (breaks the fill)
-        int *sv = e->saveR[r] + (nosave ? 0 : (size_t)s8 * e->strideS);   // this round's per-key scan over the tiles, kept for the fill
-        g.beforeS = sv; g.carryS = sv + (size_t)SKK * Wp; g.totalS = sv + (size_t)2 * SKK * Wp;
-        g.beforeT = g.beforeS; g.carryT = g.carryS; g.total = g.totalS;
+        int2 *sv = e->saveR[r] + (size_t)s8 * e->strideS;  // this round's per-key scan over the tiles, kept for the fill
+        g.scan = sv; g.total = reinterpret_cast<int *>(sv + (size_t)W * SKK);
         g.has_next = (e->k_cur + site + 8 < e->n_total) && (site + 8 < nvalid);
         g.xTnext = xT + (size_t)((site + 8) / 32) * e->strideX; g.shift_next = (site + 8) % 32;
         g.k = e->k_cur + site;
@@ -901,6 +907,18 @@ extern "C" int pbwtamd_synth_device(pbwtamd_engine *e, void *d_bitcols, int k0, 
 }
 
 // ------------------------------------------------------------------------------------ host-buffer API
+extern "C" int pbwtamd_get_packed(pbwtamd_engine *e, uint8_t **yz_out, int64_t *nz_out) {
+    HIPCHK(hipSetDevice(e->device));
+    CHK(pbwtamd_sync(e));
+    unsigned long long nz = 0;
+    HIPCHK(hipMemcpy(&nz, e->scal + 1, sizeof nz, hipMemcpyDeviceToHost));
+    uint8_t *buf = (uint8_t *)malloc(nz ? nz : 1);
+    if (!buf) return fail("pbwtamd_get_packed: out of host memory for %llu bytes", nz);
+    if (nz) HIPCHK(hipMemcpy(buf, e->yz, nz, hipMemcpyDeviceToHost));
+    *yz_out = buf; *nz_out = (int64_t)nz;
+    return 0;
+}
+
 extern "C" int pbwtamd_build(pbwtamd_engine *e, const uint32_t *bitcols, int wpc, int N, int with_d,
                              const int32_t *aFstart, uint8_t **yz_out, int64_t *nz_out, int32_t *aFend, int32_t *dFend) {
     HIPCHK(hipSetDevice(e->device));
@@ -924,14 +942,7 @@ extern "C" int pbwtamd_build(pbwtamd_engine *e, const uint32_t *bitcols, int wpc
     }
     CHK(pbwtamd_pass_end(e, opts));
     if (aFend) CHK(pbwtamd_get_state(e, aFend, with_d ? dFend : nullptr));
-    if (yz_out) {
-        unsigned long long nz = 0;
-        HIPCHK(hipMemcpy(&nz, e->scal + 1, sizeof nz, hipMemcpyDeviceToHost));
-        uint8_t *buf = (uint8_t *)malloc(nz ? nz : 1);
-        if (!buf) return fail("pbwtamd_build: out of host memory for %llu bytes", nz);
-        if (nz) HIPCHK(hipMemcpy(buf, e->yz, nz, hipMemcpyDeviceToHost));
-        *yz_out = buf; *nz_out = (int64_t)nz;
-    }
+    if (yz_out) CHK(pbwtamd_get_packed(e, yz_out, nz_out));
     return 0;
 }
 

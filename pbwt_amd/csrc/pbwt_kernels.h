@@ -746,18 +746,17 @@ __global__ __launch_bounds__(BLOCK) void transpose32_kernel(const uint32_t *cols
 // key's last occurrence (whole-tile max for absent keys).  The keys travel with the state (the rank
 // kernel of the previous round scattered them), so this reads 1 + 4 bytes per position.  Threads own
 // positions in REVERSE blocked order so that a forward scan over threads is a suffix scan over
-// positions.  Tables: ROWMAJOR ? tbl[tile][key] {count, tail} : cntT/tailT[key][Wp].
+// positions.  Output: tbl[tile][key] {count, tail}.
 struct SkArgs {
     const int *a; const int *d; const unsigned char *keys;     // input state and its 8-bit keys
     int *a_out; int *d_out; unsigned char *keys_out;
-    int2 *tbl;                                                  // [W][256] {count, tail}                (two-launch round)
-    int *cntT; int *tailT; const int *beforeT; const int *carryT; const int *total;   // [key][Wp], [key]  (three-launch round)
-    int *beforeS; int *carryS; int *totalS;                     // where the two-launch round keeps its per-key scan for the fill
+    int2 *tbl;                                                  // hist -> scan: [W][256] {count, tail}
+    int2 *scan; int *total;                                     // scan -> rank (kept for the fill): [W][256] {keys before the tile, carry}, total[256]
     const uint32_t *xTnext; int shift_next; int has_next;
-    int M, W, Wp, k;                                            // k = site of the input state
+    int M, W, k;                                                // k = site of the input state
 };
 
-template <int EPT, bool ROWMAJOR>
+template <int EPT>
 __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
@@ -808,51 +807,75 @@ __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
     for (int q = 0; q < WAVES; ++q) tilemax = max(tilemax, s_w[q]);
     lds_barrier();
     const int c = h_cnt[t], tl = c ? s_suf[h_last[t]] : tilemax;
-    if constexpr (ROWMAJOR) g.tbl[(size_t)w * SKK + t] = make_int2(c, tl);
-    else { g.cntT[(size_t)t * g.Wp + w] = c; g.tailT[(size_t)t * g.Wp + w] = tl; }
+    g.tbl[(size_t)w * SKK + t] = make_int2(c, tl);         // row-major: one coalesced 2 KB row per tile
 }
 
-// K2: one WAVE per key — exclusive scan over the W tiles (lanes own TPL consecutive tiles) of the pair
-// (count, max d since the key's last occurrence) with combine(L,R) = (L.c+R.c, R.c ? R.t : max(L.t,R.t))
-// (for a tile without the key, t is the tile's max).  Outputs, [key][Wp]: keys before the tile, the
-// carry (-1: no earlier occurrence); and total[key].  grid = 256 keys / 4 waves.
-struct Sk2Args { const int *cntT; const int *tailT; int *beforeT; int *carryT; int *total; int W, Wp; };
-template <int TPL>
+// SCAN (K2): exclusive scan over the W tiles, per key, of the pair (count, max d since the key's last
+// occurrence) with combine(L,R) = (L.c+R.c, R.c ? R.t : max(L.t,R.t)) (for a tile without the key, t
+// is the tile's max).  A workgroup owns KPW keys: it pulls the [W][KPW] slab of the row-major table
+// through LDS (8*KPW-byte row segments: whole cache lines at KPW = 16), each wave scans KPW/4 keys
+// with lanes = tiles (TPL consecutive tiles per lane, DPP scan across lanes), and the slab goes back
+// the same way.  Output scan[tile][key] = {keys before the tile, carry (-1: no earlier occurrence)},
+// total[key].  grid = 256 / KPW workgroups.
+struct Sk2Args { const int2 *tbl; int2 *scan; int *total; int W; };
+template <int KPW, int TPL>
 __global__ __launch_bounds__(BLOCK) void skel_k2_kernel(Sk2Args g) {
 #ifndef PBWT_NO_SETPRIO
-    __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
+    __builtin_amdgcn_s_setprio(3);
 #endif
-    const int lane = lane_id(), q = blockIdx.x * WAVES + wave_id();
-    const int *cn = g.cntT + (size_t)q * g.Wp, *tl = g.tailT + (size_t)q * g.Wp;
-    int c[TPL], tt[TPL];
-    int sc = 0, st = 0;                                    // this lane's tiles combined
+    constexpr int WP = 64 * TPL + 1;                        // odd row length: the transposing accesses spread over the LDS banks
+    __shared__ int2 s_v[KPW][WP];
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), key0 = blockIdx.x * KPW;
+    constexpr int NIT = 64 * TPL * KPW / BLOCK;              // all loads in flight at once (one round trip, not NIT)
+    int2 ld[NIT];
 #pragma unroll
-    for (int x = 0; x < TPL; ++x) {
-        const int w = lane * TPL + x;
-        c[x] = (w < g.W) ? cn[w] : 0; tt[x] = (w < g.W) ? tl[w] : 0;
-        st = c[x] ? tt[x] : max(st, tt[x]); sc += c[x];
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = t + i * BLOCK, r = idx / KPW, kk = idx % KPW;
+        ld[i] = (r < g.W) ? g.tbl[(size_t)r * SKK + key0 + kk] : make_int2(0, 0);
     }
-    // inclusive wave scan of (sc, st)
-    int ic = sc, it = st;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = t + i * BLOCK, r = idx / KPW, kk = idx % KPW;
+        s_v[kk][r] = ld[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kq = 0; kq < KPW / WAVES; ++kq) {
+        const int kk = kq * WAVES + wv;
+        int c[TPL], tt[TPL];
+        int sc = 0, st = 0;                                // this lane's tiles combined
+#pragma unroll
+        for (int x = 0; x < TPL; ++x) {
+            const int w = lane * TPL + x;
+            const int2 v = (w < g.W) ? s_v[kk][w] : make_int2(0, 0);
+            c[x] = v.x; tt[x] = v.y;
+            st = c[x] ? tt[x] : max(st, tt[x]); sc += c[x];
+        }
+        int ic = sc, it = st;                              // inclusive wave scan of (sc, st)
 #define SK2_STEP(CTRL, RM) { const int lc = dpp_mov<CTRL, RM>(0, ic), lt2 = dpp_mov<CTRL, RM>(0, it); it = ic ? it : max(lt2, it); /* uses OLD ic = R.c */ ic += lc; }
-    // careful: combine(L,R).t = R.c ? R.t : max(L.t, R.t) with R = current (before adding L.c)
-    SK2_STEP(0x111, 0xf) SK2_STEP(0x112, 0xf) SK2_STEP(0x114, 0xf) SK2_STEP(0x118, 0xf) SK2_STEP(0x142, 0xa) SK2_STEP(0x143, 0xc)
+        SK2_STEP(0x111, 0xf) SK2_STEP(0x112, 0xf) SK2_STEP(0x114, 0xf) SK2_STEP(0x118, 0xf) SK2_STEP(0x142, 0xa) SK2_STEP(0x143, 0xc)
 #undef SK2_STEP
-    int ec = lane_shr1(ic, 0), et = lane_shr1(it, 0);      // exclusive prefix of this lane's first tile
+        int ec = lane_shr1(ic, 0), et = lane_shr1(it, 0);  // exclusive prefix of this lane's first tile
 #pragma unroll
-    for (int x = 0; x < TPL; ++x) {
-        const int w = lane * TPL + x;
-        if (w < g.W) { g.beforeT[(size_t)q * g.Wp + w] = ec; g.carryT[(size_t)q * g.Wp + w] = ec ? et : -1; }
-        et = c[x] ? tt[x] : max(et, tt[x]); ec += c[x];
+        for (int x = 0; x < TPL; ++x) {
+            const int w = lane * TPL + x;
+            if (w < g.W) s_v[kk][w] = make_int2(ec, ec ? et : -1);
+            et = c[x] ? tt[x] : max(et, tt[x]); ec += c[x];
+        }
+        if (lane == 63) g.total[key0 + kk] = ic;
     }
-    if (lane == 63) g.total[q] = ic;
+    __syncthreads();
+    for (int idx = t; idx < g.W * KPW; idx += BLOCK) {
+        const int r = idx / KPW, kk = idx % KPW;
+        g.scan[(size_t)r * SKK + key0 + kk] = s_v[kk][r];
+    }
 }
 
 // RANK (K3): per tile — stable rank of every position among its key (ballot refinement inside
 // 64-position chunks + a per-key scan over the chunks), previous same-key position, range max of d_k
 // through a sparse table in LDS, scatter of (a | next allele tag, d', next key).
 // TR > 0 (two-launch round, W <= TR tiles): the per-key scan over the tiles is done here, from the
-// row-major table: W coalesced 8-byte loads per thread, issued first and consumed last, behind the
+// table: W coalesced 8-byte loads per thread, issued first and consumed last, behind the
 // ballot refinement and the sparse table.  TR == 0: before/carry/total come from skel_k2_kernel.
 constexpr int SKN_MAXW = 128;
 template <int EPT, int TR>
@@ -882,7 +905,8 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
 #pragma unroll
         for (int r = 0; r < TR; ++r) row[r] = (r < g.W) ? g.tbl[(size_t)r * SKK + t] : make_int2(0, 0);
     } else {
-        bq = g.beforeT[(size_t)t * g.Wp + w]; cq = g.carryT[(size_t)t * g.Wp + w]; tq = g.total[t];
+        const int2 sv = g.scan[(size_t)w * SKK + t];
+        bq = sv.x; cq = sv.y; tq = g.total[t];
     }
     for (int x = t; x < NC * SKK / 2; x += BLOCK) { reinterpret_cast<int *>(&s_cnt[0][0])[x] = 0; reinterpret_cast<int *>(&s_lastp[0][0])[x] = -1; }
 #pragma unroll
@@ -935,8 +959,8 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
             if (r < w) { cq = c ? tl : (cq >= 0 ? max(cq, tl) : -1); bq += c; }
             tq += c;
         }
-        g.beforeS[(size_t)t * g.Wp + w] = bq; g.carryS[(size_t)t * g.Wp + w] = cq;   // kept for the fill kernel
-        if (w == 0) g.totalS[t] = tq;
+        g.scan[(size_t)w * SKK + t] = make_int2(bq, cq);   // kept for the fill kernel
+        if (w == 0) g.total[t] = tq;
     }
     // bucket bases G (exclusive prefix of the key totals) and the nearest lower non-empty key
     const int ginc = wave_iscan_sum(tq), linc = wave_iscan_max(tq ? t + 1 : 0);
@@ -987,9 +1011,10 @@ __global__ void skel_keys_kernel(int *a, const uint32_t *xT, int shift, int M, u
 struct SkFillArgs {
     int *A; int *D; size_t strideA, strideD;               // ring base (slot 0 of the batch)
     const unsigned char *keys; size_t strideK;              // keys of state 8b at keys + b*strideK
-    const int *save; size_t strideS;                        // per block: beforeT[256][Wp], carryT[256][Wp], total[256]
-    int M, W, Wp, kbase;
+    const int2 *scan; size_t strideS;                       // per block: scan[W][256] {before, carry}, then total[256] (strideS in int2 units)
+    int M, W, kbase;
     int dbg_nowrite;                                        // measurement only
+    int pack_y;                                             // write d | y << 31 only (no a): for consumers that need (d, y) but not the haplotype ids
 };
 
 template <int EPT>
@@ -1003,18 +1028,21 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     __shared__ int s_gw[WAVES], s_lw[WAVES];
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x, b = blockIdx.y;
     const int S = w * T, k = g.kbase + 8 * b;
-    const int *a_in = g.A + (size_t)(8 * b) * g.strideA, *d_in = g.D + (size_t)(8 * b) * g.strideD;
+    const int *a_in = g.A + (size_t)(8 * b) * g.strideA;
+    int *d_in = g.D + (size_t)(8 * b) * g.strideD;
     const unsigned char *keys = g.keys + (size_t)b * g.strideK;
-    const int *sv = g.save + (size_t)b * g.strideS;
+    const int2 *sv = g.scan + (size_t)b * g.strideS;
     int av[EPT], key[EPT];
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
         const int l = r * BLOCK + t, i = S + l;
         const bool valid = i < g.M;
         av[r] = a_in[i] & AMASK; key[r] = valid ? (int)keys[i] : -1;
-        s_tbl[0][l] = valid ? d_in[i] : 0;
+        const int dv = valid ? d_in[i] : 0;
+        s_tbl[0][l] = dv;
+        if (g.pack_y && valid) d_in[i] = dv | (int)(((unsigned)key[r] & 1u) << 31);   // the skeleton slot itself, in the packed form of the other seven
     }
-    s_b[t] = sv[(size_t)t * g.Wp + w]; s_c[t] = sv[(size_t)(SKK + t) * g.Wp + w]; s_t[t] = sv[(size_t)2 * SKK * g.Wp + t];
+    { const int2 v = sv[(size_t)w * SKK + t]; s_b[t] = v.x; s_c[t] = v.y; s_t[t] = reinterpret_cast<const int *>(sv + (size_t)g.W * SKK)[t]; }
     for (int x = t; x < NC * SKK; x += BLOCK) { (&s_raw[0][0])[x] = 0; (&s_lastraw[0][0])[x] = -1; }
     __syncthreads();
     // ballot refinement bit by bit: after bit j-1 the mask of same-j-key lanes
@@ -1085,8 +1113,9 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
             const int pos = s_G[kj] + s_b[kj] + rank;
             if (pos == 0) dd = k + j + 1;
             if (g.dbg_nowrite && pos >= 0) continue;
-            a_out[pos] = av[r] | (int)(((unsigned)(key[r] >> j) & 1u) << 31);
-            d_out[pos] = dd;
+            const int yb = (int)(((unsigned)(key[r] >> j) & 1u) << 31);
+            if (g.pack_y) d_out[pos] = dd | yb;
+            else { a_out[pos] = av[r] | yb; d_out[pos] = dd; }
         }
         if (w == g.W - 1 && t == 0) d_out[g.M] = k + j + 1;
         __syncthreads();
@@ -1566,6 +1595,7 @@ struct SweepArgs {
 // position p with d[p + off] > thr (the block boundary; `stop` = p) or, unless `fin`, with allele
 // == yi (then the match extends: returns true = skip).  64 positions per step via ballot.
 // All 64 lanes call this with wave-uniform arguments.
+template <bool PACKED>
 __device__ __forceinline__ bool coop_walk(const int *a, const int *d, int from, int dir, int thr, unsigned yi, bool fin, int M, int &stop) {
     const int lane = lane_id();
     for (;;) {
@@ -1574,8 +1604,8 @@ __device__ __forceinline__ bool coop_walk(const int *a, const int *d, int from, 
         // down: loop test d[n]   <= thr  with n = p  -> boundary when d[p]   > thr ; y test on y[p]
         const int di = (dir < 0) ? p + 1 : p;
         const bool inb = (di >= 0) && (di <= M);
-        const bool bound = inb ? (d[di] > thr) : true;
-        const bool same = (!bound && !fin && p >= 0 && p < M) ? (((unsigned)a[p] >> 31) == yi) : false;
+        const bool bound = inb ? ((PACKED ? (d[di] & 0x7fffffff) : d[di]) > thr) : true;
+        const bool same = (!bound && !fin && p >= 0 && p < M) ? (((unsigned)(PACKED ? d[p] : a[p]) >> 31) == yi) : false;
         const unsigned long long mb = __ballot(bound), ms = __ballot(same);
         const unsigned long long any = mb | ms;
         if (any) {
@@ -1588,9 +1618,13 @@ __device__ __forceinline__ bool coop_walk(const int *a, const int *d, int from, 
     }
 }
 
-template <int MODE>
+// PACKED (MODE 2 only): the slots hold d | y << 31 in D and A is not read (what skel_fill_kernel writes
+// when no consumer needs the haplotype ids): half the bytes of the sweep.
+template <int MODE, bool PACKED = false>
 __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     __shared__ unsigned long long s_w[WAVES];
+    auto DV = [&](const int *dd, int x) -> int { return PACKED ? (dd[x] & 0x7fffffff) : dd[x]; };
+    auto YV = [&](const int *aa, const int *dd, int x) -> unsigned { return (unsigned)(PACKED ? dd[x] : aa[x]) >> 31; };
     const int site = blockIdx.y, k = g.kbase + site;
     const bool fin = (site == g.final_site);
     const int *a = g.A + (size_t)site * g.strideA;
@@ -1606,21 +1640,21 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     constexpr int BUDGET = 4;
     bool needUp = false, needDown = false;
     if (i < M) {
-        di = d[i]; dn = d[i + 1];
-        yi = (unsigned)a[i] >> 31;
+        if constexpr (PACKED) { const int v = d[i]; di = v & 0x7fffffff; yi = (unsigned)v >> 31; } else { di = d[i]; yi = (unsigned)a[i] >> 31; }
+        dn = DV(d, i + 1);
         rep = true;
         if (di <= dn) {
             int steps = 0;
-            while (d[m + 1] <= di) {
-                if (!fin && ((unsigned)a[m] >> 31) == yi) { rep = false; break; }
+            while (DV(d, m + 1) <= di) {
+                if (!fin && YV(a, d, m) == yi) { rep = false; break; }
                 --m;
                 if (++steps == BUDGET) { needUp = true; break; }
             }
         }
         if (rep && !needUp && di >= dn) {
             int steps = 0;
-            while (d[n] <= dn) {
-                if (!fin && ((unsigned)a[n] >> 31) == yi) { rep = false; break; }
+            while (DV(d, n) <= dn) {
+                if (!fin && YV(a, d, n) == yi) { rep = false; break; }
                 ++n;
                 if (++steps == BUDGET) { needDown = true; break; }
             }
@@ -1641,14 +1675,14 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
         const int from = __builtin_amdgcn_readlane(m, src), thr = __builtin_amdgcn_readlane(di, src);
         const unsigned yy = (unsigned)__builtin_amdgcn_readlane((int)yi, src);
         int stop = 0;
-        const bool skip = coop_walk(a, d, from, -1, thr, yy, fin, M, stop);
+        const bool skip = coop_walk<PACKED>(a, d, from, -1, thr, yy, fin, M, stop);
         if (lane == src) { if (skip) rep = false; else m = stop; }
     }
     // lanes whose upward walk was long still owe the downward scan
     if (needUp && rep && di >= dn) {
         int steps = 0;
-        while (d[n] <= dn) {
-            if (!fin && ((unsigned)a[n] >> 31) == yi) { rep = false; break; }
+        while (DV(d, n) <= dn) {
+            if (!fin && YV(a, d, n) == yi) { rep = false; break; }
             ++n;
             if (++steps == BUDGET) { needDown = true; break; }
         }
@@ -1658,7 +1692,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
         const int from = __builtin_amdgcn_readlane(n, src), thr = __builtin_amdgcn_readlane(dn, src);
         const unsigned yy = (unsigned)__builtin_amdgcn_readlane((int)yi, src);
         int stop = 0;
-        const bool skip = coop_walk(a, d, from, +1, thr, yy, fin, M, stop);
+        const bool skip = coop_walk<PACKED>(a, d, from, +1, thr, yy, fin, M, stop);
         if (lane == src) { if (skip) rep = false; else n = stop; }
     }
     if (MODE == 2) {

@@ -363,3 +363,31 @@ def test_both_chains_every_site(amd, orc, skel, M, N, batch, kind, monkeypatch):
     assert np.array_equal(b["yz"], o["yz"]) and np.array_equal(b["dFend"], o["d_final"])
     if 1 < M <= 3000:
         assert np.array_equal(eng.max_within(o["yz"], N, mode="records"), orc.max_within(o["yz"], M, N))
+
+
+@pytest.mark.parametrize("packed", ["1", "0"])
+@pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1025, 96, 24, 0), (70001, 80, 40, 1), (2, 40, 8, 1), (300000, 24, 8, 0)])
+def test_histogram_and_pack3_consumers_without_ids(amd, orc, packed, M, N, batch, kind, monkeypatch):
+    """the bench configuration (divergence + maxWithin histogram + pack3, no per-site checksums): on the
+    skeleton path the fill then writes d | y << 31 and no haplotype ids, the sweep reads that and emits
+    the bit columns pack3 encodes (PBWTAMD_NO_PACKED_FILL=1: the unpacked form).  Histogram, .pbwt bytes
+    and final state against the oracle."""
+    import torch
+    if packed == "0":
+        monkeypatch.setenv("PBWTAMD_NO_PACKED_FILL", "1")
+    eng = amd.Engine(M, batch_sites=batch)
+    buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    eng.synth_device(buf.data_ptr(), 0, N, seed=2000 + M, kind=kind)
+    eng.sync()
+    bits = buf.cpu().numpy().view(np.uint32)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    opts = amd.OPT_WITH_D | amd.OPT_WITHIN_HIST | amd.OPT_PACK3
+    eng.pass_begin(N)
+    half = (N // 2) // 8 * 8                   # two advances: the second starts from a carried cursor
+    eng.pass_advance(buf.data_ptr(), half, N, opts)
+    eng.pass_advance(buf.data_ptr() + half * eng.wpc * 4, N - half, N - half, opts)
+    eng.pass_end(opts)
+    a, d = eng.get_state()
+    assert np.array_equal(a, o["aFend"]) and np.array_equal(d, o["d_final"])
+    assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
+    assert np.array_equal(eng.get_packed(), o["yz"])

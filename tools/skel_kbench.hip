@@ -30,11 +30,9 @@ static void run(int M, float p1, int reps) {
     CK(hipMemcpy(dK, keys.data(), Mpad, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, xT.data(), Mpad * 4, hipMemcpyHostToDevice));
     SkArgs g;
     g.a = dA; g.d = dD; g.keys = dK; g.a_out = dA2; g.d_out = dD2; g.keys_out = dK2;
-    g.tbl = (int2 *)tab; g.cntT = tab; g.tailT = tab + (size_t)Wp * SKK;
-    int *bT = g.tailT + (size_t)Wp * SKK, *cT = bT + (size_t)Wp * SKK, *tot = cT + (size_t)Wp * SKK;
-    g.beforeT = bT; g.carryT = cT; g.total = tot; g.beforeS = bT; g.carryS = cT; g.totalS = tot;
-    g.xTnext = dX; g.shift_next = 8; g.has_next = 1; g.M = M; g.W = W; g.Wp = Wp; g.k = 100;
-    Sk2Args k2; k2.cntT = g.cntT; k2.tailT = g.tailT; k2.beforeT = bT; k2.carryT = cT; k2.total = tot; k2.W = W; k2.Wp = Wp;
+    g.tbl = (int2 *)tab; g.scan = (int2 *)tab + (size_t)(Wp + 8) * SKK; g.total = tab + (size_t)5 * (Wp + 8) * SKK;
+    g.xTnext = dX; g.shift_next = 8; g.has_next = 1; g.M = M; g.W = W; g.k = 100;
+    Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = W;
     hipStream_t s;
     if (getenv("KB_PRIO")) { int lo, hi; CK(hipDeviceGetStreamPriorityRange(&lo, &hi)); CK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, atoi(getenv("KB_PRIO")) ? hi : 0)); printf("stream: nonblocking, prio %s\n", getenv("KB_PRIO")); }
     else CK(hipStreamCreate(&s));
@@ -51,17 +49,14 @@ static void run(int M, float p1, int reps) {
     };
     printf("M=%d T=%d W=%d p1=%.2f\n", M, T, W, p1);
     timeit("empty", [&] { hipLaunchKernelGGL(empty_kernel, dim3(W), dim3(BLOCK), 0, s, (int *)nullptr); });
-    float th = timeit("hist", [&] { hipLaunchKernelGGL((skel_hist_kernel<EPT, false>), dim3(W), dim3(BLOCK), 0, s, g); });
+    float th = timeit("hist", [&] { hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, s, g); });
     auto k2l = [&] {
-        if (W <= 64) hipLaunchKernelGGL((skel_k2_kernel<1>), dim3(SKK / WAVES), dim3(BLOCK), 0, s, k2);
-        else if (W <= 128) hipLaunchKernelGGL((skel_k2_kernel<2>), dim3(SKK / WAVES), dim3(BLOCK), 0, s, k2);
-        else if (W <= 256) hipLaunchKernelGGL((skel_k2_kernel<4>), dim3(SKK / WAVES), dim3(BLOCK), 0, s, k2);
-        else if (W <= 1024) hipLaunchKernelGGL((skel_k2_kernel<16>), dim3(SKK / WAVES), dim3(BLOCK), 0, s, k2);
-        else hipLaunchKernelGGL((skel_k2_kernel<32>), dim3(SKK / WAVES), dim3(BLOCK), 0, s, k2);
+        if (W <= 256) hipLaunchKernelGGL((skel_k2_kernel<16, 4>), dim3(SKK / 16), dim3(BLOCK), 0, s, k2);
+    else hipLaunchKernelGGL((skel_k2_kernel<4, 16>), dim3(SKK / 4), dim3(BLOCK), 0, s, k2);
     };
     float t2 = timeit("k2", k2l);
     float tr = timeit("rank", [&] { hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, s, g); });
-    float ta = timeit("hist+k2+rank", [&] { hipLaunchKernelGGL((skel_hist_kernel<EPT, false>), dim3(W), dim3(BLOCK), 0, s, g); k2l(); hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, s, g); });
+    float ta = timeit("hist+k2+rank", [&] { hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, s, g); k2l(); hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, s, g); });
     printf("  sum %.2f, round %.2f us = %.2f us/site\n", th + t2 + tr, ta, ta / 8);
     {   // a real chain over NS ring slots (each round reads what the previous one scattered: nothing is L2-hot by accident)
         const int NS = 64;
@@ -74,7 +69,7 @@ static void run(int M, float p1, int reps) {
             h.a = rA + (size_t)slot * Mpad; h.d = rD + (size_t)slot * (Mpad + 64); h.keys = rK + (size_t)slot * Mpad;
             h.a_out = rA + (size_t)(slot + 1) * Mpad; h.d_out = rD + (size_t)(slot + 1) * (Mpad + 64); h.keys_out = rK + (size_t)(slot + 1) * Mpad;
             h.shift_next = (slot % 4) * 8;
-            hipLaunchKernelGGL((skel_hist_kernel<EPT, false>), dim3(W), dim3(BLOCK), 0, s, h); k2l(); hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, s, h);
+            hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, s, h); k2l(); hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, s, h);
             slot = (slot + 1) % NS;
             if (slot == 0) { CK(hipMemcpyAsync(rA, rA + (size_t)NS * Mpad, Mpad * 4, hipMemcpyDeviceToDevice, s)); CK(hipMemcpyAsync(rD, rD + (size_t)NS * (Mpad + 64), (Mpad + 64) * 4, hipMemcpyDeviceToDevice, s)); CK(hipMemcpyAsync(rK, rK + (size_t)NS * Mpad, Mpad, hipMemcpyDeviceToDevice, s)); }
         });
@@ -87,7 +82,7 @@ static void run(int M, float p1, int reps) {
             h.a = rA + (size_t)sl * Mpad; h.d = rD + (size_t)sl * (Mpad + 64); h.keys = rK + (size_t)sl * Mpad;
             h.a_out = rA + (size_t)(sl + 1) * Mpad; h.d_out = rD + (size_t)(sl + 1) * (Mpad + 64); h.keys_out = rK + (size_t)(sl + 1) * Mpad;
             h.shift_next = (sl % 4) * 8;
-            hipLaunchKernelGGL((skel_hist_kernel<EPT, false>), dim3(W), dim3(BLOCK), 0, s, h); k2l(); hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, s, h);
+            hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, s, h); k2l(); hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, s, h);
         }
         CK(hipMemcpyAsync(rA, rA + (size_t)NS * Mpad, Mpad * 4, hipMemcpyDeviceToDevice, s)); CK(hipMemcpyAsync(rD, rD + (size_t)NS * (Mpad + 64), (Mpad + 64) * 4, hipMemcpyDeviceToDevice, s)); CK(hipMemcpyAsync(rK, rK + (size_t)NS * Mpad, Mpad, hipMemcpyDeviceToDevice, s));
         CK(hipStreamEndCapture(s, &gr)); CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
