@@ -644,7 +644,7 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
         return;
     }
     Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = W;
-    if (W <= 256) hipLaunchKernelGGL((skel_k2_kernel<16, 4>), dim3(SKK / 16), dim3(BLOCK), 0, e->stream, k2);
+    if (W <= 256) hipLaunchKernelGGL((skel_k2_kernel<4, 4>), dim3(SKK / 4), dim3(BLOCK), 0, e->stream, k2);   // one key per wave (16 / 8 keys per workgroup measured slower)
     else hipLaunchKernelGGL((skel_k2_kernel<4, 16>), dim3(SKK / 4), dim3(BLOCK), 0, e->stream, k2);
     hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
 }

@@ -813,7 +813,7 @@ __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
 // SCAN (K2): exclusive scan over the W tiles, per key, of the pair (count, max d since the key's last
 // occurrence) with combine(L,R) = (L.c+R.c, R.c ? R.t : max(L.t,R.t)) (for a tile without the key, t
 // is the tile's max).  A workgroup owns KPW keys: it pulls the [W][KPW] slab of the row-major table
-// through LDS (8*KPW-byte row segments: whole cache lines at KPW = 16), each wave scans KPW/4 keys
+// through LDS (8*KPW-byte row segments: 32-byte sectors at KPW = 4), each wave scans KPW/4 keys
 // with lanes = tiles (TPL consecutive tiles per lane, DPP scan across lanes), and the slab goes back
 // the same way.  Output scan[tile][key] = {keys before the tile, carry (-1: no earlier occurrence)},
 // total[key].  grid = 256 / KPW workgroups.

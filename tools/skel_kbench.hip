@@ -51,7 +51,7 @@ static void run(int M, float p1, int reps) {
     timeit("empty", [&] { hipLaunchKernelGGL(empty_kernel, dim3(W), dim3(BLOCK), 0, s, (int *)nullptr); });
     float th = timeit("hist", [&] { hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, s, g); });
     auto k2l = [&] {
-        if (W <= 256) hipLaunchKernelGGL((skel_k2_kernel<16, 4>), dim3(SKK / 16), dim3(BLOCK), 0, s, k2);
+        if (W <= 256) hipLaunchKernelGGL((skel_k2_kernel<4, 4>), dim3(SKK / 4), dim3(BLOCK), 0, s, k2);   // one key per wave (16 / 8 keys per workgroup measured slower)
     else hipLaunchKernelGGL((skel_k2_kernel<4, 16>), dim3(SKK / 4), dim3(BLOCK), 0, s, k2);
     };
     float t2 = timeit("k2", k2l);
