@@ -74,7 +74,7 @@ def cpu_baseline(args, first_cols):
                       % (n, M, what, tb, tw)}
 
 
-def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=2048, batch=128):
+def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=4096, batch=512):
     """secondary measurement at the north-star width (1M haplotypes), same hot path, short panel:
     reported next to the headline, not part of `value`"""
     eng = pbwt_amd.Engine(M, batch_sites=batch, device=dev.index)
@@ -83,7 +83,7 @@ def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=2048, ba
     eng.sync()
     n_total = sites + batch
     eng.pass_begin(n_total)
-    eng.pass_advance(panel.data_ptr(), batch, batch + 2, opts)          # warm-up batch (graph capture)
+    eng.pass_advance(panel.data_ptr(), batch, batch + 8, opts)          # warm-up batch
     eng.sync()
     ms0, n0 = eng.chain_timing(); s0 = eng.chain_sites()
     torch.cuda.synchronize()

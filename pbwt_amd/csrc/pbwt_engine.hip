@@ -191,10 +191,10 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     ALLOC(e->colBytes, (slots + 1) * sizeof(unsigned long long));
     ALLOC(e->scal, 8 * sizeof(unsigned long long));
     if (e->skel) {
-        e->skEPT = (M <= 40000) ? 1 : (M <= 300000) ? 2 : 4;   // measured: smaller tiles = shorter per-workgroup latency chains, until the per-key tile scan grows
+        e->skEPT = (M <= 40000) ? 1 : 2;                       // measured: smaller tiles = shorter per-workgroup latency chains, and the fill fits 4 workgroups per CU (T = 1024: 2)
         if (const char *sv = getenv("PBWTAMD_SKT")) e->skEPT = (atoi(sv) == 256) ? 1 : (atoi(sv) == 512) ? 2 : 4;
 
-        if (M > 256 * e->skEPT * 1024) e->skEPT = 4;           // skel_k2_kernel scans at most 1024 tiles per key
+        if (M > 256 * e->skEPT * 2048) e->skEPT = 4;           // skel_k2_kernel scans at most 2048 tiles per key
         if (const char *sv = getenv("PBWTAMD_SKN_MAXW")) e->skn_maxw = std::min(atoi(sv), SKN_MAXW);
         e->Wt = (M + 256 * e->skEPT - 1) / (256 * e->skEPT);
         e->strideX = (size_t)e->Mpad; e->xTblocks = (e->B + 8 + 31) / 32 + 1;
@@ -393,11 +393,18 @@ static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int
     g.blockCount = nullptr; g.recs = nullptr; g.hist = e->hist; g.histlen = e->histlen; g.err = e->ctl + 2;
     static const bool no_fuse = getenv("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
     g.ycols = (!no_fuse && final_site < 0 && (opts & PBWTAMD_OPT_PACK3) && (opts & PBWTAMD_OPT_WITHIN_HIST)) ? e->ycols : nullptr; g.wpc64 = e->wpc64;
+    static const int sweep_dbg = getenv("PBWTAMD_DEBUG_SWEEP") ? atoi(getenv("PBWTAMD_DEBUG_SWEEP")) : 0; g.dbg = sweep_dbg;
     const int tiles = (e->M + BLOCK - 1) / BLOCK;
     dim3 grid(tiles, nsites);
+    static const int sweep_it = getenv("PBWTAMD_SWEEP_ITERS") ? atoi(getenv("PBWTAMD_SWEEP_ITERS")) : 0;
+    g.nvb = tiles;
+    const int iters = sweep_it > 0 ? sweep_it : (tiles >= 64 ? 4 : 1);
     if (opts & PBWTAMD_OPT_WITHIN_HIST) {
-        if (packed) hipLaunchKernelGGL((sweep_within_kernel<2, true>), grid, dim3(BLOCK), 0, st, g);
-        else hipLaunchKernelGGL((sweep_within_kernel<2>), grid, dim3(BLOCK), 0, st, g);
+        dim3 gh((tiles + iters - 1) / iters, nsites);
+#define SWEEP_HIST(P, I) hipLaunchKernelGGL((sweep_within_kernel<2, P, I>), gh, dim3(BLOCK), 0, st, g)
+        if (packed) { if (iters == 8) SWEEP_HIST(true, 8); else if (iters == 4) SWEEP_HIST(true, 4); else if (iters == 2) SWEEP_HIST(true, 2); else { gh.x = tiles; SWEEP_HIST(true, 1); } }
+        else { if (iters == 8) SWEEP_HIST(false, 8); else if (iters == 4) SWEEP_HIST(false, 4); else if (iters == 2) SWEEP_HIST(false, 2); else { gh.x = tiles; SWEEP_HIST(false, 1); } }
+#undef SWEEP_HIST
         HIPCHK(hipGetLastError());
     }
     if (opts & PBWTAMD_OPT_WITHIN_RECS) {
@@ -645,7 +652,8 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
     }
     Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = W;
     if (W <= 256) hipLaunchKernelGGL((skel_k2_kernel<4, 4>), dim3(SKK / 4), dim3(BLOCK), 0, e->stream, k2);   // one key per wave (16 / 8 keys per workgroup measured slower)
-    else hipLaunchKernelGGL((skel_k2_kernel<4, 16>), dim3(SKK / 4), dim3(BLOCK), 0, e->stream, k2);
+    else if (W <= 1024) hipLaunchKernelGGL((skel_k2_kernel<4, 16>), dim3(SKK / 4), dim3(BLOCK), 0, e->stream, k2);
+    else hipLaunchKernelGGL((skel_k2_kernel<4, 32>), dim3(SKK / 4), dim3(BLOCK), 0, e->stream, k2);
     hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
 }
 

@@ -823,7 +823,7 @@ __global__ __launch_bounds__(BLOCK) void skel_k2_kernel(Sk2Args g) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
-    constexpr int WP = 64 * TPL + 1;                        // odd row length: the transposing accesses spread over the LDS banks
+    constexpr int WP = 64 * TPL + (TPL < 32 ? 1 : 0);       // odd row length: the transposing accesses spread over the LDS banks (64 KB static limit at TPL = 32)
     __shared__ int2 s_v[KPW][WP];
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), key0 = blockIdx.x * KPW;
     constexpr int NIT = 64 * TPL * KPW / BLOCK;              // all loads in flight at once (one round trip, not NIT)
@@ -1589,6 +1589,8 @@ struct SweepArgs {
     unsigned long long *hist; int histlen;  // MODE 2
     int *err;
     unsigned long long *ycols; int wpc64;   // MODE 2, optional: also emit the sorted bit column of each site (what pack3 encodes)
+    int dbg;                                // measurement only: 1 = no histogram atomics, 2 = no walks either
+    int nvb;                                // 256-position blocks per site
 };
 
 // wave-cooperative walk: from position `from` in direction `dir` (-1 up, +1 down) find the first
@@ -1620,7 +1622,7 @@ __device__ __forceinline__ bool coop_walk(const int *a, const int *d, int from, 
 
 // PACKED (MODE 2 only): the slots hold d | y << 31 in D and A is not read (what skel_fill_kernel writes
 // when no consumer needs the haplotype ids): half the bytes of the sweep.
-template <int MODE, bool PACKED = false>
+template <int MODE, bool PACKED = false, int ITC = 1>
 __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     __shared__ unsigned long long s_w[WAVES];
     auto DV = [&](const int *dd, int x) -> int { return PACKED ? (dd[x] & 0x7fffffff) : dd[x]; };
@@ -1629,9 +1631,24 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     const bool fin = (site == g.final_site);
     const int *a = g.A + (size_t)site * g.strideA;
     const int *d = g.D + (size_t)site * g.strideD;
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
     const int M = g.M;
     const int lane = lane_id();
+    // MODE 2 walks g.iters consecutive 256-position blocks per workgroup (at M = 1M one block per workgroup is 2M workgroups
+    // per batch: dispatch-bound); the record modes keep one block per workgroup (their offsets are per block)
+    constexpr int IT = (MODE == 2) ? ITC : 1;
+    // the own entries of all IT blocks are requested up front (IT x 2 loads in flight per lane: the sweep is a stream)
+    int pre_d[IT], pre_n[IT], pre_a[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int ii = (blockIdx.x * IT + it) * BLOCK + threadIdx.x;
+        pre_d[it] = (ii < M) ? d[ii] : 0; pre_n[it] = (ii < M) ? d[ii + 1] : 0;
+        pre_a[it] = (!PACKED && ii < M) ? a[ii] : 0;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+    const int vb = blockIdx.x * IT + it;
+    if (vb >= g.nvb) break;
+    const int i = vb * BLOCK + threadIdx.x;
     int m = i - 1, n = i + 1, di = 0, dn = 0;
     unsigned yi = 0;
     bool rep = false;
@@ -1640,9 +1657,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     constexpr int BUDGET = 4;
     bool needUp = false, needDown = false;
     if (i < M) {
-        if constexpr (PACKED) { const int v = d[i]; di = v & 0x7fffffff; yi = (unsigned)v >> 31; } else { di = d[i]; yi = (unsigned)a[i] >> 31; }
-        dn = DV(d, i + 1);
+        if constexpr (PACKED) { const int v = pre_d[it]; di = v & 0x7fffffff; yi = (unsigned)v >> 31; dn = pre_n[it] & 0x7fffffff; }
+        else { di = pre_d[it]; yi = (unsigned)pre_a[it] >> 31; dn = pre_n[it]; }
         rep = true;
+        if (g.dbg == 2) { /* loads only */ } else
         if (di <= dn) {
             int steps = 0;
             while (DV(d, m + 1) <= di) {
@@ -1663,10 +1681,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     if constexpr (MODE == 2) {
         if (g.ycols) {                                      // the tags of this site as a sorted bit column (saves pack3 a pass over A)
             const unsigned long long mk = __ballot(i < M && yi);
-            const int wd = blockIdx.x * WAVES + wave_id();
+            const int wd = vb * WAVES + wave_id();
             unsigned long long *yc = g.ycols + (size_t)site * g.wpc64;
             if (lane == 0 && wd < g.wpc64) yc[wd] = mk;
-            if (blockIdx.x == gridDim.x - 1) for (int x = gridDim.x * WAVES + threadIdx.x; x < g.wpc64; x += BLOCK) yc[x] = 0ULL;
+            if (vb == g.nvb - 1) for (int x = g.nvb * WAVES + threadIdx.x; x < g.wpc64; x += BLOCK) yc[x] = 0ULL;
         }
     }
     // finish long upward walks, one lane at a time, all 64 lanes scanning
@@ -1698,9 +1716,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     if (MODE == 2) {
         if (rep) {
             const int len = (di < dn) ? k - di : k - dn;
-            if (len >= 0 && len < g.histlen) atomicAdd(g.hist + len, 1ULL); else atomicExch(g.err, 1);
+            if (g.dbg) { if (len == -12345) g.hist[0] = 1; }
+            else if (len >= 0 && len < g.histlen) atomicAdd(g.hist + len, 1ULL); else atomicExch(g.err, 1);
         }
-        return;
+        continue;
     }
     const unsigned long long cnt = rep ? (unsigned long long)((i - 1 - m) + (n - 1 - i)) : 0ULL;
     // block exclusive scan of cnt
@@ -1710,13 +1729,14 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     __syncthreads();
     unsigned long long pre = 0, tot = 0;
     for (int q = 0; q < WAVES; ++q) { if (q < wave_id()) pre += s_w[q]; tot += s_w[q]; }
-    const size_t bidx = (size_t)site * gridDim.x + blockIdx.x;
+    const size_t bidx = (size_t)site * g.nvb + vb;
     if (MODE == 0) { if (threadIdx.x == 0) g.blockCount[bidx] = tot; return; }
     if (rep && cnt) {
         int4 *out = g.recs + g.blockCount[bidx] + pre + (inc - cnt);
         const int ai = a[i] & AMASK;
         for (int jj = m + 1; jj < i; ++jj) *out++ = make_int4(ai, a[jj] & AMASK, di, k);
         for (int jj = i + 1; jj < n; ++jj) *out++ = make_int4(ai, a[jj] & AMASK, dn, k);
+    }
     }
 }
 
