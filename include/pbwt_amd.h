@@ -109,6 +109,18 @@ int pbwtamd_match_sweep(pbwtamd_engine *e, const uint8_t *pz, int64_t pnz, int N
                         pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out,
                         int64_t *n_nomatch, int64_t *tot);
 
+/* matchSequencesSweepSparse (pbwtMatch.c:501-602; declared pbwt.h:214): the query sweep against the
+ * panel AND against nSparse sparse panels (the sites = kk mod nSparse, stepped with
+ * pbwtCursorForwardsAD(upp[kk], k/nSparse)); reports carry the isSparse flag of the reference's
+ * 5-argument callback and come in its order (per site and query: dense matches, then sparse; tails:
+ * dense for every query, then each sparse cursor in turn).  nSparse <= 1: the dense sweep only. */
+typedef struct { int32_t ai, bi, start, end, sparse; } pbwtamd_match5;
+typedef void (*pbwtamd_report5_fn)(int ai, int bi, int start, int end, int isSparse);
+int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, int64_t pnz, int N, const int32_t *pStart,
+                               int Mq, const uint8_t *qz, int64_t qnz, const int32_t *qStart, int nSparse,
+                               pbwtamd_report5_fn report, pbwtamd_match5 **recs_out, int64_t *nrecs_out,
+                               int64_t *n_nomatch, int64_t *tot);
+
 /* pack3 codec on the device (pbwtCore.c:254-305): N columns <-> packed bytes.
  * unpack returns sorted-order bit columns (N*wpc words, caller buffer). */
 int pbwtamd_pack3(pbwtamd_engine *e, const uint32_t *sorted_bitcols, int wpc, int N,

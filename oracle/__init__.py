@@ -230,6 +230,50 @@ def match_sweep(pz, Mp, qz, Mq, N, pStart=None, qStart=None):
     return _take(mv), nomatch.value, (tot[0], tot[1])
 
 
+MATCH5_DTYPE = np.dtype([("ai", "<i4"), ("bi", "<i4"), ("start", "<i4"), ("end", "<i4"), ("sparse", "<i4")])
+
+
+class Match5Vec(C.Structure):
+    _fields_ = [("v", C.c_void_p), ("n", C.c_size_t), ("cap", C.c_size_t)]
+
+
+def match_sweep_sparse(pz, Mp, qz, Mq, N, nSparse, pStart=None, qStart=None):
+    """matchSequencesSweepSparse (pbwtMatch.c:501-602): records (ai, bi, start, end, sparse) in callback order"""
+    pz = np.ascontiguousarray(pz, dtype=np.uint8)
+    qz = np.ascontiguousarray(qz, dtype=np.uint8)
+    pa = np.arange(Mp, dtype=np.int32) if pStart is None else np.ascontiguousarray(pStart, dtype=np.int32)
+    qa = np.arange(Mq, dtype=np.int32) if qStart is None else np.ascontiguousarray(qStart, dtype=np.int32)
+    mv = Match5Vec()
+    nomatch = C.c_int64(0)
+    tot = (C.c_int64 * 2)()
+    rc = lib().orc_match_sweep_sparse(C.c_int(Mp), C.c_int(N), _p(pz, C.c_uint8), C.c_size_t(pz.size), _p(pa, C.c_int32),
+                                      C.c_int(Mq), _p(qz, C.c_uint8), C.c_size_t(qz.size), _p(qa, C.c_int32), C.c_int(nSparse),
+                                      C.byref(mv), C.byref(nomatch), tot)
+    assert rc == 0
+    out = np.zeros(mv.n, dtype=MATCH5_DTYPE)
+    if mv.n:
+        C.memmove(out.ctypes.data, mv.v, mv.n * MATCH5_DTYPE.itemsize)
+    lib().orc_free(C.c_void_p(mv.v))
+    return out, nomatch.value, (tot[0], tot[1])
+
+
+def ref_match_sweep_sparse(pz, Mp, qz, Mq, N, nSparse, pStart=None, qStart=None):
+    r = ref()
+    pz = np.ascontiguousarray(pz, dtype=np.uint8)
+    qz = np.ascontiguousarray(qz, dtype=np.uint8)
+    pa = np.arange(Mp, dtype=np.int32) if pStart is None else np.ascontiguousarray(pStart, dtype=np.int32)
+    qa = np.arange(Mq, dtype=np.int32) if qStart is None else np.ascontiguousarray(qStart, dtype=np.int32)
+    ptr = C.c_void_p()
+    r.ref_match_sweep_sparse.restype = C.c_long
+    n = r.ref_match_sweep_sparse(C.c_int(Mp), C.c_int(N), _p(pz, C.c_uint8), C.c_long(pz.size), _p(pa, C.c_int32),
+                                 C.c_int(Mq), _p(qz, C.c_uint8), C.c_long(qz.size), _p(qa, C.c_int32), C.c_int(nSparse), C.byref(ptr))
+    out = np.zeros(n, dtype=MATCH5_DTYPE)
+    if n:
+        C.memmove(out.ctypes.data, ptr, n * MATCH5_DTYPE.itemsize)
+    C.CDLL(None).free(ptr)
+    return out
+
+
 def haplotypes(yz, M, N, aFstart=None):
     yz = np.ascontiguousarray(yz, dtype=np.uint8)
     a0 = np.arange(M, dtype=np.int32) if aFstart is None else np.ascontiguousarray(aFstart, dtype=np.int32)

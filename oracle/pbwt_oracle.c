@@ -475,6 +475,122 @@ int orc_match_sweep(int Mp, int N, const uint8_t *pz, size_t pnz, const int32_t 
     return 0;
 }
 
+/* ------------------------------------------------------------------ matchSequencesSweepSparse */
+static void mv5_push(orc_match5vec *v, int ai, int bi, int start, int end, int sparse)
+{
+    if (v->n == v->cap) { v->cap = v->cap ? 2 * v->cap : 1024; v->v = realloc(v->v, v->cap * sizeof(orc_match5)); }
+    orc_match5 m = { ai, bi, start, end, sparse };
+    v->v[v->n++] = m;
+}
+
+/* reportAndUpdate (pbwtMatch.c:452-499): pd/py/pa = the cursor's d, y, a; for a sparse cursor k runs at
+ * 1/nS of the rate: reported starts are nS*d + k%nS, the open end uses k/nS */
+static void orc_report_update(int jj, int k, uint8_t x, int M, const int32_t *pd, const uint8_t *py, const int32_t *pa,
+                              int32_t *f, int32_t *dq, int isSparse, int nS, orc_match5vec *out,
+                              int64_t *nTot, int64_t *totLen, int64_t *nomatch)
+{
+    const int kend = isSparse ? k / nS : k;
+    int iPlus = f[jj];
+    while (++iPlus < M && pd[iPlus] <= dq[jj])
+        if (py[iPlus] == x) { f[jj] = iPlus; return; }
+    const int dj = isSparse ? nS * dq[jj] + k % nS : dq[jj];
+    for (int i = f[jj]; i < iPlus; ++i) mv5_push(out, jj, pa[i], dj, k, isSparse);
+    *nTot += iPlus - f[jj]; *totLen += (int64_t)(k - dj) * (iPlus - f[jj]);
+    int iMinus = f[jj];
+    int dPlus = (iPlus < M) ? pd[iPlus] : kend;
+    int dMinus = pd[iMinus];
+    for (;;) {
+        if (dMinus <= dPlus) {
+            int hit = -1;
+            while (pd[iMinus] <= dMinus)                  /* pd[0] = (k or k/nS)+1 stops this */
+                if (py[--iMinus] == x) hit = iMinus;
+            if (hit >= 0) { f[jj] = hit; dq[jj] = dMinus; return; }
+            dMinus = pd[iMinus];
+        } else {
+            while (iPlus < M && pd[iPlus] <= dPlus) {
+                if (py[iPlus] == x) { f[jj] = iPlus; dq[jj] = dPlus; return; }
+                ++iPlus;
+            }
+            dPlus = (iPlus < M) ? pd[iPlus] : kend;
+            if (!iMinus && iPlus == M) { ++*nomatch; dq[jj] = 1 + kend; return; }
+        }
+    }
+}
+
+int orc_match_sweep_sparse(int Mp, int N, const uint8_t *pz, size_t pnz, const int32_t *pStart,
+                           int Mq, const uint8_t *qz, size_t qnz, const int32_t *qStart, int nSparse,
+                           orc_match5vec *out, int64_t *n_nomatch, int64_t *tot)
+{
+    const int M = Mp, nS = nSparse > 1 ? nSparse : 0;
+    ocursor up, uq;
+    oc_open(&up, Mp, pz, pnz, pStart);
+    oc_open(&uq, Mq, qz, qnz, qStart);
+    int32_t *f = calloc((size_t)Mq, sizeof(int32_t)), *dq = calloc((size_t)Mq, sizeof(int32_t));
+    ocursor *upp = NULL; int32_t **ff = NULL, **dd = NULL; uint8_t *xp = NULL;
+    if (nS) {
+        upp = calloc((size_t)nS, sizeof(ocursor)); ff = calloc((size_t)nS, sizeof(int32_t *)); dd = calloc((size_t)nS, sizeof(int32_t *));
+        for (int kk = 0; kk < nS; ++kk) {                 /* pbwtNakedCursorCreate (M, 0) (pbwtCore.c:402-418) */
+            oc_open(&upp[kk], M, NULL, 0, NULL);
+            ff[kk] = calloc((size_t)Mq, sizeof(int32_t)); dd[kk] = calloc((size_t)Mq, sizeof(int32_t));
+        }
+        xp = malloc((size_t)M);
+    }
+    int64_t nTot = 0, totLen = 0, nomatch = 0;
+    for (int k = 0; k < N; ++k) {
+        const int kk = nS ? k % nS : 0;
+        if (nS) {                                         /* the sparse cursor's column: this site's alleles in ITS order (:537-541) */
+            for (int j = 0; j < M; ++j) xp[up.a[j]] = up.y[j];
+            for (int j = 0; j < M; ++j) upp[kk].y[j] = xp[upp[kk].a[j]];
+        }
+        for (int j = 0; j < Mq; ++j) {
+            const int jj = uq.a[j];
+            const uint8_t xq = uq.y[j];
+            if (up.y[f[jj]] != xq) orc_report_update(jj, k, xq, M, up.d, up.y, up.a, f, dq, 0, nS, out, &nTot, &totLen, &nomatch);
+            if (nS && upp[kk].y[ff[kk][jj]] != xq)
+                orc_report_update(jj, k, xq, M, upp[kk].d, upp[kk].y, upp[kk].a, ff[kk], dd[kk], 1, nS, out, &nTot, &totLen, &nomatch);
+        }
+        up.c = orc_calc_u(M, up.y, up.u);
+        for (int j = 0; j < Mq; ++j) {
+            const int jj = uq.a[j], i = f[jj];
+            f[jj] = uq.y[j] ? up.c + i - up.u[i] : up.u[i];
+            if (f[jj] == M) f[jj] = 0;
+        }
+        if (nS) {
+            ocursor *us = &upp[kk];
+            us->c = orc_calc_u(M, us->y, us->u);
+            for (int j = 0; j < Mq; ++j) {
+                const int jj = uq.a[j], i = ff[kk][jj];
+                ff[kk][jj] = uq.y[j] ? us->c + i - us->u[i] : us->u[i];
+                if (ff[kk][jj] == M) ff[kk][jj] = 0;
+            }
+            orc_step_AD(M, k / nS, us->y, us->a, us->d, us->b, us->e);
+        }
+        oc_forwards_read_AD(&up, k);
+        oc_forwards_read(&uq);
+    }
+    for (int j = 0; j < Mq; ++j) {                        /* dense tails (:577-583) */
+        int jj = uq.a[j], i;
+        mv5_push(out, jj, up.a[f[jj]], dq[jj], N, 0);
+        for (i = f[jj]; ++i < M && up.d[i] <= dq[jj]; ) mv5_push(out, jj, up.a[i], dq[jj], N, 0);
+        nTot += i - f[jj]; totLen += (int64_t)(N - dq[jj]) * (i - f[jj]);
+    }
+    for (int kk = 0; kk < nS; ++kk)                       /* sparse tails (:585-594) */
+        for (int j = 0; j < Mq; ++j) {
+            int jj = uq.a[j], i;
+            const int dj = nS * dd[kk][jj] + kk;
+            mv5_push(out, jj, upp[kk].a[ff[kk][jj]], dj, N, 1);
+            for (i = ff[kk][jj]; ++i < M && upp[kk].d[i] <= dd[kk][jj]; ) mv5_push(out, jj, upp[kk].a[i], dj, N, 1);
+            nTot += i - ff[kk][jj]; totLen += (int64_t)(N - dd[kk][jj]) * (i - ff[kk][jj]);
+        }
+    if (n_nomatch) *n_nomatch = nomatch;
+    if (tot) { tot[0] = nTot; tot[1] = totLen; }
+    free(f); free(dq);
+    for (int kk = 0; kk < nS; ++kk) { oc_close(&upp[kk]); free(ff[kk]); free(dd[kk]); }
+    free(upp); free(ff); free(dd); free(xp);
+    oc_close(&up); oc_close(&uq);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ -haps (pbwtIO.c:839-857) */
 int orc_haplotypes(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aFstart, uint8_t *out)
 {

@@ -86,6 +86,16 @@ int orc_match_sweep(int Mp, int N, const uint8_t *pz, size_t pnz, const int32_t 
                     int Mq, const uint8_t *qz, size_t qnz, const int32_t *qStart,
                     orc_matchvec *out, int64_t *n_nomatch, int64_t *tot);
 
+/* ---- matchSequencesSweepSparse (pbwtMatch.c:452-602): the dense sweep plus nSparse cursors over the
+ * sites k = kk (mod nSparse), stepped with pbwtCursorForwardsAD(upp[kk], k/nSparse).  Records carry the
+ * isSparse flag of the 5-argument callback; callback order kept (per site and query: dense block, then
+ * sparse block; tails: dense for every query, then each sparse cursor in turn).  nSparse <= 1: dense only. */
+typedef struct { int32_t ai, bi, start, end, sparse; } orc_match5;
+typedef struct { orc_match5 *v; size_t n, cap; } orc_match5vec;
+int orc_match_sweep_sparse(int Mp, int N, const uint8_t *pz, size_t pnz, const int32_t *pStart,
+                           int Mq, const uint8_t *qz, size_t qnz, const int32_t *qStart, int nSparse,
+                           orc_match5vec *out, int64_t *n_nomatch, int64_t *tot);
+
 /* ---- haplotype recovery (-haps, pbwtIO.c:839-857): out[k*M + h] = allele (0/1) ---- */
 int orc_haplotypes(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aFstart, uint8_t *out);
 

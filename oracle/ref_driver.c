@@ -174,6 +174,30 @@ long ref_match_sweep(int Mp, int N, const uint8_t *pz, long pnz, const int32_t *
     return (long)g_n;
 }
 
+
+/* matchSequencesSweepSparse (pbwtMatch.c:501-602) through the reference's own code, 5-field records */
+typedef struct { int ai, bi, start, end, sparse; } ref_match5;
+static ref_match5 *g_rec5; static size_t g_n5, g_cap5;
+static void capture5(int ai, int bi, int start, int end, BOOL isSparse)
+{
+    if (g_n5 == g_cap5) { g_cap5 = g_cap5 ? 2 * g_cap5 : 1024; g_rec5 = realloc(g_rec5, g_cap5 * sizeof(ref_match5)); }
+    ref_match5 m = { ai, bi, start, end, isSparse ? 1 : 0 };
+    g_rec5[g_n5++] = m;
+}
+
+long ref_match_sweep_sparse(int Mp, int N, const uint8_t *pz, long pnz, const int32_t *pStart,
+                            int Mq, const uint8_t *qz, long qnz, const int32_t *qStart, int nSparse, ref_match5 **out)
+{
+    ref_init();
+    PBWT *p = make_panel(Mp, N, pz, pnz, pStart);
+    PBWT *q = make_panel(Mq, N, qz, qnz, qStart);
+    g_rec5 = NULL; g_n5 = g_cap5 = 0;
+    matchSequencesSweepSparse(p, q, nSparse, capture5);
+    pbwtDestroy(p); pbwtDestroy(q);
+    *out = g_rec5;
+    return (long)g_n5;
+}
+
 /* file-level entry points of the reference: used to make .pbwt / -haps goldens */
 int ref_macs_to_pbwt(const char *macs, const char *pbwt_out, const char *sites_out)
 {

@@ -7,6 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 OPT_WITH_D, OPT_SORTED, OPT_WITHIN_HIST, OPT_CHECKSUM, OPT_PACK3, OPT_WITHIN_RECS = 1, 2, 4, 8, 16, 32
 MATCH_DTYPE = np.dtype([("ai", "<i4"), ("bi", "<i4"), ("start", "<i4"), ("end", "<i4")])
+MATCH5_DTYPE = np.dtype([("ai", "<i4"), ("bi", "<i4"), ("start", "<i4"), ("end", "<i4"), ("sparse", "<i4")])
+REPORT5_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
 REPORT_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_int, C.c_int)
 
 
@@ -186,6 +188,27 @@ class Engine:
             out = np.zeros(n.value, MATCH_DTYPE)
             if n.value:
                 C.memmove(out.ctypes.data, rp, n.value * MATCH_DTYPE.itemsize)
+            self._L.pbwtamd_free(rp)
+        return out, nom.value, (tot[0], tot[1])
+
+    def match_sweep_sparse(self, pz, N, qz, Mq, nSparse, pStart=None, qStart=None, callback=None):
+        """matchSequencesSweepSparse: as match_sweep plus nSparse sparse cursors; records carry `sparse`"""
+        pz = np.ascontiguousarray(pz, dtype=np.uint8)
+        qz = np.ascontiguousarray(qz, dtype=np.uint8)
+        pa, qa = _i32(pStart), _i32(qStart)
+        rp = C.c_void_p()
+        n = C.c_int64(0)
+        nom = C.c_int64(0)
+        tot = (C.c_int64 * 2)()
+        fn = REPORT5_FN(callback) if callback else None
+        self._chk(self._L.pbwtamd_match_sweep_sparse(self._h, _p(pz, C.c_uint8), C.c_int64(pz.size), C.c_int(N), _p(pa, C.c_int32),
+                                                     C.c_int(Mq), _p(qz, C.c_uint8), C.c_int64(qz.size), _p(qa, C.c_int32), C.c_int(nSparse),
+                                                     fn, None if callback else C.byref(rp), C.byref(n), C.byref(nom), tot))
+        out = None
+        if not callback:
+            out = np.zeros(n.value, MATCH5_DTYPE)
+            if n.value:
+                C.memmove(out.ctypes.data, rp, n.value * MATCH5_DTYPE.itemsize)
             self._L.pbwtamd_free(rp)
         return out, nom.value, (tot[0], tot[1])
 

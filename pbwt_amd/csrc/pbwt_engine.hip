@@ -43,6 +43,9 @@ struct DevBufs {
     }
 };
 
+// internal option: the caller reads the ring slots of the batch itself (forces the fill on the skeleton path)
+constexpr unsigned OPT_INTERNAL_KEEP_STATES = 0x100u;
+
 struct GraphKey { int with_d, sorted, ring, pair; hipGraphExec_t exec; };
 struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; bool skel = false; };
 
@@ -50,7 +53,7 @@ struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned o
 // sweep's bit columns): the fill writes d | y << 31 and no a — half the consumer stream's bytes (they are what slows the chain)
 static inline bool packed_fill(const Pending &p) {
     static const bool off = getenv("PBWTAMD_NO_PACKED_FILL") != nullptr, no_fuse = getenv("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
-    const unsigned ids = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_LONG_RECS;
+    const unsigned ids = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_LONG_RECS | 0x100u /* OPT_INTERNAL_KEEP_STATES */;
     return !off && !no_fuse && p.skel && (p.opts & PBWTAMD_OPT_WITHIN_HIST) && !(p.opts & ids);
 }
 
@@ -582,7 +585,7 @@ static int flush_pending(pbwtamd_engine *e) {
     const bool with_d = p.opts & PBWTAMD_OPT_WITH_D;
     HIPCHK(hipStreamWaitEvent(e->s2, e->evChain[p.ring], 0));
     static const bool nofill = getenv("PBWTAMD_NOFILL") && atoi(getenv("PBWTAMD_NOFILL"));   // measurement only: results are wrong
-    const unsigned consumers = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS;
+    const unsigned consumers = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS | OPT_INTERNAL_KEEP_STATES;
     const bool packed = packed_fill(p) && !e->fill_steps;
     if (p.skel && !nofill && !e->fill_steps && (p.opts & consumers)) {   // the 7 states between consecutive skeleton states: all blocks and tiles in one launch
         SkFillArgs f;
@@ -1277,6 +1280,189 @@ extern "C" int pbwtamd_match_sweep(pbwtamd_engine *e, const uint8_t *pz, int64_t
         pbwtamd_match *buf = (pbwtamd_match *)malloc(std::max<size_t>(1, all.size()) * sizeof(pbwtamd_match));
         if (!buf) return fail("pbwtamd_match_sweep: out of host memory");
         if (!all.empty()) memcpy(buf, all.data(), all.size() * sizeof(pbwtamd_match));
+        *recs_out = buf; *nrecs_out = (int64_t)all.size();
+    }
+    return 0;
+}
+
+// matchSequencesSweepSparse (pbwtMatch.c:501-602).  Phase A recovers the panel's columns in original
+// haplotype order on the device (the sparse cursors are BUILT from them: pbwtMatch.c:537-541 unsorts the
+// panel column through a[] and gathers it into the sparse cursor's order).  Phase B runs, per batch of
+// sites, the panel chain (read side, with d), the query chain, the nSparse sparse chains (build side,
+// with d, each over the sites = kk mod nSparse) and one thread per query through the batch's sites.
+extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, int64_t pnz, int N, const int32_t *pStart,
+                                          int Mq, const uint8_t *qz, int64_t qnz, const int32_t *qStart, int nSparse,
+                                          pbwtamd_report5_fn report, pbwtamd_match5 **recs_out, int64_t *nrecs_out,
+                                          int64_t *n_nomatch, int64_t *tot_out) {
+    HIPCHK(hipSetDevice(e->device));
+    if ((report ? 1 : 0) + (recs_out ? 1 : 0) != 1) return fail("pbwtamd_match_sweep_sparse: exactly one of report / recs_out must be given");
+    const int nS = nSparse > 1 ? nSparse : 0;
+    const int Mp = e->M, wpc = e->wpc, wpc64 = e->wpc64;
+    if (nS > e->B) return fail("pbwtamd_match_sweep_sparse: nSparse %d exceeds the engine's batch of %d sites", nSparse, e->B);
+    const int Bd = nS ? (e->B / nS) * nS : e->B;             // dense batch: a whole number of sparse rounds
+    const int Bs = nS ? Bd / nS : 0;
+    pbwtamd_engine *eq = nullptr;
+    CHK(pbwtamd_engine_create(&eq, e->device, Mq, e->B, nullptr));
+    struct EngGuard { std::vector<pbwtamd_engine *> v; ~EngGuard() { for (auto *p : v) if (p) pbwtamd_engine_destroy(p); } } guard;
+    guard.v.push_back(eq);
+    std::vector<pbwtamd_engine *> es((size_t)nS, nullptr);
+    for (int kk = 0; kk < nS; ++kk) { CHK(pbwtamd_engine_create(&es[kk], e->device, Mp, Bs + 1, nullptr)); guard.v.push_back(es[kk]); }
+    DevBufs bufs;
+    Packed pk, qk;
+    CHK(packed_upload(e, e->stream, Mp, pz, pnz, N, pk));
+    CHK(packed_upload(eq, eq->stream, Mq, qz, qnz, N, qk));
+    // ---- phase A: original-order bit columns of the whole panel ----
+    uint32_t *orig = nullptr;
+    if (nS) {
+        CHK(bufs.alloc(&orig, (size_t)(N + 1) * wpc));
+        unsigned char *dout; CHK(bufs.alloc(&dout, (size_t)e->B * Mp));
+        CHK(pbwtamd_pass_begin(e, pStart, 0, N));
+        for (int done = 0; done < N;) {
+            const int nb = std::min(e->B, N - done), navail = std::min(nb + 1, N - done);
+            CHK(packed_expand(e, e->stream, pk, Mp, done, navail, (unsigned long long *)e->cols_stage, wpc64));
+            CHK(pbwtamd_pass_advance(e, e->cols_stage, wpc, nb, navail, PBWTAMD_OPT_SORTED));
+            const int *A = ringA(e, e->ring ^ 1);
+            dim3 grid(std::min(64, (Mp + BLOCK - 1) / BLOCK), nb);
+            hipLaunchKernelGGL(unsort_alleles_kernel, grid, dim3(BLOCK), 0, e->stream, A, e->strideA, Mp, dout);
+            dim3 g2(std::min(64, (wpc64 + WAVES - 1) / WAVES), nb);
+            hipLaunchKernelGGL(bytes_to_bits_kernel, g2, dim3(BLOCK), 0, e->stream, (const unsigned char *)dout, Mp, (unsigned long long *)(orig + (size_t)done * wpc), wpc64);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(e->stream));
+            done += nb;
+        }
+        CHK(pbwtamd_pass_end(e, PBWTAMD_OPT_SORTED));
+    }
+    // ---- phase B ----
+    CHK(pbwtamd_pass_begin(e, pStart, 0, N));
+    CHK(pbwtamd_pass_begin(eq, qStart, 0, N));
+    std::vector<int> nTotS((size_t)nS, 0);
+    for (int kk = 0; kk < nS; ++kk) { nTotS[kk] = N > kk ? (N - kk + nS - 1) / nS : 0; CHK(pbwtamd_pass_begin(es[kk], nullptr, 0, nTotS[kk])); }
+    unsigned char *xq; int *invq, *rankdir, *fst[2], *dst[2], *fss[2], *dss[2]; unsigned long long *cnt, *tot; Rec5 *recs = nullptr; size_t recsCap = 0;
+    const size_t BQ = (size_t)e->B * Mq;
+    CHK(bufs.alloc(&xq, BQ)); CHK(bufs.alloc(&invq, BQ)); CHK(bufs.alloc(&cnt, 2 * std::max(BQ, (size_t)Mq)));
+    CHK(bufs.alloc(&rankdir, (size_t)e->B * (wpc64 + 1)));
+    for (int i = 0; i < 2; ++i) {
+        CHK(bufs.alloc(&fst[i], (size_t)Mq)); CHK(bufs.alloc(&dst[i], (size_t)Mq));
+        CHK(bufs.alloc(&fss[i], (size_t)2 * std::max(nS, 1) * Mq)); CHK(bufs.alloc(&dss[i], (size_t)2 * std::max(nS, 1) * Mq));
+    }
+    CHK(bufs.alloc(&tot, (size_t)4));
+    std::vector<unsigned long long *> ycS((size_t)nS, nullptr); std::vector<int *> rdS((size_t)nS, nullptr);
+    for (int kk = 0; kk < nS; ++kk) { CHK(bufs.alloc(&ycS[kk], (size_t)(Bs + 2) * wpc64)); CHK(bufs.alloc(&rdS[kk], (size_t)(Bs + 2) * (wpc64 + 1))); }
+    QsView *dviews = nullptr; CHK(bufs.alloc(&dviews, (size_t)std::max(nS, 1)));
+    std::vector<QsView> hviews((size_t)std::max(nS, 1));
+    hipStream_t st = e->s2;
+    HIPCHK(hipMemsetAsync(fst[0], 0, sizeof(int) * (size_t)Mq, st));       // calloc'ed f[], d[], ff[][], dd[][] (pbwtMatch.c:512-523)
+    HIPCHK(hipMemsetAsync(dst[0], 0, sizeof(int) * (size_t)Mq, st));
+    HIPCHK(hipMemsetAsync(fss[0], 0, sizeof(int) * (size_t)2 * std::max(nS, 1) * Mq, st));
+    HIPCHK(hipMemsetAsync(dss[0], 0, sizeof(int) * (size_t)2 * std::max(nS, 1) * Mq, st));
+    HIPCHK(hipMemsetAsync(tot, 0, 4 * sizeof(unsigned long long), st));
+    std::vector<pbwtamd_match5> all;
+    auto ensure_recs = [&](size_t total) -> int {
+        if (total <= recsCap) return 0;
+        recsCap = total + total / 4 + 1024;
+        return bufs.alloc(&recs, recsCap);
+    };
+    auto deliver = [&](size_t total) -> int {
+        if (!total) return 0;
+        const size_t old = all.size();
+        all.resize(old + total);
+        HIPCHK(hipMemcpyAsync(all.data() + old, recs, total * sizeof(Rec5), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (report) { for (size_t r = old; r < old + total; ++r) report(all[r].ai, all[r].bi, all[r].start, all[r].end, all[r].sparse); all.resize(old); }
+        return 0;
+    };
+    int cur = 0;
+    const int qblocks = (Mq + BLOCK - 1) / BLOCK;
+    for (int done = 0; done < N;) {
+        const int nb = std::min(Bd, N - done);
+        const int navail = std::min(nb + 1, N - done);
+        CHK(packed_expand(e, e->stream, pk, Mp, done, navail, (unsigned long long *)e->cols_stage, wpc64));
+        CHK(packed_expand(eq, eq->stream, qk, Mq, done, navail, (unsigned long long *)eq->cols_stage, eq->wpc64));
+        CHK(pbwtamd_pass_advance(e, e->cols_stage, wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D));
+        CHK(pbwtamd_pass_advance(eq, eq->cols_stage, eq->wpc, nb, navail, PBWTAMD_OPT_SORTED));
+        for (int kk = 0; kk < nS; ++kk) {                  // the sparse cursors' steps that fall into this batch
+            const int ns = nb > kk ? (nb - kk + nS - 1) / nS : 0;
+            hviews[kk] = QsView{nullptr, nullptr, 0, 0, nullptr, nullptr, done / nS};
+            if (!ns) continue;
+            pbwtamd_engine *s = es[kk];
+            const int left = nTotS[kk] - done / nS;        // sparse sites from this batch's first one on
+            const int nav = std::min(std::min(ns + 8, left), s->B + 2);
+            HIPCHK(hipMemcpy2DAsync(s->cols_stage, (size_t)wpc * 4, orig + (size_t)(done + kk) * wpc, (size_t)nS * wpc * 4, (size_t)wpc * 4, (size_t)nav,
+                                    hipMemcpyDeviceToDevice, s->stream));
+            CHK(pbwtamd_pass_advance(s, s->cols_stage, wpc, ns, nav, PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES));
+        }
+        HIPCHK(hipStreamSynchronize(e->stream));
+        HIPCHK(hipStreamSynchronize(eq->stream));
+        const int *A = ringA(e, e->ring ^ 1), *D = ringD(e, e->ring ^ 1), *AQ = ringA(eq, eq->ring ^ 1);
+        dim3 g1(std::min(64, (wpc64 + WAVES - 1) / WAVES), nb);
+        hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, st, A, e->strideA, Mp, e->ycols, wpc64);
+        hipLaunchKernelGGL(qs_rankdir_kernel, dim3(nb), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, wpc64, Mp, rankdir);
+        hipLaunchKernelGGL(qs_unsort_kernel, dim3(std::min(qblocks, 64), nb), dim3(BLOCK), 0, st, AQ, eq->strideA, Mq, xq, invq);
+        for (int kk = 0; kk < nS; ++kk) {
+            const int ns = nb > kk ? (nb - kk + nS - 1) / nS : 0;
+            if (!ns) continue;
+            pbwtamd_engine *s = es[kk];
+            CHK(pbwtamd_sync(s));                          // incl. the fill of the skeleton path
+            const int *As = ringA(s, s->ring ^ 1), *Ds = ringD(s, s->ring ^ 1);
+            dim3 gs(std::min(64, (wpc64 + WAVES - 1) / WAVES), ns);
+            hipLaunchKernelGGL(tags_to_bits_kernel, gs, dim3(BLOCK), 0, st, As, s->strideA, Mp, ycS[kk], wpc64);
+            hipLaunchKernelGGL(qs_rankdir_kernel, dim3(ns), dim3(BLOCK), 0, st, (const unsigned long long *)ycS[kk], wpc64, Mp, rdS[kk]);
+            hviews[kk] = QsView{As, Ds, s->strideA, s->strideD, ycS[kk], rdS[kk], done / nS};
+        }
+        if (nS) HIPCHK(hipMemcpyAsync(dviews, hviews.data(), sizeof(QsView) * (size_t)nS, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * 2 * (size_t)nb * Mq, st));
+        QssArgs g;
+        g.dense = QsView{A, D, e->strideA, e->strideD, e->ycols, rankdir, 0}; g.sparse = dviews; g.wpc64 = wpc64; g.nS = nS;
+        g.xq = xq; g.invq = invq; g.Mp = Mp; g.Mq = Mq; g.kbase = done; g.nsites = nb;
+        g.f_in = fst[cur]; g.dq_in = dst[cur]; g.f_out = fst[cur ^ 1]; g.dq_out = dst[cur ^ 1];
+        g.fs_in = fss[cur]; g.ds_in = dss[cur]; g.fs_out = fss[cur ^ 1]; g.ds_out = dss[cur ^ 1];
+        g.cnt = cnt; g.recs = nullptr; g.tot = tot;
+        hipLaunchKernelGGL((qss_sweep_kernel<0>), dim3(qblocks), dim3(BLOCK), 0, st, g);
+        hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, cnt, 2 * (size_t)nb * Mq, tot + 3, 0ULL);
+        HIPCHK(hipGetLastError());
+        unsigned long long total = 0;
+        HIPCHK(hipMemcpyAsync(&total, tot + 3, sizeof total, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (total) {
+            CHK(ensure_recs((size_t)total));
+            g.recs = recs;
+            hipLaunchKernelGGL((qss_sweep_kernel<1>), dim3(qblocks), dim3(BLOCK), 0, st, g);
+            HIPCHK(hipGetLastError());
+            CHK(deliver((size_t)total));
+        }
+        cur ^= 1;
+        done += nb;
+    }
+    // ---- matches still open at N: the panel cursor for every query, then each sparse cursor in turn (pbwtMatch.c:577-594) ----
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipStreamSynchronize(eq->stream));
+    for (int c = -1; c < nS; ++c) {
+        pbwtamd_engine *s = c < 0 ? e : es[c];
+        if (c >= 0) CHK(pbwtamd_sync(s));
+        const int *A = ringA(s, s->ring), *D = ringD(s, s->ring), *AQ = ringA(eq, eq->ring);
+        const int *fp = c < 0 ? fst[cur] : fss[cur] + (size_t)c * Mq, *dp = c < 0 ? dst[cur] : dss[cur] + (size_t)c * Mq;
+        hipLaunchKernelGGL((qss_tail_kernel<0>), dim3(qblocks), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, nS, std::max(c, 0), c >= 0 ? 1 : 0, fp, dp, cnt, (Rec5 *)nullptr, tot);
+        hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, cnt, (size_t)Mq, tot + 3, 0ULL);
+        HIPCHK(hipGetLastError());
+        unsigned long long total = 0;
+        HIPCHK(hipMemcpyAsync(&total, tot + 3, sizeof total, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        CHK(ensure_recs((size_t)total));
+        hipLaunchKernelGGL((qss_tail_kernel<1>), dim3(qblocks), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, nS, std::max(c, 0), c >= 0 ? 1 : 0, fp, dp, cnt, recs, tot);
+        HIPCHK(hipGetLastError());
+        CHK(deliver((size_t)total));
+    }
+    unsigned long long htot[4];
+    HIPCHK(hipMemcpy(htot, tot, sizeof htot, hipMemcpyDeviceToHost));
+    if (tot_out) { tot_out[0] = (int64_t)htot[0]; tot_out[1] = (int64_t)htot[1]; }
+    if (n_nomatch) *n_nomatch = (int64_t)htot[2];
+    CHK(pbwtamd_pass_end(e, 0));
+    CHK(pbwtamd_pass_end(eq, 0));
+    for (int kk = 0; kk < nS; ++kk) CHK(pbwtamd_pass_end(es[kk], 0));
+    if (recs_out) {
+        pbwtamd_match5 *buf = (pbwtamd_match5 *)malloc(std::max<size_t>(1, all.size()) * sizeof(pbwtamd_match5));
+        if (!buf) return fail("pbwtamd_match_sweep_sparse: out of host memory");
+        if (!all.empty()) memcpy(buf, all.data(), all.size() * sizeof(pbwtamd_match5));
         *recs_out = buf; *nrecs_out = (int64_t)all.size();
     }
     return 0;

@@ -2148,4 +2148,142 @@ __global__ __launch_bounds__(BLOCK) void qs_tail_kernel(const int *A, const int 
     else { int4 *o = recs + cnt[j]; for (int q = f0; q < i; ++q) *o++ = make_int4(jj, A[q] & AMASK, d0, N); }
 }
 
+// ---------------------------------------------------------------------------------------------
+// matchSequencesSweepSparse (pbwtMatch.c:452-602): the query sweep against the panel cursor AND, at
+// site k, against the sparse cursor kk = k % nS (a PBWT of the sites = kk mod nS, stepped with
+// pbwtCursorForwardsAD(.., k/nS)).  One thread per query walks the batch's sites carrying (f, d) for
+// the dense cursor and for each of the nS sparse cursors; counts -> scan -> emit keeps callback order
+// (per site and query rank: dense block, then sparse block).
+struct Rec5 { int ai, bi, start, end, sparse; };
+struct QsView {                                              // one cursor's states for the sites of a batch
+    const int *A; const int *D; size_t strideA, strideD;
+    const unsigned long long *ycols; const int *rankdir;    // sorted bit columns, zero-prefix directory [slot][wpc64+1]
+    int sbase;                                               // sparse cursors: index of the cursor's first step in this batch
+};
+struct QssArgs {
+    QsView dense; const QsView *sparse;                      // sparse[nS] in device memory
+    int wpc64, nS;
+    const unsigned char *xq; const int *invq;                // [site][Mq]
+    int Mp, Mq, kbase, nsites;
+    const int *f_in; const int *dq_in; int *f_out; int *dq_out;            // [Mq]
+    const int *fs_in; const int *ds_in; int *fs_out; int *ds_out;          // [nS][Mq]
+    unsigned long long *cnt;                                 // [site][Mq rank][2]: counts / exclusive offsets (dense, sparse)
+    Rec5 *recs;
+    unsigned long long *tot;                                 // [0] nTot [1] totLen [2] no-match events
+};
+
+// reportAndUpdate (pbwtMatch.c:452-499) for one query at one site against one cursor state
+template <int MODE>
+__device__ __forceinline__ void qss_update(const int *a, const int *d, const unsigned long long *yc, int M, unsigned x, int jj, int k,
+                                           int kend, int nS, int isSparse, int &f, int &dq, unsigned long long *cntslot, Rec5 *recs,
+                                           unsigned long long &nTot, unsigned long long &totLen, unsigned long long &nomatch) {
+#define PY(i) ((unsigned)((yc[(i) >> 6] >> ((i) & 63)) & 1ULL))
+    if (PY(f) == x) return;
+    int iPlus = f;
+    while (++iPlus < M && d[iPlus] <= dq)
+        if (PY(iPlus) == x) { f = iPlus; return; }
+    const int n = iPlus - f;
+    const int dj = isSparse ? nS * dq + k % nS : dq;
+    if (MODE == 0) { *cntslot = (unsigned long long)n; nTot += n; totLen += (unsigned long long)(k - dj) * n; }
+    else { Rec5 *o = recs + *cntslot; for (int i = f; i < iPlus; ++i) { o->ai = jj; o->bi = a[i] & AMASK; o->start = dj; o->end = k; o->sparse = isSparse; ++o; } }
+    int iMinus = f;
+    int dPlus = (iPlus < M) ? d[iPlus] : kend;
+    int dMinus = d[iMinus];
+    for (;;) {
+        if (dMinus <= dPlus) {
+            int hit = -1;
+            while (d[iMinus] <= dMinus) { --iMinus; if (PY(iMinus) == x) hit = iMinus; }
+            if (hit >= 0) { f = hit; dq = dMinus; return; }
+            dMinus = d[iMinus];
+        } else {
+            while (iPlus < M && d[iPlus] <= dPlus) {
+                if (PY(iPlus) == x) { f = iPlus; dq = dPlus; return; }
+                ++iPlus;
+            }
+            dPlus = (iPlus < M) ? d[iPlus] : kend;
+            if (!iMinus && iPlus == M) { ++nomatch; dq = 1 + kend; return; }
+        }
+    }
+#undef PY
+}
+
+__device__ __forceinline__ int qss_lfmap(const unsigned long long *yc, const int *rd, int wpc64, int M, unsigned x, int f) {
+    const unsigned long long wdv = yc[f >> 6];               // pbwtCursorMap (pbwt.h:130-131) with the f == M trap (pbwtMatch.c:552,561)
+    const int uf = rd[f >> 6] + ((f & 63) - __popcll(wdv & ((1ULL << (f & 63)) - 1ULL)));
+    const int c = rd[wpc64];
+    f = x ? c + f - uf : uf;
+    return (f == M) ? 0 : f;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
+    const int jj = blockIdx.x * BLOCK + threadIdx.x;
+    if (jj >= g.Mq) return;
+    const int M = g.Mp, nS = g.nS;
+    int f = g.f_in[jj], dq = g.dq_in[jj];
+    unsigned long long nTot = 0, totLen = 0, nomatch = 0;
+    // the sparse (f, d) pairs live in global memory (nS is a run-time value): working copy in the out arrays
+    if (MODE == 0) for (int kk = 0; kk < nS; ++kk) { g.fs_out[(size_t)kk * g.Mq + jj] = g.fs_in[(size_t)kk * g.Mq + jj]; g.ds_out[(size_t)kk * g.Mq + jj] = g.ds_in[(size_t)kk * g.Mq + jj]; }
+    int fsl = 0, dsl = 0;
+    for (int s = 0; s < g.nsites; ++s) {
+        const int k = g.kbase + s;
+        const unsigned x = g.xq[(size_t)s * g.Mq + jj];
+        const size_t slot = ((size_t)s * g.Mq + g.invq[(size_t)s * g.Mq + jj]) * 2;
+        {
+            const int *a = g.dense.A + (size_t)s * g.dense.strideA, *d = g.dense.D + (size_t)s * g.dense.strideD;
+            const unsigned long long *yc = g.dense.ycols + (size_t)s * g.wpc64;
+            qss_update<MODE>(a, d, yc, M, x, jj, k, k, nS, 0, f, dq, g.cnt + slot, g.recs, nTot, totLen, nomatch);
+            f = qss_lfmap(yc, g.dense.rankdir + (size_t)s * (g.wpc64 + 1), g.wpc64, M, x, f);
+        }
+        if (nS > 1) {
+            const int kk = k % nS;
+            const QsView v = g.sparse[kk];
+            const int t = k / nS - v.sbase;                 // this cursor's slot in its ring
+            const int *a = v.A + (size_t)t * v.strideA, *d = v.D + (size_t)t * v.strideD;
+            const unsigned long long *yc = v.ycols + (size_t)t * g.wpc64;
+            // MODE 1 replays the same walk from the batch's input state
+            int *fp = (MODE == 0 ? g.fs_out : (int *)nullptr), *dp = (MODE == 0 ? g.ds_out : (int *)nullptr);
+            if (MODE == 0) { fsl = fp[(size_t)kk * g.Mq + jj]; dsl = dp[(size_t)kk * g.Mq + jj]; }
+            else if (s < nS) { fsl = g.fs_in[(size_t)kk * g.Mq + jj]; dsl = g.ds_in[(size_t)kk * g.Mq + jj]; }
+            else { fsl = g.fs_out[(size_t)(nS + kk) * g.Mq + jj]; dsl = g.ds_out[(size_t)(nS + kk) * g.Mq + jj]; }
+            qss_update<MODE>(a, d, yc, M, x, jj, k, k / nS, nS, 1, fsl, dsl, g.cnt + slot + 1, g.recs, nTot, totLen, nomatch);
+            fsl = qss_lfmap(yc, v.rankdir + (size_t)t * (g.wpc64 + 1), g.wpc64, M, x, fsl);
+            if (MODE == 0) { fp[(size_t)kk * g.Mq + jj] = fsl; dp[(size_t)kk * g.Mq + jj] = dsl; }
+            else { g.fs_out[(size_t)(nS + kk) * g.Mq + jj] = fsl; g.ds_out[(size_t)(nS + kk) * g.Mq + jj] = dsl; }   // scratch half of the out arrays
+        }
+    }
+    if (MODE == 0) {
+        g.f_out[jj] = f; g.dq_out[jj] = dq;
+        if (nTot) { atomicAdd(g.tot, nTot); atomicAdd(g.tot + 1, totLen); }
+        if (nomatch) atomicAdd(g.tot + 2, nomatch);
+    }
+}
+
+// matches still running at the end of the panel for one cursor (pbwtMatch.c:577-594), in final query
+// order; sparse cursor kk: start nS*d + kk, totLen with the cursor's own d (as the reference)
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void qss_tail_kernel(const int *A, const int *D, const int *AQ, int Mp, int Mq, int N, int nS, int kk, int isSparse,
+                                                        const int *f, const int *dq, unsigned long long *cnt, Rec5 *recs, unsigned long long *tot) {
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= Mq) return;
+    const int jj = AQ[j] & AMASK;
+    const int f0 = f[jj], d0 = dq[jj];
+    int i = f0;
+    while (++i < Mp && D[i] <= d0) {}
+    const int n = i - f0;
+    const int dj = isSparse ? nS * d0 + kk : d0;
+    if (MODE == 0) { cnt[j] = (unsigned long long)n; atomicAdd(tot, (unsigned long long)n); atomicAdd(tot + 1, (unsigned long long)(N - d0) * n); }
+    else { Rec5 *o = recs + cnt[j]; for (int q = f0; q < i; ++q) { o->ai = jj; o->bi = A[q] & AMASK; o->start = dj; o->end = N; o->sparse = isSparse; ++o; } }
+}
+
+// bytes (0/1 per haplotype, original order) -> bit column words; grid (words/4, sites)
+__global__ __launch_bounds__(BLOCK) void bytes_to_bits_kernel(const unsigned char *in, int M, unsigned long long *out, int wpc64) {
+    const int s = blockIdx.y;
+    for (int wd = blockIdx.x * WAVES + wave_id(); wd < wpc64; wd += gridDim.x * WAVES) {
+        const int i = wd * 64 + lane_id();
+        const unsigned long long mk = __ballot(i < M && in[(size_t)s * M + i] != 0);
+        if (lane_id() == 0) out[(size_t)s * wpc64 + wd] = mk;
+    }
+}
+
 }  // namespace pbwtk

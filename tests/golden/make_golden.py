@@ -63,6 +63,33 @@ def mosaic(M, N, seed, kind, qsplit):
     print("wrote", name, "within", len(recs), "qrecs", len(qrecs))
 
 
+def sparse_sweep():
+    """matchSequencesSweepSparse (pbwtMatch.c:501-602) records of the reference: the query splits of two mosaic
+    goldens at nSparse = 2, 3, 4 and a crafted panel with a site where no panel haplotype carries the query's allele
+    (the 'no match to query' branch, dense and sparse)"""
+    out = {}
+    for name in ("mosaic_M70_N150_k1.npz", "mosaic_M300_N400_k0.npz"):
+        g = np.load(os.path.join(HERE, name))
+        M, N, Mq = int(g["M"]), int(g["N"]), int(g["Mq"])
+        for nS in (2, 3, 4):
+            out["%s_s%d" % (name.split("_N")[0], nS)] = oracle.ref_match_sweep_sparse(g["pz"], M - Mq, g["qz"], Mq, N, nS)
+    rng = np.random.default_rng(5)
+    Mp, Mq, N = 20, 4, 31
+    hap = (rng.random((N, Mp + Mq)) < 0.5).astype(np.uint8)
+    for k in (0, 7, 8, 20):
+        hap[k, :Mp] = 0; hap[k, Mp:] = [1, 0, 1, 1]
+    hap[13, :Mp] = 1; hap[13, Mp:] = [0, 0, 1, 0]
+    pz = oracle.ref_build_bitcols(oracle.pack_bitcols(hap[:, :Mp]), Mp, with_d=False)["yz"]
+    qz = oracle.ref_build_bitcols(oracle.pack_bitcols(hap[:, Mp:]), Mq, with_d=False)["yz"]
+    out["nomatch_pz"] = pz; out["nomatch_qz"] = qz
+    out["nomatch_shape"] = np.array([Mp, Mq, N])
+    for nS in (1, 2, 3):
+        out["nomatch_s%d" % nS] = oracle.ref_match_sweep_sparse(pz, Mp, qz, Mq, N, nS)
+    out["nomatch_dense"] = oracle.ref_match_sweep(pz, Mp, qz, Mq, N)
+    np.savez_compressed(os.path.join(HERE, "sparse_sweep.npz"), **out)
+    print("wrote sparse_sweep.npz", {k: len(v) for k, v in out.items()})
+
+
 def merge1():
     tab = "/root/reference/test/merge.1.tab"
     out = os.path.join(HERE, "merge1.pbwt")
@@ -102,3 +129,4 @@ if __name__ == "__main__":
     mosaic(70, 150, 11, 1, 10)       # iid, M not a multiple of 64
     mosaic(300, 400, 5, 0, 40)       # founder mosaic
     mosaic(1100, 260, 6, 0, 100)     # spans two 1024-position tiles
+    sparse_sweep()                   # needs the mosaic goldens above

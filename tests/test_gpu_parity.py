@@ -391,3 +391,39 @@ def test_histogram_and_pack3_consumers_without_ids(amd, orc, packed, M, N, batch
     assert np.array_equal(a, o["aFend"]) and np.array_equal(d, o["d_final"])
     assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
     assert np.array_equal(eng.get_packed(), o["yz"])
+
+
+@pytest.mark.parametrize("Mp,Mq,N,kind,nS,batch", [(8, 3, 10, 1, 2, 4), (50, 7, 61, 0, 3, 16), (200, 20, 150, 0, 4, 32), (64, 10, 33, 1, 5, 10),
+                                                  (300, 25, 100, 0, 2, 512), (40, 6, 50, 1, 1, 16), (3000, 50, 200, 0, 4, 64), (2500, 30, 130, 1, 8, 128)])
+def test_match_sweep_sparse_vs_oracle(amd, orc, Mp, Mq, N, kind, nS, batch):
+    """matchSequencesSweepSparse (pbwtMatch.c:501-602): records incl. the isSparse flag, in callback order, totals"""
+    bits = orc.synth_bitcols(Mp + Mq, N, seed=Mp * 7 + N, kind=kind)
+    hap = orc.unpack_bitcols(bits, Mp + Mq)
+    pz = orc.build_bitcols(orc.pack_bitcols(hap[:, :Mp]), Mp, with_d=False)["yz"]
+    qz = orc.build_bitcols(orc.pack_bitcols(hap[:, Mp:]), Mq, with_d=False)["yz"]
+    want, nomatch, tot = orc.match_sweep_sparse(pz, Mp, qz, Mq, N, nS)
+    eng = amd.Engine(Mp, batch_sites=batch)
+    got, gn, gt = eng.match_sweep_sparse(pz, N, qz, Mq, nS)
+    assert np.array_equal(got, want) and gn == nomatch and tuple(gt) == tuple(tot)
+    if Mp <= 64:                               # callback form delivers the same stream
+        seen = []
+        eng.match_sweep_sparse(pz, N, qz, Mq, nS, callback=lambda a, b, s, e, sp: seen.append((a, b, s, e, sp)))
+        assert seen == [tuple(r) for r in want.tolist()]
+
+
+def test_match_sweep_sparse_golden_and_no_match_branch(amd, orc):
+    """records captured from the reference itself (tests/golden/sparse_sweep.npz), incl. sites where no panel
+    haplotype carries the query's allele; and nSparse larger than the batch is refused"""
+    g = np.load(os.path.join(GOLDEN, "sparse_sweep.npz"))
+    Mp, Mq, N = (int(v) for v in g["nomatch_shape"])
+    eng = amd.Engine(Mp, batch_sites=8)
+    for nS in (1, 2, 3):
+        got, gn, _ = eng.match_sweep_sparse(g["nomatch_pz"], N, g["nomatch_qz"], Mq, nS)
+        assert np.array_equal(got, g["nomatch_s%d" % nS].view(got.dtype).reshape(-1)) and gn > 0
+    m = np.load(os.path.join(GOLDEN, "mosaic_M300_N400_k0.npz"))
+    M, N, Mq = int(m["M"]), int(m["N"]), int(m["Mq"])
+    eng = amd.Engine(M - Mq, batch_sites=64)
+    got, _, _ = eng.match_sweep_sparse(m["pz"], N, m["qz"], Mq, 3)
+    assert np.array_equal(got, g["mosaic_M300_s3"].view(got.dtype).reshape(-1))
+    with pytest.raises(amd.PbwtAmdError):
+        amd.Engine(M - Mq, batch_sites=4).match_sweep_sparse(m["pz"], N, m["qz"], Mq, 9)

@@ -105,3 +105,27 @@ def test_long_within_oracle_vs_reference_text(orc):
     recs = orc.long_within(g["yz"], int(g["M"]), int(g["N"]), 100)
     txt = "".join("MATCH\t%d\t%d\t%d\t%d\t%d\n" % (r["ai"], r["bi"], r["start"], r["end"], r["end"] - r["start"]) for r in recs if r["start"] != r["end"])
     assert txt == open(os.path.join(GOLDEN, "longwithin_M300_L100.txt")).read()
+
+
+def test_sparse_sweep_matches_reference_goldens(orc):
+    """matchSequencesSweepSparse (pbwtMatch.c:501-602): the oracle's restatement against records captured from the
+    reference (tests/golden/sparse_sweep.npz, made by make_golden.py::sparse_sweep), incl. the 'no match to query'
+    branch; nSparse = 1 degenerates to the dense sweep"""
+    g = np.load(os.path.join(GOLDEN, "sparse_sweep.npz"))
+    for name in ("mosaic_M70_N150_k1.npz", "mosaic_M300_N400_k0.npz"):
+        m = np.load(os.path.join(GOLDEN, name))
+        M, N, Mq = int(m["M"]), int(m["N"]), int(m["Mq"])
+        for nS in (2, 3, 4):
+            recs, nomatch, tot = orc.match_sweep_sparse(m["pz"], M - Mq, m["qz"], Mq, N, nS)
+            want = g["%s_s%d" % (name.split("_N")[0], nS)]
+            assert np.array_equal(recs, want.view(recs.dtype).reshape(-1)) and tot[0] == len(recs)
+    Mp, Mq, N = (int(v) for v in g["nomatch_shape"])
+    for nS in (1, 2, 3):
+        recs, nomatch, tot = orc.match_sweep_sparse(g["nomatch_pz"], Mp, g["nomatch_qz"], Mq, N, nS)
+        want = g["nomatch_s%d" % nS]
+        assert np.array_equal(recs, want.view(recs.dtype).reshape(-1))
+        assert nomatch > 0
+    dense, nomatch_d, _ = orc.match_sweep(g["nomatch_pz"], Mp, g["nomatch_qz"], Mq, N)
+    s1 = orc.match_sweep_sparse(g["nomatch_pz"], Mp, g["nomatch_qz"], Mq, N, 1)[0]
+    assert np.array_equal(dense, g["nomatch_dense"].view(dense.dtype).reshape(-1))
+    assert len(s1) == len(dense) and all(np.array_equal(s1[f], dense[f]) for f in ("ai", "bi", "start", "end")) and not s1["sparse"].any()
