@@ -211,6 +211,23 @@ int ref_macs_to_pbwt(const char *macs, const char *pbwt_out, const char *sites_o
     return 0;
 }
 
+/* -checkpoint n -readMacs f (pbwtIO.c:27,158-168,481): the reference writes check_A / check_B .pbwt and .sites into the
+ * current directory every n sites; run inside `dir` */
+int ref_macs_checkpoint(const char *macs, int n, const char *dir)
+{
+    ref_init();
+    char cwd[4096];
+    if (!getcwd(cwd, sizeof cwd)) return -1;
+    FILE *fp = fopen(macs, "r"); if (!fp) return -2;
+    if (chdir(dir)) { fclose(fp); return -3; }
+    nCheckPoint = n;
+    PBWT *p = pbwtReadMacs(fp); fclose(fp);
+    nCheckPoint = 0;
+    pbwtDestroy(p);
+    if (chdir(cwd)) return -4;
+    return 0;
+}
+
 int ref_vcfq_to_pbwt(const char *vcfq, const char *pbwt_out, const char *sites_out)
 {
     ref_init();

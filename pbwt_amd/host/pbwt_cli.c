@@ -1,6 +1,6 @@
 /* pbwt_cli.c — `pbwt` command interpreter for the hot-path subset of the reference's CLI
  * (pbwtMain.c:276-494): a sequence of "-command args" applied in order to one current panel.
- * Supported: -check -stats -log -read -readSites -readAll -readMacs -write -writeSites -writeAll
+ * Supported: -check -stats -log -checkpoint -read -readSites -readAll -readMacs -write -writeSites -writeAll
  * -haps -maxWithin -longWithin -matchDynamic -siteInfo -subsample -buildReverse -writeReverse -readReverse.  Everything else: "not on the accelerated
  * path of this build". */
 #include "pbwt_host.h"
@@ -21,7 +21,7 @@ int main (int argc, char *argv[])
   --argc ; ++argv ;
   if (!argc)
     { fprintf (stderr, "Program: pbwt (MI355X hot-path build, pbwt_amd)\nUsage: pbwt [ -<command> [options]* ]+\n"
-	       "Commands: -check -stats -log <file> -read <file> -readSites <file> -readAll <root> -readMacs <file>\n"
+	       "Commands: -check -stats -log <file> -checkpoint <n> -read <file> -readSites <file> -readAll <root> -readMacs <file>\n"
 	       "          -write <file> -writeSites <file> -writeAll <root> -haps <file> -maxWithin -longWithin <L>\n"
 	       "          -matchDynamic <file> -siteInfo <file> <kmin> <kmax> -subsample <start> <n>\n"
 	       "          -buildReverse -writeReverse <file> -readReverse <file>\n") ;
@@ -41,6 +41,8 @@ int main (int argc, char *argv[])
 	{ NEEDP ; fp = openOrDie (argv[1], "readSites", "r") ; panelReadSites (p, fp) ; fclose (fp) ; argc -= 2 ; argv += 2 ; }
       else if (!strcmp (argv[0], "-readAll") && argc > 1)
 	{ if (p) panelDestroy (p) ; p = panelReadAll (argv[1]) ; argc -= 2 ; argv += 2 ; }
+      else if (!strcmp (argv[0], "-checkpoint") && argc > 1)
+	{ nCheckPoint = atoi (argv[1]) ; argc -= 2 ; argv += 2 ; }
       else if (!strcmp (argv[0], "-readMacs") && argc > 1)
 	{ if (p) panelDestroy (p) ; fp = openOrDie (argv[1], "readMacs", "r") ; p = panelReadMacs (fp) ; fclose (fp) ; argc -= 2 ; argv += 2 ; }
       else if (!strcmp (argv[0], "-write") && argc > 1)

@@ -190,6 +190,28 @@ static char *word (FILE *fp, char *buf, int cap)
   buf[n] = 0 ; return buf ;
 }
 
+int nCheckPoint = 0 ;
+
+/* extend the panel by the parsed columns [*built, n): the device build continues from the cursor the previous chunk
+ * ended with (aFend), the new pack3 bytes are appended (runs never span columns) */
+static void buildMore (Panel *p, pbwtamd_engine *e, const uint32_t *cols, int wpc, int n, int *built)
+{
+  if (!p->aFend) p->aFend = xalloc (sizeof (int) * p->M) ;
+  if (n > *built || !*built)
+    { uint8_t *yz = 0 ; int64_t nz = 0 ;
+      int *start = *built ? xalloc (sizeof (int) * p->M) : p->aFstart ;
+      if (*built) memcpy (start, p->aFend, sizeof (int) * p->M) ;
+      if (pbwtamd_build (e, cols + (size_t) *built * wpc, wpc, n - *built, 0, start, &yz, &nz, p->aFend, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+      if (*built) free (start) ;
+      if (!p->yz) { p->yz = yz ; p->nz = nz ; }
+      else
+	{ p->yz = realloc (p->yz, (size_t) (p->nz + nz) + 1) ; if (!p->yz) die ("out of memory extending the panel") ;
+	  memcpy (p->yz + p->nz, yz, (size_t) nz) ; p->nz += nz ; pbwtamd_free (yz) ;
+	}
+    }
+  p->N = n ; *built = n ;
+}
+
 Panel *panelReadMacs (FILE *fp)
 {
   char w[256] ;
@@ -206,6 +228,7 @@ Panel *panelReadMacs (FILE *fp)
   pbwtamd_engine *e = engineFor (M) ;
   const int wpc = pbwtamd_engine_wpc (e) ;
   size_t cap = 1024, n = 0 ;
+  int built = 0 ;
   uint32_t *cols = xalloc (cap * wpc * sizeof (uint32_t)) ;
   p->sites = xalloc (cap * sizeof (HostSite)) ;
   while (!feof (fp) && !strcmp (word (fp, w, 256), "SITE:"))
@@ -222,10 +245,14 @@ Panel *panelReadMacs (FILE *fp)
       if (feof (fp)) break ;
       if (getc (fp) != '\n') die ("end of line error for MaCS SITE %d", number) ;
       ++n ;
+      if (nCheckPoint && !(n % nCheckPoint))		/* pbwtIO.c:481 -> pbwtCheckPoint (pbwtIO.c:158-168) */
+	{ static int isA = 1 ;
+	  buildMore (p, e, cols, wpc, (int) n, &built) ;
+	  panelWriteAll (p, isA ? "check_A" : "check_B") ;
+	  isA = !isA ;
+	}
     }
-  p->N = (int) n ;
-  p->aFend = xalloc (sizeof (int) * M) ;
-  if (pbwtamd_build (e, cols, wpc, p->N, 0, p->aFstart, &p->yz, &p->nz, p->aFend, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+  buildMore (p, e, cols, wpc, (int) n, &built) ;
   free (cols) ;
   fprintf (logFile, "read MaCS file: M, N are\t%d\t%d\n", M, p->N) ;
   return p ;

@@ -36,6 +36,7 @@ void panelReadSites (Panel *p, FILE *fp) ;	/* pbwtReadSites, pbwtIO.c:232-276 */
 void panelWriteSites (Panel *p, FILE *fp) ;	/* pbwtWriteSites, pbwtIO.c:59-77 */
 Panel *panelReadAll (const char *root) ;	/* pbwtReadAll, pbwtIO.c:408-422 (.pbwt + .sites) */
 void panelWriteAll (Panel *p, const char *root) ;	/* pbwtWriteAll, pbwtIO.c:134-144 */
+extern int nCheckPoint ;			/* -checkpoint n: write check_A/check_B .pbwt + .sites every n sites while reading (pbwtIO.c:27,158-168) */
 Panel *panelReadMacs (FILE *fp) ;		/* pbwtReadMacs, pbwtIO.c:426-492 */
 void panelWriteHaplotypes (FILE *fp, Panel *p) ;	/* pbwtWriteHaplotypes, pbwtIO.c:839-857 */
 void panelLongMatches (Panel *p, int L) ;	/* pbwtLongMatches, pbwtMatch.c:148-183 (L == 0: maximal) */

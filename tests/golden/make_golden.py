@@ -119,6 +119,13 @@ def macs_small():
     assert ref.ref_macs_to_pbwt(path.encode(), os.path.join(HERE, "macs_small.pbwt").encode(),
                                 os.path.join(HERE, "macs_small.sites").encode()) == 0
     assert ref.ref_build_reverse(os.path.join(HERE, "macs_small.pbwt").encode(), os.path.join(HERE, "macs_small.reverse.pbwt").encode()) == 0
+    # -checkpoint 50: the reference drops check_A (50 sites) and check_B (100 sites) into the working directory
+    import tempfile, shutil
+    with tempfile.TemporaryDirectory() as td:
+        assert ref.ref_macs_checkpoint(path.encode(), 50, td.encode()) == 0
+        for ab in "AB":
+            for ext in ("pbwt", "sites"):
+                shutil.copy(os.path.join(td, "check_%s.%s" % (ab, ext)), os.path.join(HERE, "macs_small.check_%s.%s" % (ab, ext)))
     print("wrote macs_small.*")
 
 

@@ -16,8 +16,8 @@ def cli():
     return pbwt_amd.build_cli()
 
 
-def run(cli, *args, check=True):
-    r = subprocess.run([cli] + [str(a) for a in args], capture_output=True, text=True)
+def run(cli, *args, check=True, cwd=None):
+    r = subprocess.run([cli] + [str(a) for a in args], capture_output=True, text=True, cwd=cwd)
     if check:
         assert r.returncode == 0, r.stderr
     return r
@@ -62,6 +62,21 @@ def test_readMacs_write_matches_reference_bytes(cli, tmp_path):
     run(cli, "-readMacs", os.path.join(GOLDEN, "macs_small.macs"), "-write", out, "-writeSites", sites)
     assert open(out, "rb").read() == open(os.path.join(GOLDEN, "macs_small.pbwt"), "rb").read()
     assert open(sites).read() == open(os.path.join(GOLDEN, "macs_small.sites")).read()
+
+
+@pytest.mark.gpu
+def test_checkpoint_files_match_reference_bytes(cli, tmp_path):
+    """-checkpoint n (pbwtIO.c:27,158-168,481): check_A / check_B .pbwt + .sites dropped into the working directory
+    every n sites, alternating; bytes as the reference writes them, and the final panel unchanged"""
+    out = tmp_path / "m.pbwt"
+    run(cli, "-checkpoint", 50, "-readMacs", os.path.join(GOLDEN, "macs_small.macs"), "-write", out, cwd=tmp_path)
+    for ab in "AB":
+        assert open(tmp_path / ("check_%s.pbwt" % ab), "rb").read() == open(os.path.join(GOLDEN, "macs_small.check_%s.pbwt" % ab), "rb").read()
+        assert open(tmp_path / ("check_%s.sites" % ab)).read() == open(os.path.join(GOLDEN, "macs_small.check_%s.sites" % ab)).read()
+    assert open(out, "rb").read() == open(os.path.join(GOLDEN, "macs_small.pbwt"), "rb").read()
+    # a checkpoint is a complete panel of the first n sites
+    r = run(cli, "-read", tmp_path / "check_A.pbwt", "-readSites", tmp_path / "check_A.sites", "-haps", tmp_path / "a.haps")
+    assert len(open(tmp_path / "a.haps").read().splitlines()) == 50
 
 
 @pytest.mark.gpu
