@@ -95,6 +95,7 @@ struct pbwtamd_engine {
     unsigned char *keysR[2] = {nullptr, nullptr};         // per ring: the keys of states 0, 8, 16, ... of the batch ([B/8+1][Mpad]), kept for the fill
     int2 *saveR[2] = {nullptr, nullptr}; size_t strideS = 0;  // per ring and round: scan[W][256] {before, carry}, total[256] (stride in int2)
     hipEvent_t tev[16] = {}; long long tev_n = 0; int thr_rounds = 32, thr_depth = 2;   // host throttle: an event every thr_rounds rounds, host at most thr_depth events ahead
+    int *rankdirS = nullptr;                // read-side skeleton: zero-prefix directories of the batch's sorted columns [B+2][wpc64+1]
     bool keys_ready[2] = {false, false};     // slot-0 keys of the ring delivered by the previous batch's last round
     bool fill_steps = false;                // PBWTAMD_FILL_STEPS=1: fill with 14 batched single-site launches instead of skel_fill_kernel
     int Wt = 0, skEPT = 4;                  // skeleton tiles: 256*skEPT positions, Wt of them; PBWTAMD_SKT=512|1024
@@ -133,7 +134,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->summF, (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->skT, e->cols_stage, e->ycols, e->colBytes,
+    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->summF, (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->rankdirS, (void *)e->skT, e->cols_stage, e->ycols, e->colBytes,
                     e->blockCount, e->scal, e->hist, e->csum, e->recs, e->yz};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -218,6 +219,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             }
         }
         ALLOC(e->skT, (size_t)(e->Wt + 1) * SKK * sizeof(int2));
+        ALLOC(e->rankdirS, (size_t)(e->B + 2) * (e->wpc64 + 1) * sizeof(int));
     }
 #undef ALLOC
     HIPCHK(hipMemsetAsync(e->A, 0, 2 * slots * e->strideA * sizeof(int), e->stream));
@@ -669,11 +671,19 @@ static void skel_transpose(pbwtamd_engine *e, hipStream_t st, uint32_t *xT, cons
     hipLaunchKernelGGL(transpose32_kernel, gt, dim3(BLOCK), 0, st, cols, e->wpc, nvalid, xT, e->strideX, e->Mpad);
 }
 
-static int skel_prepare(pbwtamd_engine *e, int r, const uint32_t *cols, int nb, int navail) {
+static int skel_prepare(pbwtamd_engine *e, int r, const uint32_t *cols, int nb, int navail, bool sorted) {
     const int nvalid = std::min(navail, e->n_total - e->k_cur);
-    skel_transpose(e, e->stream, e->xTr[r], cols, nb, nvalid);
-    if (!e->keys_ready[r])
-        hipLaunchKernelGGL(skel_keys_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, ringA(e, r), (const uint32_t *)e->xTr[r], 0, e->M, e->keysR[r]);
+    if (sorted) {                                          // read side: keys of every round from the sorted columns (LF-mapping), slot 0 tagged by position
+        const unsigned long long *yc = (const unsigned long long *)cols;
+        hipLaunchKernelGGL(qs_rankdir_kernel, dim3(nb), dim3(BLOCK), 0, e->stream, yc, e->wpc64, e->M, e->rankdirS);
+        hipLaunchKernelGGL(skel_keys_sorted_kernel, dim3((e->M + BLOCK - 1) / BLOCK, nb / 8), dim3(BLOCK), 0, e->stream, yc, e->wpc64,
+                           (const int *)e->rankdirS, e->M, e->keysR[r], (size_t)e->Mpad);
+        if (!e->keys_ready[r]) hipLaunchKernelGGL(skel_tag_sorted_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, ringA(e, r), yc, e->M);
+    } else {
+        skel_transpose(e, e->stream, e->xTr[r], cols, nb, nvalid);
+        if (!e->keys_ready[r])
+            hipLaunchKernelGGL(skel_keys_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, ringA(e, r), (const uint32_t *)e->xTr[r], 0, e->M, e->keysR[r]);
+    }
     e->keys_ready[r] = false;
     HIPCHK(hipGetLastError());
     return 0;
@@ -681,7 +691,7 @@ static int skel_prepare(pbwtamd_engine *e, int r, const uint32_t *cols, int nb, 
 
 // rounds [s_from, s_to) of the batch; `direct`: the batch's last round scatters straight into slot 0
 // (and the slot-0 keys) of the other ring, where the next batch starts
-static int skel_rounds(pbwtamd_engine *e, int r, int nb, int navail, int s_from, int s_to, bool direct) {
+static int skel_rounds(pbwtamd_engine *e, int r, const uint32_t *cols, bool sorted, int nb, int navail, int s_from, int s_to, bool direct) {
     int *A = ringA(e, r), *D = ringD(e, r);
     const int nvalid = std::min(navail, e->n_total - e->k_cur);
     unsigned char *kb = e->keysR[r];
@@ -702,6 +712,7 @@ static int skel_rounds(pbwtamd_engine *e, int r, int nb, int navail, int s_from,
         g.scan = sv; g.total = reinterpret_cast<int *>(sv + (size_t)W * SKK);
         g.has_next = (e->k_cur + site + 8 < e->n_total) && (site + 8 < nvalid);
         g.xTnext = xT + (size_t)((site + 8) / 32) * e->strideX; g.shift_next = (site + 8) % 32;
+        g.ycnext = sorted ? (const unsigned long long *)cols + (size_t)(site + 8) * e->wpc64 : nullptr;
         g.k = e->k_cur + site;
         if (e->skEPT == 1) launch_skel_round<1>(e, g, two); else if (e->skEPT == 2) launch_skel_round<2>(e, g, two); else launch_skel_round<4>(e, g, two);
         if (last) e->keys_ready[r ^ 1] = g.has_next != 0;
@@ -741,7 +752,8 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         const int left = ncols_avail - done;               // columns available from bc on
         const int remaining = e->n_total - e->k_cur;
         const int L = (nb + 1) / 2;
-        const bool skel = e->skel && !sorted && with_d && (nb % 8 == 0) && left >= std::min(nb + 8, remaining);
+        static const bool skel_read = !(getenv("PBWTAMD_SKEL_READ") && !atoi(getenv("PBWTAMD_SKEL_READ")));
+        const bool skel = e->skel && with_d && (nb % 8 == 0) && (sorted ? skel_read && left >= std::min(nb + 1, remaining) : left >= std::min(nb + 8, remaining));
         const bool pair = !skel && e->pair && !sorted && (e->T == 256 || e->T == 1024 || e->T == 2048 || e->T == 4096) && left >= std::min(2 * L + 2, remaining);
         if (!skel) {
             CHK(ensure_prepared(e, bc, sorted, with_d, pair, left));
@@ -761,18 +773,18 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         if (skel) {
             // ring r's consumers (incl. the fill that read xTr[r], keysR[r], saveR[r]) were waited for before slot 0 of ring r was written
             e->xT = e->xTr[r];
-            CHK(skel_prepare(e, r, bc, nb, left));
+            CHK(skel_prepare(e, r, bc, nb, left, sorted));
             // the other stream's work is enqueued once all but the last round of this batch are (measured: better than right away)
             static const bool early_flush = getenv("PBWTAMD_EARLY_FLUSH") != nullptr;
             const int nr = nb / 8, head = early_flush ? std::min(4, nr - 1) : nr - 1;
-            CHK(skel_rounds(e, r, nb, left, 0, head, true));
+            CHK(skel_rounds(e, r, bc, sorted, nb, left, 0, head, true));
             // consumers of the PREVIOUS batch (other ring) are enqueued now, beside this batch's chain
             CHK(flush_pending(e));
             // the last round scatters straight into slot 0 of the other ring, once its readers are done
             static const bool no_direct = getenv("PBWTAMD_NO_DIRECT") != nullptr;
-            CHK(skel_rounds(e, r, nb, left, head, nr - 1, !no_direct));
+            CHK(skel_rounds(e, r, bc, sorted, nb, left, head, nr - 1, !no_direct));
             if (e->consRecorded[r ^ 1]) HIPCHK(hipStreamWaitEvent(e->stream, e->evCons[r ^ 1], 0));
-            CHK(skel_rounds(e, r, nb, left, nr - 1, nr, !no_direct));
+            CHK(skel_rounds(e, r, bc, sorted, nb, left, nr - 1, nr, !no_direct));
             if (no_direct) {
                 HIPCHK(hipMemcpyAsync(ringA(e, r ^ 1), A + (size_t)nb * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->stream));
                 HIPCHK(hipMemcpyAsync(ringD(e, r ^ 1), D + (size_t)nb * e->strideD, sizeof(int) * e->strideD, hipMemcpyDeviceToDevice, e->stream));
@@ -1223,9 +1235,9 @@ extern "C" int pbwtamd_match_sweep(pbwtamd_engine *e, const uint8_t *pz, int64_t
         const int navail = std::min(nb + 1, N - done);
         CHK(packed_expand(e, e->stream, pk, Mp, done, navail, (unsigned long long *)e->cols_stage, e->wpc64));
         CHK(packed_expand(eq, eq->stream, qk, Mq, done, navail, (unsigned long long *)eq->cols_stage, eq->wpc64));
-        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D));
+        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES));
         CHK(pbwtamd_pass_advance(eq, eq->cols_stage, eq->wpc, nb, navail, PBWTAMD_OPT_SORTED));
-        HIPCHK(hipStreamSynchronize(e->stream));
+        CHK(pbwtamd_sync(e));                              // every state of the batch is in the ring (incl. the fill of the skeleton path)
         HIPCHK(hipStreamSynchronize(eq->stream));
         const int *A = ringA(e, e->ring ^ 1), *D = ringD(e, e->ring ^ 1), *AQ = ringA(eq, eq->ring ^ 1);
         dim3 g1(std::min(64, (e->wpc64 + WAVES - 1) / WAVES), nb);
@@ -1378,7 +1390,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         const int navail = std::min(nb + 1, N - done);
         CHK(packed_expand(e, e->stream, pk, Mp, done, navail, (unsigned long long *)e->cols_stage, wpc64));
         CHK(packed_expand(eq, eq->stream, qk, Mq, done, navail, (unsigned long long *)eq->cols_stage, eq->wpc64));
-        CHK(pbwtamd_pass_advance(e, e->cols_stage, wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D));
+        CHK(pbwtamd_pass_advance(e, e->cols_stage, wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES));
         CHK(pbwtamd_pass_advance(eq, eq->cols_stage, eq->wpc, nb, navail, PBWTAMD_OPT_SORTED));
         for (int kk = 0; kk < nS; ++kk) {                  // the sparse cursors' steps that fall into this batch
             const int ns = nb > kk ? (nb - kk + nS - 1) / nS : 0;
@@ -1391,7 +1403,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
                                     hipMemcpyDeviceToDevice, s->stream));
             CHK(pbwtamd_pass_advance(s, s->cols_stage, wpc, ns, nav, PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES));
         }
-        HIPCHK(hipStreamSynchronize(e->stream));
+        CHK(pbwtamd_sync(e));
         HIPCHK(hipStreamSynchronize(eq->stream));
         const int *A = ringA(e, e->ring ^ 1), *D = ringD(e, e->ring ^ 1), *AQ = ringA(eq, eq->ring ^ 1);
         dim3 g1(std::min(64, (wpc64 + WAVES - 1) / WAVES), nb);

@@ -753,6 +753,7 @@ struct SkArgs {
     int2 *tbl;                                                  // hist -> scan: [W][256] {count, tail}
     int2 *scan; int *total;                                     // scan -> rank (kept for the fill): [W][256] {keys before the tile, carry}, total[256]
     const uint32_t *xTnext; int shift_next; int has_next;
+    const unsigned long long *ycnext;                           // read side: sorted bit column of the OUTPUT state's site (tag by position); keys are precomputed
     int M, W, k;                                                // k = site of the input state
 };
 
@@ -915,7 +916,7 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
         const bool valid = S + l < g.M;
         av[r] &= AMASK; if (!valid) { dv[r] = 0; key[r] = -1; }
         s_tbl[0][l] = dv[r];
-        nk[r] = (g.has_next && valid) ? ((g.xTnext[av[r]] >> g.shift_next) & 0xffu) : 0u;   // next round's key (bit 0 = the output state's tag)
+        nk[r] = (g.has_next && valid && !g.ycnext) ? ((g.xTnext[av[r]] >> g.shift_next) & 0xffu) : 0u;   // next round's key (bit 0 = the output state's tag)
     }
     int rk[EPT], pl[EPT];
     const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
@@ -988,11 +989,46 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
         else dd = 0;
         const int pos = s_G[ky] + s_before[ky] + rank;
         if (pos == 0) dd = g.k + SKB + 1;                  // sentinel (pbwtCore.c:507 after the 8th site)
-        g.a_out[pos] = av[r] | (int)((nk[r] & 1u) << 31);
-        g.d_out[pos] = dd;
-        g.keys_out[pos] = (unsigned char)nk[r];
+        if (g.ycnext) {                                     // read side: the tag of a position is a bit of the sorted column, the keys were derived from the columns
+            const unsigned tg = g.has_next ? (unsigned)((g.ycnext[pos >> 6] >> (pos & 63)) & 1ULL) : 0u;
+            g.a_out[pos] = av[r] | (int)(tg << 31);
+            g.d_out[pos] = dd;
+        } else {
+            g.a_out[pos] = av[r] | (int)((nk[r] & 1u) << 31);
+            g.d_out[pos] = dd;
+            g.keys_out[pos] = (unsigned char)nk[r];
+        }
     }
     if (w == g.W - 1 && t == 0) g.d_out[g.M] = g.k + SKB + 1;
+}
+
+// READ SIDE: the columns arrive in PBWT order (y_k by position), so the 8-bit key of position i of the
+// state before site k follows the LF-mapping through the 8 columns: bit j = y_{k+j}[p_j], p_0 = i,
+// p_{j+1} = y ? c + p_j - u(p_j) : u(p_j) with u = zeros before p_j (rank directory + popcount).  It
+// depends on the columns only, not on a[]: all rounds of a batch at once.  grid (tiles, rounds).
+__global__ __launch_bounds__(BLOCK) void skel_keys_sorted_kernel(const unsigned long long *ycols, int wpc64, const int *rankdir, int M,
+                                                                unsigned char *keys, size_t strideK) {
+    const int r = blockIdx.y, i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= M) return;
+    int pos = i;
+    unsigned key = 0;
+#pragma unroll
+    for (int j = 0; j < SKB; ++j) {
+        const int site = SKB * r + j;
+        const unsigned long long w = ycols[(size_t)site * wpc64 + (pos >> 6)];
+        const int *rd = rankdir + (size_t)site * (wpc64 + 1);
+        const unsigned bit = (unsigned)((w >> (pos & 63)) & 1ULL);
+        key |= bit << j;
+        const int u = rd[pos >> 6] + ((pos & 63) - __popcll(w & ((1ULL << (pos & 63)) - 1ULL)));
+        pos = bit ? rd[wpc64] + pos - u : u;
+    }
+    keys[(size_t)r * strideK + i] = (unsigned char)key;
+}
+
+// read side: tag slot 0 of a batch with its column (by position)
+__global__ void skel_tag_sorted_kernel(int *a, const unsigned long long *yc, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) a[i] = (a[i] & AMASK) | (int)((unsigned)((yc[i >> 6] >> (i & 63)) & 1ULL) << 31);
 }
 
 // keys (and tags) of a state from the transposed panel: start of a batch

@@ -427,3 +427,23 @@ def test_match_sweep_sparse_golden_and_no_match_branch(amd, orc):
     assert np.array_equal(got, g["mosaic_M300_s3"].view(got.dtype).reshape(-1))
     with pytest.raises(amd.PbwtAmdError):
         amd.Engine(M - Mq, batch_sites=4).match_sweep_sparse(m["pz"], N, m["qz"], Mq, 9)
+
+
+@pytest.mark.parametrize("skel_read", ["1", "0"])
+@pytest.mark.parametrize("M,N,batch,kind", [(3000, 200, 64, 0), (1025, 96, 24, 1), (70001, 80, 40, 0), (2, 33, 8, 1), (300000, 24, 8, 0)])
+def test_read_side_both_chains(amd, orc, skel_read, M, N, batch, kind, monkeypatch):
+    """the read side (ForwardsReadAD over a packed panel, the reference's -read ... -maxWithin path): the skeleton chain
+    with keys derived from the sorted columns through the LF-mapping (default) and the one-site-per-launch chain
+    (PBWTAMD_SKEL_READ=0) — a, d, y at every site, histogram, records, -longWithin against the oracle"""
+    monkeypatch.setenv("PBWTAMD_SKEL_READ", skel_read)
+    bits = orc.synth_bitcols(M, N, seed=3000 + M, kind=kind)
+    yz = orc.build_bitcols(bits, M, with_d=False)["yz"]
+    eng = amd.Engine(M, batch_sites=batch)
+    sw = eng.sweep_AD(yz, N)
+    s = orc.sweep_AD(yz, M, N)
+    for f in ("csum_a", "csum_d", "csum_y"):
+        assert np.array_equal(sw[f], s[f]), "%s differs first at site %d" % (f, int(np.argmax(sw[f] != s[f])))
+    assert np.array_equal(eng.max_within(yz, N, mode="hist"), orc.max_within_hist(yz, M, N)[: N + 1])
+    if M <= 3000:
+        assert np.array_equal(eng.max_within(yz, N, mode="records"), orc.max_within(yz, M, N))
+        assert np.array_equal(eng.long_within(yz, N, 20), orc.long_within(yz, M, N, 20))

@@ -1,0 +1,17 @@
+"""read side (-read x.pbwt -maxWithin -stats): decode + ForwardsReadAD chain + sweep, us per site"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, pbwt_amd as amd
+M, N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000, int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+eng = amd.Engine(M, batch_sites=512)
+buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+eng.synth_device(buf.data_ptr(), 0, N, seed=3, kind=0); eng.sync()
+bits = buf.cpu().numpy().view(np.uint32)
+b = eng.build(bits, with_d=False)
+yz = b["yz"]
+print("panel", M, "x", N, "packed bytes", len(yz))
+for rep in range(3):
+    t0 = time.perf_counter()
+    h = eng.max_within(yz, N, mode="hist")
+    dt = time.perf_counter() - t0
+    print("maxWithin hist: %.1f ms = %.2f us/site, %.3e site*haps/s (reports %d)" % (1e3 * dt, 1e6 * dt / N, M * N / dt, int(h.sum())))
