@@ -190,7 +190,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     ALLOC(e->ctl, 16 * sizeof(int));
     ALLOC(e->ctlblk, sizeof(Ctl));
     if (const char *s = getenv("PBWTAMD_PROFILE")) if (atoi(s)) { ALLOC(e->prof, (size_t)e->W * 8 * sizeof(long long)); HIPCHK(hipMemset(e->prof, 0, (size_t)e->W * 8 * sizeof(long long))); }
-    ALLOC(e->cols_stage, slots * e->wpc * sizeof(uint32_t));
+    ALLOC(e->cols_stage, 2 * (slots + 6) * e->wpc * sizeof(uint32_t));   // two halves of B+8 columns: batch + look-ahead, double-buffered by the host entry points
     ALLOC(e->ycols, slots * e->wpc64 * sizeof(unsigned long long));
     ALLOC(e->colBytes, (slots + 1) * sizeof(unsigned long long));
     ALLOC(e->scal, 8 * sizeof(unsigned long long));
@@ -753,7 +753,8 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         const int remaining = e->n_total - e->k_cur;
         const int L = (nb + 1) / 2;
         static const bool skel_read = !(getenv("PBWTAMD_SKEL_READ") && !atoi(getenv("PBWTAMD_SKEL_READ")));
-        const bool skel = e->skel && with_d && (nb % 8 == 0) && (sorted ? skel_read && left >= std::min(nb + 1, remaining) : left >= std::min(nb + 8, remaining));
+        // the skeleton always carries d (A-only builds run it too: the divergences cost nothing on its critical path)
+        const bool skel = e->skel && (with_d || !sorted) && (nb % 8 == 0) && (sorted ? skel_read && left >= std::min(nb + 1, remaining) : left >= std::min(nb + 8, remaining));
         const bool pair = !skel && e->pair && !sorted && (e->T == 256 || e->T == 1024 || e->T == 2048 || e->T == 4096) && left >= std::min(2 * L + 2, remaining);
         if (!skel) {
             CHK(ensure_prepared(e, bc, sorted, with_d, pair, left));
@@ -948,19 +949,22 @@ extern "C" int pbwtamd_build(pbwtamd_engine *e, const uint32_t *bitcols, int wpc
     if (wpc < (e->M + 31) / 32) return fail("pbwtamd_build: wpc %d too small for M %d", wpc, e->M);
     CHK(pbwtamd_pass_begin(e, aFstart, 0, N));
     const unsigned opts = (with_d ? PBWTAMD_OPT_WITH_D : 0u) | (yz_out ? PBWTAMD_OPT_PACK3 : 0u);
-    int done = 0;
+    int done = 0, half = 0;
     while (done < N) {
         const int nb = std::min(e->B, N - done);
-        const int navail = std::min(nb + 2, N - done);
+        const int navail = std::min(nb + 8, N - done);       // look-ahead: the skeleton chain's radix step spans 8 sites
+        uint32_t *stage = e->cols_stage + (size_t)half * (e->B + 8) * e->wpc;
+        // this half was read by the chain two batches ago (same ring): wait for that chain, not for the one in flight
+        if (e->chainRecorded[e->ring]) HIPCHK(hipEventSynchronize(e->evChain[e->ring]));
         if (wpc == e->wpc)
-            HIPCHK(hipMemcpyAsync(e->cols_stage, bitcols + (size_t)done * wpc, (size_t)navail * wpc * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+            HIPCHK(hipMemcpyAsync(stage, bitcols + (size_t)done * wpc, (size_t)navail * wpc * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
         else {
-            HIPCHK(hipMemsetAsync(e->cols_stage, 0, (size_t)navail * e->wpc * sizeof(uint32_t), e->stream));
-            HIPCHK(hipMemcpy2DAsync(e->cols_stage, (size_t)e->wpc * 4, bitcols + (size_t)done * wpc, (size_t)wpc * 4,
+            HIPCHK(hipMemsetAsync(stage, 0, (size_t)navail * e->wpc * sizeof(uint32_t), e->stream));
+            HIPCHK(hipMemcpy2DAsync(stage, (size_t)e->wpc * 4, bitcols + (size_t)done * wpc, (size_t)wpc * 4,
                                     (size_t)std::min(wpc, e->wpc) * 4, (size_t)navail, hipMemcpyHostToDevice, e->stream));
         }
-        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, opts));
-        HIPCHK(hipStreamSynchronize(e->stream));           // staging buffer is reused
+        CHK(pbwtamd_pass_advance(e, stage, e->wpc, nb, navail, opts));
+        half ^= 1;
         done += nb;
     }
     CHK(pbwtamd_pass_end(e, opts));
@@ -1398,7 +1402,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
             if (!ns) continue;
             pbwtamd_engine *s = es[kk];
             const int left = nTotS[kk] - done / nS;        // sparse sites from this batch's first one on
-            const int nav = std::min(std::min(ns + 8, left), s->B + 2);
+            const int nav = std::min(std::min(ns + 8, left), s->B + 8);
             HIPCHK(hipMemcpy2DAsync(s->cols_stage, (size_t)wpc * 4, orig + (size_t)(done + kk) * wpc, (size_t)nS * wpc * 4, (size_t)wpc * 4, (size_t)nav,
                                     hipMemcpyDeviceToDevice, s->stream));
             CHK(pbwtamd_pass_advance(s, s->cols_stage, wpc, ns, nav, PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES));
