@@ -90,14 +90,12 @@ struct pbwtamd_engine {
     bool skel = true;                       // skeleton + fill (8 sites per round of K1/K2/K3 on the chain, the 7 states between filled beside it); PBWTAMD_SKEL=0: two-site chain
     uint32_t *xT = nullptr; size_t strideX = 0; int xTblocks = 0;   // transposed panel of the batch in flight (= xTr[ring])
     uint32_t *xTr[2] = {nullptr, nullptr}; // one per ring: the fill of batch n reads it while the chain transposes batch n+1
-    int4 *summF = nullptr; int wpadF = 0;  // fill: tile summaries [B/8][wpadF]
-    unsigned char *keys8 = nullptr; int *skT = nullptr;   // skT: hist table of the round in flight, [W][256] {cnt, tail}
+    int *skT = nullptr;                     // hist table of the round in flight, [W][256] {cnt, tail}
     unsigned char *keysR[2] = {nullptr, nullptr};         // per ring: the keys of states 0, 8, 16, ... of the batch ([B/8+1][Mpad]), kept for the fill
     int2 *saveR[2] = {nullptr, nullptr}; size_t strideS = 0;  // per ring and round: scan[W][256] {before, carry}, total[256] (stride in int2)
     hipEvent_t tev[16] = {}; long long tev_n = 0; int thr_rounds = 32, thr_depth = 2;   // host throttle: an event every thr_rounds rounds, host at most thr_depth events ahead
     int *rankdirS = nullptr;                // read-side skeleton: zero-prefix directories of the batch's sorted columns [B+2][wpc64+1]
     bool keys_ready[2] = {false, false};     // slot-0 keys of the ring delivered by the previous batch's last round
-    bool fill_steps = false;                // PBWTAMD_FILL_STEPS=1: fill with 14 batched single-site launches instead of skel_fill_kernel
     int Wt = 0, skEPT = 4;                  // skeleton tiles: 256*skEPT positions, Wt of them; PBWTAMD_SKT=512|1024
     int skn_maxw = 16;                      // two-launch round (rank scans the tile table itself) up to this many tiles; PBWTAMD_SKN_MAXW
     bool summ_pair = false;                 // format of the current tile summaries (two-site keys or single site)
@@ -134,7 +132,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->summF, (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->rankdirS, (void *)e->skT, e->cols_stage, e->ycols, e->colBytes,
+    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->rankdirS, (void *)e->skT, e->cols_stage, e->ycols, e->colBytes,
                     e->blockCount, e->scal, e->hist, e->csum, e->recs, e->yz};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -204,9 +202,6 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         e->strideX = (size_t)e->Mpad; e->xTblocks = (e->B + 8 + 31) / 32 + 1;
         ALLOC(e->xTr[0], (size_t)e->xTblocks * e->strideX * sizeof(uint32_t));
         ALLOC(e->xTr[1], (size_t)e->xTblocks * e->strideX * sizeof(uint32_t));
-        e->wpadF = ((M + BLOCK - 1) / BLOCK + 63) / 64 * 64;
-        ALLOC(e->summF, (size_t)(e->B / 8 + 1) * e->wpadF * sizeof(int4));
-        if (const char *sv = getenv("PBWTAMD_FILL_STEPS")) e->fill_steps = atoi(sv) != 0;
         if (const char *sv = getenv("PBWTAMD_THR_ROUNDS")) e->thr_rounds = atoi(sv);
         if (const char *sv = getenv("PBWTAMD_THR_DEPTH")) e->thr_depth = std::max(1, std::min(atoi(sv), 15));
         for (int i = 0; i < 16; ++i) HIPCHK(hipEventCreateWithFlags(&e->tev[i], hipEventDisableTiming));
@@ -588,8 +583,8 @@ static int flush_pending(pbwtamd_engine *e) {
     HIPCHK(hipStreamWaitEvent(e->s2, e->evChain[p.ring], 0));
     static const bool nofill = getenv("PBWTAMD_NOFILL") && atoi(getenv("PBWTAMD_NOFILL"));   // measurement only: results are wrong
     const unsigned consumers = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS | OPT_INTERNAL_KEEP_STATES;
-    const bool packed = packed_fill(p) && !e->fill_steps;
-    if (p.skel && !nofill && !e->fill_steps && (p.opts & consumers)) {   // the 7 states between consecutive skeleton states: all blocks and tiles in one launch
+    const bool packed = packed_fill(p);
+    if (p.skel && !nofill && (p.opts & consumers)) {   // the 7 states between consecutive skeleton states: all blocks and tiles in one launch
         SkFillArgs f;
         f.A = ringA(e, p.ring); f.D = ringD(e, p.ring); f.strideA = e->strideA; f.strideD = e->strideD;
         f.keys = e->keysR[p.ring]; f.strideK = e->Mpad; f.scan = e->saveR[p.ring]; f.strideS = e->strideS;
@@ -601,22 +596,6 @@ static int flush_pending(pbwtamd_engine *e) {
         if (e->skEPT == 1) hipLaunchKernelGGL((skel_fill_kernel<1>), grid, dim3(BLOCK), dyn, e->s2, f);
         else if (e->skEPT == 2) hipLaunchKernelGGL((skel_fill_kernel<2>), grid, dim3(BLOCK), dyn, e->s2, f);
         else hipLaunchKernelGGL((skel_fill_kernel<4>), grid, dim3(BLOCK), dyn, e->s2, f);
-        HIPCHK(hipGetLastError());
-    }
-    if (p.skel && !nofill && e->fill_steps) {                               // fill the 7 states between consecutive skeleton states, all blocks at once
-        FillArgs f;
-        f.A = ringA(e, p.ring); f.D = ringD(e, p.ring); f.strideA = e->strideA; f.strideD = e->strideD;
-        f.xT = e->xTr[p.ring]; f.strideX = e->strideX; f.summ = e->summF; f.M = e->M;
-        f.W = (e->M + BLOCK - 1) / BLOCK; f.wpad = e->wpadF; f.kbase = p.kbase; f.n_total = e->n_total;
-        dim3 grid(f.W, p.nb / 8);
-        for (int j = 1; j < 8; ++j) {
-            f.j = j;
-            hipLaunchKernelGGL(fill_count_kernel, grid, dim3(BLOCK), 0, e->s2, f);
-            if (f.W <= 256) hipLaunchKernelGGL((fill_step_kernel<1>), grid, dim3(BLOCK), 0, e->s2, f);
-            else if (f.W <= 512) hipLaunchKernelGGL((fill_step_kernel<2>), grid, dim3(BLOCK), 0, e->s2, f);
-            else if (f.W <= 1024) hipLaunchKernelGGL((fill_step_kernel<4>), grid, dim3(BLOCK), 0, e->s2, f);
-            else hipLaunchKernelGGL((fill_step_kernel<16>), grid, dim3(BLOCK), 0, e->s2, f);
-        }
         HIPCHK(hipGetLastError());
     }
     if (p.opts & PBWTAMD_OPT_CHECKSUM) {

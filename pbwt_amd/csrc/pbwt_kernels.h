@@ -1158,105 +1158,6 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// FILL: the seven states between two skeleton states, for ALL blocks of a batch at once.  Launch j
-// (1..7) turns slot 8b+j-1 into slot 8b+j for every block b: grid (tiles of 256, blocks).  Same
-// single-site step as step1_kernel (fold of tile summaries, carry tuple scan, scatter), but the
-// summaries come from a count kernel over the same batch (two launches per level instead of one:
-// this runs beside the chain, throughput matters here, not latency).
-struct FillArgs {
-    int *A; int *D; size_t strideA, strideD;               // ring base (slot 0 of the batch)
-    const uint32_t *xT; size_t strideX;                     // transposed panel blocks of the batch
-    int4 *summ;                                             // [blocks][wpad] {cnt0, last0+1, last1+1, maxd}
-    int j, M, W, wpad, kbase, n_total;
-};
-
-__global__ __launch_bounds__(BLOCK) void fill_count_kernel(FillArgs g) {
-    __shared__ int s_red[WAVES][4];
-    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x, b = blockIdx.y;
-    const int slot = 8 * b + g.j - 1, i = w * BLOCK + t;
-    int c0 = 0, l0 = 0, l1 = 0, md = 0;
-    if (i < g.M) {
-        const int a = g.A[(size_t)slot * g.strideA + i];
-        if (a < 0) l1 = i + 1; else { c0 = 1; l0 = i + 1; }
-        md = g.D[(size_t)slot * g.strideD + i];
-    }
-    c0 = wave_sum(c0); l0 = wave_max(l0); l1 = wave_max(l1); md = wave_max(md);
-    if (lane == 0) { s_red[wv][0] = c0; s_red[wv][1] = l0; s_red[wv][2] = l1; s_red[wv][3] = md; }
-    __syncthreads();
-    if (t == 0) {
-        c0 = 0; l0 = 0; l1 = 0; md = 0;
-        for (int q = 0; q < WAVES; ++q) { c0 += s_red[q][0]; l0 = max(l0, s_red[q][1]); l1 = max(l1, s_red[q][2]); md = max(md, s_red[q][3]); }
-        g.summ[(size_t)b * g.wpad + w] = make_int4(c0, l0, l1, md);
-    }
-}
-
-template <int SPT>
-__global__ __launch_bounds__(BLOCK) void fill_step_kernel(FillArgs g) {
-    constexpr int T = BLOCK;
-    __shared__ Tup s_tup[WAVES];
-    __shared__ int s_red[WAVES][6];
-    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x, b = blockIdx.y;
-    const int slot = 8 * b + g.j - 1, S = w * T, i = S + t, M = g.M, W = g.W;
-    const int k = g.kbase + slot;                          // site of the input state
-    const int *a_in = g.A + (size_t)slot * g.strideA, *d_in = g.D + (size_t)slot * g.strideD;
-    int *a_out = g.A + (size_t)(slot + 1) * g.strideA, *d_out = g.D + (size_t)(slot + 1) * g.strideD;
-    const int4 *sm = g.summ + (size_t)b * g.wpad;
-    int a = a_in[i];
-    const int d = d_in[i];
-    int4 sv[SPT];
-#pragma unroll
-    for (int q = 0; q < SPT; ++q) { const int jn = t + q * BLOCK; sv[q] = (jn < W) ? sm[jn] : make_int4(0, 0, 0, 0); }
-    const bool valid = i < M;
-    const unsigned y = ((unsigned)a) >> 31;
-    a &= AMASK;
-    // allele of this haplotype at the next site = the tag of the output state
-    unsigned tag = 0;
-    if (valid && k + 1 < g.n_total) { const int rel = slot + 1; tag = (g.xT[(size_t)(rel / 32) * g.strideX + a] >> (rel % 32)) & 1u; }
-    int sumBefore = 0, total = 0, l0 = 0, l1 = 0;
-#pragma unroll
-    for (int q = 0; q < SPT; ++q) {
-        const int jn = t + q * BLOCK;
-        total += sv[q].x;
-        if (jn < w) { sumBefore += sv[q].x; l0 = max(l0, sv[q].y); l1 = max(l1, sv[q].z); }
-    }
-    sumBefore = wave_sum(sumBefore); total = wave_sum(total); l0 = wave_max(l0); l1 = wave_max(l1);
-    if (lane == 0) { s_red[wv][0] = sumBefore; s_red[wv][1] = total; s_red[wv][2] = l0; s_red[wv][3] = l1; }
-    __syncthreads();
-    sumBefore = 0; total = 0; l0 = 0; l1 = 0;
-#pragma unroll
-    for (int q = 0; q < WAVES; ++q) { sumBefore += s_red[q][0]; total += s_red[q][1]; l0 = max(l0, s_red[q][2]); l1 = max(l1, s_red[q][3]); }
-    const int Zw = sumBefore, C = total;
-    int m0 = 0, m1 = 0;
-    {
-        const int tl0 = l0 ? (l0 - 1) / T : -1, tl1 = l1 ? (l1 - 1) / T : -1;
-        const int hi0 = l0 ? min((tl0 + 1) * T, S) : 0, hi1 = l1 ? min((tl1 + 1) * T, S) : 0;
-        if (l0 + t < hi0) m0 = d_in[l0 + t];
-        if (l1 + t < hi1) m1 = d_in[l1 + t];
-#pragma unroll
-        for (int q = 0; q < SPT; ++q) { const int jn = t + q * BLOCK; if (jn < w) { if (jn > tl0) m0 = max(m0, sv[q].w); if (jn > tl1) m1 = max(m1, sv[q].w); } }
-    }
-    Tup me = Tup{0, 0, 0, 0, 0};
-    if (valid) { if (y) { me.c1 = 1; me.t0 = d; } else { me.c0 = 1; me.t1 = d; } me.all = d; }
-    m0 = wave_max(m0); m1 = wave_max(m1);
-    if (lane == 0) { s_red[wv][4] = m0; s_red[wv][5] = m1; }
-    Tup tot;
-    const Tup pre = block_scan_tup<true>(me, s_tup, tot);  // (its barrier also publishes s_red[.][4..5])
-    m0 = 0; m1 = 0;
-#pragma unroll
-    for (int q = 0; q < WAVES; ++q) { m0 = max(m0, s_red[q][4]); m1 = max(m1, s_red[q][5]); }
-    const int carry0 = l0 ? m0 : k + 1, carry1 = l1 ? m1 : k + 1;
-    if (valid) {
-        const int pin = y ? (pre.c1 ? pre.t1 : max(carry1, pre.all)) : (pre.c0 ? pre.t0 : max(carry0, pre.all));
-        int dn = max(pin, d);
-        const int P = y ? C + (S - Zw) + pre.c1 : Zw + pre.c0;
-        if (P == 0) dn = k + 2;
-        a_out[P] = a | (int)(tag << 31);
-        d_out[P] = dn;
-    }
-    if (w == W - 1 && t == 0) d_out[M] = k + 2;
-}
-
 // first pair of a pass (or after an odd-length batch): both allele tags of slot 0 from columns k, k+1
 // and the pair summaries from scratch; clears the accumulation buffer of the first launch
 struct Prep2Args { int *a; const int *d; const uint32_t *col0; const uint32_t *col1; int4 *summ; int M, W, wpad, with_d, T; };
