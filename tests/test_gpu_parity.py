@@ -447,3 +447,18 @@ def test_read_side_both_chains(amd, orc, skel_read, M, N, batch, kind, monkeypat
     if M <= 3000:
         assert np.array_equal(eng.max_within(yz, N, mode="records"), orc.max_within(yz, M, N))
         assert np.array_equal(eng.long_within(yz, N, 20), orc.long_within(yz, M, N, 20))
+
+
+def test_chunked_build_from_carried_cursor(amd, orc):
+    """a panel built in chunks, each starting from the previous chunk's aFend (what -checkpoint does): .pbwt bytes
+    concatenate to the one-shot build's, on the skeleton chain (chunks of 64 and 128 sites) and on the fallback (50)"""
+    M, N = 5000, 320
+    bits = orc.synth_bitcols(M, N, seed=77, kind=0)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    for chunk in (64, 128, 50):
+        eng = amd.Engine(M, batch_sites=64)
+        a, yz = None, []
+        for k0 in range(0, N, chunk):
+            b = eng.build(bits[k0:k0 + chunk], with_d=True, aFstart=a)
+            a = b["aFend"]; yz.append(b["yz"])
+        assert np.array_equal(np.concatenate(yz), o["yz"]) and np.array_equal(a, o["aFend"])
