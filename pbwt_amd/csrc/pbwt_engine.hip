@@ -508,7 +508,9 @@ __global__ void pack3_offsets_kernel(unsigned long long *colBytes, size_t n, con
 static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites, bool have_ycols) {
     dim3 g1(std::min(64, (e->wpc64 + WAVES - 1) / WAVES), nsites);
     if (!have_ycols) hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, st, A, e->strideA, e->M, e->ycols, e->wpc64);   // else: emitted by the maxWithin sweep
-    hipLaunchKernelGGL((pack3_kernel<0>), dim3(nsites), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
+    const bool wide = e->wpc64 > 2048;                      // > 131072 haplotypes: 1024 threads per column
+    if (wide) hipLaunchKernelGGL((pack3_kernel<0, 1024>), dim3(nsites), dim3(1024), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
+    else hipLaunchKernelGGL((pack3_kernel<0>), dim3(nsites), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
     // exclusive offsets inside the batch; batch total -> scal[2]
     hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, e->colBytes, (size_t)nsites, e->scal + 2, 0ULL);
     HIPCHK(hipGetLastError());
@@ -532,7 +534,8 @@ static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites
     }
     hipLaunchKernelGGL(pack3_offsets_kernel, dim3((nsites + 255) / 256), dim3(256), 0, st, e->colBytes, (size_t)nsites, (const unsigned long long *)(e->scal + 1),
                        e->scal + 2, e->scal + 1, (unsigned long long)e->yzCap, e->ctl + 2);
-    hipLaunchKernelGGL((pack3_kernel<1>), dim3(nsites), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
+    if (wide) hipLaunchKernelGGL((pack3_kernel<1, 1024>), dim3(nsites), dim3(1024), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
+    else hipLaunchKernelGGL((pack3_kernel<1>), dim3(nsites), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
     hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->scal + 1, (const unsigned long long *)(e->scal + 2), (unsigned long long)e->yzCap, e->ctl + 2);
     HIPCHK(hipGetLastError());
     e->yz_upper += worst;
@@ -637,7 +640,7 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
     Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = W;
     if (W <= 256) hipLaunchKernelGGL((skel_k2_kernel<4, 4>), dim3(SKK / 4), dim3(BLOCK), 0, e->stream, k2);   // one key per wave (16 / 8 keys per workgroup measured slower)
     else if (W <= 1024) hipLaunchKernelGGL((skel_k2_kernel<4, 16>), dim3(SKK / 4), dim3(BLOCK), 0, e->stream, k2);
-    else hipLaunchKernelGGL((skel_k2_kernel<4, 32>), dim3(SKK / 4), dim3(BLOCK), 0, e->stream, k2);
+    else hipLaunchKernelGGL((skel_k2_kernel<2, 32>), dim3(SKK / 2), dim3(128), 0, e->stream, k2);
     hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
 }
 

@@ -817,38 +817,37 @@ __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
 // through LDS (8*KPW-byte row segments: 32-byte sectors at KPW = 4), each wave scans KPW/4 keys
 // with lanes = tiles (TPL consecutive tiles per lane, DPP scan across lanes), and the slab goes back
 // the same way.  Output scan[tile][key] = {keys before the tile, carry (-1: no earlier occurrence)},
-// total[key].  grid = 256 / KPW workgroups.
+// total[key].  grid = 256 / KPW workgroups of KPW waves.
 struct Sk2Args { const int2 *tbl; int2 *scan; int *total; int W; };
 template <int KPW, int TPL>
-__global__ __launch_bounds__(BLOCK) void skel_k2_kernel(Sk2Args g) {
+__global__ __launch_bounds__(KPW * 64) void skel_k2_kernel(Sk2Args g) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
-    constexpr int WP = 64 * TPL + (TPL < 32 ? 1 : 0);       // odd row length: the transposing accesses spread over the LDS banks (64 KB static limit at TPL = 32)
+    constexpr int NT = KPW * 64;                            // one wave per key
+    constexpr int WP = 64 * (TPL + 1);                      // a lane's TPL tiles + one pad entry: lane stride TPL+1 is odd, no LDS bank conflicts
     __shared__ int2 s_v[KPW][WP];
-    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), key0 = blockIdx.x * KPW;
-    constexpr int NIT = 64 * TPL * KPW / BLOCK;              // all loads in flight at once (one round trip, not NIT)
+    const int t = threadIdx.x, lane = lane_id(), kk = t >> 6, key0 = blockIdx.x * KPW;
+    constexpr int NIT = 64 * TPL * KPW / NT;                // = TPL: all loads in flight at once (one round trip, not NIT)
     int2 ld[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-        const int idx = t + i * BLOCK, r = idx / KPW, kk = idx % KPW;
-        ld[i] = (r < g.W) ? g.tbl[(size_t)r * SKK + key0 + kk] : make_int2(0, 0);
+        const int idx = t + i * NT, r = idx / KPW, kq = idx % KPW;
+        ld[i] = (r < g.W) ? g.tbl[(size_t)r * SKK + key0 + kq] : make_int2(0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
-        const int idx = t + i * BLOCK, r = idx / KPW, kk = idx % KPW;
-        s_v[kk][r] = ld[i];
+        const int idx = t + i * NT, r = idx / KPW, kq = idx % KPW;
+        s_v[kq][r + r / TPL] = ld[i];
     }
     __syncthreads();
-#pragma unroll
-    for (int kq = 0; kq < KPW / WAVES; ++kq) {
-        const int kk = kq * WAVES + wv;
+    {
         int c[TPL], tt[TPL];
         int sc = 0, st = 0;                                // this lane's tiles combined
 #pragma unroll
         for (int x = 0; x < TPL; ++x) {
             const int w = lane * TPL + x;
-            const int2 v = (w < g.W) ? s_v[kk][w] : make_int2(0, 0);
+            const int2 v = (w < g.W) ? s_v[kk][lane * (TPL + 1) + x] : make_int2(0, 0);
             c[x] = v.x; tt[x] = v.y;
             st = c[x] ? tt[x] : max(st, tt[x]); sc += c[x];
         }
@@ -860,15 +859,15 @@ __global__ __launch_bounds__(BLOCK) void skel_k2_kernel(Sk2Args g) {
 #pragma unroll
         for (int x = 0; x < TPL; ++x) {
             const int w = lane * TPL + x;
-            if (w < g.W) s_v[kk][w] = make_int2(ec, ec ? et : -1);
+            if (w < g.W) s_v[kk][lane * (TPL + 1) + x] = make_int2(ec, ec ? et : -1);
             et = c[x] ? tt[x] : max(et, tt[x]); ec += c[x];
         }
         if (lane == 63) g.total[key0 + kk] = ic;
     }
     __syncthreads();
-    for (int idx = t; idx < g.W * KPW; idx += BLOCK) {
-        const int r = idx / KPW, kk = idx % KPW;
-        g.scan[(size_t)r * SKK + key0 + kk] = s_v[kk][r];
+    for (int idx = t; idx < g.W * KPW; idx += NT) {
+        const int r = idx / KPW, kq = idx % KPW;
+        g.scan[(size_t)r * SKK + key0 + kq] = s_v[kq][r + r / TPL];
     }
 }
 
@@ -1789,10 +1788,13 @@ __device__ __forceinline__ uint8_t *p3_emit(uint8_t *o, unsigned v, int n) {
 }
 
 // MODE 0: colBytes[col] = encoded size; MODE 1: write bytes at colOffset[col]
-template <int MODE>
-__global__ __launch_bounds__(BLOCK) void pack3_kernel(const unsigned long long *ycols, int wpc64, int M,
+// NT threads per column: the loop over chunks of NT words is a chain of barriers and dependent loads (latency of ONE
+// workgroup, whatever the batch), so wide columns take 1024 threads.
+template <int MODE, int NT = BLOCK>
+__global__ __launch_bounds__(NT) void pack3_kernel(const unsigned long long *ycols, int wpc64, int M,
                                                      unsigned long long *colBytes, uint8_t *out) {
-    __shared__ int s_wi[WAVES];
+    constexpr int NWV = NT / 64;
+    __shared__ int s_wi[NWV];
     __shared__ int s_carry_start;       // start position of the run open at the chunk boundary
     __shared__ int s_carry_bytes;       // bytes emitted so far in this column
     const int col = blockIdx.x;
@@ -1802,7 +1804,7 @@ __global__ __launch_bounds__(BLOCK) void pack3_kernel(const unsigned long long *
     if (threadIdx.x == 0) { s_carry_start = 0; s_carry_bytes = 0; }
     __syncthreads();
     uint8_t *obase = (MODE == 1) ? out + colBytes[col] : nullptr;
-    for (int b = 0; b < nw; b += BLOCK) {
+    for (int b = 0; b < nw; b += NT) {
         const int wd = b + threadIdx.x;
         unsigned long long cur = 0, trans = 0;
         int nbits = 0;
@@ -1822,9 +1824,9 @@ __global__ __launch_bounds__(BLOCK) void pack3_kernel(const unsigned long long *
         int exclT = __shfl_up(incl, 1); if (lane == 0) exclT = -1;
         __syncthreads();
         int preT = -1;
-        for (int q = 0; q < WAVES; ++q) if (q < wv) preT = max(preT, s_wi[q]);
+        for (int q = 0; q < NWV; ++q) if (q < wv) preT = max(preT, s_wi[q]);
         int chunkLast = -1;
-        for (int q = 0; q < WAVES; ++q) chunkLast = max(chunkLast, s_wi[q]);
+        for (int q = 0; q < NWV; ++q) chunkLast = max(chunkLast, s_wi[q]);
         int open = max(max(exclT, preT), -1);
         if (open < 0) open = s_carry_start;                // run opened in an earlier chunk (or at 0)
         // runs closed by this word: one per transition, plus the final run if this word holds M-1
@@ -1842,7 +1844,7 @@ __global__ __launch_bounds__(BLOCK) void pack3_kernel(const unsigned long long *
         if (lane == 63) s_wi[wv] = inc;
         __syncthreads();
         int preB = s_carry_bytes, totB = 0;
-        for (int q = 0; q < WAVES; ++q) { if (q < wv) preB += s_wi[q]; totB += s_wi[q]; }
+        for (int q = 0; q < NWV; ++q) { if (q < wv) preB += s_wi[q]; totB += s_wi[q]; }
         if (MODE == 1 && myBytes) {
             uint8_t *o = obase + preB + inc - myBytes;
             unsigned long long tr = trans; int st = open;

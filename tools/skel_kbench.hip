@@ -52,7 +52,8 @@ static void run(int M, float p1, int reps) {
     float th = timeit("hist", [&] { hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, s, g); });
     auto k2l = [&] {
         if (W <= 256) hipLaunchKernelGGL((skel_k2_kernel<4, 4>), dim3(SKK / 4), dim3(BLOCK), 0, s, k2);   // one key per wave (16 / 8 keys per workgroup measured slower)
-    else hipLaunchKernelGGL((skel_k2_kernel<4, 16>), dim3(SKK / 4), dim3(BLOCK), 0, s, k2);
+        else if (W <= 1024) hipLaunchKernelGGL((skel_k2_kernel<4, 16>), dim3(SKK / 4), dim3(BLOCK), 0, s, k2);
+        else hipLaunchKernelGGL((skel_k2_kernel<2, 32>), dim3(SKK / 2), dim3(128), 0, s, k2);
     };
     float t2 = timeit("k2", k2l);
     float tr = timeit("rank", [&] { hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, s, g); });
