@@ -1572,13 +1572,17 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     // MODE 2 walks g.iters consecutive 256-position blocks per workgroup (at M = 1M one block per workgroup is 2M workgroups
     // per batch: dispatch-bound); the record modes keep one block per workgroup (their offsets are per block)
     constexpr int IT = (MODE == 2) ? ITC : 1;
-    // the own entries of all IT blocks are requested up front (IT x 2 loads in flight per lane: the sweep is a stream)
-    int pre_d[IT], pre_n[IT], pre_a[IT];
+    // every entry is handled as one word d | y << 31 (the packed slots hold exactly that; otherwise d and the tag of a are
+    // merged on load).  The own word and its three neighbours of all IT blocks are requested up front: the first step of
+    // both scans and the stop test of the second are then decided from registers, and 4 x IT loads are in flight per lane.
+    auto WD = [&](int x) -> int { return PACKED ? d[x] : (d[x] | (a[x] & (int)0x80000000)); };
+    int pre_m[IT], pre_0[IT], pre_1[IT], pre_2[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int ii = (blockIdx.x * IT + it) * BLOCK + threadIdx.x;
-        pre_d[it] = (ii < M) ? d[ii] : 0; pre_n[it] = (ii < M) ? d[ii + 1] : 0;
-        pre_a[it] = (!PACKED && ii < M) ? a[ii] : 0;
+        const bool in = ii < M;
+        pre_m[it] = (in && ii > 0) ? WD(ii - 1) : 0; pre_0[it] = in ? WD(ii) : 0;
+        pre_1[it] = in ? WD(ii + 1) : 0; pre_2[it] = (in && ii + 2 <= M) ? WD(ii + 2) : 0;
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -1593,24 +1597,27 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     constexpr int BUDGET = 4;
     bool needUp = false, needDown = false;
     if (i < M) {
-        if constexpr (PACKED) { const int v = pre_d[it]; di = v & 0x7fffffff; yi = (unsigned)v >> 31; dn = pre_n[it] & 0x7fffffff; }
-        else { di = pre_d[it]; yi = (unsigned)pre_a[it] >> 31; dn = pre_n[it]; }
+        di = pre_0[it] & 0x7fffffff; yi = (unsigned)pre_0[it] >> 31; dn = pre_1[it] & 0x7fffffff;
         rep = true;
         if (g.dbg == 2) { /* loads only */ } else
-        if (di <= dn) {
-            int steps = 0;
-            while (DV(d, m + 1) <= di) {
-                if (!fin && YV(a, d, m) == yi) { rep = false; break; }
-                --m;
+        if (di <= dn) {                                     // while (d[m+1] <= d[i]) if (y[m--] == y[i]) skip   (pbwtMatch.c:124-126)
+            int steps = 0, wcur = pre_0[it];                // wcur = the word at m+1
+            for (;;) {
+                if ((wcur & 0x7fffffff) > di) break;
+                const int wm = (m == i - 1) ? pre_m[it] : WD(m);
+                if (!fin && ((unsigned)wm >> 31) == yi) { rep = false; break; }
+                --m; wcur = wm;
                 if (++steps == BUDGET) { needUp = true; break; }
             }
         }
-        if (rep && !needUp && di >= dn) {
-            int steps = 0;
-            while (DV(d, n) <= dn) {
-                if (!fin && YV(a, d, n) == yi) { rep = false; break; }
+        if (rep && !needUp && di >= dn) {                   // while (d[n] <= d[i+1]) if (y[n++] == y[i]) skip    (pbwtMatch.c:127-129)
+            int steps = 0, wn = pre_1[it];
+            for (;;) {
+                if ((wn & 0x7fffffff) > dn) break;
+                if (!fin && ((unsigned)wn >> 31) == yi) { rep = false; break; }
                 ++n;
                 if (++steps == BUDGET) { needDown = true; break; }
+                wn = (n == i + 2) ? pre_2[it] : WD(n);
             }
         }
     }
