@@ -1056,11 +1056,10 @@ template <int EPT>
 __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     constexpr int T = BLOCK * EPT, NC = EPT * WAVES;
     constexpr int NL = (EPT == 4) ? 10 : (EPT == 2) ? 9 : 8;
-    __shared__ short s_raw[NC][SKK], s_lastraw[NC][SKK];    // per chunk and key: count, last local position (-1: none); folded in place level by level
-    __shared__ short s_base[NC][SKK / 2], s_prev[NC][SKK / 2];   // per level: exclusive over the chunks
+    // heap layout: level j (keys of j bits) lives at [2^j, 2^(j+1)), the rank kernel's level 8 at [256, 512)
+    __shared__ short s_rawH[NC][2 * SKK], s_lastH[NC][2 * SKK];  // per chunk: count / last local position (-1) -> levels 1..7 become base / previous position (exclusive over the chunks)
     __shared__ int s_tbl[NL][T];
-    __shared__ int s_b[SKK], s_c[SKK], s_t[SKK], s_G[SKK], s_lower[SKK];
-    __shared__ int s_gw[WAVES], s_lw[WAVES];
+    __shared__ int s_bH[2 * SKK], s_cH[2 * SKK], s_tH[2 * SKK], s_GH[SKK], s_lowH[SKK];
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x, b = blockIdx.y;
     const int S = w * T, k = g.kbase + 8 * b;
     const int *a_in = g.A + (size_t)(8 * b) * g.strideA;
@@ -1077,8 +1076,9 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
         s_tbl[0][l] = dv;
         if (g.pack_y && valid) d_in[i] = dv | (int)(((unsigned)key[r] & 1u) << 31);   // the skeleton slot itself, in the packed form of the other seven
     }
-    { const int2 v = sv[(size_t)w * SKK + t]; s_b[t] = v.x; s_c[t] = v.y; s_t[t] = reinterpret_cast<const int *>(sv + (size_t)g.W * SKK)[t]; }
-    for (int x = t; x < NC * SKK; x += BLOCK) { (&s_raw[0][0])[x] = 0; (&s_lastraw[0][0])[x] = -1; }
+    { const int2 v = sv[(size_t)w * SKK + t]; s_bH[SKK + t] = v.x; s_cH[SKK + t] = v.y; s_tH[SKK + t] = reinterpret_cast<const int *>(sv + (size_t)g.W * SKK)[t]; }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { s_rawH[c][SKK + t] = 0; s_lastH[c][SKK + t] = -1; }
     __syncthreads();
     // ballot refinement bit by bit: after bit j-1 the mask of same-j-key lanes
     short rk[EPT][8], pl[EPT][8];                           // [.][j]: rank inside the chunk, previous same-j-key position in the chunk (-1)
@@ -1093,59 +1093,87 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
             same &= ((key[r] >> bb) & 1) ? bal : ~bal;
             const unsigned long long before = same & lt;
             if (bb < SKB - 1) { rk[r][bb + 1] = (short)__popcll(before); pl[r][bb + 1] = before ? (short)(c * 64 + (63 - __clzll(before))) : (short)-1; }
-            else if (key[r] >= 0 && !before) { s_raw[c][key[r]] = (short)__popcll(same); s_lastraw[c][key[r]] = (short)(c * 64 + (63 - __clzll(same))); }
+            else if (key[r] >= 0 && !before) { s_rawH[c][SKK + key[r]] = (short)__popcll(same); s_lastH[c][SKK + key[r]] = (short)(c * 64 + (63 - __clzll(same))); }
         }
     }
+    // one barrier per step: sparse-table level l and, beside it, the fold of level 8-l out of level 9-l (bit 8-l folded away)
+    constexpr int NSTEP = (NL - 1 > SKB - 1) ? NL - 1 : SKB - 1;
 #pragma unroll
-    for (int l = 1; l < NL; ++l) {
+    for (int l = 1; l <= NSTEP; ++l) {
         __syncthreads();
+        if (l < NL) {
 #pragma unroll
-        for (int r = 0; r < EPT; ++r) {
-            const int i = r * BLOCK + t, j = i - (1 << (l - 1));
-            s_tbl[l][i] = (j >= 0) ? max(s_tbl[l - 1][i], s_tbl[l - 1][j]) : s_tbl[l - 1][i];
+            for (int r = 0; r < EPT; ++r) {
+                const int i = r * BLOCK + t, jn = i - (1 << (l - 1));
+                s_tbl[l][i] = (jn >= 0) ? max(s_tbl[l - 1][i], s_tbl[l - 1][jn]) : s_tbl[l - 1][i];
+            }
+        }
+        const int j = SKB - l;
+        if (j >= 1) {
+            const int K = 1 << j;
+            for (int e = t; e < (NC << j); e += BLOCK) {
+                const int c = e >> j, kj = e & (K - 1);
+                s_rawH[c][K + kj] = (short)(s_rawH[c][2 * K + kj] + s_rawH[c][3 * K + kj]);
+                s_lastH[c][K + kj] = (short)max((int)s_lastH[c][2 * K + kj], (int)s_lastH[c][3 * K + kj]);
+            }
+            if (t < K) {
+                const int c0 = s_cH[2 * K + t], c1 = s_cH[3 * K + t];
+                s_bH[K + t] = s_bH[2 * K + t] + s_bH[3 * K + t];
+                s_tH[K + t] = s_tH[2 * K + t] + s_tH[3 * K + t];
+                s_cH[K + t] = (c0 < 0) ? c1 : (c1 < 0) ? c0 : min(c0, c1);   // the later last occurrence has the smaller suffix maximum
+            }
         }
     }
     __syncthreads();
+    // (i) every level entry (heap index 2..255): exclusive scan over the chunks, in place (count -> base, last -> previous)
+    if (t >= 2) {
+        int base = 0, last = -1;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int cn = s_rawH[c][t], lp = s_lastH[c][t];
+            s_rawH[c][t] = (short)base; s_lastH[c][t] = (short)last;
+            base += cn; if (cn) last = lp;
+        }
+    }
+    // (ii) per level: bucket bases G (exclusive prefix of the key totals) and the nearest lower non-empty key; one wave per level
+    {
+        auto level_scan = [&](int j) {
+            const int K = 1 << j;
+            int carryG = 0, carryL = 0;
+            for (int base = 0; base < K; base += 64) {
+                const int kj = base + lane;
+                const int v = (kj < K) ? s_tH[K + kj] : 0;
+                const int ginc = wave_iscan_sum(v), linc = wave_iscan_max(v ? kj + 1 : 0);
+                const int lexc = lane_shr1(linc, 0);
+                if (kj < K) { s_GH[K + kj] = carryG + ginc - v; s_lowH[K + kj] = max(carryL, lexc) - 1; }
+                carryG += __builtin_amdgcn_readlane(ginc, 63); carryL = max(carryL, __builtin_amdgcn_readlane(linc, 63));
+            }
+        };
+        if (wv == 0) level_scan(6);
+        else if (wv == 1) { level_scan(5); level_scan(1); }
+        else if (wv == 2) { level_scan(4); level_scan(2); }
+        else { level_scan(3); level_scan(7); }
+    }
+    __syncthreads();
+    // all seven levels, no barrier in between: positions, divergences, scatter
 #pragma unroll
     for (int j = SKB - 1; j >= 1; --j) {
         const int K = 1 << j;
-        int tq = 0;
-        if (t < K) {                                        // fold bit j away, then the exclusive scan over the chunks
-            int base = 0, last = -1;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int cn = s_raw[c][t] + s_raw[c][t + K], lp = max((int)s_lastraw[c][t], (int)s_lastraw[c][t + K]);
-                s_raw[c][t] = (short)cn; s_lastraw[c][t] = (short)lp;
-                s_base[c][t] = (short)base; s_prev[c][t] = (short)last;
-                base += cn; if (cn) last = lp;
-            }
-            const int c0 = s_c[t], c1 = s_c[t + K];
-            s_b[t] += s_b[t + K]; tq = s_t[t] + s_t[t + K]; s_t[t] = tq;
-            s_c[t] = (c0 < 0) ? c1 : (c1 < 0) ? c0 : min(c0, c1);
-        }
-        const int ginc = wave_iscan_sum(tq), linc = wave_iscan_max(tq ? t + 1 : 0);
-        if (lane == 63) { s_gw[wv] = ginc; s_lw[wv] = linc; }
-        const int lexc = lane_shr1(linc, 0);
-        __syncthreads();
-        int Gq = ginc - tq, lq = lexc;
-        for (int x = 0; x < wv; ++x) { Gq += s_gw[x]; lq = max(lq, s_lw[x]); }
-        s_G[t] = Gq; s_lower[t] = lq - 1;
-        __syncthreads();
         int *a_out = g.A + (size_t)(8 * b + j) * g.strideA, *d_out = g.D + (size_t)(8 * b + j) * g.strideD;
 #pragma unroll
         for (int r = 0; r < EPT; ++r) {
             if (key[r] < 0) continue;
-            const int l = r * BLOCK + t, c = r * 4 + wv, kj = key[r] & (K - 1);
-            const int rank = s_base[c][kj] + rk[r][j];
-            const int p = (pl[r][j] >= 0) ? pl[r][j] : s_prev[c][kj];
+            const int l = r * BLOCK + t, c = r * 4 + wv, kj = key[r] & (K - 1), h = K + kj;
+            const int rank = s_rawH[c][h] + rk[r][j];
+            const int p = (pl[r][j] >= 0) ? pl[r][j] : s_lastH[c][h];
             const int len = l - p, lv = min(31 - __clz(len), NL - 1);
             const int rm = max(s_tbl[lv][l], s_tbl[lv][p + (1 << lv)]);
             int dd;
             if (p >= 0) dd = rm;
-            else if (s_c[kj] >= 0) dd = max(s_c[kj], rm);
-            else if (s_lower[kj] >= 0) dd = k + 1 + (31 - __clz(kj ^ s_lower[kj]));
+            else if (s_cH[h] >= 0) dd = max(s_cH[h], rm);
+            else if (s_lowH[h] >= 0) dd = k + 1 + (31 - __clz(kj ^ s_lowH[h]));
             else dd = 0;
-            const int pos = s_G[kj] + s_b[kj] + rank;
+            const int pos = s_GH[h] + s_bH[h] + rank;
             if (pos == 0) dd = k + j + 1;
             if (g.dbg_nowrite && pos >= 0) continue;
             const int yb = (int)(((unsigned)(key[r] >> j) & 1u) << 31);
@@ -1153,7 +1181,6 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
             else { a_out[pos] = av[r] | yb; d_out[pos] = dd; }
         }
         if (w == g.W - 1 && t == 0) d_out[g.M] = k + j + 1;
-        __syncthreads();
     }
 }
 
