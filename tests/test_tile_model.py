@@ -53,3 +53,38 @@ def test_skeleton_tile_model_matches_oracle(orc, M, N, kind, T, B):
         a, d = stepB_tiles(a, d, key, k, B, T)
         assert np.array_equal(a, o["a_dump"][k + B]), "a at site %d" % (k + B)
         assert np.array_equal(d, o["d_dump"][k + B]), "d at site %d" % (k + B)
+
+
+@pytest.mark.parametrize("M,N,kind,T,B", [(37, 64, 1, 8, 8), (100, 72, 0, 8, 8), (257, 48, 0, 32, 8), (300, 30, 0, 16, 3), (64, 35, 1, 16, 5)])
+def test_fill_model_matches_oracle(orc, M, N, kind, T, B):
+    """the fill (skel_fill_kernel's formulation): every state between two skeleton states from the skeleton's per-tile
+    tables folded down bit by bit (counts add, carries min, lower key per level)"""
+    from tile_model import fillB_tiles, stepB_tiles
+    bits = orc.synth_bitcols(M, N, seed=9 * M + N, kind=kind)
+    hap = orc.unpack_bitcols(bits, M).astype(np.int64)
+    o = orc.build_bitcols(bits, M, with_d=True, dump_sites=range(N + 1))
+    a, d = o["a_dump"][0].astype(np.int64), o["d_dump"][0].astype(np.int64)
+    for k in range(0, N - B + 1, B):
+        key = np.zeros(M, np.int64)
+        for j in range(B):
+            key |= hap[k + j][a] << j
+        for j, (aj, dj) in enumerate(fillB_tiles(a, d, key, k, B, T), start=1):
+            assert np.array_equal(aj, o["a_dump"][k + j]), "a at site %d" % (k + j)
+            assert np.array_equal(dj, o["d_dump"][k + j]), "d at site %d" % (k + j)
+        a, d = stepB_tiles(a, d, key, k, B, T)
+
+
+@pytest.mark.parametrize("M,N,kind,B", [(37, 64, 1, 8), (300, 40, 0, 8), (1000, 24, 0, 8), (64, 35, 1, 5)])
+def test_read_side_keys_through_lf_mapping(orc, M, N, kind, B):
+    """read side: the key of a position follows the LF-mapping through the sorted columns and equals the key the build
+    side gathers by haplotype"""
+    from tile_model import keys_from_sorted_columns
+    bits = orc.synth_bitcols(M, N, seed=11 * M + N, kind=kind)
+    hap = orc.unpack_bitcols(bits, M).astype(np.int64)
+    o = orc.build_bitcols(bits, M, with_d=False, dump_sites=range(N + 1))
+    for k in range(0, N - B + 1, B):
+        ys = [hap[k + j][o["a_dump"][k + j]] for j in range(B)]          # y_{k+j} in the order of a_{k+j}
+        want = np.zeros(M, np.int64)
+        for j in range(B):
+            want |= hap[k + j][o["a_dump"][k]] << j
+        assert np.array_equal(keys_from_sorted_columns(ys, B), want)

@@ -201,3 +201,90 @@ def stepB_tiles(a, d, key, k, B, T):
             seen_at[q] = i; rank[q] = r + 1
     d2[0] = k + B + 1; d2[M] = k + B + 1
     return a2, d2
+
+
+# ------------------------------------------------------------------------------------------------
+# the fill (skel_fill_kernel): the states between two skeleton states out of the SAME per-tile tables.
+# State k+j (1 <= j < B) is the stable sort of state k by the low j bits of the keys; for a j-bit key q
+#   count  = sum of the counts of the B-bit keys with low bits q            (per tile)
+#   before = sum of their `before`;  G from the folded totals
+#   carry  = min over those keys' carries that exist (a later last occurrence has the smaller suffix max)
+#   lower  = nearest lower non-empty j-bit key
+def fillB_tiles(a, d, key, k, B, T):
+    """returns [(a_j, d_j) for j = 1..B-1], each computed tile by tile from level-B tables folded down"""
+    M = len(a)
+    W = (M + T - 1) // T
+    K = 1 << B
+    cnt = np.zeros((W, K), np.int64); tail = np.zeros((W, K), np.int64)
+    for w in range(W):
+        lo, hi = w * T, min((w + 1) * T, M)
+        kk = key[lo:hi]; dd = d[lo:hi]
+        for q in range(K):
+            idx = np.nonzero(kk == q)[0]
+            cnt[w, q] = len(idx)
+            tail[w, q] = (dd[idx[-1] + 1:].max() if len(idx) and idx[-1] + 1 < len(dd) else 0) if len(idx) else dd.max()
+    before = np.zeros((W, K), np.int64); carry = -np.ones((W, K), np.int64)
+    for q in range(K):
+        run, ex, c = 0, False, 0
+        for w in range(W):
+            before[w, q] = run
+            carry[w, q] = c if ex else -1
+            if cnt[w, q]:
+                ex = True; c = tail[w, q]
+            elif ex:
+                c = max(c, tail[w, q])
+            run += cnt[w, q]
+    total = cnt.sum(axis=0)
+    out = []
+    for j in range(1, B):
+        Kj = 1 << j
+        fold = lambda arr: arr.reshape(-1, K >> j, Kj).sum(axis=1) if arr.ndim == 2 else arr.reshape(K >> j, Kj).sum(axis=0)
+        before_j = fold(before); total_j = fold(total)
+        cj = carry.reshape(W, K >> j, Kj).astype(np.float64)
+        cj[cj < 0] = np.inf
+        carry_j = cj.min(axis=1); carry_j[np.isinf(carry_j)] = -1
+        G = np.concatenate([[0], np.cumsum(total_j)])[:Kj]
+        lower = -np.ones(Kj, np.int64); last = -1
+        for q in range(Kj):
+            lower[q] = last
+            if total_j[q]:
+                last = q
+        a2 = np.zeros(M, np.int64); d2 = np.zeros(M + 1, np.int64)
+        for w in range(W):
+            lo, hi = w * T, min((w + 1) * T, M)
+            seen_at, rank = {}, {}
+            for i in range(lo, hi):
+                q = int(key[i]) & (Kj - 1)
+                r = rank.get(q, 0)
+                if q in seen_at:
+                    dd = int(d[seen_at[q] + 1: i + 1].max())
+                elif carry_j[w, q] >= 0:
+                    dd = max(int(carry_j[w, q]), int(d[lo: i + 1].max()))
+                elif lower[q] >= 0:
+                    dd = k + 1 + ((q ^ int(lower[q])).bit_length() - 1)
+                else:
+                    dd = 0
+                pos = int(G[q] + before_j[w, q] + r)
+                a2[pos] = a[i]; d2[pos] = dd
+                seen_at[q] = i; rank[q] = r + 1
+        d2[0] = k + j + 1; d2[M] = k + j + 1
+        out.append((a2, d2))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# read side (skel_keys_sorted_kernel): the B-bit key of POSITION i of state k from the columns in PBWT order,
+# through the LF-mapping: bit j = y_{k+j}[p_j], p_0 = i, p_{j+1} = y ? c + p_j - u(p_j) : u(p_j)
+def keys_from_sorted_columns(ys, B):
+    """ys[j] = y_{k+j} in the order of a_{k+j} (what unpack3 yields); returns the key of every position of state k"""
+    M = len(ys[0])
+    pos = np.arange(M)
+    key = np.zeros(M, np.int64)
+    for j in range(B):
+        y = ys[j].astype(np.int64)
+        u = np.concatenate([[0], np.cumsum(1 - y)])          # zeros before each position
+        c = int(u[M])
+        bit = y[pos]
+        key |= bit << j
+        pos = np.where(bit == 1, c + pos - u[pos], u[pos])
+    return key
