@@ -14,7 +14,7 @@ while time.time() - t0 < budget:
     bits = orc.synth_bitcols(M, N, seed=int(rng.integers(1, 1 << 30)), kind=kind)
     o = orc.build_bitcols(bits, M, with_d=True)
     eng = amd.Engine(M, batch_sites=B)
-    mode = int(rng.integers(0, 4))
+    mode = int(rng.integers(0, 5))
     ok = True
     try:
         if mode == 0:      # device pass API, every site, split into random advances
@@ -41,6 +41,21 @@ while time.time() - t0 < budget:
             ok = np.array_equal(b["yz"], o["yz"]) and np.array_equal(b["aFend"], o["aFend"])
             sw = eng.sweep_AD(o["yz"], N); s = orc.sweep_AD(o["yz"], M, N)
             ok = ok and np.array_equal(sw["csum_a"], s["csum_a"]) and np.array_equal(sw["csum_d"], s["csum_d"]) and np.array_equal(sw["csum_y"][:N], s["csum_y"][:N])
+        elif mode == 4:    # query sweeps (dense and sparse)
+            if M <= 5000 and M >= 4:
+                Mq = int(rng.integers(1, min(M - 1, 40)))
+                hap = orc.unpack_bitcols(bits, M)
+                pz = orc.build_bitcols(orc.pack_bitcols(hap[:, :M - Mq]), M - Mq, with_d=False)["yz"]
+                qz = orc.build_bitcols(orc.pack_bitcols(hap[:, M - Mq:]), Mq, with_d=False)["yz"]
+                e2 = amd.Engine(M - Mq, batch_sites=max(B, 8))
+                got, gn, gt = e2.match_sweep(pz, N, qz, Mq)
+                want, wn, wt = orc.match_sweep(pz, M - Mq, qz, Mq, N)
+                ok = np.array_equal(got, want) and gn == wn and tuple(gt) == tuple(wt)
+                nS = int(rng.integers(1, 6))
+                got, gn, gt = e2.match_sweep_sparse(pz, N, qz, Mq, nS)
+                want, wn, wt = orc.match_sweep_sparse(pz, M - Mq, qz, Mq, N, nS)
+                ok = ok and np.array_equal(got, want) and gn == wn and tuple(gt) == tuple(wt)
+                e2.close()
         else:              # records
             if M <= 3000:
                 ok = np.array_equal(eng.max_within(o["yz"], N, mode="records"), orc.max_within(o["yz"], M, N))
