@@ -738,8 +738,8 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         const int remaining = e->n_total - e->k_cur;
         const int L = (nb + 1) / 2;
         static const bool skel_read = !(getenv("PBWTAMD_SKEL_READ") && !atoi(getenv("PBWTAMD_SKEL_READ")));
-        // the skeleton always carries d (A-only builds run it too: the divergences cost nothing on its critical path)
-        const bool skel = e->skel && (with_d || !sorted) && (nb % 8 == 0) && (sorted ? skel_read && left >= std::min(nb + 1, remaining) : left >= std::min(nb + 8, remaining));
+        // the skeleton always carries d (A-only passes run it too: the divergences cost nothing on its critical path)
+        const bool skel = e->skel && (nb % 8 == 0) && (sorted ? skel_read && left >= std::min(nb + 1, remaining) : left >= std::min(nb + 8, remaining));
         const bool pair = !skel && e->pair && !sorted && (e->T == 256 || e->T == 1024 || e->T == 2048 || e->T == 4096) && left >= std::min(2 * L + 2, remaining);
         if (!skel) {
             CHK(ensure_prepared(e, bc, sorted, with_d, pair, left));
@@ -1095,7 +1095,8 @@ extern "C" int pbwtamd_haplotypes(pbwtamd_engine *e, const uint8_t *yz, int64_t 
         const int nb = std::min(e->B, N - done);
         const int navail = std::min(nb + 1, N - done);
         CHK(packed_expand(e, e->stream, pk, e->M, done, navail, (unsigned long long *)e->cols_stage, e->wpc64));
-        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, PBWTAMD_OPT_SORTED));
+        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, PBWTAMD_OPT_SORTED | OPT_INTERNAL_KEEP_STATES));
+        CHK(pbwtamd_sync(e));                              // every state of the batch is in the ring (incl. the fill of the skeleton path)
         const int *A = ringA(e, e->ring ^ 1);
         dim3 grid(std::min(64, (e->M + BLOCK - 1) / BLOCK), nb);
         hipLaunchKernelGGL(unsort_alleles_kernel, grid, dim3(BLOCK), 0, e->stream, A, e->strideA, e->M, dout);
@@ -1171,119 +1172,44 @@ extern "C" int pbwtamd_unpack3(pbwtamd_engine *e, const uint8_t *yz, int64_t nz,
     return pbwtamd_sync(e);
 }
 
-static int deliver_records(pbwtamd_engine *e, hipStream_t st, const int4 *drecs, size_t total, std::vector<pbwtamd_match> &all, pbwtamd_report_fn report) {
-    if (!total) return 0;
-    const size_t old = all.size();
-    all.resize(old + total);
-    HIPCHK(hipMemcpyAsync(all.data() + old, drecs, total * sizeof(int4), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (report) {
-        for (size_t r = old; r < old + total; ++r) report(all[r].ai, all[r].bi, all[r].start, all[r].end);
-        all.resize(old);
-    }
-    (void)e;
-    return 0;
-}
+
+extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, int64_t pnz, int N, const int32_t *pStart,
+                                          int Mq, const uint8_t *qz, int64_t qnz, const int32_t *qStart, int nSparse,
+                                          pbwtamd_report5_fn report, pbwtamd_match5 **recs_out, int64_t *nrecs_out,
+                                          int64_t *n_nomatch, int64_t *tot_out);
+
+// matchSequencesSweep (pbwtMatch.c:363-443) = the sparse sweep without sparse cursors (same kernels: one wave per query)
+static thread_local pbwtamd_report_fn g_report4 = nullptr;
+static void report4_thunk(int ai, int bi, int start, int end, int) { g_report4(ai, bi, start, end); }
 
 extern "C" int pbwtamd_match_sweep(pbwtamd_engine *e, const uint8_t *pz, int64_t pnz, int N, const int32_t *pStart,
                                    int Mq, const uint8_t *qz, int64_t qnz, const int32_t *qStart,
                                    pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out,
                                    int64_t *n_nomatch, int64_t *tot_out) {
-    HIPCHK(hipSetDevice(e->device));
     if ((report ? 1 : 0) + (recs_out ? 1 : 0) != 1) return fail("pbwtamd_match_sweep: exactly one of report / recs_out must be given");
-    pbwtamd_engine *eq = nullptr;
-    CHK(pbwtamd_engine_create(&eq, e->device, Mq, e->B, nullptr));
-    struct EngGuard { pbwtamd_engine *p; ~EngGuard() { pbwtamd_engine_destroy(p); } } guard{eq};
-    const int Mp = e->M;
-    Packed pk, qk;
-    CHK(packed_upload(e, e->stream, Mp, pz, pnz, N, pk));
-    CHK(packed_upload(eq, eq->stream, Mq, qz, qnz, N, qk));
-    CHK(pbwtamd_pass_begin(e, pStart, 0, N));
-    CHK(pbwtamd_pass_begin(eq, qStart, 0, N));
-    DevBufs bufs;
-    unsigned char *xq; int *invq, *rankdir, *fst[2], *dst[2]; unsigned long long *cnt, *tot; int4 *recs = nullptr; size_t recsCap = 0;
-    const size_t BQ = (size_t)e->B * Mq;
-    CHK(bufs.alloc(&xq, BQ)); CHK(bufs.alloc(&invq, BQ)); CHK(bufs.alloc(&cnt, std::max(BQ, (size_t)Mq)));
-    CHK(bufs.alloc(&rankdir, (size_t)e->B * (e->wpc64 + 1)));
-    for (int i = 0; i < 2; ++i) { CHK(bufs.alloc(&fst[i], (size_t)Mq)); CHK(bufs.alloc(&dst[i], (size_t)Mq)); }
-    CHK(bufs.alloc(&tot, (size_t)4));
-    hipStream_t st = e->s2;
-    HIPCHK(hipMemsetAsync(fst[0], 0, sizeof(int) * (size_t)Mq, st));      // calloc'ed f[], d[] (pbwtMatch.c:368-369)
-    HIPCHK(hipMemsetAsync(dst[0], 0, sizeof(int) * (size_t)Mq, st));
-    HIPCHK(hipMemsetAsync(tot, 0, 4 * sizeof(unsigned long long), st));
-    std::vector<pbwtamd_match> all;
-    int cur = 0;
-    const int qblocks = (Mq + BLOCK - 1) / BLOCK;
-    auto ensure_recs = [&](size_t total) -> int {
-        if (total <= recsCap) return 0;
-        recsCap = total + total / 4 + 1024;
-        return bufs.alloc(&recs, recsCap);
-    };
-    for (int done = 0; done < N;) {
-        const int nb = std::min(e->B, N - done);
-        const int navail = std::min(nb + 1, N - done);
-        CHK(packed_expand(e, e->stream, pk, Mp, done, navail, (unsigned long long *)e->cols_stage, e->wpc64));
-        CHK(packed_expand(eq, eq->stream, qk, Mq, done, navail, (unsigned long long *)eq->cols_stage, eq->wpc64));
-        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES));
-        CHK(pbwtamd_pass_advance(eq, eq->cols_stage, eq->wpc, nb, navail, PBWTAMD_OPT_SORTED));
-        CHK(pbwtamd_sync(e));                              // every state of the batch is in the ring (incl. the fill of the skeleton path)
-        HIPCHK(hipStreamSynchronize(eq->stream));
-        const int *A = ringA(e, e->ring ^ 1), *D = ringD(e, e->ring ^ 1), *AQ = ringA(eq, eq->ring ^ 1);
-        dim3 g1(std::min(64, (e->wpc64 + WAVES - 1) / WAVES), nb);
-        hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, st, A, e->strideA, Mp, e->ycols, e->wpc64);
-        hipLaunchKernelGGL(qs_rankdir_kernel, dim3(nb), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, Mp, rankdir);
-        hipLaunchKernelGGL(qs_unsort_kernel, dim3(std::min(qblocks, 64), nb), dim3(BLOCK), 0, st, AQ, eq->strideA, Mq, xq, invq);
-        HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * (size_t)nb * Mq, st));
-        QSweepArgs g;
-        g.A = A; g.D = D; g.strideA = e->strideA; g.strideD = e->strideD; g.ycols = e->ycols; g.wpc64 = e->wpc64;
-        g.rankdir = rankdir; g.xq = xq; g.invq = invq; g.Mp = Mp; g.Mq = Mq; g.kbase = done; g.nsites = nb;
-        g.f_in = fst[cur]; g.dq_in = dst[cur]; g.f_out = fst[cur ^ 1]; g.dq_out = dst[cur ^ 1];
-        g.cnt = cnt; g.recs = nullptr; g.tot = tot;
-        hipLaunchKernelGGL((qs_sweep_kernel<0>), dim3(qblocks), dim3(BLOCK), 0, st, g);
-        hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, cnt, (size_t)nb * Mq, tot + 3, 0ULL);
-        HIPCHK(hipGetLastError());
-        unsigned long long total = 0;
-        HIPCHK(hipMemcpyAsync(&total, tot + 3, sizeof total, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (total) {
-            CHK(ensure_recs((size_t)total));
-            g.recs = recs;
-            hipLaunchKernelGGL((qs_sweep_kernel<1>), dim3(qblocks), dim3(BLOCK), 0, st, g);
-            HIPCHK(hipGetLastError());
-            CHK(deliver_records(e, st, recs, (size_t)total, all, report));
-        }
-        cur ^= 1;
-        done += nb;
+    if (report) {
+        g_report4 = report;
+        const int rc = pbwtamd_match_sweep_sparse(e, pz, pnz, N, pStart, Mq, qz, qnz, qStart, 0, report4_thunk, nullptr, nullptr, n_nomatch, tot_out);
+        g_report4 = nullptr;
+        return rc;
     }
-    // matches still open at the end of the panel, in final query order (pbwtMatch.c:430-436)
-    HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipStreamSynchronize(eq->stream));
-    {
-        const int *A = ringA(e, e->ring), *D = ringD(e, e->ring), *AQ = ringA(eq, eq->ring);
-        hipLaunchKernelGGL((qs_tail_kernel<0>), dim3(qblocks), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, (const int *)fst[cur], (const int *)dst[cur], cnt, (int4 *)nullptr, tot);
-        hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, cnt, (size_t)Mq, tot + 3, 0ULL);
-        HIPCHK(hipGetLastError());
-        unsigned long long total = 0;
-        HIPCHK(hipMemcpyAsync(&total, tot + 3, sizeof total, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        CHK(ensure_recs((size_t)total));
-        hipLaunchKernelGGL((qs_tail_kernel<1>), dim3(qblocks), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, (const int *)fst[cur], (const int *)dst[cur], cnt, recs, tot);
-        HIPCHK(hipGetLastError());
-        CHK(deliver_records(e, st, recs, (size_t)total, all, report));
-    }
-    unsigned long long htot[4];
-    HIPCHK(hipMemcpy(htot, tot, sizeof htot, hipMemcpyDeviceToHost));
-    if (tot_out) { tot_out[0] = (int64_t)htot[0]; tot_out[1] = (int64_t)htot[1]; }
-    if (n_nomatch) *n_nomatch = (int64_t)htot[2];
-    CHK(pbwtamd_pass_end(e, 0));
-    CHK(pbwtamd_pass_end(eq, 0));
-    if (recs_out) {
-        pbwtamd_match *buf = (pbwtamd_match *)malloc(std::max<size_t>(1, all.size()) * sizeof(pbwtamd_match));
-        if (!buf) return fail("pbwtamd_match_sweep: out of host memory");
-        if (!all.empty()) memcpy(buf, all.data(), all.size() * sizeof(pbwtamd_match));
-        *recs_out = buf; *nrecs_out = (int64_t)all.size();
-    }
+    pbwtamd_match5 *r5 = nullptr; int64_t n5 = 0;
+    CHK(pbwtamd_match_sweep_sparse(e, pz, pnz, N, pStart, Mq, qz, qnz, qStart, 0, nullptr, &r5, &n5, n_nomatch, tot_out));
+    pbwtamd_match *buf = (pbwtamd_match *)malloc(std::max<size_t>(1, (size_t)n5) * sizeof(pbwtamd_match));
+    if (!buf) { free(r5); return fail("pbwtamd_match_sweep: out of host memory"); }
+    for (int64_t i = 0; i < n5; ++i) { buf[i].ai = r5[i].ai; buf[i].bi = r5[i].bi; buf[i].start = r5[i].start; buf[i].end = r5[i].end; }
+    free(r5);
+    *recs_out = buf; *nrecs_out = n5;
     return 0;
+}
+
+// exclusive scan of n 64-bit counts in place, total -> *total (device); `bsum` = scratch of n / SCAN_CHUNK + 1 values
+static void scan_u64(hipStream_t st, unsigned long long *v, size_t n, unsigned long long *total, unsigned long long *bsum) {
+    if (n <= 65536 || !bsum) { hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, v, n, total, 0ULL); return; }
+    const size_t nblk = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(scan_u64_blocksum_kernel, dim3((unsigned)nblk), dim3(BLOCK), 0, st, (const unsigned long long *)v, n, bsum);
+    hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, bsum, nblk, total, 0ULL);
+    hipLaunchKernelGGL(scan_u64_apply_kernel, dim3((unsigned)nblk), dim3(BLOCK), 0, st, v, n, (const unsigned long long *)bsum);
 }
 
 // matchSequencesSweepSparse (pbwtMatch.c:501-602).  Phase A recovers the panel's columns in original
@@ -1321,7 +1247,8 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         for (int done = 0; done < N;) {
             const int nb = std::min(e->B, N - done), navail = std::min(nb + 1, N - done);
             CHK(packed_expand(e, e->stream, pk, Mp, done, navail, (unsigned long long *)e->cols_stage, wpc64));
-            CHK(pbwtamd_pass_advance(e, e->cols_stage, wpc, nb, navail, PBWTAMD_OPT_SORTED));
+            CHK(pbwtamd_pass_advance(e, e->cols_stage, wpc, nb, navail, PBWTAMD_OPT_SORTED | OPT_INTERNAL_KEEP_STATES));
+            CHK(pbwtamd_sync(e));
             const int *A = ringA(e, e->ring ^ 1);
             dim3 grid(std::min(64, (Mp + BLOCK - 1) / BLOCK), nb);
             hipLaunchKernelGGL(unsort_alleles_kernel, grid, dim3(BLOCK), 0, e->stream, A, e->strideA, Mp, dout);
@@ -1347,6 +1274,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         CHK(bufs.alloc(&fss[i], (size_t)2 * std::max(nS, 1) * Mq)); CHK(bufs.alloc(&dss[i], (size_t)2 * std::max(nS, 1) * Mq));
     }
     CHK(bufs.alloc(&tot, (size_t)4));
+    unsigned long long *bsum; CHK(bufs.alloc(&bsum, 2 * std::max(BQ, (size_t)Mq) / SCAN_CHUNK + 2));
     std::vector<unsigned long long *> ycS((size_t)nS, nullptr); std::vector<int *> rdS((size_t)nS, nullptr);
     for (int kk = 0; kk < nS; ++kk) { CHK(bufs.alloc(&ycS[kk], (size_t)(Bs + 2) * wpc64)); CHK(bufs.alloc(&rdS[kk], (size_t)(Bs + 2) * (wpc64 + 1))); }
     QsView *dviews = nullptr; CHK(bufs.alloc(&dviews, (size_t)std::max(nS, 1)));
@@ -1373,14 +1301,15 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         return 0;
     };
     int cur = 0;
-    const int qblocks = (Mq + BLOCK - 1) / BLOCK;
+    const int qblocks = (Mq + BLOCK - 1) / BLOCK;          // thread per query (qs_unsort)
+    const int qwaves = (Mq + WAVES - 1) / WAVES;            // wave per query (sweep, tails)
     for (int done = 0; done < N;) {
         const int nb = std::min(Bd, N - done);
         const int navail = std::min(nb + 1, N - done);
         CHK(packed_expand(e, e->stream, pk, Mp, done, navail, (unsigned long long *)e->cols_stage, wpc64));
         CHK(packed_expand(eq, eq->stream, qk, Mq, done, navail, (unsigned long long *)eq->cols_stage, eq->wpc64));
         CHK(pbwtamd_pass_advance(e, e->cols_stage, wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES));
-        CHK(pbwtamd_pass_advance(eq, eq->cols_stage, eq->wpc, nb, navail, PBWTAMD_OPT_SORTED));
+        CHK(pbwtamd_pass_advance(eq, eq->cols_stage, eq->wpc, nb, navail, PBWTAMD_OPT_SORTED | OPT_INTERNAL_KEEP_STATES));
         for (int kk = 0; kk < nS; ++kk) {                  // the sparse cursors' steps that fall into this batch
             const int ns = nb > kk ? (nb - kk + nS - 1) / nS : 0;
             hviews[kk] = QsView{nullptr, nullptr, 0, 0, nullptr, nullptr, done / nS};
@@ -1393,7 +1322,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
             CHK(pbwtamd_pass_advance(s, s->cols_stage, wpc, ns, nav, PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES));
         }
         CHK(pbwtamd_sync(e));
-        HIPCHK(hipStreamSynchronize(eq->stream));
+        CHK(pbwtamd_sync(eq));
         const int *A = ringA(e, e->ring ^ 1), *D = ringD(e, e->ring ^ 1), *AQ = ringA(eq, eq->ring ^ 1);
         dim3 g1(std::min(64, (wpc64 + WAVES - 1) / WAVES), nb);
         hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, st, A, e->strideA, Mp, e->ycols, wpc64);
@@ -1418,8 +1347,8 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         g.f_in = fst[cur]; g.dq_in = dst[cur]; g.f_out = fst[cur ^ 1]; g.dq_out = dst[cur ^ 1];
         g.fs_in = fss[cur]; g.ds_in = dss[cur]; g.fs_out = fss[cur ^ 1]; g.ds_out = dss[cur ^ 1];
         g.cnt = cnt; g.recs = nullptr; g.tot = tot;
-        hipLaunchKernelGGL((qss_sweep_kernel<0>), dim3(qblocks), dim3(BLOCK), 0, st, g);
-        hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, cnt, 2 * (size_t)nb * Mq, tot + 3, 0ULL);
+        hipLaunchKernelGGL((qss_sweep_kernel<0>), dim3(qwaves), dim3(BLOCK), 0, st, g);
+        scan_u64(st, cnt, 2 * (size_t)nb * Mq, tot + 3, bsum);
         HIPCHK(hipGetLastError());
         unsigned long long total = 0;
         HIPCHK(hipMemcpyAsync(&total, tot + 3, sizeof total, hipMemcpyDeviceToHost, st));
@@ -1427,7 +1356,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         if (total) {
             CHK(ensure_recs((size_t)total));
             g.recs = recs;
-            hipLaunchKernelGGL((qss_sweep_kernel<1>), dim3(qblocks), dim3(BLOCK), 0, st, g);
+            hipLaunchKernelGGL((qss_sweep_kernel<1>), dim3(qwaves), dim3(BLOCK), 0, st, g);
             HIPCHK(hipGetLastError());
             CHK(deliver((size_t)total));
         }
@@ -1442,14 +1371,14 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         if (c >= 0) CHK(pbwtamd_sync(s));
         const int *A = ringA(s, s->ring), *D = ringD(s, s->ring), *AQ = ringA(eq, eq->ring);
         const int *fp = c < 0 ? fst[cur] : fss[cur] + (size_t)c * Mq, *dp = c < 0 ? dst[cur] : dss[cur] + (size_t)c * Mq;
-        hipLaunchKernelGGL((qss_tail_kernel<0>), dim3(qblocks), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, nS, std::max(c, 0), c >= 0 ? 1 : 0, fp, dp, cnt, (Rec5 *)nullptr, tot);
+        hipLaunchKernelGGL((qss_tail_kernel<0>), dim3(qwaves), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, nS, std::max(c, 0), c >= 0 ? 1 : 0, fp, dp, cnt, (Rec5 *)nullptr, tot);
         hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, cnt, (size_t)Mq, tot + 3, 0ULL);
         HIPCHK(hipGetLastError());
         unsigned long long total = 0;
         HIPCHK(hipMemcpyAsync(&total, tot + 3, sizeof total, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         CHK(ensure_recs((size_t)total));
-        hipLaunchKernelGGL((qss_tail_kernel<1>), dim3(qblocks), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, nS, std::max(c, 0), c >= 0 ? 1 : 0, fp, dp, cnt, recs, tot);
+        hipLaunchKernelGGL((qss_tail_kernel<1>), dim3(qwaves), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, nS, std::max(c, 0), c >= 0 ? 1 : 0, fp, dp, cnt, recs, tot);
         HIPCHK(hipGetLastError());
         CHK(deliver((size_t)total));
     }

@@ -1787,6 +1787,42 @@ __global__ __launch_bounds__(1024) void scan_u64_kernel(unsigned long long *v, s
     if (threadIdx.x == 0 && total) *total = s_carry;
 }
 
+// large arrays: per-block sums (SCAN_CHUNK values per workgroup) -> scan_u64_kernel over the block sums -> local
+// exclusive scan + block offset.  (the single-block kernel streams at one workgroup's bandwidth: 5 ms for 10 M values)
+constexpr int SCAN_CHUNK = 4096;
+__global__ __launch_bounds__(BLOCK) void scan_u64_blocksum_kernel(const unsigned long long *v, size_t n, unsigned long long *bsum) {
+    __shared__ unsigned long long s_w[WAVES];
+    const size_t b0 = (size_t)blockIdx.x * SCAN_CHUNK;
+    unsigned long long acc = 0;
+    for (int x = threadIdx.x; x < SCAN_CHUNK; x += BLOCK) { const size_t i = b0 + x; if (i < n) acc += v[i]; }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if (lane_id() == 0) s_w[wave_id()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (int q = 0; q < WAVES; ++q) t += s_w[q]; bsum[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(BLOCK) void scan_u64_apply_kernel(unsigned long long *v, size_t n, const unsigned long long *boff) {
+    __shared__ unsigned long long s_w[WAVES];
+    __shared__ unsigned long long s_carry;
+    const size_t b0 = (size_t)blockIdx.x * SCAN_CHUNK;
+    const int lane = lane_id(), wv = wave_id();
+    if (threadIdx.x == 0) s_carry = boff[blockIdx.x];
+    __syncthreads();
+    for (int x0 = 0; x0 < SCAN_CHUNK; x0 += BLOCK) {
+        const size_t i = b0 + x0 + threadIdx.x;
+        const unsigned long long x = (i < n) ? v[i] : 0ULL;
+        unsigned long long inc = x;
+        for (int o = 1; o < 64; o <<= 1) { unsigned long long u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        unsigned long long pre = s_carry, tot = 0;
+        for (int q = 0; q < WAVES; ++q) { if (q < wv) pre += s_w[q]; tot += s_w[q]; }
+        if (i < n) v[i] = pre + inc - x;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // sorted bit columns out of the ring tags: ycol[site][word] (one wave per 64 positions)
 __global__ __launch_bounds__(BLOCK) void tags_to_bits_kernel(const int *A, size_t strideA, int M, unsigned long long *ycols,
@@ -2030,98 +2066,6 @@ __global__ __launch_bounds__(BLOCK) void qs_rankdir_kernel(const unsigned long l
     if (threadIdx.x == 0) rd[wpc64] = s_carry;
 }
 
-struct QSweepArgs {
-    const int *A; const int *D; size_t strideA, strideD;     // panel ring slots of the batch
-    const unsigned long long *ycols; int wpc64;              // panel sorted bit columns of the batch
-    const int *rankdir;                                      // [site][wpc64+1]
-    const unsigned char *xq; const int *invq;                // [site][Mq]
-    int Mp, Mq, kbase, nsites;
-    const int *f_in; const int *dq_in; int *f_out; int *dq_out;
-    unsigned long long *cnt;                                 // [site][Mq] in query-PBWT order: counts / exclusive offsets
-    int4 *recs;
-    unsigned long long *tot;                                 // [0] nTot [1] totLen [2] no-match events
-};
-
-// MODE 0: count reports per (site, query rank), accumulate totals, write the new state;
-// MODE 1: emit records at the scanned offsets (state is recomputed, not stored).
-template <int MODE>
-__global__ __launch_bounds__(BLOCK) void qs_sweep_kernel(QSweepArgs g) {
-    const int jj = blockIdx.x * BLOCK + threadIdx.x;
-    if (jj >= g.Mq) return;
-    const int M = g.Mp;
-    int f = g.f_in[jj], dq = g.dq_in[jj];
-    unsigned long long nTot = 0, totLen = 0, nomatch = 0;
-    for (int s = 0; s < g.nsites; ++s) {
-        const int k = g.kbase + s;
-        const int *a = g.A + (size_t)s * g.strideA;
-        const int *d = g.D + (size_t)s * g.strideD;
-        const unsigned long long *yc = g.ycols + (size_t)s * g.wpc64;
-        const unsigned x = g.xq[(size_t)s * g.Mq + jj];
-#define PY(i) ((unsigned)((yc[(i) >> 6] >> ((i) & 63)) & 1ULL))
-        if (PY(f) != x) {
-            int iPlus = f;
-            bool found = false;
-            while (++iPlus < M && d[iPlus] <= dq)                     // pbwtMatch.c:381-383
-                if (PY(iPlus) == x) { f = iPlus; found = true; break; }
-            if (!found) {
-                const int n = iPlus - f;                              // pbwtMatch.c:385-386
-                const size_t slot = (size_t)s * g.Mq + g.invq[(size_t)s * g.Mq + jj];
-                if (MODE == 0) { g.cnt[slot] = (unsigned long long)n; nTot += n; totLen += (unsigned long long)(k - dq) * n; }
-                else { int4 *o = g.recs + g.cnt[slot]; for (int i = f; i < iPlus; ++i) *o++ = make_int4(jj, a[i] & AMASK, dq, k); }
-                int iMinus = f;
-                int dPlus = (iPlus < M) ? d[iPlus] : k;
-                int dMinus = d[iMinus];
-                for (;;) {                                            // pbwtMatch.c:389-411
-                    if (dMinus <= dPlus) {
-                        int hit = -1;
-                        while (d[iMinus] <= dMinus) { --iMinus; if (PY(iMinus) == x) hit = iMinus; }
-                        if (hit >= 0) { f = hit; dq = dMinus; break; }
-                        dMinus = d[iMinus];
-                    } else {
-                        bool got = false;
-                        while (iPlus < M && d[iPlus] <= dPlus) {
-                            if (PY(iPlus) == x) { f = iPlus; dq = dPlus; got = true; break; }
-                            ++iPlus;
-                        }
-                        if (got) break;
-                        dPlus = (iPlus == M) ? k : d[iPlus];
-                        if (!iMinus && iPlus == M) { ++nomatch; dq = k + 1; break; }
-                    }
-                }
-            }
-        }
-#undef PY
-        // pbwtCursorMap (pbwt.h:130-131) with the f == M trap of pbwtMatch.c:422
-        const int *rd = g.rankdir + (size_t)s * (g.wpc64 + 1);
-        const unsigned long long wdv = yc[f >> 6];
-        const int uf = rd[f >> 6] + ((f & 63) - __popcll(wdv & ((1ULL << (f & 63)) - 1ULL)));
-        const int c = rd[g.wpc64];
-        f = x ? c + f - uf : uf;
-        if (f == M) f = 0;
-    }
-    if (MODE == 0) {
-        g.f_out[jj] = f; g.dq_out[jj] = dq;
-        if (nTot) { atomicAdd(g.tot, nTot); atomicAdd(g.tot + 1, totLen); }
-        if (nomatch) atomicAdd(g.tot + 2, nomatch);
-    }
-}
-
-// matches still running at the end of the panel (pbwtMatch.c:430-436), in final query order
-template <int MODE>
-__global__ __launch_bounds__(BLOCK) void qs_tail_kernel(const int *A, const int *D, const int *AQ, int Mp, int Mq, int N,
-                                                       const int *f, const int *dq, unsigned long long *cnt, int4 *recs,
-                                                       unsigned long long *tot) {
-    const int j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j >= Mq) return;
-    const int jj = AQ[j] & AMASK;
-    const int f0 = f[jj], d0 = dq[jj];
-    int i = f0;
-    while (++i < Mp && D[i] <= d0) {}
-    const int n = i - f0;
-    if (MODE == 0) { cnt[j] = (unsigned long long)n; atomicAdd(tot, (unsigned long long)n); atomicAdd(tot + 1, (unsigned long long)(N - d0) * n); }
-    else { int4 *o = recs + cnt[j]; for (int q = f0; q < i; ++q) *o++ = make_int4(jj, A[q] & AMASK, d0, N); }
-}
-
 // ---------------------------------------------------------------------------------------------
 // matchSequencesSweepSparse (pbwtMatch.c:452-602): the query sweep against the panel cursor AND, at
 // site k, against the sparse cursor kk = k % nS (a PBWT of the sites = kk mod nS, stepped with
@@ -2146,34 +2090,61 @@ struct QssArgs {
     unsigned long long *tot;                                 // [0] nTot [1] totLen [2] no-match events
 };
 
-// reportAndUpdate (pbwtMatch.c:452-499) for one query at one site against one cursor state
+// reportAndUpdate (pbwtMatch.c:452-499) for one query at one site against one cursor state, executed by a whole
+// WAVE: every walk of the reference (the scan for an equally long match further down, the alternating widening of
+// [iMinus, iPlus]) tests 64 positions per step with ballots.  A single lane walking them one dependent load at a time
+// costs ~1 us per position on this machine (measured: 5.5 ms per site at M = 100 k) where the CPU pays ~1 ns.
+// All arguments and results are wave-uniform.
 template <int MODE>
 __device__ __forceinline__ void qss_update(const int *a, const int *d, const unsigned long long *yc, int M, unsigned x, int jj, int k,
                                            int kend, int nS, int isSparse, int &f, int &dq, unsigned long long *cntslot, Rec5 *recs,
                                            unsigned long long &nTot, unsigned long long &totLen, unsigned long long &nomatch) {
+    const int lane = lane_id();
 #define PY(i) ((unsigned)((yc[(i) >> 6] >> ((i) & 63)) & 1ULL))
     if (PY(f) == x) return;
-    int iPlus = f;
-    while (++iPlus < M && d[iPlus] <= dq)
-        if (PY(iPlus) == x) { f = iPlus; return; }
-    const int n = iPlus - f;
+    // downward scan from `from` while d <= thr: the first position that either fails the test (or is M) or carries x
+    auto scan_down = [&](int from, int thr, bool &found) -> int {
+        for (int base = from;; base += 64) {
+            const int i = base + lane;
+            const bool bound = (i >= M) || (d[i] > thr);
+            const bool same = !bound && PY(i) == x;
+            const unsigned long long mb = __ballot(bound), ms = __ballot(same), any = mb | ms;
+            if (any) { const int first = __ffsll((long long)any) - 1; found = (ms >> first) & 1ULL; return base + first; }
+        }
+    };
+    bool found = false;
+    int iPlus = scan_down(f + 1, dq, found);                 // pbwtMatch.c:455-457
+    if (found) { f = iPlus; return; }
+    const int n = iPlus - f;                                 // these matches end here (pbwtMatch.c:459-461)
     const int dj = isSparse ? nS * dq + k % nS : dq;
-    if (MODE == 0) { *cntslot = (unsigned long long)n; nTot += n; totLen += (unsigned long long)(k - dj) * n; }
-    else { Rec5 *o = recs + *cntslot; for (int i = f; i < iPlus; ++i) { o->ai = jj; o->bi = a[i] & AMASK; o->start = dj; o->end = k; o->sparse = isSparse; ++o; } }
+    if (MODE == 0) { if (lane == 0) *cntslot = (unsigned long long)n; nTot += n; totLen += (unsigned long long)(k - dj) * n; }
+    else {
+        Rec5 *o = recs + *cntslot;
+        for (int i = f + lane; i < iPlus; i += 64) { Rec5 r; r.ai = jj; r.bi = a[i] & AMASK; r.start = dj; r.end = k; r.sparse = isSparse; o[i - f] = r; }
+    }
     int iMinus = f;
     int dPlus = (iPlus < M) ? d[iPlus] : kend;
     int dMinus = d[iMinus];
-    for (;;) {
+    for (;;) {                                               // widen [iMinus, iPlus] by the smaller divergence until an x is met (:477-498)
         if (dMinus <= dPlus) {
+            // while (d[iMinus] <= dMinus) if (y[--iMinus] == x) hit = iMinus;   d[0] = kend+1 stops it; the LOWEST hit counts
             int hit = -1;
-            while (d[iMinus] <= dMinus) { --iMinus; if (PY(iMinus) == x) hit = iMinus; }
+            for (int base = iMinus;; base -= 64) {
+                const int j = base - lane;
+                const bool stop = (j < 0) || (d[j] > dMinus);
+                const unsigned long long mstop = __ballot(stop);
+                const int nlive = mstop ? __ffsll((long long)mstop) - 1 : 64;     // lanes 0..nlive-1 passed the test: candidates j-1
+                const bool cand = (lane < nlive) && (j - 1 >= 0) && PY(j - 1) == x;
+                const unsigned long long mc = __ballot(cand);
+                if (mc) hit = base - (63 - __clzll(mc)) - 1;                       // highest lane = lowest index
+                if (mstop) { iMinus = base - nlive; break; }
+            }
             if (hit >= 0) { f = hit; dq = dMinus; return; }
             dMinus = d[iMinus];
         } else {
-            while (iPlus < M && d[iPlus] <= dPlus) {
-                if (PY(iPlus) == x) { f = iPlus; dq = dPlus; return; }
-                ++iPlus;
-            }
+            bool got = false;
+            iPlus = scan_down(iPlus, dPlus, got);
+            if (got) { f = iPlus; dq = dPlus; return; }
             dPlus = (iPlus < M) ? d[iPlus] : kend;
             if (!iMinus && iPlus == M) { ++nomatch; dq = 1 + kend; return; }
         }
@@ -2189,25 +2160,43 @@ __device__ __forceinline__ int qss_lfmap(const unsigned long long *yc, const int
     return (f == M) ? 0 : f;
 }
 
+// one WAVE per query
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
-    const int jj = blockIdx.x * BLOCK + threadIdx.x;
+    const int jj = blockIdx.x * WAVES + wave_id(), lane = lane_id();
     if (jj >= g.Mq) return;
     const int M = g.Mp, nS = g.nS;
     int f = g.f_in[jj], dq = g.dq_in[jj];
     unsigned long long nTot = 0, totLen = 0, nomatch = 0;
     // the sparse (f, d) pairs live in global memory (nS is a run-time value): working copy in the out arrays
-    if (MODE == 0) for (int kk = 0; kk < nS; ++kk) { g.fs_out[(size_t)kk * g.Mq + jj] = g.fs_in[(size_t)kk * g.Mq + jj]; g.ds_out[(size_t)kk * g.Mq + jj] = g.ds_in[(size_t)kk * g.Mq + jj]; }
+    if (MODE == 0 && lane == 0) for (int kk = 0; kk < nS; ++kk) { g.fs_out[(size_t)kk * g.Mq + jj] = g.fs_in[(size_t)kk * g.Mq + jj]; g.ds_out[(size_t)kk * g.Mq + jj] = g.ds_in[(size_t)kk * g.Mq + jj]; }
     int fsl = 0, dsl = 0;
+    unsigned xpre = 0; int ipre = 0;                         // this query's allele and PBWT rank at 64 sites: lane l holds site s0 + l
     for (int s = 0; s < g.nsites; ++s) {
         const int k = g.kbase + s;
-        const unsigned x = g.xq[(size_t)s * g.Mq + jj];
-        const size_t slot = ((size_t)s * g.Mq + g.invq[(size_t)s * g.Mq + jj]) * 2;
+        if ((s & 63) == 0) {
+            const int sl = s + lane;
+            xpre = (sl < g.nsites) ? g.xq[(size_t)sl * g.Mq + jj] : 0u;
+            ipre = (sl < g.nsites) ? g.invq[(size_t)sl * g.Mq + jj] : 0;
+        }
+        const unsigned x = (unsigned)__builtin_amdgcn_readlane((int)xpre, s & 63);
+        const size_t slot = ((size_t)s * g.Mq + __builtin_amdgcn_readlane(ipre, s & 63)) * 2;
         {
             const int *a = g.dense.A + (size_t)s * g.dense.strideA, *d = g.dense.D + (size_t)s * g.dense.strideD;
             const unsigned long long *yc = g.dense.ycols + (size_t)s * g.wpc64;
-            qss_update<MODE>(a, d, yc, M, x, jj, k, k, nS, 0, f, dq, g.cnt + slot, g.recs, nTot, totLen, nomatch);
-            f = qss_lfmap(yc, g.dense.rankdir + (size_t)s * (g.wpc64 + 1), g.wpc64, M, x, f);
+            const int *rd = g.dense.rankdir + (size_t)s * (g.wpc64 + 1);
+            // the common case (the match extends) is ONE memory round trip per site: the column word, its rank directory
+            // entry and the zero count depend on f only and are requested together
+            const unsigned long long w0 = yc[f >> 6];
+            const int r0 = rd[f >> 6], c0 = rd[g.wpc64];
+            if ((unsigned)((w0 >> (f & 63)) & 1ULL) == x) {
+                const int uf = r0 + ((f & 63) - __popcll(w0 & ((1ULL << (f & 63)) - 1ULL)));
+                f = x ? c0 + f - uf : uf;
+                if (f == M) f = 0;
+            } else {
+                qss_update<MODE>(a, d, yc, M, x, jj, k, k, nS, 0, f, dq, g.cnt + slot, g.recs, nTot, totLen, nomatch);
+                f = qss_lfmap(yc, rd, g.wpc64, M, x, f);
+            }
         }
         if (nS > 1) {
             const int kk = k % nS;
@@ -2215,18 +2204,22 @@ __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
             const int t = k / nS - v.sbase;                 // this cursor's slot in its ring
             const int *a = v.A + (size_t)t * v.strideA, *d = v.D + (size_t)t * v.strideD;
             const unsigned long long *yc = v.ycols + (size_t)t * g.wpc64;
-            // MODE 1 replays the same walk from the batch's input state
-            int *fp = (MODE == 0 ? g.fs_out : (int *)nullptr), *dp = (MODE == 0 ? g.ds_out : (int *)nullptr);
-            if (MODE == 0) { fsl = fp[(size_t)kk * g.Mq + jj]; dsl = dp[(size_t)kk * g.Mq + jj]; }
-            else if (s < nS) { fsl = g.fs_in[(size_t)kk * g.Mq + jj]; dsl = g.ds_in[(size_t)kk * g.Mq + jj]; }
-            else { fsl = g.fs_out[(size_t)(nS + kk) * g.Mq + jj]; dsl = g.ds_out[(size_t)(nS + kk) * g.Mq + jj]; }
+            // MODE 1 replays the same walk from the batch's input state (scratch half of the out arrays)
+            const size_t ix = (size_t)kk * g.Mq + jj, sx = (size_t)(nS + kk) * g.Mq + jj;
+            if (MODE == 0) { fsl = g.fs_out[ix]; dsl = g.ds_out[ix]; }
+            else if (s < nS) { fsl = g.fs_in[ix]; dsl = g.ds_in[ix]; }
+            else { fsl = g.fs_out[sx]; dsl = g.ds_out[sx]; }
             qss_update<MODE>(a, d, yc, M, x, jj, k, k / nS, nS, 1, fsl, dsl, g.cnt + slot + 1, g.recs, nTot, totLen, nomatch);
             fsl = qss_lfmap(yc, v.rankdir + (size_t)t * (g.wpc64 + 1), g.wpc64, M, x, fsl);
-            if (MODE == 0) { fp[(size_t)kk * g.Mq + jj] = fsl; dp[(size_t)kk * g.Mq + jj] = dsl; }
-            else { g.fs_out[(size_t)(nS + kk) * g.Mq + jj] = fsl; g.ds_out[(size_t)(nS + kk) * g.Mq + jj] = dsl; }   // scratch half of the out arrays
+            if (lane == 0) {
+                if (MODE == 0) { g.fs_out[ix] = fsl; g.ds_out[ix] = dsl; }
+                else { g.fs_out[sx] = fsl; g.ds_out[sx] = dsl; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();                          // the wave reads its own lane-0 store back at its next visit of this cursor
         }
     }
-    if (MODE == 0) {
+    if (MODE == 0 && lane == 0) {
         g.f_out[jj] = f; g.dq_out[jj] = dq;
         if (nTot) { atomicAdd(g.tot, nTot); atomicAdd(g.tot + 1, totLen); }
         if (nomatch) atomicAdd(g.tot + 2, nomatch);
@@ -2234,20 +2227,24 @@ __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
 }
 
 // matches still running at the end of the panel for one cursor (pbwtMatch.c:577-594), in final query
-// order; sparse cursor kk: start nS*d + kk, totLen with the cursor's own d (as the reference)
+// order; sparse cursor kk: start nS*d + kk, totLen with the cursor's own d (as the reference).  One wave per query.
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void qss_tail_kernel(const int *A, const int *D, const int *AQ, int Mp, int Mq, int N, int nS, int kk, int isSparse,
                                                         const int *f, const int *dq, unsigned long long *cnt, Rec5 *recs, unsigned long long *tot) {
-    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    const int j = blockIdx.x * WAVES + wave_id(), lane = lane_id();
     if (j >= Mq) return;
     const int jj = AQ[j] & AMASK;
     const int f0 = f[jj], d0 = dq[jj];
-    int i = f0;
-    while (++i < Mp && D[i] <= d0) {}
+    int i = f0 + 1;                                          // for (i = f; ++i < M && d[i] <= dq; )
+    for (;; i += 64) {
+        const int p = i + lane;
+        const unsigned long long mb = __ballot((p >= Mp) || (D[p] > d0));
+        if (mb) { i += __ffsll((long long)mb) - 1; break; }
+    }
     const int n = i - f0;
     const int dj = isSparse ? nS * d0 + kk : d0;
-    if (MODE == 0) { cnt[j] = (unsigned long long)n; atomicAdd(tot, (unsigned long long)n); atomicAdd(tot + 1, (unsigned long long)(N - d0) * n); }
-    else { Rec5 *o = recs + cnt[j]; for (int q = f0; q < i; ++q) { o->ai = jj; o->bi = A[q] & AMASK; o->start = dj; o->end = N; o->sparse = isSparse; ++o; } }
+    if (MODE == 0) { if (lane == 0) { cnt[j] = (unsigned long long)n; atomicAdd(tot, (unsigned long long)n); atomicAdd(tot + 1, (unsigned long long)(N - d0) * n); } }
+    else { Rec5 *o = recs + cnt[j]; for (int q = f0 + lane; q < i; q += 64) { Rec5 r; r.ai = jj; r.bi = A[q] & AMASK; r.start = dj; r.end = N; r.sparse = isSparse; o[q - f0] = r; } }
 }
 
 // bytes (0/1 per haplotype, original order) -> bit column words; grid (words/4, sites)
