@@ -1059,7 +1059,8 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     // heap layout: level j (keys of j bits) lives at [2^j, 2^(j+1)), the rank kernel's level 8 at [256, 512)
     __shared__ short s_rawH[NC][2 * SKK], s_lastH[NC][2 * SKK];  // per chunk: count / last local position (-1) -> levels 1..7 become base / previous position (exclusive over the chunks)
     __shared__ int s_tbl[NL][T];
-    __shared__ int s_bH[2 * SKK], s_cH[2 * SKK], s_tH[2 * SKK], s_GH[SKK], s_lowH[SKK];
+    __shared__ int s_bH[2 * SKK], s_cH[2 * SKK], s_tH[2 * SKK];
+    int *const s_GH = &s_bH[SKK], *const s_lowH = &s_cH[SKK];   // the level-8 halves are dead once level 7 is folded: 40 KB in all, 4 workgroups per CU
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x, b = blockIdx.y;
     const int S = w * T, k = g.kbase + 8 * b;
     const int *a_in = g.A + (size_t)(8 * b) * g.strideA;
