@@ -791,8 +791,17 @@ __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
         if (!valid) dv[e] = 0;
     }
     lds_barrier();
+    // one LDS atomic pair per (wave, key) instead of per position: real panels are skewed (most positions share the all-zero
+    // key), and same-address LDS atomics serialise.  The first lane of a key group holds its highest position (reverse order).
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) if (key[e] >= 0) { atomicAdd(&h_cnt[key[e]], 1); atomicMax(&h_last[key[e]], l0 + e); }
+    for (int e = 0; e < EPT; ++e) {
+        unsigned long long same = __ballot(key[e] >= 0);
+#pragma unroll
+        for (int b = 0; b < SKB; ++b) { const unsigned long long bal = __ballot((key[e] >> b) & 1); same &= ((key[e] >> b) & 1) ? bal : ~bal; }
+        if (key[e] >= 0 && (same & ((lane == 0) ? 0ULL : (~0ULL >> (64 - lane)))) == 0) {
+            atomicAdd(&h_cnt[key[e]], __popcll(same)); atomicMax(&h_last[key[e]], l0 + e);
+        }
+    }
     int own = dv[0];
 #pragma unroll
     for (int e = 1; e < EPT; ++e) own = max(own, dv[e]);
