@@ -730,8 +730,6 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         const uint32_t *bc = cols + (size_t)done * wpc;
         const int r = e->ring;
         int *A = ringA(e, r), *D = ringD(e, r);
-        static const int throttle = getenv("PBWTAMD_THROTTLE") ? atoi(getenv("PBWTAMD_THROTTLE")) : 0;
-        if (throttle && e->chainRecorded[r]) HIPCHK(hipEventSynchronize(e->evChain[r]));   // host at most one batch ahead of the chain
         // two sites per launch when the columns are in original order (the keys of the next pair are
         // gathered by haplotype) and the pair's successor columns are at hand
         const int left = ncols_avail - done;               // columns available from bc on
