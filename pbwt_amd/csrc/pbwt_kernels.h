@@ -728,15 +728,18 @@ __global__ __launch_bounds__(BLOCK) void transpose32_kernel(const uint32_t *cols
     uint32_t r[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) { const int site = blk * 32 + j; r[j] = (site < n_valid) ? cols[(size_t)site * wpc + wd] : 0u; }
-    // r[j] bit i = hap 32*wd+i at site j  ->  out[i] bit j
-    uint32_t o[32];
+    // r[j] bit i = hap 32*wd+i at site j  ->  r[i] bit j: five butterfly stages (80 swaps instead of 1024 bit moves)
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        uint32_t v = 0;
+    for (int j = 16, st = 0; st < 5; ++st, j >>= 1) {
+        const uint32_t m = (j == 16) ? 0x0000ffffu : (j == 8) ? 0x00ff00ffu : (j == 4) ? 0x0f0f0f0fu : (j == 2) ? 0x33333333u : 0x55555555u;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) v |= ((r[j] >> i) & 1u) << j;
-        o[i] = v;
+        for (int k = 0; k < 32; ++k) {
+            if (k & j) continue;                            // pairs (k, k + j) with bit j of k clear
+            const uint32_t tt = ((r[k] >> j) ^ r[k + j]) & m;
+            r[k + j] ^= tt; r[k] ^= tt << j;
+        }
     }
+    uint32_t (&o)[32] = r;
     uint32_t *dst = xT + (size_t)blk * strideX + (size_t)wd * 32;
 #pragma unroll
     for (int i = 0; i < 32; ++i) if (wd * 32 + i < Mpad) dst[i] = o[i];
