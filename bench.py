@@ -101,6 +101,21 @@ def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=4096, ba
             "sites_per_launch": spl, "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS}
 
 
+def host_entry_points(torch, pbwt_amd, panel, M, sites=16384, batch=512):
+    """PCIe-inclusive rates of the host-buffer entry points on the first `sites` columns of the same panel (reported
+    next to the headline, never part of `value`): pbwtamd_build (columns in host memory -> .pbwt bytes) and the read side
+    pbwtamd_max_within in -stats mode (packed panel up, decode, ForwardsReadAD chain, sweep, histogram back)"""
+    bits = panel[:sites].cpu().numpy().view(np.uint32)
+    eng = pbwt_amd.Engine(M, batch_sites=batch)
+    eng.build(bits[:1024], with_d=False)                                 # warm-up (allocations)
+    t0 = time.perf_counter(); b = eng.build(bits, with_d=False); t1 = time.perf_counter()
+    eng.max_within(b["yz"], sites, mode="hist"); t2 = time.perf_counter()
+    eng.max_within(b["yz"], sites, mode="hist"); t3 = time.perf_counter()
+    eng.close()
+    return {"sites": sites, "build_site_haps_per_s": M * sites / (t1 - t0), "read_maxwithin_stats_site_haps_per_s": M * sites / (t3 - t2),
+            "note": "host buffers in pageable memory, transfers included"}
+
+
 def main():
     args = parse()
     import torch
@@ -181,6 +196,7 @@ def main():
     achieved = alg_bytes_per_launch / (us_per_launch * 1e-6) / 1e9
     hist = eng.get_hist(n_total + 1)
     first = panel[:min(args.cpu_sites, n_total)].cpu().numpy().view(np.uint32) if (rank == 0 and world == 1 and not args.no_cpu) else None
+    hep = host_entry_points(torch, pbwt_amd, panel, M) if (rank == 0 and world == 1 and not args.no_1m and n_total >= 16384) else None
     traffic, traffic_src = None, None
     try:                                   # HBM-side bytes per launch measured with rocprofv3 PMC (separate run)
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(str(M))
@@ -208,6 +224,8 @@ def main():
                      "note": "one launch = sites_per_launch sites; duration = HIP-event time of the dependent launch chain / launches, i.e. including launch gaps"},
         "within_reports_hist_total": int(hist.sum()),
     }
+    if hep:
+        out["host_entry_points"] = hep
     if rank == 0 and world == 1 and not args.no_1m:
         del panel
         torch.cuda.empty_cache()
