@@ -932,6 +932,13 @@ extern "C" int pbwtamd_build(pbwtamd_engine *e, const uint32_t *bitcols, int wpc
     if (wpc < (e->M + 31) / 32) return fail("pbwtamd_build: wpc %d too small for M %d", wpc, e->M);
     CHK(pbwtamd_pass_begin(e, aFstart, 0, N));
     const unsigned opts = (with_d ? PBWTAMD_OPT_WITH_D : 0u) | (yz_out ? PBWTAMD_OPT_PACK3 : 0u);
+    // pin the caller's columns for the duration of the build: the per-batch copies then run as DMA at link speed beside the
+    // chain instead of through the runtime's bounce buffers (falls back to pageable copies if registration is refused)
+    static const bool no_pin = getenv("PBWTAMD_NO_PIN") != nullptr;
+    const size_t in_bytes = (size_t)N * wpc * sizeof(uint32_t);
+    const bool pinned = !no_pin && in_bytes >= (1u << 20) && hipHostRegister((void *)bitcols, in_bytes, hipHostRegisterDefault) == hipSuccess;
+    if (!pinned) (void)hipGetLastError();
+    struct Unpin { const void *p; bool on; ~Unpin() { if (on) (void)hipHostUnregister((void *)p); } } unpin{bitcols, pinned};
     int done = 0, half = 0;
     while (done < N) {
         const int nb = std::min(e->B, N - done);
