@@ -113,7 +113,7 @@ def host_entry_points(torch, pbwt_amd, panel, M, sites=16384, batch=512):
     eng.max_within(b["yz"], sites, mode="hist"); t3 = time.perf_counter()
     eng.close()
     return {"sites": sites, "build_site_haps_per_s": M * sites / (t1 - t0), "read_maxwithin_stats_site_haps_per_s": M * sites / (t3 - t2),
-            "note": "host buffers in pageable memory, transfers included"}
+            "note": "caller buffers in ordinary host memory (the build pins its input for the call), transfers included, first call at this size"}
 
 
 def main():
