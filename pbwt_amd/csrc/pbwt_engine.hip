@@ -93,7 +93,7 @@ struct pbwtamd_engine {
     int *skT = nullptr;                     // hist table of the round in flight, [W][256] {cnt, tail}
     unsigned char *keysR[2] = {nullptr, nullptr};         // per ring: the keys of states 0, 8, 16, ... of the batch ([B/8+1][Mpad]), kept for the fill
     int2 *saveR[2] = {nullptr, nullptr}; size_t strideS = 0;  // per ring and round: scan[W][256] {before, carry}, total[256] (stride in int2)
-    hipEvent_t tev[16] = {}; long long tev_n = 0; int thr_rounds = 32, thr_depth = 2;   // host throttle: an event every thr_rounds rounds, host at most thr_depth events ahead
+    hipEvent_t tev[16] = {}; long long tev_n = 0; int thr_rounds = 28, thr_depth = 2;   // host throttle: an event every thr_rounds rounds, host at most thr_depth events ahead
     int *rankdirS = nullptr;                // read-side skeleton: zero-prefix directories of the batch's sorted columns [B+2][wpc64+1]
     bool keys_ready[2] = {false, false};     // slot-0 keys of the ring delivered by the previous batch's last round
     int Wt = 0, skEPT = 4;                  // skeleton tiles: 256*skEPT positions, Wt of them; PBWTAMD_SKT=512|1024
