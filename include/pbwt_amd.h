@@ -80,6 +80,16 @@ int pbwtamd_sweep_AD(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, co
                      uint64_t *csum_a, uint64_t *csum_d, uint64_t *csum_y,
                      const int32_t *dump_sites, int ndump, int32_t *a_dump, int32_t *d_dump, uint8_t *y_dump);
 
+/* The PbwtCursor struct (pbwt.h:74-87) at site k of a packed panel: fills the caller's cursor arrays with exactly what
+ * pbwtCursorCreate(p,TRUE,TRUE) + k calls of pbwtCursorForwardsReadAD (pbwtCore.c:420-445,543-557) leave there —
+ *   a[M], d[M+1] (sentinels d[0] = d[M] = k+1), y[M] (the column of site k; at k == N the stale column N-1, pbwtCore.c:539),
+ *   *c = zeros in y, u[M+1] as pbwtCursorCalculateU (pbwtCore.c:510-519) computes it,
+ *   *nBlockStart / *n = the cursor's byte offsets into yz (isBlockEnd = k < N) —
+ * so a host caller can stop the device sweep at any site and go on with the per-column API (pbwt.h:114-127) on the CPU.
+ * Any output pointer may be NULL. */
+int pbwtamd_cursor_at(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart, int k,
+                      int32_t *a, int32_t *d, uint8_t *y, int32_t *c, int32_t *u, int64_t *nBlockStart, int64_t *n);
+
 /* -haps: pbwtWriteHaplotypes (pbwtIO.c:839-857) without the text formatting: out[k*M + h] = allele
  * (0/1) of haplotype h at site k, recovered by a forward sweep of the packed panel */
 int pbwtamd_haplotypes(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart, uint8_t *out);
@@ -93,6 +103,12 @@ int pbwtamd_haplotypes(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, 
 int pbwtamd_max_within(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart,
                        pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out,
                        int64_t *hist, int histlen);
+
+/* the same sweep, reports restricted to the sites k_lo <= end < k_hi (k_hi <= N+1; end == N is the closing
+ * all-positions report): for callers whose report() only keeps a window of `end` values — the chain still runs
+ * over every site, the record traffic is the window's */
+int pbwtamd_max_within_range(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart,
+                             int k_lo, int k_hi, pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out);
 
 /* matchLongWithin2 (pbwtMatch.c:85-113), the -longWithin L command: every pair of haplotypes
  * whose match ending at a site is at least L sites long, reported when the block closes; report

@@ -62,7 +62,9 @@ def ref():
     """the real reference, or None when oracle/_ref was not built"""
     global _ref
     if _ref is None:
-        path = os.path.join(_HERE, "_ref", "libpbwtref.so")
+        # PBWT_ORACLE_REF_LIB: tests/test_integration.py points this at _ref/libpbwtref_gpu.so (the reference compiled with
+        # integration/pbwtGpu.c, i.e. with the product underneath) to drive it through the same wrappers below
+        path = os.environ.get("PBWT_ORACLE_REF_LIB") or os.path.join(_HERE, "_ref", "libpbwtref.so")
         if not os.path.exists(path) and os.path.isdir("/root/reference"):
             build()
         _ref = _load(path)
@@ -191,6 +193,17 @@ def max_within(yz, M, N, aFstart=None):
     mv = MatchVec()
     rc = lib().orc_max_within(C.c_int(M), C.c_int(N), _p(yz, C.c_uint8), C.c_size_t(yz.size), _p(a0, C.c_int32),
                               C.c_int(0), C.byref(mv), None, C.c_int(0))
+    assert rc == 0
+    return _take(mv)
+
+
+def max_within_range(yz, M, N, k_lo, k_hi, aFstart=None):
+    """records of the sites k_lo <= k < k_hi only, in callback order"""
+    yz = np.ascontiguousarray(yz, dtype=np.uint8)
+    a0 = np.arange(M, dtype=np.int32) if aFstart is None else np.ascontiguousarray(aFstart, dtype=np.int32)
+    mv = MatchVec()
+    rc = lib().orc_max_within_range(C.c_int(M), C.c_int(N), _p(yz, C.c_uint8), C.c_size_t(yz.size), _p(a0, C.c_int32),
+                                    C.c_int(k_lo), C.c_int(k_hi), C.byref(mv))
     assert rc == 0
     return _take(mv)
 

@@ -330,8 +330,8 @@ static void mv_push(orc_matchvec *mv, int ai, int bi, int start, int end)
 /* pbwtMatch.c:115-142.  The two scans walk away from i while the divergence stays within the
  * best-match block; finding an equal allele there (and not being at the final site) means the
  * match extends, so i is skipped. */
-int orc_max_within(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aFstart,
-                   int mode, orc_matchvec *out, int64_t *hist, int histlen)
+static int max_within_range(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aFstart,
+                            int mode, orc_matchvec *out, int64_t *hist, int histlen, int k_lo, int k_hi)
 {
     ocursor u;
     int rc = 0;
@@ -341,7 +341,7 @@ int orc_max_within(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aF
         const int32_t *d = u.d, *a = u.a;
         const uint8_t *y = u.y;
         int live = k < N;
-        for (int i = 0; i < M; ++i) {
+        for (int i = 0; i < M && k >= k_lo && k < k_hi; ++i) {
             int m = i - 1, n = i + 1, skip = 0;
             if (d[i] <= d[i + 1])
                 while (d[m + 1] <= d[i]) { if (y[m--] == y[i] && live) { skip = 1; break; } }
@@ -362,6 +362,21 @@ int orc_max_within(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aF
 done:
     oc_close(&u);
     return rc;
+}
+
+int orc_max_within(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aFstart,
+                   int mode, orc_matchvec *out, int64_t *hist, int histlen)
+{
+    return max_within_range(M, N, yz, nz, aFstart, mode, out, hist, histlen, 0, N + 1);
+}
+
+/* the same sweep with the report callback filtered to the sites k_lo <= k < k_hi (what a caller's
+ * report() does when it only wants the matches ending in a window): full-width parity checks at
+ * M = 1 M without materialising every site's records */
+int orc_max_within_range(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aFstart,
+                         int k_lo, int k_hi, orc_matchvec *out)
+{
+    return max_within_range(M, N, yz, nz, aFstart, 0, out, NULL, 0, k_lo, k_hi);
 }
 
 /* ------------------------------------------------------------------ matchLongWithin2 */

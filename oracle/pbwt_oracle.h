@@ -76,6 +76,10 @@ int orc_sweep_AD(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aFst
 int orc_max_within(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aFstart,
                    int mode, orc_matchvec *out, int64_t *hist, int histlen);
 
+/* the same, reports filtered to the sites k_lo <= k < k_hi (mode 0 only) */
+int orc_max_within_range(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aFstart,
+                         int k_lo, int k_hi, orc_matchvec *out);
+
 /* ---- matchLongWithin2 (pbwtMatch.c:85-113), the -longWithin L command: records in callback order */
 int orc_long_within(int M, int N, int L, const uint8_t *yz, size_t nz, const int32_t *aFstart, orc_matchvec *out);
 

@@ -137,6 +137,17 @@ class Engine:
                                            _p(y_dump, C.c_uint8)))
         return dict(csum_a=ca, csum_d=cd, csum_y=cy, a_dump=a_dump, d_dump=d_dump, y_dump=y_dump)
 
+    def cursor_at(self, yz, N, k, aFstart=None):
+        """the PbwtCursor fields (a, d, y, c, u, nBlockStart, n) before site k of a packed panel"""
+        yz = np.ascontiguousarray(yz, dtype=np.uint8)
+        aF = _i32(aFstart)
+        a = np.zeros(self.M, np.int32); d = np.zeros(self.M + 1, np.int32); y = np.zeros(self.M, np.uint8)
+        u = np.zeros(self.M + 1, np.int32); c = C.c_int32(0); nbs = C.c_int64(0); n = C.c_int64(0)
+        self._chk(self._L.pbwtamd_cursor_at(self._h, _p(yz, C.c_uint8), C.c_int64(yz.size), C.c_int(N), _p(aF, C.c_int32), C.c_int(k),
+                                            _p(a, C.c_int32), _p(d, C.c_int32), _p(y, C.c_uint8), C.byref(c), _p(u, C.c_int32),
+                                            C.byref(nbs), C.byref(n)))
+        return dict(a=a, d=d, y=y, c=c.value, u=u, nBlockStart=nbs.value, n=n.value)
+
     def haplotypes(self, yz, N, aFstart=None):
         yz = np.ascontiguousarray(yz, dtype=np.uint8)
         aF = _i32(aFstart)
@@ -163,6 +174,20 @@ class Engine:
         n = C.c_int64(0)
         self._chk(self._L.pbwtamd_max_within(self._h, _p(yz, C.c_uint8), C.c_int64(yz.size), C.c_int(N), _p(aF, C.c_int32),
                                              None, C.byref(rp), C.byref(n), None, C.c_int(0)))
+        out = np.zeros(n.value, MATCH_DTYPE)
+        if n.value:
+            C.memmove(out.ctypes.data, rp, n.value * MATCH_DTYPE.itemsize)
+        self._L.pbwtamd_free(rp)
+        return out
+
+    def max_within_range(self, yz, N, k_lo, k_hi, aFstart=None):
+        """records (callback order) of the sites k_lo <= k < k_hi only"""
+        yz = np.ascontiguousarray(yz, dtype=np.uint8)
+        aF = _i32(aFstart)
+        rp = C.c_void_p()
+        n = C.c_int64(0)
+        self._chk(self._L.pbwtamd_max_within_range(self._h, _p(yz, C.c_uint8), C.c_int64(yz.size), C.c_int(N), _p(aF, C.c_int32),
+                                                   C.c_int(k_lo), C.c_int(k_hi), None, C.byref(rp), C.byref(n)))
         out = np.zeros(n.value, MATCH_DTYPE)
         if n.value:
             C.memmove(out.ctypes.data, rp, n.value * MATCH_DTYPE.itemsize)

@@ -317,7 +317,10 @@ static void launch_step2(pbwtamd_engine *e, int ring, int jl, bool with_d) {
 #define L2(WD, SP, NT, EE) hipLaunchKernelGGL((step2_kernel<WD, SP, NT, EE>), dim3(e->W), dim3(NT), 0, e->stream, g)
     if (e->T == 1024 && e->pair1024) { if (with_d) L2(true, 1, 1024, 1); else L2(false, 1, 1024, 1); }     // 16-wave workgroups (opt-in)
     else if (e->T == 4096) { if (with_d) L2(true, 1, 1024, 4); else L2(false, 1, 1024, 4); }              // one 16-wave workgroup per CU, 4 positions per thread
-    else if (e->T == 2048) { if (with_d) L2(true, 1, 512, 4); else L2(false, 1, 512, 4); }                // 8-wave workgroups, 4 positions per thread
+    else if (e->T == 2048) {                               // 8-wave workgroups, 4 positions per thread; SPT summaries per thread cover W <= 512 * SPT tiles
+        if (with_d) { if (e->W <= 512) L2(true, 1, 512, 4); else L2(true, 2, 512, 4); }
+        else        { if (e->W <= 512) L2(false, 1, 512, 4); else L2(false, 2, 512, 4); }
+    }
     else if (e->T == 1024) {                               // 4 positions per thread, 4-wave workgroups
         if (with_d) { if (e->W <= 256) L2(true, 1, 256, 4); else if (e->W <= 512) L2(true, 2, 256, 4); else L2(true, 4, 256, 4); }
         else        { if (e->W <= 256) L2(false, 1, 256, 4); else if (e->W <= 512) L2(false, 2, 256, 4); else L2(false, 4, 256, 4); }
@@ -1014,8 +1017,10 @@ static int get_state_y(pbwtamd_engine *e, uint8_t *y) {
     return 0;
 }
 
+// [rec_lo, rec_hi): the sites whose states the consumers in `opts` see (default: all of 0..N); the chain runs over every site
 static int sweep_packed(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart, unsigned opts,
-                        const int32_t *dump_sites, int ndump, int32_t *a_dump, int32_t *d_dump, uint8_t *y_dump = nullptr) {
+                        const int32_t *dump_sites, int ndump, int32_t *a_dump, int32_t *d_dump, uint8_t *y_dump = nullptr,
+                        int rec_lo = 0, int rec_hi = 0x7fffffff) {
     Packed pk;
     CHK(packed_upload(e, e->stream, e->M, yz, nz, N, pk));
     CHK(pbwtamd_pass_begin(e, aFstart, 0, N));
@@ -1037,6 +1042,9 @@ static int sweep_packed(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N,
             for (int q = 0; q < ndump; ++q) if (dump_sites[q] > done && dump_sites[q] < nxt) nxt = dump_sites[q];
             nb = std::min(nb, nxt - done);
         }
+        if (done < rec_lo) nb = std::min(nb, rec_lo - done);   // batches do not straddle the window's ends
+        else if (done < rec_hi) nb = std::min(nb, rec_hi - done);
+        const bool in_window = done >= rec_lo && done < rec_hi;
         const int navail = std::min(nb + 1, N - done);
         // decode straight into the column staging buffer (ycols is scratch for pack3/get_state)
         CHK(packed_expand(e, e->stream, pk, e->M, done, navail, (unsigned long long *)e->cols_stage, e->wpc64));
@@ -1044,11 +1052,11 @@ static int sweep_packed(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N,
             CHK(ensure_prepared(e, e->cols_stage, true, true, false, navail));   // tags of the first site exist before it is dumped
             CHK(dump_at(done));
         }
-        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, opts));
+        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, in_window ? opts : (PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D)));
         done += nb;
     }
     if (any_dump) CHK(dump_at(N));
-    CHK(pbwtamd_pass_end(e, opts));
+    CHK(pbwtamd_pass_end(e, (N >= rec_lo && N < rec_hi) ? opts : (PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D)));
     return 0;
 }
 
@@ -1080,6 +1088,76 @@ extern "C" int pbwtamd_max_within(pbwtamd_engine *e, const uint8_t *yz, int64_t 
     if (recs_out) {
         pbwtamd_match *buf = (pbwtamd_match *)malloc(std::max<size_t>(1, recs.size()) * sizeof(pbwtamd_match));
         if (!buf) return fail("pbwtamd_max_within: out of host memory");
+        if (!recs.empty()) memcpy(buf, recs.data(), recs.size() * sizeof(pbwtamd_match));
+        *recs_out = buf; *nrecs_out = (int64_t)recs.size();
+    }
+    return 0;
+}
+
+// PbwtCursor view (pbwt.h:74-87) of the read-side cursor before site k: what pbwtCursorCreate(p,TRUE,TRUE) followed by k calls of
+// pbwtCursorForwardsReadAD (pbwtCore.c:420-445,543-557) leave in u->a, u->d, u->y, u->c, plus u->u as pbwtCursorCalculateU would
+// fill it, and the cursor's byte offsets into yz (u->nBlockStart, u->n; isBlockEnd = k < N).  y, c, u come from the packed column
+// itself (y_k in sorted order IS column k of yz); at k == N they are the stale column N-1, as in the reference.
+extern "C" int pbwtamd_cursor_at(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart, int k,
+                                 int32_t *a, int32_t *d, uint8_t *y, int32_t *c, int32_t *u, int64_t *nBlockStart, int64_t *n) {
+    HIPCHK(hipSetDevice(e->device));
+    if (k < 0 || k > N) return fail("pbwtamd_cursor_at: site %d outside 0..%d", k, N);
+    Packed pk;
+    CHK(packed_upload(e, e->stream, e->M, yz, nz, N, pk));
+    CHK(pbwtamd_pass_begin(e, aFstart, 0, N));
+    for (int done = 0; done < k;) {
+        const int nb = std::min(e->B, k - done), navail = std::min(nb + 1, N - done);
+        CHK(packed_expand(e, e->stream, pk, e->M, done, navail, (unsigned long long *)e->cols_stage, e->wpc64));
+        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D));
+        done += nb;
+    }
+    if (a) CHK(pbwtamd_get_state(e, a, d));
+    e->pass_open = false;
+    CHK(pbwtamd_sync(e));
+    const int ky = std::min(k, N - 1);
+    if (ky >= 0) {
+        DevBufs bufs;
+        unsigned char *dy; int *du, *rd;
+        CHK(bufs.alloc(&dy, (size_t)e->M)); CHK(bufs.alloc(&du, (size_t)e->M + 1)); CHK(bufs.alloc(&rd, (size_t)e->wpc64 + 1));
+        CHK(packed_expand(e, e->stream, pk, e->M, ky, 1, e->ycols, e->wpc64));
+        hipLaunchKernelGGL(qs_rankdir_kernel, dim3(1), dim3(BLOCK), 0, e->stream, (const unsigned long long *)e->ycols, e->wpc64, e->M, rd);
+        hipLaunchKernelGGL(cursor_y_u_kernel, dim3((e->M + 256) / 256), dim3(256), 0, e->stream, (const unsigned long long *)e->ycols, (const int *)rd, e->M, dy, du);
+        HIPCHK(hipGetLastError());
+        if (y) HIPCHK(hipMemcpyAsync(y, dy, (size_t)e->M, hipMemcpyDeviceToHost, e->stream));
+        if (u) HIPCHK(hipMemcpyAsync(u, du, sizeof(int) * ((size_t)e->M + 1), hipMemcpyDeviceToHost, e->stream));
+        if (c) HIPCHK(hipMemcpyAsync(c, rd + e->wpc64, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        long long cs[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(cs, pk.colStart + ky, sizeof cs, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (nBlockStart) *nBlockStart = cs[0];
+        if (n) *n = (k < N) ? cs[1] : nz;
+        CHK(pbwtamd_sync(e));                               // device error flag of the expand
+    } else {                                                // empty panel: pbwtCursorCreate leaves n = 0, y unset (pbwtCore.c:436-439)
+        if (y) memset(y, 0, (size_t)e->M);
+        if (u) memset(u, 0, sizeof(int) * ((size_t)e->M + 1));
+        if (c) *c = 0;
+        if (nBlockStart) *nBlockStart = 0;
+        if (n) *n = 0;
+    }
+    return 0;
+}
+
+// matchMaximalWithin with the reports restricted to the sites k_lo <= k < k_hi (k_hi <= N + 1; k == N is the final
+// all-positions report of pbwtMatch.c:126 `k < p->N`): what a caller's report() sees if it ignores every other `end`
+extern "C" int pbwtamd_max_within_range(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart,
+                                        int k_lo, int k_hi, pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out) {
+    HIPCHK(hipSetDevice(e->device));
+    if ((report ? 1 : 0) + (recs_out ? 1 : 0) != 1) return fail("pbwtamd_max_within_range: exactly one of report / recs_out must be given");
+    if (e->M < 2) return fail("pbwtamd_max_within_range: needs at least 2 haplotypes");
+    if (k_lo < 0 || k_hi > N + 1 || k_lo > k_hi) return fail("pbwtamd_max_within_range: window [%d, %d) outside 0..%d", k_lo, k_hi, N + 1);
+    std::vector<pbwtamd_match> recs;
+    e->rec_sink = &recs; e->rec_cb = report;
+    const int rc = sweep_packed(e, yz, nz, N, aFstart, PBWTAMD_OPT_WITHIN_RECS, nullptr, 0, nullptr, nullptr, nullptr, k_lo, k_hi);
+    e->rec_sink = nullptr; e->rec_cb = nullptr;
+    if (rc) return rc;
+    if (recs_out) {
+        pbwtamd_match *buf = (pbwtamd_match *)malloc(std::max<size_t>(1, recs.size()) * sizeof(pbwtamd_match));
+        if (!buf) return fail("pbwtamd_max_within_range: out of host memory");
         if (!recs.empty()) memcpy(buf, recs.data(), recs.size() * sizeof(pbwtamd_match));
         *recs_out = buf; *nrecs_out = (int64_t)recs.size();
     }

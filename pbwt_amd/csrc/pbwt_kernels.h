@@ -2260,6 +2260,17 @@ __global__ __launch_bounds__(BLOCK) void qss_tail_kernel(const int *A, const int
     else { Rec5 *o = recs + cnt[j]; for (int q = f0 + lane; q < i; q += 64) { Rec5 r; r.ai = jj; r.bi = A[q] & AMASK; r.start = dj; r.end = N; r.sparse = isSparse; o[q - f0] = r; } }
 }
 
+// PbwtCursor view of one sorted bit column (pbwt.h:78-83): y[i] as bytes, u[i] = zeros in y[0..i) for i = 0..M
+// (pbwtCursorCalculateU, pbwtCore.c:510-519) from the column's zero-prefix directory
+__global__ void cursor_y_u_kernel(const unsigned long long *yc, const int *rd, int M, unsigned char *y, int *u) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > M) return;
+    const int wd = i >> 6, bo = i & 63;
+    const unsigned long long w = (i < M || bo) ? yc[wd] : 0ULL;
+    if (i < M) y[i] = (unsigned char)((w >> bo) & 1ULL);
+    u[i] = (i < M || bo) ? rd[wd] + (bo - __popcll(w & ((1ULL << bo) - 1ULL))) : rd[wd];
+}
+
 // bytes (0/1 per haplotype, original order) -> bit column words; grid (words/4, sites)
 __global__ __launch_bounds__(BLOCK) void bytes_to_bits_kernel(const unsigned char *in, int M, unsigned long long *out, int wpc64) {
     const int s = blockIdx.y;
