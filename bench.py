@@ -216,7 +216,7 @@ def main():
                    "haplotypes": M, "sites_per_step": S, "sites_timed": K * S, "device_batch_sites": args.batch,
                    "panel": "founder-mosaic" if args.kind == 0 else "iid", "within": not args.no_within,
                    "pack3": not args.no_pack3, "units_per_rank": "independent panel per rank", "panels_per_gpu": args.panels},
-        "roofline": {"bound": "hbm", "kernel": ("skeleton chain: skel_k1/k2/k3_kernel, 3 launches per 8 sites" if sites_per_launch > 2.5 else
+        "roofline": {"bound": "hbm", "kernel": ("skeleton chain: skel_hist_kernel + skel_k2_kernel + skel_rank_kernel, 3 launches per 8 sites" if sites_per_launch > 2.5 else
                                 "step2_kernel<WITH_D> (two sites per launch)" if sites_per_launch > 1.5 else "step1_kernel<WITH_D,GATHER>"), "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "alg_bytes_per_launch": alg_bytes_per_launch, "us_per_launch": us_per_launch,

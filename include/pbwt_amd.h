@@ -125,6 +125,11 @@ int pbwtamd_match_sweep(pbwtamd_engine *e, const uint8_t *pz, int64_t pnz, int N
                         pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out,
                         int64_t *n_nomatch, int64_t *tot);
 
+/* the "no match to query %d value %d at site %d" events (pbwtMatch.c:405-410, 489-494) of the last pbwtamd_match_sweep /
+ * pbwtamd_match_sweep_sparse call on this engine, in the order the reference logs them: *n quadruples
+ * (query jj, allele x, site k, isSparse) in a malloc()ed array (at most 65536 are kept; n_nomatch is exact) */
+int pbwtamd_get_nomatch_events(pbwtamd_engine *e, int32_t **events, int64_t *n);
+
 /* matchSequencesSweepSparse (pbwtMatch.c:501-602; declared pbwt.h:214): the query sweep against the
  * panel AND against nSparse sparse panels (the sites = kk mod nSparse, stepped with
  * pbwtCursorForwardsAD(upp[kk], k/nSparse)); reports carry the isSparse flag of the reference's

@@ -175,6 +175,25 @@ long ref_match_sweep(int Mp, int N, const uint8_t *pz, long pnz, const int32_t *
 }
 
 
+/* matchSequencesSweep with the reference's log lines (the "no match to query" events of pbwtMatch.c:405-410 and the
+ * averages line :438-439) written to `path` */
+int ref_match_sweep_log_to_file(int Mp, int N, const uint8_t *pz, long pnz, const int32_t *pStart,
+                                int Mq, const uint8_t *qz, long qnz, const int32_t *qStart, const char *path)
+{
+    ref_init();
+    PBWT *p = make_panel(Mp, N, pz, pnz, pStart);
+    PBWT *q = make_panel(Mq, N, qz, qnz, qStart);
+    FILE *saved = logFile;
+    logFile = fopen(path, "w");
+    if (!logFile) { logFile = saved; return -1; }
+    g_rec = NULL; g_n = g_cap = 0;
+    matchSequencesSweep(p, q, capture);
+    fclose(logFile); logFile = saved;
+    free(g_rec); g_rec = NULL;
+    pbwtDestroy(p); pbwtDestroy(q);
+    return 0;
+}
+
 /* matchSequencesSweepSparse (pbwtMatch.c:501-602) through the reference's own code, 5-field records */
 typedef struct { int ai, bi, start, end, sparse; } ref_match5;
 static ref_match5 *g_rec5; static size_t g_n5, g_cap5;

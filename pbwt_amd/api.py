@@ -216,6 +216,14 @@ class Engine:
             self._L.pbwtamd_free(rp)
         return out, nom.value, (tot[0], tot[1])
 
+    def nomatch_events(self):
+        """(jj, x, k, isSparse) rows of the last query sweep's "no match to query" events, in the reference's log order"""
+        ev = C.POINTER(C.c_int32)(); n = C.c_int64(0)
+        self._chk(self._L.pbwtamd_get_nomatch_events(self._h, C.byref(ev), C.byref(n)))
+        out = np.ctypeslib.as_array(ev, shape=(max(n.value, 1) * 4,))[: n.value * 4].reshape(-1, 4).copy()
+        self._L.pbwtamd_free(ev)
+        return out
+
     def match_sweep_sparse(self, pz, N, qz, Mq, nSparse, pStart=None, qStart=None, callback=None):
         """matchSequencesSweepSparse: as match_sweep plus nSparse sparse cursors; records carry `sparse`"""
         pz = np.ascontiguousarray(pz, dtype=np.uint8)

@@ -23,6 +23,8 @@ def build_library(force=False, verbose=False):
         hipcc = "hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", "-o", OUT] + [os.path.join(_HERE, s) for s in SOURCES]
+    if os.environ.get("PBWTAMD_MEASURE_BUILD"):            # measurement build: compiles in the result-corrupting probe switches
+        cmd.insert(1, "-DPBWTAMD_MEASURE")
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -105,6 +105,7 @@ struct pbwtamd_engine {
     std::vector<pbwtamd_match> *rec_sink = nullptr; pbwtamd_report_fn rec_cb = nullptr;
     int longL = 0;                          // L of the -longWithin consumer (PBWTAMD_OPT_LONG_RECS)
     int *ystale = nullptr;                  // copy of the previous state's tagged a, for the k == N quirk of -longWithin
+    std::vector<int32_t> nomatch_events;    // (jj, x, k[, isSparse]) of the last query sweep, in the reference's log order
 };
 
 extern "C" int pbwtamd_abi_version(void) { return PBWTAMD_ABI_VERSION; }
@@ -158,7 +159,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     if (const char *s = getenv("PBWTAMD_T")) { int v = atoi(s); if (v == 256 || v == 1024 || v == 2048 || v == 4096) e->E = v / BLOCK; }
     e->T = BLOCK * e->E;
     e->W = (M + e->T - 1) / e->T;
-    if (e->W > 1024) { delete e; return fail("pbwtamd: M=%d too large for this build (max %d)", M, 1024 * 4096); }
+    if (e->W > 1024) { delete e; return fail("pbwtamd: M=%d too large for this build (max %d)", M, 1024 * 4096); }   // nothing allocated yet
     e->Mpad = (M + 4095) / 4096 * 4096;                    // every tile geometry (256 / 1024 / 4096 positions) stays inside the padding
     e->wpad = (e->W + 63) / 64 * 64;
     e->wpc = wpc_for(M);
@@ -187,7 +188,8 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     ALLOC(e->zerocol, (size_t)e->wpc * sizeof(uint32_t));
     ALLOC(e->ctl, 16 * sizeof(int));
     ALLOC(e->ctlblk, sizeof(Ctl));
-    if (const char *s = getenv("PBWTAMD_PROFILE")) if (atoi(s)) { ALLOC(e->prof, (size_t)e->W * 8 * sizeof(long long)); HIPCHK(hipMemset(e->prof, 0, (size_t)e->W * 8 * sizeof(long long))); }
+#define ECHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { int r = fail("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); pbwtamd_engine_destroy(e); return r; } } while (0)
+    if (const char *s = getenv("PBWTAMD_PROFILE")) if (atoi(s)) { ALLOC(e->prof, (size_t)e->W * 8 * sizeof(long long)); ECHK(hipMemset(e->prof, 0, (size_t)e->W * 8 * sizeof(long long))); }
     ALLOC(e->cols_stage, 2 * (slots + 6) * e->wpc * sizeof(uint32_t));   // two halves of B+8 columns: batch + look-ahead, double-buffered by the host entry points
     ALLOC(e->ycols, slots * e->wpc64 * sizeof(unsigned long long));
     ALLOC(e->colBytes, (slots + 1) * sizeof(unsigned long long));
@@ -204,7 +206,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         ALLOC(e->xTr[1], (size_t)e->xTblocks * e->strideX * sizeof(uint32_t));
         if (const char *sv = getenv("PBWTAMD_THR_ROUNDS")) e->thr_rounds = atoi(sv);
         if (const char *sv = getenv("PBWTAMD_THR_DEPTH")) e->thr_depth = std::max(1, std::min(atoi(sv), 15));
-        for (int i = 0; i < 16; ++i) HIPCHK(hipEventCreateWithFlags(&e->tev[i], hipEventDisableTiming));
+        for (int i = 0; i < 16; ++i) ECHK(hipEventCreateWithFlags(&e->tev[i], hipEventDisableTiming));
         {
             const int rounds = e->B / 8 + 1;
             e->strideS = (size_t)SKK * e->Wt + SKK / 2;
@@ -217,8 +219,8 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         ALLOC(e->rankdirS, (size_t)(e->B + 2) * (e->wpc64 + 1) * sizeof(int));
     }
 #undef ALLOC
-    HIPCHK(hipMemsetAsync(e->A, 0, 2 * slots * e->strideA * sizeof(int), e->stream));
-    HIPCHK(hipMemsetAsync(e->D, 0, 2 * slots * e->strideD * sizeof(int), e->stream));
+    ECHK(hipMemsetAsync(e->A, 0, 2 * slots * e->strideA * sizeof(int), e->stream));
+    ECHK(hipMemsetAsync(e->D, 0, 2 * slots * e->strideD * sizeof(int), e->stream));
     {   // consumers yield to the dependent chain: low priority; and while the chain is the bottleneck (narrow panels) they run on
         // the first 5/8 of the CUs only, so the chain's workgroups find whole shader arrays without scattered-store traffic in
         // their memory pipelines (measured +3 % at M = 100 k with 160 of 256 CUs; at M = 1 M the consumers are the bottleneck: no mask)
@@ -230,13 +232,14 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             for (int i = 0; i < std::min(ncus, 256); ++i) mask[i / 32] |= 1u << (i % 32);
             if (hipExtStreamCreateWithCUMask(&e->s2, 8, mask) != hipSuccess) { (void)hipGetLastError(); e->s2 = nullptr; }
         }
-        if (!e->s2) HIPCHK(hipStreamCreateWithPriority(&e->s2, hipStreamNonBlocking, prLow));
+        if (!e->s2) ECHK(hipStreamCreateWithPriority(&e->s2, hipStreamNonBlocking, prLow));
     }
-    for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&e->evChain[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&e->evCons[i], hipEventDisableTiming)); }
-    HIPCHK(hipMemsetAsync(e->ctl, 0, 16 * sizeof(int), e->stream));
-    HIPCHK(hipMemsetAsync(e->scal, 0, 8 * sizeof(unsigned long long), e->stream));
-    HIPCHK(hipMemsetAsync(e->zerocol, 0, (size_t)e->wpc * sizeof(uint32_t), e->stream));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int i = 0; i < 2; ++i) { ECHK(hipEventCreateWithFlags(&e->evChain[i], hipEventDisableTiming)); ECHK(hipEventCreateWithFlags(&e->evCons[i], hipEventDisableTiming)); }
+    ECHK(hipMemsetAsync(e->ctl, 0, 16 * sizeof(int), e->stream));
+    ECHK(hipMemsetAsync(e->scal, 0, 8 * sizeof(unsigned long long), e->stream));
+    ECHK(hipMemsetAsync(e->zerocol, 0, (size_t)e->wpc * sizeof(uint32_t), e->stream));
+    ECHK(hipStreamSynchronize(e->stream));
+#undef ECHK
     *out = e;
     return 0;
 }
@@ -351,6 +354,14 @@ static int get_graph(pbwtamd_engine *e, bool with_d, bool sorted, int ring, bool
 extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k0, int n_total) {
     HIPCHK(hipSetDevice(e->device));
     if (n_total < k0) return fail("pbwtamd_pass_begin: n_total %d < k0 %d", n_total, k0);
+    if (aInit) {                                           // it drives device gathers and scatters: must be a permutation of [0, M)
+        std::vector<bool> seen((size_t)e->M, false);
+        for (int i = 0; i < e->M; ++i) {
+            const int v = aInit[i];
+            if (v < 0 || v >= e->M || seen[(size_t)v]) return fail("pbwtamd_pass_begin: the start order is not a permutation of [0, %d) (entry %d = %d)", e->M, i, v);
+            seen[(size_t)v] = true;
+        }
+    }
     e->pend.valid = false;
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipStreamSynchronize(e->s2));
@@ -399,7 +410,9 @@ static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int
     g.blockCount = nullptr; g.recs = nullptr; g.hist = e->hist; g.histlen = e->histlen; g.err = e->ctl + 2;
     static const bool no_fuse = getenv("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
     g.ycols = (!no_fuse && final_site < 0 && (opts & PBWTAMD_OPT_PACK3) && (opts & PBWTAMD_OPT_WITHIN_HIST)) ? e->ycols : nullptr; g.wpc64 = e->wpc64;
+#ifdef PBWTAMD_MEASURE
     static const int sweep_dbg = getenv("PBWTAMD_DEBUG_SWEEP") ? atoi(getenv("PBWTAMD_DEBUG_SWEEP")) : 0; g.dbg = sweep_dbg;
+#endif
     const int tiles = (e->M + BLOCK - 1) / BLOCK;
     dim3 grid(tiles, nsites);
     static const int sweep_it = getenv("PBWTAMD_SWEEP_ITERS") ? atoi(getenv("PBWTAMD_SWEEP_ITERS")) : 0;
@@ -590,7 +603,11 @@ static int flush_pending(pbwtamd_engine *e) {
     const int *A = ringA(e, p.ring), *D = ringD(e, p.ring);
     const bool with_d = p.opts & PBWTAMD_OPT_WITH_D;
     HIPCHK(hipStreamWaitEvent(e->s2, e->evChain[p.ring], 0));
-    static const bool nofill = getenv("PBWTAMD_NOFILL") && atoi(getenv("PBWTAMD_NOFILL"));   // measurement only: results are wrong
+#ifdef PBWTAMD_MEASURE                                     // measurement builds only (-DPBWTAMD_MEASURE): these switches give WRONG results
+    static const bool nofill = getenv("PBWTAMD_NOFILL") && atoi(getenv("PBWTAMD_NOFILL"));
+#else
+    constexpr bool nofill = false;
+#endif
     const unsigned consumers = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS | OPT_INTERNAL_KEEP_STATES;
     const bool packed = packed_fill(p);
     if (p.skel && !nofill && (p.opts & consumers)) {   // the 7 states between consecutive skeleton states: all blocks and tiles in one launch
@@ -598,7 +615,9 @@ static int flush_pending(pbwtamd_engine *e) {
         f.A = ringA(e, p.ring); f.D = ringD(e, p.ring); f.strideA = e->strideA; f.strideD = e->strideD;
         f.keys = e->keysR[p.ring]; f.strideK = e->Mpad; f.scan = e->saveR[p.ring]; f.strideS = e->strideS;
         f.M = e->M; f.W = e->Wt; f.kbase = p.kbase;
+#ifdef PBWTAMD_MEASURE
         static const int dbg_nowrite = getenv("PBWTAMD_DEBUG_FILL_NOWRITE") ? 1 : 0; f.dbg_nowrite = dbg_nowrite;
+#endif
         f.pack_y = packed ? 1 : 0;
         dim3 grid(e->Wt, p.nb / 8);
         const size_t dyn = 0;
@@ -941,7 +960,8 @@ extern "C" int pbwtamd_build(pbwtamd_engine *e, const uint32_t *bitcols, int wpc
     const size_t in_bytes = (size_t)N * wpc * sizeof(uint32_t);
     const bool pinned = !no_pin && in_bytes >= (1u << 20) && hipHostRegister((void *)bitcols, in_bytes, hipHostRegisterDefault) == hipSuccess;
     if (!pinned) (void)hipGetLastError();
-    struct Unpin { const void *p; bool on; ~Unpin() { if (on) (void)hipHostUnregister((void *)p); } } unpin{bitcols, pinned};
+    // on any exit — errors included — the async copies out of the caller's buffer are drained before it is unregistered
+    struct Unpin { const void *p; bool on; hipStream_t st; ~Unpin() { if (on) { (void)hipStreamSynchronize(st); (void)hipHostUnregister((void *)p); } } } unpin{bitcols, pinned, e->stream};
     int done = 0, half = 0;
     while (done < N) {
         const int nb = std::min(e->B, N - done);
@@ -993,6 +1013,17 @@ static int packed_upload(pbwtamd_engine *e, hipStream_t st, int M, const uint8_t
     HIPCHK(hipStreamSynchronize(st));
     if (total != (unsigned long long)M * (unsigned long long)N)
         return fail("pbwtamd: packed panel decodes to %llu alleles, expected M*N = %llu", total, (unsigned long long)M * (unsigned long long)N);
+    if (N > 0) {                                           // every column boundary found, in order, <= M bytes apart: before any expand
+        int *bad = nullptr, hbad = 0;
+        DevBufs tmp;
+        CHK(tmp.alloc(&bad, 1));
+        HIPCHK(hipMemsetAsync(bad, 0, sizeof(int), st));
+        hipLaunchKernelGGL(dec_validate_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (const long long *)pk.colStart, (long long)N, (long long)nz, M, bad);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (hbad) return fail("pbwtamd: malformed packed panel (a run straddles a column boundary, or a column of more than M bytes)");
+    }
     (void)e;
     return 0;
 }
@@ -1286,6 +1317,15 @@ extern "C" int pbwtamd_match_sweep(pbwtamd_engine *e, const uint8_t *pz, int64_t
     return 0;
 }
 
+extern "C" int pbwtamd_get_nomatch_events(pbwtamd_engine *e, int32_t **events, int64_t *n) {
+    const size_t cnt = e->nomatch_events.size();
+    int32_t *buf = (int32_t *)malloc(std::max<size_t>(1, cnt) * sizeof(int32_t));
+    if (!buf) return fail("pbwtamd_get_nomatch_events: out of host memory");
+    if (cnt) memcpy(buf, e->nomatch_events.data(), cnt * sizeof(int32_t));
+    *events = buf; *n = (int64_t)(cnt / 4);
+    return 0;
+}
+
 // exclusive scan of n 64-bit counts in place, total -> *total (device); `bsum` = scratch of n / SCAN_CHUNK + 1 values
 static void scan_u64(hipStream_t st, unsigned long long *v, size_t n, unsigned long long *total, unsigned long long *bsum) {
     if (n <= 65536 || !bsum) { hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, v, n, total, 0ULL); return; }
@@ -1357,6 +1397,10 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         CHK(bufs.alloc(&fss[i], (size_t)2 * std::max(nS, 1) * Mq)); CHK(bufs.alloc(&dss[i], (size_t)2 * std::max(nS, 1) * Mq));
     }
     CHK(bufs.alloc(&tot, (size_t)4));
+    constexpr unsigned NM_CAP = 1u << 16;                   // no-match events kept for the log (the count is exact beyond that)
+    int4 *nm_ev; unsigned *nm_n;
+    CHK(bufs.alloc(&nm_ev, (size_t)NM_CAP)); CHK(bufs.alloc(&nm_n, (size_t)1));
+    e->nomatch_events.clear();
     unsigned long long *bsum; CHK(bufs.alloc(&bsum, 2 * std::max(BQ, (size_t)Mq) / SCAN_CHUNK + 2));
     std::vector<unsigned long long *> ycS((size_t)nS, nullptr); std::vector<int *> rdS((size_t)nS, nullptr);
     for (int kk = 0; kk < nS; ++kk) { CHK(bufs.alloc(&ycS[kk], (size_t)(Bs + 2) * wpc64)); CHK(bufs.alloc(&rdS[kk], (size_t)(Bs + 2) * (wpc64 + 1))); }
@@ -1368,6 +1412,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     HIPCHK(hipMemsetAsync(fss[0], 0, sizeof(int) * (size_t)2 * std::max(nS, 1) * Mq, st));
     HIPCHK(hipMemsetAsync(dss[0], 0, sizeof(int) * (size_t)2 * std::max(nS, 1) * Mq, st));
     HIPCHK(hipMemsetAsync(tot, 0, 4 * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(nm_n, 0, sizeof(unsigned), st));
     std::vector<pbwtamd_match5> all;
     auto ensure_recs = [&](size_t total) -> int {
         if (total <= recsCap) return 0;
@@ -1430,6 +1475,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         g.f_in = fst[cur]; g.dq_in = dst[cur]; g.f_out = fst[cur ^ 1]; g.dq_out = dst[cur ^ 1];
         g.fs_in = fss[cur]; g.ds_in = dss[cur]; g.fs_out = fss[cur ^ 1]; g.ds_out = dss[cur ^ 1];
         g.cnt = cnt; g.recs = nullptr; g.tot = tot;
+        g.nm_ev = nm_ev; g.nm_n = nm_n; g.nm_cap = NM_CAP;
         hipLaunchKernelGGL((qss_sweep_kernel<0>), dim3(qwaves), dim3(BLOCK), 0, st, g);
         scan_u64(st, cnt, 2 * (size_t)nb * Mq, tot + 3, bsum);
         HIPCHK(hipGetLastError());
@@ -1469,6 +1515,15 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     HIPCHK(hipMemcpy(htot, tot, sizeof htot, hipMemcpyDeviceToHost));
     if (tot_out) { tot_out[0] = (int64_t)htot[0]; tot_out[1] = (int64_t)htot[1]; }
     if (n_nomatch) *n_nomatch = (int64_t)htot[2];
+    if (htot[2]) {                                          // the events, in the order the reference logs them: site, then query PBWT rank, dense before sparse
+        unsigned nev = 0;
+        HIPCHK(hipMemcpy(&nev, nm_n, sizeof nev, hipMemcpyDeviceToHost));
+        nev = std::min(nev, NM_CAP);
+        std::vector<int4> ev(nev);
+        if (nev) HIPCHK(hipMemcpy(ev.data(), nm_ev, sizeof(int4) * nev, hipMemcpyDeviceToHost));
+        std::sort(ev.begin(), ev.end(), [](const int4 &a, const int4 &b) { return a.x != b.x ? a.x < b.x : a.y != b.y ? a.y < b.y : (a.w >> 1) < (b.w >> 1); });
+        for (const int4 &v : ev) { e->nomatch_events.push_back(v.z); e->nomatch_events.push_back(v.w & 1); e->nomatch_events.push_back(v.x); e->nomatch_events.push_back(v.w >> 1); }
+    }
     CHK(pbwtamd_pass_end(e, 0));
     CHK(pbwtamd_pass_end(eq, 0));
     for (int kk = 0; kk < nS; ++kk) CHK(pbwtamd_pass_end(es[kk], 0));

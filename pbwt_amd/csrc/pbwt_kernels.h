@@ -1060,7 +1060,9 @@ struct SkFillArgs {
     const unsigned char *keys; size_t strideK;              // keys of state 8b at keys + b*strideK
     const int2 *scan; size_t strideS;                       // per block: scan[W][256] {before, carry}, then total[256] (strideS in int2 units)
     int M, W, kbase;
-    int dbg_nowrite;                                        // measurement only
+#ifdef PBWTAMD_MEASURE
+    int dbg_nowrite;                                        // measurement builds only (results WRONG): no stores
+#endif
     int pack_y;                                             // write d | y << 31 only (no a): for consumers that need (d, y) but not the haplotype ids
 };
 
@@ -1188,7 +1190,9 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
             else dd = 0;
             const int pos = s_GH[h] + s_bH[h] + rank;
             if (pos == 0) dd = k + j + 1;
+#ifdef PBWTAMD_MEASURE
             if (g.dbg_nowrite && pos >= 0) continue;
+#endif
             const int yb = (int)(((unsigned)(key[r] >> j) & 1u) << 31);
             // streamed once by the consumers: non-temporal, so the chain's working set stays in L2 (measured +1 %)
             if (g.pack_y) __builtin_nontemporal_store(dd | yb, d_out + pos);
@@ -1566,7 +1570,9 @@ struct SweepArgs {
     unsigned long long *hist; int histlen;  // MODE 2
     int *err;
     unsigned long long *ycols; int wpc64;   // MODE 2, optional: also emit the sorted bit column of each site (what pack3 encodes)
-    int dbg;                                // measurement only: 1 = no histogram atomics, 2 = no walks either
+#ifdef PBWTAMD_MEASURE
+    int dbg;                                // measurement builds only (results WRONG): 1 = no histogram atomics, 2 = no walks either
+#endif
     int nvb;                                // 256-position blocks per site
 };
 
@@ -1640,7 +1646,9 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     if (i < M) {
         di = pre_0[it] & 0x7fffffff; yi = (unsigned)pre_0[it] >> 31; dn = pre_1[it] & 0x7fffffff;
         rep = true;
+#ifdef PBWTAMD_MEASURE
         if (g.dbg == 2) { /* loads only */ } else
+#endif
         if (di <= dn) {                                     // while (d[m+1] <= d[i]) if (y[m--] == y[i]) skip   (pbwtMatch.c:124-126)
             int steps = 0, wcur = pre_0[it];                // wcur = the word at m+1
             for (;;) {
@@ -1700,8 +1708,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     if (MODE == 2) {
         if (rep) {
             const int len = (di < dn) ? k - di : k - dn;
-            if (g.dbg) { if (len == -12345) g.hist[0] = 1; }
-            else if (len >= 0 && len < g.histlen) atomicAdd(g.hist + len, 1ULL); else atomicExch(g.err, 1);
+#ifdef PBWTAMD_MEASURE
+            if (g.dbg) { if (len == -12345) g.hist[0] = 1; } else
+#endif
+            if (len >= 0 && len < g.histlen) atomicAdd(g.hist + len, 1ULL); else atomicExch(g.err, 1);
         }
         continue;
     }
@@ -1993,31 +2003,43 @@ __global__ __launch_bounds__(BLOCK) void dec_colstart_kernel(const uint8_t *z, s
         __syncthreads();
     }
 }
+// pass 2b: a well-formed panel has every column start found (a run never straddles a column boundary,
+// pbwtCore.c:254-267), strictly increasing, at most M bytes per column.  Checked BEFORE any expand: a crafted file
+// otherwise leaves colStart[c] = -1 (the memset) and the expand would index z[] and y[] out of bounds.
+__global__ void dec_validate_kernel(const long long *colStart, long long N, long long nz, int M, int *err) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const long long bs = colStart[c], be = (c + 1 < N) ? colStart[c + 1] : nz;
+    if (bs < 0 || be <= bs || be > nz || be - bs > (long long)M) atomicExch(err, 2);
+}
+
 // pass 3: expand columns [c0, c0+nc) into sorted bit columns (zero-initialised by the caller).
-// One block per column; runs of ones set bits.
+// One block per column; runs of ones set bits.  Malformed input (already rejected by dec_validate_kernel on the
+// upload path) cannot write outside the column: bounds are re-checked and the accumulators are 64-bit.
 __global__ __launch_bounds__(BLOCK) void dec_expand_kernel(const uint8_t *z, const long long *colStart, long long c0, int M,
                                                           unsigned long long *ycols, int wpc64, int *err) {
-    __shared__ int s_w[WAVES];
-    __shared__ int s_carry;
+    __shared__ long long s_w[WAVES];
+    __shared__ long long s_carry;
     const long long c = c0 + blockIdx.x;
     const long long bs = colStart[c], be = colStart[c + 1];
     unsigned long long *y = ycols + (size_t)blockIdx.x * wpc64;
+    if (bs < 0 || be < bs || be - bs > (long long)M) { if (threadIdx.x == 0) atomicExch(err, 2); return; }
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
     for (long long b = bs; b < be; b += BLOCK) {
         const long long i = b + threadIdx.x;
         const uint8_t byte = (i < be) ? z[i] : 0;
         const int len = (i < be) ? p3_len(byte) : 0;
-        int inc = len;
-        for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o); if (lane_id() >= o) inc += v; }
+        long long inc = len;
+        for (int o = 1; o < 64; o <<= 1) { long long v = __shfl_up(inc, o); if (lane_id() >= o) inc += v; }
         if (lane_id() == 63) s_w[wave_id()] = inc;
         __syncthreads();
-        int pre = s_carry, tot = 0;
+        long long pre = s_carry, tot = 0;
         for (int q = 0; q < WAVES; ++q) { if (q < wave_id()) pre += s_w[q]; tot += s_w[q]; }
-        const int start = pre + inc - len;
-        if (len && (byte & 0x80)) {
-            int lo = start, hi = min(start + len, M);      // [lo,hi)
-            if (start + len > M) atomicExch(err, 2);
+        const long long start = pre + inc - len;
+        if (start + len > (long long)M) atomicExch(err, 2);
+        if (len && (byte & 0x80) && start < (long long)M) {
+            int lo = (int)start, hi = (int)min(start + len, (long long)M);      // [lo,hi)
             while (lo < hi) {
                 const int wd = lo >> 6, bo = lo & 63;
                 const int take = min(64 - bo, hi - lo);
@@ -2030,7 +2052,7 @@ __global__ __launch_bounds__(BLOCK) void dec_expand_kernel(const uint8_t *z, con
         if (threadIdx.x == 0) s_carry += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0 && s_carry != M) atomicExch(err, 3);
+    if (threadIdx.x == 0 && s_carry != (long long)M) atomicExch(err, 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2101,6 +2123,7 @@ struct QssArgs {
     unsigned long long *cnt;                                 // [site][Mq rank][2]: counts / exclusive offsets (dense, sparse)
     Rec5 *recs;
     unsigned long long *tot;                                 // [0] nTot [1] totLen [2] no-match events
+    int4 *nm_ev; unsigned *nm_n; unsigned nm_cap;            // the no-match events themselves: {site k, query rank, query jj, x | isSparse << 1}
 };
 
 // reportAndUpdate (pbwtMatch.c:452-499) for one query at one site against one cursor state, executed by a whole
@@ -2111,7 +2134,8 @@ struct QssArgs {
 template <int MODE>
 __device__ __forceinline__ void qss_update(const int *a, const int *d, const unsigned long long *yc, int M, unsigned x, int jj, int k,
                                            int kend, int nS, int isSparse, int &f, int &dq, unsigned long long *cntslot, Rec5 *recs,
-                                           unsigned long long &nTot, unsigned long long &totLen, unsigned long long &nomatch) {
+                                           unsigned long long &nTot, unsigned long long &totLen, unsigned long long &nomatch,
+                                           int rank, int4 *nm_ev, unsigned *nm_n, unsigned nm_cap) {
     const int lane = lane_id();
 #define PY(i) ((unsigned)((yc[(i) >> 6] >> ((i) & 63)) & 1ULL))
     if (PY(f) == x) return;
@@ -2159,7 +2183,11 @@ __device__ __forceinline__ void qss_update(const int *a, const int *d, const uns
             iPlus = scan_down(iPlus, dPlus, got);
             if (got) { f = iPlus; dq = dPlus; return; }
             dPlus = (iPlus < M) ? d[iPlus] : kend;
-            if (!iMinus && iPlus == M) { ++nomatch; dq = 1 + kend; return; }
+            if (!iMinus && iPlus == M) {                     // "no match to query jj value x at site k" (pbwtMatch.c:405-410)
+                ++nomatch; dq = 1 + kend;
+                if (MODE == 0 && lane == 0 && nm_ev) { const unsigned at = atomicAdd(nm_n, 1u); if (at < nm_cap) nm_ev[at] = make_int4(k, rank, jj, (int)x | (isSparse << 1)); }
+                return;
+            }
         }
     }
 #undef PY
@@ -2193,7 +2221,8 @@ __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
             ipre = (sl < g.nsites) ? g.invq[(size_t)sl * g.Mq + jj] : 0;
         }
         const unsigned x = (unsigned)__builtin_amdgcn_readlane((int)xpre, s & 63);
-        const size_t slot = ((size_t)s * g.Mq + __builtin_amdgcn_readlane(ipre, s & 63)) * 2;
+        const int qrank = __builtin_amdgcn_readlane(ipre, s & 63);
+        const size_t slot = ((size_t)s * g.Mq + qrank) * 2;
         {
             const int *a = g.dense.A + (size_t)s * g.dense.strideA, *d = g.dense.D + (size_t)s * g.dense.strideD;
             const unsigned long long *yc = g.dense.ycols + (size_t)s * g.wpc64;
@@ -2207,7 +2236,7 @@ __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
                 f = x ? c0 + f - uf : uf;
                 if (f == M) f = 0;
             } else {
-                qss_update<MODE>(a, d, yc, M, x, jj, k, k, nS, 0, f, dq, g.cnt + slot, g.recs, nTot, totLen, nomatch);
+                qss_update<MODE>(a, d, yc, M, x, jj, k, k, nS, 0, f, dq, g.cnt + slot, g.recs, nTot, totLen, nomatch, qrank, g.nm_ev, g.nm_n, g.nm_cap);
                 f = qss_lfmap(yc, rd, g.wpc64, M, x, f);
             }
         }
@@ -2222,7 +2251,7 @@ __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
             if (MODE == 0) { fsl = g.fs_out[ix]; dsl = g.ds_out[ix]; }
             else if (s < nS) { fsl = g.fs_in[ix]; dsl = g.ds_in[ix]; }
             else { fsl = g.fs_out[sx]; dsl = g.ds_out[sx]; }
-            qss_update<MODE>(a, d, yc, M, x, jj, k, k / nS, nS, 1, fsl, dsl, g.cnt + slot + 1, g.recs, nTot, totLen, nomatch);
+            qss_update<MODE>(a, d, yc, M, x, jj, k, k / nS, nS, 1, fsl, dsl, g.cnt + slot + 1, g.recs, nTot, totLen, nomatch, qrank, g.nm_ev, g.nm_n, g.nm_cap);
             fsl = qss_lfmap(yc, v.rankdir + (size_t)t * (g.wpc64 + 1), g.wpc64, M, x, fsl);
             if (lane == 0) {
                 if (MODE == 0) { g.fs_out[ix] = fsl; g.ds_out[ix] = dsl; }

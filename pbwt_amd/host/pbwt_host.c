@@ -22,23 +22,38 @@ void die (const char *format, ...)
   exit (-1) ;
 }
 
-static void *xalloc (size_t n)
-{ void *p = calloc (n ? n : 1, 1) ; if (!p) die ("out of memory allocating %zu bytes", n) ; return p ; }
+/* allocation accounting for the "Memory" field of the timing line (the reference counts myalloc'ed bytes, utils.c:46-73) */
+static long totalAllocated = 0 ;
 
-/* user/system time and memory lines after every command (utils.c:173-198) */
+static void *xalloc (size_t n)
+{ void *p = calloc (n ? n : 1, 1) ; if (!p) die ("out of memory allocating %zu bytes", n) ;
+  totalAllocated += (long) n ; return p ;
+}
+
+static void *xrealloc (void *old, size_t oldBytes, size_t newBytes)
+{ void *p = realloc (old, newBytes ? newBytes : 1) ; if (!p) die ("out of memory growing a buffer to %zu bytes", newBytes) ;
+  totalAllocated += (long) newBytes - (long) oldBytes ; return p ;
+}
+
+/* the timing line after every command, in the reference's format (utils.c:173-198):
+   user\t<s.us>\tsystem\t<s.us>\tmax_RSS\t<growth since the last line>\tMemory\t<bytes allocated> */
 void timeUpdate (FILE *f)
 {
-  static int isFirst = 1 ;
-  static struct rusage rOld ;
-  struct rusage rNew ;
-  getrusage (RUSAGE_SELF, &rNew) ;
-  if (!isFirst)
-    { double u = (rNew.ru_utime.tv_sec - rOld.ru_utime.tv_sec) + 1e-6 * (rNew.ru_utime.tv_usec - rOld.ru_utime.tv_usec) ;
-      double s = (rNew.ru_stime.tv_sec - rOld.ru_stime.tv_sec) + 1e-6 * (rNew.ru_stime.tv_usec - rOld.ru_stime.tv_usec) ;
-      fprintf (f, "user\t%.6f\tsystem\t%.6f\tmax_RSS\t%ld\n", u, s, rNew.ru_maxrss) ;
+  static int started = 0 ;
+  static struct rusage last ;
+  struct rusage now ;
+  getrusage (RUSAGE_SELF, &now) ;
+  if (started)
+    { const struct timeval *t1[2] = { &now.ru_utime, &now.ru_stime }, *t0[2] = { &last.ru_utime, &last.ru_stime } ;
+      const char *label[2] = { "user", "\tsystem" } ;
+      for (int i = 0 ; i < 2 ; ++i)
+	{ long us = (long) (t1[i]->tv_sec - t0[i]->tv_sec) * 1000000L + (t1[i]->tv_usec - t0[i]->tv_usec) ;
+	  fprintf (f, "%s\t%d.%06d", label[i], (int) (us / 1000000L), (int) (us % 1000000L)) ;
+	}
+      fprintf (f, "\tmax_RSS\t%ld\tMemory\t%li\n", now.ru_maxrss - last.ru_maxrss, totalAllocated) ;
     }
-  else isFirst = 0 ;
-  rOld = rNew ;
+  started = 1 ;
+  last = now ;
 }
 
 /* one engine per panel width, created on first use; failure is fatal (no CPU fallback) */
@@ -83,31 +98,39 @@ void panelWrite (Panel *p, FILE *fp)
   fprintf (logFile, "written %ld chars pbwt: M, N are %d, %d\n", n, p->M, p->N) ;
 }
 
+/* the four on-disk variants differ in two things only: whether the index arrays are stored and how wide the byte count is */
+static const struct { const char *tag ; int hasIndex, wideCount ; } pbwtKinds[] =
+  { { "PBW3", 1, 1 }, { "PBW2", 1, 0 }, { "PBWT", 0, 0 }, { "GBWT", 0, 0 } } ;
+
+static void readOrDie (void *dst, size_t size, size_t n, FILE *fp, const char *what)
+{ if (fread (dst, size, n, fp) != n) die ("error reading %s in pbwtRead", what) ; }
+
 Panel *panelRead (FILE *fp)
 {
-  char tag[5] = "test", pad[4] ;
-  int m, n, version ;
-  long nz ;
-  if (fread (tag, 1, 4, fp) != 4) die ("failed to read 4 char tag - is file readable?") ;
-  if (!strcmp (tag, "PBW3")) version = 3 ;
-  else if (!strcmp (tag, "PBW2")) version = 2 ;
-  else if (!strcmp (tag, "PBWT")) version = 1 ;
-  else if (!strcmp (tag, "GBWT")) version = 0 ;
-  else die ("failed to recognise file type %s in pbwtRead - was it written by pbwt?", tag) ;
-  if (fread (&m, sizeof (int), 1, fp) != 1) die ("error reading m in pbwtRead") ;
-  if (fread (&n, sizeof (int), 1, fp) != 1) die ("error reading n in pbwtRead") ;
-  Panel *p = panelCreate (m, n) ;
-  if (version > 1)
-    { if (fread (p->aFstart, sizeof (int), m, fp) != (size_t) m) die ("error reading aFstart in pbwtRead") ;
-      p->aFend = xalloc (sizeof (int) * m) ;
-      if (fread (p->aFend, sizeof (int), m, fp) != (size_t) m) die ("error reading aFend in pbwtRead") ;
+  struct { char tag[4] ; int32_t M, N ; } head ;		/* 12 bytes, no padding */
+  if (fread (head.tag, 1, 4, fp) != 4) die ("failed to read 4 char tag - is file readable?") ;
+  int kind = -1 ;
+  for (int i = 0 ; i < 4 ; ++i) if (!memcmp (head.tag, pbwtKinds[i].tag, 4)) kind = i ;
+  if (kind < 0) die ("failed to recognise file type %.4s in pbwtRead - was it written by pbwt?", head.tag) ;
+  readOrDie (&head.M, sizeof (int32_t), 1, fp, "m") ;
+  readOrDie (&head.N, sizeof (int32_t), 1, fp, "n") ;
+  Panel *p = panelCreate (head.M, head.N) ;
+  if (pbwtKinds[kind].hasIndex)
+    { p->aFend = xalloc (sizeof (int) * (size_t) p->M) ;
+      readOrDie (p->aFstart, sizeof (int), (size_t) p->M, fp, "aFstart") ;
+      readOrDie (p->aFend, sizeof (int), (size_t) p->M, fp, "aFend") ;
     }
-  if (version <= 2)
-    { int nn ; if (fread (&nn, sizeof (int), 1, fp) != 1) die ("error reading pbwt file") ; nz = nn ; }
-  else if (fread (&nz, sizeof (long), 1, fp) != 1 || fread (pad, 1, 4, fp) != 4) die ("error reading pbwt file") ;
-  p->yz = xalloc ((size_t) nz) ; p->nz = nz ;
-  if (fread (p->yz, 1, (size_t) nz, fp) != (size_t) nz) die ("error reading data in pbwt file") ;
-  fprintf (logFile, "read pbwt %s file with %ld bytes: M, N are %d, %d\n", tag, nz, p->M, p->N) ;
+  if (pbwtKinds[kind].wideCount)
+    { struct { int64_t n ; char pad[4] ; } cnt ;
+      if (fread (&cnt.n, 8, 1, fp) != 1 || fread (cnt.pad, 1, 4, fp) != 4) die ("error reading pbwt file") ;
+      p->nz = cnt.n ;
+    }
+  else
+    { int32_t n32 ; if (fread (&n32, 4, 1, fp) != 1) die ("error reading pbwt file") ; p->nz = n32 ; }
+  if (p->nz < 0) die ("error reading pbwt file") ;
+  p->yz = xalloc ((size_t) p->nz) ;
+  if (fread (p->yz, 1, (size_t) p->nz, fp) != (size_t) p->nz) die ("error reading data in pbwt file") ;
+  fprintf (logFile, "read pbwt %.4s file with %ld bytes: M, N are %d, %d\n", head.tag, (long) p->nz, p->M, p->N) ;
   return p ;
 }
 
@@ -143,7 +166,7 @@ void panelReadSites (Panel *p, FILE *fp)
 	}
       char *q = tab + 1 ;
       if (!isdigit ((unsigned char) *q)) die ("bad position line %d in sites file", lineNo) ;
-      if (n == cap) { cap *= 2 ; sites = realloc (sites, cap * sizeof (HostSite)) ; }
+      if (n == cap) { sites = xrealloc (sites, cap * sizeof (HostSite), 2 * cap * sizeof (HostSite)) ; cap *= 2 ; }
       sites[n].x = 0 ; while (isdigit ((unsigned char) *q)) sites[n].x = sites[n].x * 10 + (*q++ - '0') ;
       sites[n].var = 0 ;
       if (*q) { while (*q && isspace ((unsigned char) *q)) ++q ; if (*q) sites[n].var = strdup (q) ; }
@@ -168,6 +191,7 @@ void panelWriteAll (Panel *p, const char *root)
   if (!(fp = fopenTag (root, "pbwt", "w"))) die ("failed to open root.%s", "pbwt") ;
   panelWrite (p, fp) ; fclose (fp) ;
   if (p->sites) { if (!(fp = fopenTag (root, "sites", "w"))) die ("failed to open root.%s", "sites") ; panelWriteSites (p, fp) ; fclose (fp) ; }
+  if (p->zz) { if (!(fp = fopenTag (root, "reverse", "w"))) die ("failed to open root.%s", "reverse") ; panelWriteReverse (p, fp) ; fclose (fp) ; }	/* pbwtIO.c:143 */
 }
 
 Panel *panelReadAll (const char *root)
@@ -176,6 +200,7 @@ Panel *panelReadAll (const char *root)
   if ((fp = fopenTag (root, "pbwt", "r"))) { p = panelRead (fp) ; fclose (fp) ; }
   else die ("failed to open %s.pbwt", root) ;
   if ((fp = fopenTag (root, "sites", "r"))) { panelReadSites (p, fp) ; fclose (fp) ; }
+  if ((fp = fopenTag (root, "reverse", "r"))) { panelReadReverse (p, fp) ; fclose (fp) ; }	/* pbwtIO.c:419 */
   return p ;
 }
 
@@ -205,7 +230,7 @@ static void buildMore (Panel *p, pbwtamd_engine *e, const uint32_t *cols, int wp
       if (*built) free (start) ;
       if (!p->yz) { p->yz = yz ; p->nz = nz ; }
       else
-	{ p->yz = realloc (p->yz, (size_t) (p->nz + nz) + 1) ; if (!p->yz) die ("out of memory extending the panel") ;
+	{ p->yz = xrealloc (p->yz, (size_t) p->nz, (size_t) (p->nz + nz) + 1) ;
 	  memcpy (p->yz + p->nz, yz, (size_t) nz) ; p->nz += nz ; pbwtamd_free (yz) ;
 	}
     }
@@ -233,8 +258,9 @@ Panel *panelReadMacs (FILE *fp)
   p->sites = xalloc (cap * sizeof (HostSite)) ;
   while (!feof (fp) && !strcmp (word (fp, w, 256), "SITE:"))
     { if (n == cap)
-	{ cap *= 2 ; cols = realloc (cols, cap * wpc * sizeof (uint32_t)) ; p->sites = realloc (p->sites, cap * sizeof (HostSite)) ;
-	  if (!cols || !p->sites) die ("out of memory reading MaCS file") ;
+	{ cols = xrealloc (cols, cap * wpc * sizeof (uint32_t), 2 * cap * wpc * sizeof (uint32_t)) ;
+	  p->sites = xrealloc (p->sites, cap * sizeof (HostSite), 2 * cap * sizeof (HostSite)) ;
+	  cap *= 2 ;
 	}
       int number = atoi (word (fp, w, 256)) ;
       p->sites[n].x = (int) (L * atof (word (fp, w, 256))) ; p->sites[n].var = 0 ;
@@ -299,22 +325,20 @@ void panelLongMatches (Panel *p, int L)
   if (L < 0) die ("L %d for longWithin must be >= 0", L) ;
   pbwtamd_engine *e = engineFor (p->M) ;
   if (isCheck) { checkA = checkB = decodeHaps (p) ; checkMA = checkMB = p->M ; checkN = p->N ; }
-  if (L)				/* matchLongWithin2 (pbwtMatch.c:85-113) */
-    { if (pbwtamd_long_within (e, p->yz, p->nz, p->N, p->aFstart, L, reportMatch, 0, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
-      if (isCheck) { free (checkA) ; checkA = checkB = 0 ; }
-      return ;
-    }
-  if (isStats)				/* histogram instead of reports (pbwtMatch.c:130-131,158-178) */
-    { int64_t *h = xalloc (sizeof (int64_t) * ((size_t) p->N + 1)) ;
-      if (pbwtamd_max_within (e, p->yz, p->nz, p->N, p->aFstart, 0, 0, 0, h, p->N + 1)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
-      long nTot = 0, hTot = 0 ;
+  int64_t *h = isStats ? xalloc (sizeof (int64_t) * ((size_t) p->N + 1)) : 0 ;	/* matchLengthHist (pbwtMatch.c:158-159) */
+  if (L)				/* matchLongWithin2 (pbwtMatch.c:85-113): reports even under -stats, fills no histogram */
+    { if (pbwtamd_long_within (e, p->yz, p->nz, p->N, p->aFstart, L, reportMatch, 0, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ; }
+  else if (isStats)			/* histogram instead of reports (pbwtMatch.c:130-131) */
+    { if (pbwtamd_max_within (e, p->yz, p->nz, p->N, p->aFstart, 0, 0, 0, h, p->N + 1)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ; }
+  else if (pbwtamd_max_within (e, p->yz, p->nz, p->N, p->aFstart, reportMatch, 0, 0, 0, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+  if (isStats)				/* pbwtMatch.c:166-178, also after -longWithin (all-zero histogram, 0/0 average) */
+    { long nTot = 0, hTot = 0 ;
       for (int i = 0 ; i <= p->N ; ++i)
 	if (h[i]) { nTot += h[i] ; hTot += h[i] * i ; printf ("%d\t%ld\n", i, (long) h[i]) ; }
       fprintf (logFile, "Average %.1f matches per sample\n", nTot / (double) p->M) ;
       fprintf (logFile, "Average length %.1f\n", hTot / (double) nTot) ;
       free (h) ;
     }
-  else if (pbwtamd_max_within (e, p->yz, p->nz, p->N, p->aFstart, reportMatch, 0, 0, 0, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
   if (isCheck) { free (checkA) ; checkA = checkB = 0 ; }
 }
 
@@ -327,6 +351,13 @@ void panelMatchDynamic (Panel *p, FILE *fp)
   if (pbwtamd_match_sweep (engineFor (p->M), p->yz, p->nz, p->N, p->aFstart, q->M, q->yz, q->nz, q->aFstart,
 			   reportMatch, 0, 0, &nomatch, tot))
     die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+  if (nomatch)				/* pbwtMatch.c:405-410, one line per event in the reference's order */
+    { int32_t *ev = 0 ; int64_t nev = 0 ;
+      if (pbwtamd_get_nomatch_events (engineFor (p->M), &ev, &nev)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+      for (int64_t i = 0 ; i < nev ; ++i)
+	fprintf (logFile, "no match to query %d value %d at site %d\n", ev[4*i], ev[4*i+1], ev[4*i+2]) ;
+      pbwtamd_free (ev) ;
+    }
   fprintf (logFile, "Average number of best matches including alternates %.1f, Average length %.1f, Av number per position %.1f\n",
 	   tot[0] / (double) q->M, tot[1] / (double) tot[0], tot[1] / (double) ((long) q->M * q->N)) ;
   if (isCheck) { free (checkA) ; free (checkB) ; checkA = checkB = 0 ; }

@@ -86,6 +86,11 @@ def sparse_sweep():
     for nS in (1, 2, 3):
         out["nomatch_s%d" % nS] = oracle.ref_match_sweep_sparse(pz, Mp, qz, Mq, N, nS)
     out["nomatch_dense"] = oracle.ref_match_sweep(pz, Mp, qz, Mq, N)
+    # the reference's log for that sweep: one "no match to query ..." line per event, then the averages line
+    vp = lambda x: np.ascontiguousarray(x).ctypes.data_as(C.c_void_p)
+    logp = os.path.join(HERE, "nomatch_dense.log")
+    assert ref.ref_match_sweep_log_to_file(C.c_int(Mp), C.c_int(N), vp(pz), C.c_long(len(pz)), None,
+                                           C.c_int(Mq), vp(qz), C.c_long(len(qz)), None, logp.encode()) == 0
     np.savez_compressed(os.path.join(HERE, "sparse_sweep.npz"), **out)
     print("wrote sparse_sweep.npz", {k: len(v) for k, v in out.items()})
 

@@ -41,6 +41,13 @@ def main():
     nchk = 0
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "out.txt")
+        # ---- -stats first: ref_max_within_hist_to_file forks (the reference keeps its histogram static set afterwards), and
+        # a child can only bring up HIP if the parent has not yet.  The histogram travels through pbwtMatch.c's
+        # file-static matchLengthHist, filled by the replacement matchMaximalWithin in the same (unity) TU.
+        for name in ("mosaic_M300_N400_k0.npz", "mosaic_M70_N150_k1.npz", "mosaic_M1100_N260_k0.npz"):
+            g = np.load(os.path.join(GOLDEN, name))
+            oracle.ref_max_within_file(g["yz"], int(g["M"]), int(g["N"]), out, hist=True, check=False)
+            assert open(out).read() == bytes(g["hist_txt"]).decode(); nchk += 1
         # ---- the reference's own test panel: pbwtLongMatches + reportMatch + -check, GPU underneath
         g = np.load(os.path.join(GOLDEN, "merge1.npz"))
         M, N = int(g["M"]), int(g["N"])
@@ -52,9 +59,6 @@ def main():
             M, N, Mq = int(g["M"]), int(g["N"]), int(g["Mq"])
             # callback stream of matchMaximalWithin as the reference's callers see it
             assert np.array_equal(oracle.ref_max_within(g["yz"], M, N), g["within"]); nchk += 1
-            # -stats: the histogram travels through pbwtMatch.c's file-static matchLengthHist (forked child)
-            oracle.ref_max_within_file(g["yz"], M, N, out, hist=True, check=False)
-            assert open(out).read() == bytes(g["hist_txt"]).decode(); nchk += 1
             # -matchDynamic: the reference's matchSequencesDynamic (pbwtRead of the query file + reportMatch)
             pp, qp = os.path.join(td, "p.pbwt"), os.path.join(td, "q.pbwt")
             write_pbwt(pp, M - Mq, N, g["pz"]); write_pbwt(qp, Mq, N, g["qz"])

@@ -149,3 +149,45 @@ def test_buildReverse_matches_reference_bytes(cli, tmp_path):
     # and it reads back as the reverse of the same panel
     run(cli, "-read", os.path.join(GOLDEN, "macs_small.pbwt"), "-readReverse", tmp_path / "rev.pbwt", "-writeReverse", tmp_path / "rev2.pbwt")
     assert open(tmp_path / "rev2.pbwt", "rb").read() == open(tmp_path / "rev.pbwt", "rb").read()
+
+
+def write_pbwt(path, M, N, yz):
+    ident = np.arange(M, dtype="<i4").tobytes()
+    open(path, "wb").write(b"PBW3" + np.array([M, N], "<i4").tobytes() + ident + ident + np.array([len(yz)], "<i8").tobytes() + b"    " + np.asarray(yz, np.uint8).tobytes())
+
+
+@pytest.mark.gpu
+def test_log_lines_match_the_reference(cli, tmp_path):
+    """what log scrapers see: the "no match to query" events of -matchDynamic, one line each in the reference's order
+    (golden written by the reference: tests/golden/nomatch_dense.log), the averages line, and the timing line after
+    every command in the format of utils.c:173-198"""
+    import re
+    s = np.load(os.path.join(GOLDEN, "sparse_sweep.npz"))
+    Mp, Mq, N = [int(x) for x in s["nomatch_shape"]]
+    write_pbwt(tmp_path / "p.pbwt", Mp, N, s["nomatch_pz"])
+    write_pbwt(tmp_path / "q.pbwt", Mq, N, s["nomatch_qz"])
+    r = run(cli, "-log", tmp_path / "log.txt", "-read", tmp_path / "p.pbwt", "-matchDynamic", tmp_path / "q.pbwt")
+    log = open(tmp_path / "log.txt").read().splitlines()
+    want = open(os.path.join(GOLDEN, "nomatch_dense.log")).read().splitlines()
+    assert [ln for ln in log if ln.startswith("no match") or ln.startswith("Average number")] == want
+    assert r.stdout == "".join("MATCH\t%d\t%d\t%d\t%d\t%d\n" % (m["ai"], m["bi"], m["start"], m["end"], m["end"] - m["start"])
+                               for m in s["nomatch_dense"] if m["start"] != m["end"])
+    timing = [ln for ln in log if ln.startswith("user\t")]
+    assert len(timing) == 2 and all(re.fullmatch(r"user\t\d+\.\d{6}\tsystem\t\d+\.\d{6}\tmax_RSS\t-?\d+\tMemory\t\d+", ln) for ln in timing)
+
+
+@pytest.mark.gpu
+def test_stats_after_longWithin_and_writeAll_reverse(cli, tmp_path):
+    """-stats -longWithin L: the MATCH lines, then the stats block over an empty histogram (pbwtMatch.c:166-178: no bins,
+    0.0 matches per sample, 0/0 average length); -buildReverse -writeAll / -readAll carry root.reverse (pbwtIO.c:143,419)"""
+    f = os.path.join(GOLDEN, "mosaic_M300_N400_k0.npz")
+    g = np.load(f)
+    write_pbwt(tmp_path / "m.pbwt", 300, 400, g["yz"])
+    r = run(cli, "-stats", "-read", tmp_path / "m.pbwt", "-longWithin", 100)
+    assert r.stdout == open(os.path.join(GOLDEN, "longwithin_M300_L100.txt")).read()
+    assert "Average 0.0 matches per sample" in r.stderr and "Average length -nan" in r.stderr
+    root = tmp_path / "all"
+    run(cli, "-read", os.path.join(GOLDEN, "macs_small.pbwt"), "-buildReverse", "-writeAll", root)
+    assert open(str(root) + ".reverse", "rb").read() == open(os.path.join(GOLDEN, "macs_small.reverse.pbwt"), "rb").read()
+    run(cli, "-readAll", root, "-writeReverse", tmp_path / "again.reverse")
+    assert open(tmp_path / "again.reverse", "rb").read() == open(os.path.join(GOLDEN, "macs_small.reverse.pbwt"), "rb").read()

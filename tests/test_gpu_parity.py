@@ -324,6 +324,28 @@ def test_malformed_packed_panel_is_rejected(amd, orc):
         eng.max_within(yz[:-3], N, mode="hist")          # truncated
     with pytest.raises(amd.PbwtAmdError, match="decodes to"):
         eng.max_within(yz, N + 1, mode="hist")           # wrong N
+    # a crafted file whose run lengths still total M*N but with a run straddling a column boundary: the two runs
+    # either side of the boundary between columns 3 and 4 are merged into one (same allele) or the boundary is moved
+    # by shifting one position from the last run of column 3 to the first run of column 4
+    import oracle
+    starts = [0]
+    for k in range(N):
+        _, used, _ = oracle.unpack3(yz[starts[-1]:], M)
+        starts.append(starts[-1] + used)
+    bad = yz.copy()
+    i, j = starts[4] - 1, starts[4]                      # last byte of column 3, first byte of column 4
+    if (bad[i] & 0x7f) > 1 and (bad[j] & 0x7f) < 63:
+        bad[i] -= 1; bad[j] += 1                         # column 3 is one position short, column 4 one long
+        with pytest.raises(amd.PbwtAmdError, match="malformed packed panel"):
+            eng.max_within(bad, N, mode="hist")
+        with pytest.raises(amd.PbwtAmdError, match="malformed packed panel"):
+            eng.haplotypes(bad, N)
+    # the start order drives device gathers: anything but a permutation of [0, M) is refused
+    with pytest.raises(amd.PbwtAmdError, match="not a permutation"):
+        eng.max_within(yz, N, aFstart=np.zeros(M, np.int32), mode="hist")
+    with pytest.raises(amd.PbwtAmdError, match="not a permutation"):
+        eng.build(bits, aFstart=np.arange(1, M + 1, dtype=np.int32))
+    assert np.array_equal(eng.max_within(yz, N, mode="hist"), orc.max_within_hist(yz, M, N)[: N + 1])   # the engine is still usable
 
 
 @pytest.mark.parametrize("skel", ["1", "0"])
@@ -462,3 +484,24 @@ def test_chunked_build_from_carried_cursor(amd, orc):
             b = eng.build(bits[k0:k0 + chunk], with_d=True, aFstart=a)
             a = b["aFend"]; yz.append(b["yz"])
         assert np.array_equal(np.concatenate(yz), o["yz"]) and np.array_equal(a, o["aFend"])
+
+
+@pytest.mark.parametrize("path", golden_panels() + [os.path.join(GOLDEN, "merge1.npz")])
+def test_cursor_at_is_the_reference_PbwtCursor(amd, orc, path):
+    """pbwtamd_cursor_at: every field of the reference's PbwtCursor (pbwt.h:74-87) before site k — a, d, y (stale at
+    k == N), c, u, and the byte offsets n / nBlockStart into yz — against the dumps the reference itself produced"""
+    g = np.load(path)
+    M, N = int(g["M"]), int(g["N"])
+    aF = g["aFstart"] if "aFstart" in g else None
+    eng = amd.Engine(M, batch_sites=16)
+    yz = g["yz"]
+    starts = [0]
+    for k in range(N):
+        starts.append(starts[-1] + orc.unpack3(yz[starts[-1]:], M)[1])
+    for k in sorted({0, 1, min(7, N), min(16, N), N // 2, N - 1, N}):
+        c = eng.cursor_at(yz, N, k, aFstart=aF)
+        assert np.array_equal(c["a"], g["sweep_a"][k]) and np.array_equal(c["d"], g["sweep_d"][k])
+        assert np.array_equal(c["y"], g["sweep_y"][k]) and c["c"] == int(g["sweep_c"][k])
+        assert np.array_equal(c["u"], np.concatenate([[0], np.cumsum(1 - c["y"].astype(np.int32))]))
+        ky = min(k, N - 1)
+        assert c["nBlockStart"] == starts[ky] and c["n"] == (starts[k + 1] if k < N else len(yz))
