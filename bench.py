@@ -12,9 +12,13 @@ sweep (histogram sink, the reference's -stats mode) + pack3 encoding of the PBWT
 default K = 122 steps is the whole 1M-site panel of configs[2].  Steps continue one forward pass,
 so every step works on a realistic cursor state.
 
-Multi-GPU (⑤): the site recurrence does not shard without a per-site exchange that costs more than
-the step itself, so ranks process independent panels (different chromosomes = seeds)
-with no data-path collective: weak scaling, value = total site*haps over all ranks / max time.
+Multi-GPU (⑤), two modes:
+  --mode replicas (default): ranks process independent panels (different chromosomes = seeds) with no data-path
+      collective: weak scaling, value = total site*haps over all ranks / max time.
+  --mode siteblock: ONE panel of K*S sites sharded by site blocks (pbwt_amd/siteblock.py): every rank
+      runs the chain alone up to its block, then the full hot path over its block; one all-reduce (RCCL) of the
+      histogram at the end, inside the timed region.  Strong scaling, value = M*K*S / max time; bounded by
+      t_full / t_chain because the recurrence itself stays serial (1.2x at M = 100 k, 2.1x at M = 1 M on 8 GPUs).
 """
 import argparse
 import json
@@ -46,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-1m", action="store_true", help="skip the secondary measurement at the north-star width (1M haplotypes)")
     ap.add_argument("--own-stream", action="store_true", help="let the engine create its own (high-priority) chain stream instead of torch's current stream")
+    ap.add_argument("--mode", default=os.environ.get("PBWT_BENCH_MODE", "replicas"), choices=["replicas", "siteblock"],
+                    help="multi-GPU mode: independent panels per rank (weak) or one panel sharded by site blocks (strong)")
     ap.add_argument("--panels", type=int, default=1, help="independent panels run concurrently on this GPU (throughput mode; default 1 = the named config)")
     return ap.parse_args()
 
@@ -116,6 +122,46 @@ def host_entry_points(torch, pbwt_amd, panel, M, sites=16384, batch=512):
             "note": "caller buffers in ordinary host memory (the build pins its input for the call), transfers included, first call at this size"}
 
 
+def run_siteblock(args, torch, pdist, pbwt_amd, dev, rank, world):
+    """--mode siteblock: one panel, sharded by site blocks across the ranks (strong scaling)"""
+    from pbwt_amd import siteblock as sb
+    M, S, K, Wm = args.haps, args.sites_per_step, args.steps, args.warmup
+    N = K * S
+    eng = pbwt_amd.Engine(M, batch_sites=args.batch, device=dev.index)
+    panel = torch.empty((N, eng.wpc), dtype=torch.int32, device=dev)          # every rank holds the panel's columns
+    eng.synth_device(panel.data_ptr(), 0, N, seed=0x5EED0001, kind=args.kind)
+    eng.sync()
+    opts = pbwt_amd.OPT_WITH_D | (0 if args.no_within else pbwt_amd.OPT_WITHIN_HIST) | (0 if args.no_pack3 else pbwt_amd.OPT_PACK3)
+    col = lambda k: panel.data_ptr() + k * eng.wpc * 4
+    # warm-up = the calibration of rho = t_chain / t_full on this GPU (untimed), agreed between the ranks
+    rho = sb.calibrate_rho(eng, col, N, opts, args.batch, nbatches=max(2, min(8, Wm * S // args.batch)))
+    rho = pdist.max_over_ranks(rho, device=dev)
+    blocks = sb.plan_blocks(N, world, rho, align=args.batch)
+    pdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sb.run_block(eng, col, N, blocks[rank], opts, is_last=(rank == world - 1), step=S)
+    hist = sb.reduce_hist(eng.get_hist(N + 1), device=dev)                     # the one collective of the mode
+    pdist.barrier(); torch.cuda.synchronize()
+    dt = pdist.max_over_ranks(time.perf_counter() - t0, device=dev)
+    ms, nl = eng.chain_timing(); sites = eng.chain_sites()
+    us = 1e3 * ms / max(nl, 1); spl = sites / max(nl, 1)
+    ach = ALG_BYTES_PER_SITEHAP * M * spl / (us * 1e-6) / 1e9
+    out = {"metric": "sites*haplotypes/sec PBWT build + maxWithin", "value": M * N / dt, "unit": "site*haps/s",
+           "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+           "config": {"workload": "configs[2]: ONE panel of %d haplotypes x %d sites, build (ForwardsAD + pack3) + maxWithin (hist sink), "
+                                  "site-block sharded over %d ranks" % (M, N, world),
+                      "haplotypes": M, "sites_per_step": S, "sites_timed": N, "device_batch_sites": args.batch, "mode": "siteblock",
+                      "rho_t_chain_over_t_full": rho, "blocks": blocks, "collective": "all-reduce of the histogram (RCCL), once"},
+           "roofline": {"bound": "hbm", "kernel": "skeleton chain: skel_hist_kernel + skel_k2_kernel + skel_rank_kernel, 3 launches per 8 sites",
+                        "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                        "us_per_launch": us, "sites_per_launch": spl, "note": "rank 0's chain (prefix + block)"},
+           "within_reports_hist_total": int(hist.sum())}
+    if rank == 0:
+        print(json.dumps(out))
+    pdist.finish()
+
+
 def main():
     args = parse()
     import torch
@@ -125,6 +171,8 @@ def main():
     torch.cuda.set_device(dev)
     pdist.init("nccl", device_id=dev)      # backend "nccl" is RCCL on ROCm; only barrier + max-reduce use it
     import pbwt_amd
+    if args.mode == "siteblock":
+        return run_siteblock(args, torch, pdist, pbwt_amd, dev, rank, world)
 
     M, S, K, Wm = args.haps, args.sites_per_step, args.steps, args.warmup
     n_total = (K + Wm) * S

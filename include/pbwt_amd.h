@@ -182,6 +182,13 @@ int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, int wpc, int 
 /* finish: runs the k==N sweep if a WITHIN sink is active; synchronises */
 int pbwtamd_pass_end(pbwtamd_engine *e, unsigned opts);
 
+/* close a pass before the panel's last site (no k == N sweep): for a caller that owns a block of sites only */
+int pbwtamd_pass_stop(pbwtamd_engine *e);
+
+/* right after pbwtamd_pass_begin(e, a_k, k0, N): also install the divergences d_k[0..M] of a checkpointed cursor
+ * (d[0] = d[M] = k0+1, pbwtCore.c:507), so that a pass restarts at site k0 exactly where another one stopped */
+int pbwtamd_pass_set_d(pbwtamd_engine *e, const int32_t *d);
+
 int pbwtamd_sync(pbwtamd_engine *e);
 
 /* results of the pass so far (host copies) */

@@ -289,6 +289,14 @@ class Engine:
     def pass_advance(self, dptr, ncols, ncols_avail, opts):
         self._chk(self._L.pbwtamd_pass_advance(self._h, C.c_void_p(dptr), C.c_int(self.wpc), C.c_int(ncols), C.c_int(ncols_avail), C.c_uint(opts)))
 
+    def pass_stop(self):
+        self._chk(self._L.pbwtamd_pass_stop(self._h))
+
+    def pass_set_d(self, d):
+        d = np.ascontiguousarray(d, dtype=np.int32)
+        assert d.size == self.M + 1
+        self._chk(self._L.pbwtamd_pass_set_d(self._h, _p(d, C.c_int32)))
+
     def pass_end(self, opts):
         self._chk(self._L.pbwtamd_pass_end(self._h, C.c_uint(opts)))
 

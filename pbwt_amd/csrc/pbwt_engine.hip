@@ -853,6 +853,27 @@ extern "C" int pbwtamd_pass_end(pbwtamd_engine *e, unsigned opts) {
     return pbwtamd_sync(e);
 }
 
+// close a pass before the panel's last site: the consumers of every batch advanced so far complete, no k == N sweep.
+// For callers that own a block of sites only (site-block sharding across GPUs, pbwt_amd/siteblock.py).
+extern "C" int pbwtamd_pass_stop(pbwtamd_engine *e) {
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->pass_open) return fail("pbwtamd_pass_stop without pass_begin");
+    CHK(flush_pending(e));
+    e->pass_open = false;
+    return pbwtamd_sync(e);
+}
+
+// restart a pass from a checkpoint (a_k, d_k) — the state pbwtCheckPoint / a cursor dump holds (pbwtIO.c:158-168 keeps a;
+// d is what ForwardsAD needs in addition): pbwtamd_pass_begin at site k0 with the order, then the divergences
+extern "C" int pbwtamd_pass_set_d(pbwtamd_engine *e, const int32_t *d) {
+    HIPCHK(hipSetDevice(e->device));
+    if (!e->pass_open || e->k_cur != e->k0) return fail("pbwtamd_pass_set_d: only right after pbwtamd_pass_begin");
+    if (d[0] != e->k0 + 1 || d[e->M] != e->k0 + 1) return fail("pbwtamd_pass_set_d: d[0] and d[M] must be the sentinels k0+1 = %d", e->k0 + 1);
+    HIPCHK(hipMemcpyAsync(ringD(e, e->ring), d, sizeof(int) * ((size_t)e->M + 1), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
 extern "C" int pbwtamd_get_state(pbwtamd_engine *e, int32_t *a, int32_t *d) {
     HIPCHK(hipSetDevice(e->device));
     CHK(flush_pending(e));

@@ -173,7 +173,7 @@ def test_log_lines_match_the_reference(cli, tmp_path):
     assert r.stdout == "".join("MATCH\t%d\t%d\t%d\t%d\t%d\n" % (m["ai"], m["bi"], m["start"], m["end"], m["end"] - m["start"])
                                for m in s["nomatch_dense"] if m["start"] != m["end"])
     timing = [ln for ln in log if ln.startswith("user\t")]
-    assert len(timing) == 2 and all(re.fullmatch(r"user\t\d+\.\d{6}\tsystem\t\d+\.\d{6}\tmax_RSS\t-?\d+\tMemory\t\d+", ln) for ln in timing)
+    assert len(timing) == 3 and all(re.fullmatch(r"user\t\d+\.\d{6}\tsystem\t\d+\.\d{6}\tmax_RSS\t-?\d+\tMemory\t\d+", ln) for ln in timing)
 
 
 @pytest.mark.gpu

@@ -78,15 +78,16 @@ SHARD_WORKER = textwrap.dedent("""
     want = oracle.build_bitcols(bits, M, with_d=True, dump_sites=range(N + 1))
     b = owner_ranges(M, world)
     lo, hi = b[rank], b[rank + 1]
-    a = np.arange(lo, hi, dtype=np.int64)
-    d = np.zeros(hi - lo, dtype=np.int64)
+    import torch
+    a = torch.arange(lo, hi, dtype=torch.int64)                     # CPU tensors under gloo; the same calls take device tensors under RCCL
+    d = torch.zeros(hi - lo, dtype=torch.int64)
     if rank == 0 and hi > lo:
         d[0] = 1
     ok = True
     for k in range(N):
-        y = hap[k][a]
+        y = torch.from_numpy(hap[k].astype(np.int64))[a]
         a, d = sharded_step_AD(a, d, y, k, M)
-        ok &= bool(np.array_equal(a, want["a_dump"][k + 1][lo:hi])) and bool(np.array_equal(d, want["d_dump"][k + 1][lo:hi]))
+        ok &= bool(np.array_equal(a.numpy(), want["a_dump"][k + 1][lo:hi])) and bool(np.array_equal(d.numpy(), want["d_dump"][k + 1][lo:hi]))
     with open(os.path.join(os.environ["OUT_DIR"], "shard" + str(rank) + ".json"), "w") as f:
         json.dump({"rank": rank, "ok": ok, "n": int(hi - lo)}, f)
     pd.finish()
@@ -107,3 +108,59 @@ def test_position_sharded_step_protocol_gloo(world, M, N, kind, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     outs = [json.load(open(tmp_path / ("shard%d.json" % rk))) for rk in range(world)]
     assert all(o["ok"] for o in outs) and sum(o["n"] for o in outs) == M
+
+
+def test_site_block_plan():
+    """pbwt_amd/siteblock.py: the blocks cover [0, N) in order, boundaries sit on batch multiples, and the geometric sizes
+    balance the ranks under the cost model (chain-only prefix at rho per site + the block at 1)"""
+    from pbwt_amd.siteblock import plan_blocks, model_time
+    for N in (1000000, 200000, 4096, 512, 0):
+        for world in (1, 2, 3, 4, 8):
+            for rho in (0.2, 0.48, 0.84):
+                b = plan_blocks(N, world, rho, align=512)
+                assert len(b) == world and b[0][0] == 0 and b[-1][1] == N
+                assert all(b[g][1] == b[g + 1][0] for g in range(world - 1)) and all(lo <= hi for lo, hi in b)
+                assert all(lo % 512 == 0 for lo, _ in b)
+                if N >= 100000:
+                    t = model_time(b, rho)
+                    assert max(t) - min(t) <= 2 * 512 + 1e-9                          # balanced to the alignment
+                    assert max(t) <= N * rho / (1 - (1 - rho) ** world) + 2 * 512   # the closed form of the docstring
+
+
+BLOCK_WORKER = textwrap.dedent("""
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    from pbwt_amd import dist as pd
+    from pbwt_amd import siteblock as sb
+    rank, world = pd.init("gloo")
+    N = 4096
+    blocks = sb.plan_blocks(N, world, 0.5, align=512)
+    lo, hi = blocks[rank]
+    hist = np.zeros(N + 1, np.int64); hist[lo:hi] = np.arange(lo, hi) + 1                 # each rank contributes its own sites
+    if rank == world - 1: hist[N] = 7
+    total = sb.reduce_hist(hist)
+    yz = sb.gather_packed(np.arange(lo, hi, dtype=np.int64).astype(np.uint8), dst=0)      # site order = rank order
+    ok = bool(np.array_equal(total[:N], np.arange(N) + 1)) and total[N] == 7
+    if rank == 0:
+        ok = ok and bool(np.array_equal(yz, np.arange(N, dtype=np.int64).astype(np.uint8)))
+    else:
+        ok = ok and yz is None
+    with open(os.path.join(os.environ["OUT_DIR"], "blk" + str(rank) + ".json"), "w") as f:
+        json.dump({"rank": rank, "ok": bool(ok)}, f)
+    pd.finish()
+""") % ROOT
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_site_block_combine_gloo(world, tmp_path):
+    """the two collectives of the site-block mode — all-reduce of the histogram, gather of the packed blocks in rank order"""
+    import json
+    script = tmp_path / "blk_worker.py"
+    script.write_text(BLOCK_WORKER)
+    env = dict(os.environ, OUT_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert all(json.load(open(tmp_path / ("blk%d.json" % rk)))["ok"] for rk in range(world))

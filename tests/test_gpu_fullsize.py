@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 def device_panel(eng, N, seed, kind=0):
     import torch
     buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()               # the engine enqueues on its own stream: the fill must have landed
     eng.synth_device(buf.data_ptr(), 0, N, seed=seed, kind=kind)
     eng.sync()
     return buf

@@ -1,0 +1,106 @@
+"""GPU (-m gpu): the multi-GPU device paths at world_size 2 on the ONE GPU of the test box — two processes launched by
+torch.distributed.run, each with its own engine on device 0, gloo for the (small) collectives — and the checkpoint
+restart they rest on.  On an 8-GPU node the same code runs one rank per GPU over RCCL (bench.py --mode siteblock)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+WORKER = textwrap.dedent("""
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    import torch
+    from pbwt_amd import dist as pd
+    from pbwt_amd import siteblock as sb
+    import pbwt_amd as amd
+    rank, world = pd.init("gloo")
+    M, N, B = int(os.environ["SB_M"]), int(os.environ["SB_N"]), 512
+    eng = amd.Engine(M, batch_sites=B, device=0)
+    panel = torch.empty((N, eng.wpc), dtype=torch.int32, device="cuda:0")
+    eng.synth_device(panel.data_ptr(), 0, N, seed=0xB10C, kind=int(os.environ["SB_KIND"]))     # every rank holds the panel's columns
+    eng.sync()
+    opts = amd.OPT_WITH_D | amd.OPT_WITHIN_HIST | amd.OPT_PACK3
+    blocks = sb.plan_blocks(N, world, float(os.environ["SB_RHO"]), align=B)
+    sb.run_block(eng, lambda k: panel.data_ptr() + k * eng.wpc * 4, N, blocks[rank], opts, is_last=(rank == world - 1), step=2048)
+    hist = sb.reduce_hist(eng.get_hist(N + 1))
+    yz = sb.gather_packed(eng.get_packed(), dst=0)
+    ok = True
+    if rank == 0:
+        import oracle
+        bits = panel.cpu().numpy().view(np.uint32)
+        o = oracle.build_bitcols(bits, M, with_d=True, want_csum=False)
+        ok = bool(np.array_equal(yz, o["yz"])) and bool(np.array_equal(hist, oracle.max_within_hist(o["yz"], M, N)[: N + 1]))
+    with open(os.path.join(os.environ["OUT_DIR"], "sb" + str(rank) + ".json"), "w") as f:
+        json.dump({"rank": rank, "ok": bool(ok), "block": list(blocks[rank])}, f)
+    eng.close()
+    pd.finish()
+""") % ROOT
+
+
+@pytest.mark.parametrize("world,M,N,kind,rho", [(2, 30000, 4096, 0, 0.6), (3, 5000, 6144, 1, 0.3), (2, 100000, 2048, 0, 0.84)])
+def test_site_block_sharding_two_ranks_one_gpu(world, M, N, kind, rho, tmp_path):
+    """one panel, G ranks: chain-only prefix + own block with consumers on each rank; summed histogram and concatenated
+    pack3 bytes equal the oracle's for the whole panel"""
+    script = tmp_path / "sb_worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, OUT_DIR=str(tmp_path), SB_M=str(M), SB_N=str(N), SB_KIND=str(kind), SB_RHO=str(rho))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    outs = [json.load(open(tmp_path / ("sb%d.json" % rk))) for rk in range(world)]
+    assert all(o["ok"] for o in outs), outs
+    assert outs[0]["block"][0] == 0 and outs[-1]["block"][1] == N
+
+
+def test_restart_from_checkpoint(gpu_lib, orc):
+    """pbwtamd_pass_begin(a_k, k0) + pbwtamd_pass_set_d(d_k): a pass restarted from the (a, d) another one stopped with
+    reproduces the uninterrupted pass — every later site's a/d, the histogram of the remaining sites, the final state"""
+    import torch
+    amd = gpu_lib
+    M, N, k0 = 20000, 1536, 520
+    eng = amd.Engine(M, batch_sites=256)
+    buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()               # the engine enqueues on its own stream: the fill must have landed
+    eng.synth_device(buf.data_ptr(), 0, N, seed=5, kind=0); eng.sync()
+    bits = buf.cpu().numpy().view(np.uint32)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    ptr = lambda k: buf.data_ptr() + k * eng.wpc * 4
+    eng.pass_begin(N)
+    eng.pass_advance(ptr(0), k0, k0 + 8, amd.OPT_WITH_D)
+    a, d = eng.get_state()
+    eng.pass_stop()
+    opts = amd.OPT_WITH_D | amd.OPT_CHECKSUM | amd.OPT_WITHIN_HIST
+    e2 = amd.Engine(M, batch_sites=256)                       # "another rank"
+    e2.pass_begin(N, k0=k0, aInit=a)
+    e2.pass_set_d(d)
+    e2.pass_advance(ptr(k0), N - k0, N - k0, opts)
+    e2.pass_end(opts)
+    ca, cd, _ = e2.get_checksums(k0, N - k0 + 1)
+    assert np.array_equal(ca, o["csum_a"][k0:]) and np.array_equal(cd, o["csum_d"][k0:])
+    a2, d2 = e2.get_state()
+    assert np.array_equal(a2, o["aFend"]) and np.array_equal(d2, o["d_final"])
+    # histogram of the sites k0..N only = the whole panel's minus the first k0 sites' (from an uninterrupted pass stopped at k0)
+    eng.pass_begin(N)
+    eng.pass_advance(ptr(0), 512, 520, amd.OPT_WITH_D | amd.OPT_WITHIN_HIST)
+    eng.pass_advance(ptr(512), 8, 16, amd.OPT_WITH_D | amd.OPT_WITHIN_HIST)
+    eng.pass_stop()
+    head = eng.get_hist(N + 1)
+    assert np.array_equal(head + e2.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
+    with pytest.raises(amd.PbwtAmdError, match="sentinels"):
+        e2.pass_begin(N, k0=k0, aInit=a); e2.pass_set_d(np.zeros(M + 1, np.int32))

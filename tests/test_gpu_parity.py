@@ -90,6 +90,7 @@ def test_two_site_launch_paths(amd, orc, M, N, batch, avail_extra):
     import torch
     eng = amd.Engine(M, batch_sites=batch)
     buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()               # the engine enqueues on its own stream: the fill must have landed
     eng.synth_device(buf.data_ptr(), 0, N, seed=5, kind=0)
     eng.sync()
     bits = buf.cpu().numpy().view(np.uint32)
@@ -164,6 +165,7 @@ def test_synth_generator_matches_oracle(amd, orc):
     eng = amd.Engine(M, batch_sites=16)
     for kind in (0, 1):
         buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()               # the engine enqueues on its own stream: the fill must have landed
         eng.synth_device(buf.data_ptr(), 5, N, seed=77, kind=kind)
         eng.sync()
         got = buf.cpu().numpy().view(np.uint32)
@@ -176,6 +178,7 @@ def test_device_pass_api_with_graph(amd, orc):
     M, N, B = 9000, 700, 256
     eng = amd.Engine(M, batch_sites=B)
     buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()               # the engine enqueues on its own stream: the fill must have landed
     eng.synth_device(buf.data_ptr(), 0, N, seed=3, kind=0)
     eng.sync()
     bits = buf.cpu().numpy().view(np.uint32)
@@ -247,6 +250,7 @@ def test_large_panel_1024_position_tiles(amd, orc, pair1024, monkeypatch):
     M, N = 300000, 41
     eng = amd.Engine(M, batch_sites=16)
     buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()               # the engine enqueues on its own stream: the fill must have landed
     eng.synth_device(buf.data_ptr(), 0, N, seed=2, kind=0)
     eng.sync()
     bits = buf.cpu().numpy().view(np.uint32)
@@ -271,6 +275,7 @@ def test_mode_switches_inside_a_pass(amd, orc):
     M, N = 2000, 300
     eng = amd.Engine(M, batch_sites=32)
     buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()               # the engine enqueues on its own stream: the fill must have landed
     eng.synth_device(buf.data_ptr(), 0, N, seed=21, kind=0)
     eng.sync()
     bits = buf.cpu().numpy().view(np.uint32)
@@ -359,6 +364,7 @@ def test_both_chains_every_site(amd, orc, skel, M, N, batch, kind, monkeypatch):
     monkeypatch.setenv("PBWTAMD_SKEL", skel)
     eng = amd.Engine(M, batch_sites=batch)
     buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()               # the engine enqueues on its own stream: the fill must have landed
     eng.synth_device(buf.data_ptr(), 0, N, seed=1000 + M, kind=kind)
     eng.sync()
     bits = buf.cpu().numpy().view(np.uint32)
@@ -399,6 +405,7 @@ def test_histogram_and_pack3_consumers_without_ids(amd, orc, packed, M, N, batch
         monkeypatch.setenv("PBWTAMD_NO_PACKED_FILL", "1")
     eng = amd.Engine(M, batch_sites=batch)
     buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()               # the engine enqueues on its own stream: the fill must have landed
     eng.synth_device(buf.data_ptr(), 0, N, seed=2000 + M, kind=kind)
     eng.sync()
     bits = buf.cpu().numpy().view(np.uint32)
