@@ -80,21 +80,27 @@ def cpu_baseline(args, first_cols):
                       % (n, M, what, tb, tw)}
 
 
-def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=4096, batch=512):
-    """secondary measurement at the north-star width (1M haplotypes), same hot path, short panel:
-    reported next to the headline, not part of `value`"""
+def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=65536, batch=512, step=8192, want_hist=False):
+    """the same hot path at the north-star width (1 M haplotypes) over `sites` sites, device-resident, with its own
+    roofline object.  A secondary measurement (the headline `value` stays BASELINE configs[2]); its histogram total is
+    pinned to the oracle by tests/test_gpu_configs.py::test_bench_north_star_width_path (same function, a prefix)."""
     eng = pbwt_amd.Engine(M, batch_sites=batch, device=dev.index)
-    panel = torch.empty((sites + batch, eng.wpc), dtype=torch.int32, device=dev)
-    eng.synth_device(panel.data_ptr(), 0, sites + batch, seed=0x1A2B3C, kind=kind)
-    eng.sync()
     n_total = sites + batch
+    panel = torch.empty((n_total, eng.wpc), dtype=torch.int32, device=dev)
+    eng.synth_device(panel.data_ptr(), 0, n_total, seed=0x1A2B3C, kind=kind)
+    eng.sync()
+    col = lambda k: panel.data_ptr() + k * eng.wpc * 4
     eng.pass_begin(n_total)
-    eng.pass_advance(panel.data_ptr(), batch, batch + 8, opts)          # warm-up batch
+    eng.pass_advance(col(0), batch, batch + 8, opts)                     # warm-up batch
     eng.sync()
     ms0, n0 = eng.chain_timing(); s0 = eng.chain_sites()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    eng.pass_advance(panel.data_ptr() + batch * eng.wpc * 4, sites, sites, opts)
+    k = batch
+    while k < n_total:
+        n = min(step, n_total - k)
+        eng.pass_advance(col(k), n, min(n + 8, n_total - k), opts)
+        k += n
     eng.pass_end(opts)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -102,9 +108,21 @@ def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=4096, ba
     us = 1e3 * (ms1 - ms0) / max(n1 - n0, 1)
     spl = (s1 - s0) / max(n1 - n0, 1)
     ach = ALG_BYTES_PER_SITEHAP * M * spl / (us * 1e-6) / 1e9
+    hist = eng.get_hist(n_total + 1)
+    out = {"haplotypes": M, "sites_timed": sites, "value": M * sites / dt, "unit": "site*haps/s", "us_per_site": 1e6 * dt / sites,
+           "within_reports_hist_total": int(hist.sum()),
+           "whole_job_achieved_GBps": ALG_BYTES_PER_SITEHAP * M * sites / dt / 1e9,
+           "whole_job_frac_of_hbm_peak": ALG_BYTES_PER_SITEHAP * M * sites / dt / 1e9 / HBM_PEAK_GBPS,
+           "roofline": {"bound": "hbm", "kernel": "skeleton chain: skel_hist_kernel + skel_k2_wide_kernel + skel_rank_kernel, 3 launches per 8 sites",
+                        "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                        "us_per_launch": us, "sites_per_launch": spl,
+                        "note": "chain launches only (HIP events around the dependent chain, launch gaps included); whole_job_* = the job's algorithmic bytes over wall time, consumers included"}}
+    if want_hist:
+        out["hist"] = hist
+        out["packed"] = eng.get_packed() if (opts & pbwt_amd.OPT_PACK3) else None
+        out["panel"] = panel
     eng.close()
-    return {"haplotypes": M, "sites_timed": sites, "value": M * sites / dt, "unit": "site*haps/s", "us_per_launch": us,
-            "sites_per_launch": spl, "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBPS}
+    return out
 
 
 def host_entry_points(torch, pbwt_amd, panel, M, sites=16384, batch=512):

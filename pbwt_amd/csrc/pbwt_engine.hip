@@ -75,6 +75,7 @@ struct pbwtamd_engine {
     unsigned long long *blockCount = nullptr; size_t blockCountCap = 0;
     unsigned long long *scal = nullptr;     // [0]=record total of the batch  [1]=yz bytes so far
     unsigned long long *hist = nullptr; int histlen = 0;
+    unsigned long long *hist_rep = nullptr;  // HIST_REP replicas of the low histogram bins (streaming sweep), folded on read
     unsigned long long *csum = nullptr; int csum_sites = 0;               // 3 * csum_sites
     int4 *recs = nullptr; size_t recsCap = 0;
     uint8_t *yz = nullptr; size_t yzCap = 0;
@@ -91,6 +92,7 @@ struct pbwtamd_engine {
     uint32_t *xT = nullptr; size_t strideX = 0; int xTblocks = 0;   // transposed panel of the batch in flight (= xTr[ring])
     uint32_t *xTr[2] = {nullptr, nullptr}; // one per ring: the fill of batch n reads it while the chain transposes batch n+1
     int *skT = nullptr;                     // hist table of the round in flight, [W][256] {cnt, tail}
+    unsigned long long *k2agg = nullptr; unsigned *k2cnt = nullptr; unsigned k2epoch = 0;   // two-level tile scan of wide panels (skel_k2_wide_kernel)
     unsigned char *keysR[2] = {nullptr, nullptr};         // per ring: the keys of states 0, 8, 16, ... of the batch ([B/8+1][Mpad]), kept for the fill
     int2 *saveR[2] = {nullptr, nullptr}; size_t strideS = 0;  // per ring and round: scan[W][256] {before, carry}, total[256] (stride in int2)
     hipEvent_t tev[16] = {}; long long tev_n = 0; int thr_rounds = 28, thr_depth = 2;   // host throttle: an event every thr_rounds rounds, host at most thr_depth events ahead
@@ -133,8 +135,8 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->rankdirS, (void *)e->skT, e->cols_stage, e->ycols, e->colBytes,
-                    e->blockCount, e->scal, e->hist, e->csum, e->recs, e->yz};
+    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->rankdirS, (void *)e->skT, (void *)e->k2agg, (void *)e->k2cnt, e->cols_stage, e->ycols, e->colBytes,
+                    e->blockCount, e->scal, e->hist, e->hist_rep, e->csum, e->recs, e->yz};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -194,6 +196,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     ALLOC(e->ycols, slots * e->wpc64 * sizeof(unsigned long long));
     ALLOC(e->colBytes, (slots + 1) * sizeof(unsigned long long));
     ALLOC(e->scal, 8 * sizeof(unsigned long long));
+    ALLOC(e->hist_rep, (size_t)HIST_REP * HIST_LBINS * sizeof(unsigned long long));
     if (e->skel) {
         e->skEPT = (M <= 40000) ? 1 : 2;                       // measured: smaller tiles = shorter per-workgroup latency chains, and the fill fits 4 workgroups per CU (T = 1024: 2)
         if (const char *sv = getenv("PBWTAMD_SKT")) e->skEPT = (atoi(sv) == 256) ? 1 : (atoi(sv) == 512) ? 2 : 4;
@@ -216,6 +219,9 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             }
         }
         ALLOC(e->skT, (size_t)(e->Wt + 1) * SKK * sizeof(int2));
+        ALLOC(e->k2agg, (size_t)64 * SKK * sizeof(unsigned long long));
+        ALLOC(e->k2cnt, 64);
+        ECHK(hipMemsetAsync(e->k2cnt, 0, 64, e->stream));
         ALLOC(e->rankdirS, (size_t)(e->B + 2) * (e->wpc64 + 1) * sizeof(int));
     }
 #undef ALLOC
@@ -388,6 +394,7 @@ extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k
         e->histlen = hl;
     }
     HIPCHK(hipMemsetAsync(e->hist, 0, (size_t)e->histlen * sizeof(unsigned long long), e->stream));
+    HIPCHK(hipMemsetAsync(e->hist_rep, 0, (size_t)HIST_REP * HIST_LBINS * sizeof(unsigned long long), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     e->yz_bytes_host = 0; e->yz_upper = 0; e->used_n = 0;
     e->ev_used = 0; e->launches = 0; e->sites_done = 0;
@@ -418,7 +425,15 @@ static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int
     static const int sweep_it = getenv("PBWTAMD_SWEEP_ITERS") ? atoi(getenv("PBWTAMD_SWEEP_ITERS")) : 0;
     g.nvb = tiles;
     const int iters = sweep_it > 0 ? sweep_it : (tiles >= 64 ? 4 : 1);
-    if (opts & PBWTAMD_OPT_WITHIN_HIST) {
+    static const bool old_sweep = getenv("PBWTAMD_OLD_SWEEP") != nullptr;   // the walking form of the histogram sweep (A/B runs)
+    if ((opts & PBWTAMD_OPT_WITHIN_HIST) && !old_sweep) {  // streaming form: a wave per 256 positions
+        const int ngroups = (e->M / 256 + 1 + WAVES - 1) / WAVES;    // 1024-position groups (a wave per 256 positions)
+        g.hist_rep = e->hist_rep; g.iters = ngroups >= 64 ? 8 : (ngroups >= 8 ? 2 : 1);
+        dim3 gs((ngroups + g.iters - 1) / g.iters, nsites);
+        if (packed) hipLaunchKernelGGL((sweep_hist_kernel<true>), gs, dim3(BLOCK), 0, st, g);
+        else hipLaunchKernelGGL((sweep_hist_kernel<false>), gs, dim3(BLOCK), 0, st, g);
+        HIPCHK(hipGetLastError());
+    } else if (opts & PBWTAMD_OPT_WITHIN_HIST) {
         dim3 gh((tiles + iters - 1) / iters, nsites);
 #define SWEEP_HIST(P, I) hipLaunchKernelGGL((sweep_within_kernel<2, P, I>), gh, dim3(BLOCK), 0, st, g)
         if (packed) { if (iters == 8) SWEEP_HIST(true, 8); else if (iters == 4) SWEEP_HIST(true, 4); else if (iters == 2) SWEEP_HIST(true, 2); else { gh.x = tiles; SWEEP_HIST(true, 1); } }
@@ -524,11 +539,23 @@ __global__ void pack3_offsets_kernel(unsigned long long *colBytes, size_t n, con
     if (i == 0) { if (b + *batchTotal > cap) atomicExch(err, 4); }
     (void)acc;
 }
+// pack3v2_kernel<MODE, NT, IT>: NT/64 waves of 64*IT words each cover the column
+template <int MODE>
+static void launch_pack3v2(hipStream_t st, int nsites, const unsigned long long *ycols, int wpc64, int M, unsigned long long *colBytes, uint8_t *out) {
+    const int nw = (M + 63) / 64;
+#define P3(NT, IT) hipLaunchKernelGGL((pack3v2_kernel<MODE, NT, IT>), dim3(nsites), dim3(NT), 0, st, ycols, wpc64, M, colBytes, out)
+    if (nw <= 256 * 2) P3(256, 2); else if (nw <= 256 * 8) P3(256, 8); else if (nw <= 1024 * 4) P3(1024, 4);
+    else if (nw <= 1024 * 16) P3(1024, 16); else P3(1024, 64);
+#undef P3
+}
+
 static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites, bool have_ycols) {
     dim3 g1(std::min(64, (e->wpc64 + WAVES - 1) / WAVES), nsites);
     if (!have_ycols) hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, st, A, e->strideA, e->M, e->ycols, e->wpc64);   // else: emitted by the maxWithin sweep
     const bool wide = e->wpc64 > 2048;                      // > 131072 haplotypes: 1024 threads per column
-    if (wide) hipLaunchKernelGGL((pack3_kernel<0, 1024>), dim3(nsites), dim3(1024), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
+    static const bool old_pack3 = getenv("PBWTAMD_OLD_PACK3") != nullptr;   // the chunk-loop encoder (A/B runs)
+    if (!old_pack3) launch_pack3v2<0>(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
+    else if (wide) hipLaunchKernelGGL((pack3_kernel<0, 1024>), dim3(nsites), dim3(1024), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
     else hipLaunchKernelGGL((pack3_kernel<0>), dim3(nsites), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
     // exclusive offsets inside the batch; batch total -> scal[2]
     hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, e->colBytes, (size_t)nsites, e->scal + 2, 0ULL);
@@ -553,7 +580,8 @@ static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites
     }
     hipLaunchKernelGGL(pack3_offsets_kernel, dim3((nsites + 255) / 256), dim3(256), 0, st, e->colBytes, (size_t)nsites, (const unsigned long long *)(e->scal + 1),
                        e->scal + 2, e->scal + 1, (unsigned long long)e->yzCap, e->ctl + 2);
-    if (wide) hipLaunchKernelGGL((pack3_kernel<1, 1024>), dim3(nsites), dim3(1024), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
+    if (!old_pack3) launch_pack3v2<1>(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
+    else if (wide) hipLaunchKernelGGL((pack3_kernel<1, 1024>), dim3(nsites), dim3(1024), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
     else hipLaunchKernelGGL((pack3_kernel<1>), dim3(nsites), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
     hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->scal + 1, (const unsigned long long *)(e->scal + 2), (unsigned long long)e->yzCap, e->ctl + 2);
     HIPCHK(hipGetLastError());
@@ -621,9 +649,10 @@ static int flush_pending(pbwtamd_engine *e) {
         f.pack_y = packed ? 1 : 0;
         dim3 grid(e->Wt, p.nb / 8);
         const size_t dyn = 0;
-        if (e->skEPT == 1) hipLaunchKernelGGL((skel_fill_kernel<1>), grid, dim3(BLOCK), dyn, e->s2, f);
-        else if (e->skEPT == 2) hipLaunchKernelGGL((skel_fill_kernel<2>), grid, dim3(BLOCK), dyn, e->s2, f);
-        else hipLaunchKernelGGL((skel_fill_kernel<4>), grid, dim3(BLOCK), dyn, e->s2, f);
+#define FILL(EP) do { if (packed) hipLaunchKernelGGL((skel_fill_kernel<EP, true>), grid, dim3(BLOCK), dyn, e->s2, f); \
+                      else hipLaunchKernelGGL((skel_fill_kernel<EP, false>), grid, dim3(BLOCK), dyn, e->s2, f); } while (0)
+        if (e->skEPT == 1) FILL(1); else if (e->skEPT == 2) FILL(2); else FILL(4);
+#undef FILL
         HIPCHK(hipGetLastError());
     }
     if (p.opts & PBWTAMD_OPT_CHECKSUM) {
@@ -660,6 +689,15 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
         else if (W <= 32) hipLaunchKernelGGL((skel_rank_kernel<EPT, 32>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         else if (W <= 64) hipLaunchKernelGGL((skel_rank_kernel<EPT, 64>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         else hipLaunchKernelGGL((skel_rank_kernel<EPT, SKN_MAXW>), dim3(W), dim3(BLOCK), 0, e->stream, g);
+        return;
+    }
+    static const bool k2_wide = !(getenv("PBWTAMD_K2_WIDE") && !atoi(getenv("PBWTAMD_K2_WIDE")));
+    if (W > 512 && W <= 64 * 32 && k2_wide) {              // two-level scan in one launch: <= 64 co-resident workgroups of 32 tiles
+        Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = W; kw.agg = e->k2agg; kw.counter = e->k2cnt;
+        const int nwg = (W + 31) / 32;
+        e->k2epoch += (unsigned)nwg; kw.target = e->k2epoch;
+        hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, e->stream, kw);
+        hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         return;
     }
     Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = W;
@@ -901,6 +939,9 @@ extern "C" int pbwtamd_get_hist(pbwtamd_engine *e, int64_t *hist, int histlen) {
     CHK(flush_pending(e));
     const int n = std::min(histlen, e->histlen);
     memset(hist, 0, sizeof(int64_t) * (size_t)histlen);
+    HIPCHK(hipStreamSynchronize(e->stream));               // pass_end's k == N sweep may have run on either stream
+    hipLaunchKernelGGL(hist_fold_kernel, dim3((HIST_LBINS + 255) / 256), dim3(256), 0, e->s2, e->hist, e->hist_rep, e->histlen);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(hist, e->hist, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, e->s2));
     HIPCHK(hipStreamSynchronize(e->s2));
     return 0;
@@ -1271,14 +1312,14 @@ extern "C" int pbwtamd_pack3(pbwtamd_engine *e, const uint32_t *sorted_bitcols, 
     for (int done = 0; done < N; done += e->B) {
         const int nb = std::min(e->B, N - done);
         HIPCHK(hipMemcpyAsync(e->ycols, sorted_bitcols + (size_t)done * wpc, (size_t)nb * wpc * 4, hipMemcpyHostToDevice, e->stream));
-        hipLaunchKernelGGL((pack3_kernel<0>), dim3(nb), dim3(BLOCK), 0, e->stream, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
+        launch_pack3v2<0>(e->stream, nb, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
         hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, e->stream, e->colBytes, (size_t)nb, e->scal + 2, 0ULL);
         HIPCHK(hipGetLastError());
         unsigned long long tot = 0;
         HIPCHK(hipMemcpyAsync(&tot, e->scal + 2, sizeof tot, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         CHK(ensure_yz(e, e->stream, (size_t)tot + 16));
-        hipLaunchKernelGGL((pack3_kernel<1>), dim3(nb), dim3(BLOCK), 0, e->stream, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
+        launch_pack3v2<1>(e->stream, nb, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
         HIPCHK(hipGetLastError());
         const size_t old = all.size();
         all.resize(old + tot);

@@ -883,6 +883,55 @@ __global__ __launch_bounds__(KPW * 64) void skel_k2_kernel(Sk2Args g) {
     }
 }
 
+// SCAN for wide panels (more than 512 tiles): the per-key scan over the tiles in two levels inside ONE launch.
+// skel_k2_kernel reads the row-major table in 16-byte pieces of 2 KB rows (a quarter of every 64-byte sector is used) and
+// walks 32 tiles per lane serially: 13.9 us at M = 1 M (1954 tiles).  Here a workgroup owns TPW consecutive TILES and all
+// 256 keys (thread = key): whole rows, every load in flight at once; it publishes its (count, carry) aggregate per key,
+// arrives on a counter, and once all workgroups have arrived folds the aggregates of the workgroups before it.
+// All of them are resident at once (W / TPW <= 64 workgroups).  Cross-workgroup visibility: 8-byte agent-scope relaxed
+// atomics on both sides (write-through stores, L1-bypassing loads), `s_waitcnt vmcnt(0)` before the arrival — the
+// granule form of MI355X_MICROARCH.md "Workgroup dispatch ... inter-workgroup visibility".
+struct Sk2WArgs { const int2 *tbl; int2 *scan; int *total; int W; unsigned long long *agg; unsigned *counter; unsigned target; };
+template <int TPW>
+__global__ __launch_bounds__(SKK) void skel_k2_wide_kernel(Sk2WArgs g) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    const int t = threadIdx.x, j = blockIdx.x, w0 = j * TPW;
+    int c[TPW], tl[TPW];
+#pragma unroll
+    for (int x = 0; x < TPW; ++x) {
+        const int2 v = (w0 + x < g.W) ? g.tbl[(size_t)(w0 + x) * SKK + t] : make_int2(0, 0);
+        c[x] = v.x; tl[x] = v.y;
+    }
+    int ac = 0, at = 0;                                      // this workgroup's aggregate for key t
+#pragma unroll
+    for (int x = 0; x < TPW; ++x) { at = c[x] ? tl[x] : max(at, tl[x]); ac += c[x]; }
+    __hip_atomic_store(g.agg + (size_t)j * SKK + t, ((unsigned long long)(unsigned)at << 32) | (unsigned)ac, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        __hip_atomic_fetch_add(g.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((int)(__hip_atomic_load(g.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.target) < 0) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    int ec = 0, et = 0;                                      // prefix over the workgroups before this one: every load in flight at once
+    unsigned long long pv[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) pv[i] = (i < j) ? __hip_atomic_load(g.agg + (size_t)i * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32);     // beyond j: (0, 0), the identity
+        et = vc ? vt : max(et, vt); ec += vc;
+    }
+#pragma unroll
+    for (int x = 0; x < TPW; ++x) {
+        if (w0 + x < g.W) g.scan[(size_t)(w0 + x) * SKK + t] = make_int2(ec, ec ? et : -1);
+        et = c[x] ? tl[x] : max(et, tl[x]); ec += c[x];
+    }
+    if (j == (int)gridDim.x - 1) g.total[t] = ec;
+}
+
 // RANK (K3): per tile — stable rank of every position among its key (ballot refinement inside
 // 64-position chunks + a per-key scan over the chunks), previous same-key position, range max of d_k
 // through a sparse table in LDS, scatter of (a | next allele tag, d', next key).
@@ -1066,7 +1115,8 @@ struct SkFillArgs {
     int pack_y;                                             // write d | y << 31 only (no a): for consumers that need (d, y) but not the haplotype ids
 };
 
-template <int EPT>
+// PACKY: the consumers need (d, y) of every site but not the haplotype ids — a[] is neither read nor written
+template <int EPT, bool PACKY>
 __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     constexpr int T = BLOCK * EPT, NC = EPT * WAVES;
     constexpr int NL = (EPT == 4) ? 10 : (EPT == 2) ? 9 : 8;
@@ -1086,10 +1136,10 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     for (int r = 0; r < EPT; ++r) {
         const int l = r * BLOCK + t, i = S + l;
         const bool valid = i < g.M;
-        av[r] = a_in[i] & AMASK; key[r] = valid ? (int)keys[i] : -1;
+        av[r] = PACKY ? 0 : (a_in[i] & AMASK); key[r] = valid ? (int)keys[i] : -1;
         const int dv = valid ? d_in[i] : 0;
         s_tbl[0][l] = dv;
-        if (g.pack_y && valid) d_in[i] = dv | (int)(((unsigned)key[r] & 1u) << 31);   // the skeleton slot itself, in the packed form of the other seven
+        if (PACKY && valid) d_in[i] = dv | (int)(((unsigned)key[r] & 1u) << 31);   // the skeleton slot itself, in the packed form of the other seven
     }
     { const int2 v = sv[(size_t)w * SKK + t]; s_bH[SKK + t] = v.x; s_cH[SKK + t] = v.y; s_tH[SKK + t] = reinterpret_cast<const int *>(sv + (size_t)g.W * SKK)[t]; }
 #pragma unroll
@@ -1195,7 +1245,7 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
 #endif
             const int yb = (int)(((unsigned)(key[r] >> j) & 1u) << 31);
             // streamed once by the consumers: non-temporal, so the chain's working set stays in L2 (measured +1 %)
-            if (g.pack_y) __builtin_nontemporal_store(dd | yb, d_out + pos);
+            if (PACKY) __builtin_nontemporal_store(dd | yb, d_out + pos);
             else { __builtin_nontemporal_store(av[r] | yb, a_out + pos); __builtin_nontemporal_store(dd, d_out + pos); }
         }
         if (w == g.W - 1 && t == 0) d_out[g.M] = k + j + 1;
@@ -1574,7 +1624,20 @@ struct SweepArgs {
     int dbg;                                // measurement builds only (results WRONG): 1 = no histogram atomics, 2 = no walks either
 #endif
     int nvb;                                // 256-position blocks per site
+    unsigned long long *hist_rep;           // streaming form: HIST_REP copies of the first HIST_LBINS bins, folded into hist by hist_fold_kernel
+    int iters;                              // streaming form: 1024-position groups per workgroup
 };
+// Same-address global atomics serialise chip-wide (~12 ns each): a panel whose matches all have similar lengths (iid: every
+// report lands in ~30 bins) would spend seconds there.  So the short lengths are counted in LDS per workgroup first and
+// flushed to one of HIST_REP replicas of the low bins; long lengths (spread over many bins) go straight to hist.
+constexpr int HIST_LBINS = 2048, HIST_REP = 32;
+__global__ void hist_fold_kernel(unsigned long long *hist, unsigned long long *rep, int histlen) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= HIST_LBINS) return;
+    unsigned long long s = 0;
+    for (int r = 0; r < HIST_REP; ++r) { s += rep[(size_t)r * HIST_LBINS + b]; rep[(size_t)r * HIST_LBINS + b] = 0; }
+    if (s && b < histlen) hist[b] += s;
+}
 
 // wave-cooperative walk: from position `from` in direction `dir` (-1 up, +1 down) find the first
 // position p with d[p + off] > thr (the block boundary; `stop` = p) or, unless `fin`, with allele
@@ -1734,6 +1797,148 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
     }
 }
 
+// as coop_walk, 256 positions per step (four independent loads per lane in flight): the long walks of the histogram
+// sweep — a rare allele beside a block of thousands of identical haplotypes carrying the other one — are chains of
+// dependent round trips, so fewer, wider steps.  Only the decision is returned (the histogram needs no stop index).
+template <bool PACKED>
+__device__ __forceinline__ bool coop_walk4(const int *a, const int *d, int from, int dir, int thr, unsigned yi, int M) {
+    const int lane = lane_id();
+    for (;; from += dir * 256) {
+        int wd[4], wy[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = from + dir * (lane + 64 * j);
+            const int di = (dir < 0) ? p + 1 : p;           // the divergence tested for candidate p (see coop_walk)
+            const bool inb = (di >= 0) && (di <= M);
+            wd[j] = inb ? __builtin_nontemporal_load(d + di) : 0x7fffffff;
+            wy[j] = (p >= 0 && p < M) ? (PACKED ? ((dir < 0) ? __builtin_nontemporal_load(d + p) : wd[j]) : __builtin_nontemporal_load(a + p)) : (int)((yi ^ 1u) << 31);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool bound = (wd[j] & 0x7fffffff) > thr;
+            const bool same = !bound && (((unsigned)wy[j] >> 31) == yi);
+            const unsigned long long mb = __ballot(bound), ms = __ballot(same), any = mb | ms;
+            if (any) return (ms >> (__ffsll((long long)any) - 1)) & 1ULL;      // the first event in walking order decides: same allele = skip
+        }
+    }
+}
+
+// matchMaximalWithin, histogram sink (pbwtMatch.c:115-131 with matchLengthHist set): the streaming form.  A wave owns 256
+// consecutive positions as four 64-position chunks (one coalesced load each, neighbours by DPP), and almost every position
+// is decided from its own word and its two neighbours: with b = y[i],
+//     d[i] <= d[i+1] and y[i-1] == b   -> the upward scan meets b at its first step: not reported
+//     d[i] >= d[i+1] and y[i+1] == b   -> the downward scan does: not reported
+// What is left are run boundaries of the allele column whose scan has to go on (pbwtMatch.c:124-129: until a divergence
+// above the threshold ends the block, or the same allele turns up).  Those few are resolved wave-cooperatively: first
+// inside the wave's own 256 words with ballots (no memory access), then 256 positions per step through memory.
+// Emits the site's sorted bit column as a by-product (one ballot per chunk) when ycols is set.
+template <bool PACKED>
+__global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
+    constexpr int CH = 4;
+    __shared__ unsigned s_hist[HIST_LBINS];
+    const int site = blockIdx.y, k = g.kbase + site;
+    const bool fin = (site == g.final_site);
+    const int *a = g.A + (size_t)site * g.strideA;
+    const int *d = g.D + (size_t)site * g.strideD;
+    const int M = g.M, lane = lane_id();
+    for (int x = threadIdx.x; x < HIST_LBINS; x += BLOCK) s_hist[x] = 0;
+    __syncthreads();
+    for (int it = 0; it < g.iters; ++it) {
+    const int wv = (blockIdx.x * g.iters + it) * WAVES + wave_id();
+    const int wbase = wv * (64 * CH);
+    if (wbase > M) break;
+    auto WD = [&](int x) -> int { return PACKED ? __builtin_nontemporal_load(d + x) : (__builtin_nontemporal_load(d + x) | ((x < M) ? (__builtin_nontemporal_load(a + x) & (int)0x80000000) : 0)); };
+    int w[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) { const int p = wbase + 64 * c + lane; w[c] = (p <= M) ? WD(p) : 0; }   // index M: the sentinel d[M], as a right neighbour
+    const int hl = (lane == 0 && wbase > 0) ? WD(wbase - 1) : 0;
+    const int hr = (lane == 63 && wbase + 64 * CH <= M) ? WD(wbase + 64 * CH) : 0;
+    int dI[CH], dN[CH]; unsigned yI[CH];
+    bool pendUp[CH], pendDn[CH], rep[CH];
+    unsigned long long mPendUp = 0, mPendDn = 0;             // any pending lane in the wave (per chunk bit sets are re-balloted below)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int p = wbase + 64 * c + lane;
+        const int fillL = (c > 0) ? __builtin_amdgcn_readlane(w[c > 0 ? c - 1 : 0], 63) : __builtin_amdgcn_readfirstlane(hl);
+        const int fillR = (c < CH - 1) ? __builtin_amdgcn_readlane(w[c < CH - 1 ? c + 1 : c], 0) : __builtin_amdgcn_readlane(hr, 63);
+        const int wl = lane_shr1(w[c], fillL);
+        const int wr = __builtin_amdgcn_update_dpp(fillR, w[c], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        const bool valid = p < M;
+        dI[c] = w[c] & 0x7fffffff; yI[c] = (unsigned)w[c] >> 31; dN[c] = wr & 0x7fffffff;
+        const bool up = dI[c] <= dN[c], down = dI[c] >= dN[c];
+        const bool sameL = (p > 0) && (((unsigned)wl >> 31) == yI[c]), sameR = (p + 1 < M) && (((unsigned)wr >> 31) == yI[c]);
+        const bool skip = !fin && ((up && sameL) || (down && sameR));
+        rep[c] = valid && !skip;
+        pendUp[c] = rep[c] && !fin && up;                      // the scans that go beyond their first step
+        pendDn[c] = rep[c] && !fin && down;
+        if (g.ycols) {                                      // this site's sorted bit column (what pack3 encodes)
+            const unsigned long long mk = __ballot(valid && yI[c]);
+            const int wd = wv * CH + c;
+            if (lane == 0 && wd < g.wpc64) (g.ycols + (size_t)site * g.wpc64)[wd] = mk;
+        }
+        mPendUp |= __ballot(pendUp[c]); mPendDn |= __ballot(pendDn[c]);
+    }
+    if (mPendUp) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            for (unsigned long long pend = __ballot(pendUp[c]); pend; pend &= pend - 1) {
+                const int src = __ffsll((long long)pend) - 1;
+                const int thr = __builtin_amdgcn_readlane(dI[c], src);
+                const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)yI[c], src);
+                // candidates q < i, nearest first: the scan stops at q when d[q+1] > thr (tested first), skips i when y[q] == b
+                int decided = 0;                            // 1 = not reported (same allele met), 2 = the block ended first
+#pragma unroll
+                for (int cc = CH - 1; cc >= 0; --cc) {
+                    if (cc > c || decided) continue;
+                    const int q = wbase + 64 * cc + lane;
+                    unsigned long long ms = __ballot(dN[cc] > thr), my = __ballot(q < M && yI[cc] == b);
+                    if (cc == c) { const unsigned long long below = (src == 0) ? 0ULL : (~0ULL >> (64 - src)); ms &= below; my &= below; }
+                    const unsigned long long any = ms | my;
+                    if (any) decided = ((ms >> (63 - __clzll(any))) & 1ULL) ? 2 : 1;
+                }
+                if (!decided) decided = coop_walk4<PACKED>(a, d, wbase - 1, -1, thr, b, M) ? 1 : 2;
+                if (decided == 1 && lane == src) { rep[c] = false; pendDn[c] = false; }
+            }
+        }
+    }
+    if (mPendDn) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            for (unsigned long long pend = __ballot(pendDn[c]); pend; pend &= pend - 1) {
+                const int src = __ffsll((long long)pend) - 1;
+                const int thr = __builtin_amdgcn_readlane(dN[c], src);
+                const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)yI[c], src);
+                // candidates q > i, nearest first: the scan stops at q when d[q] > thr (d[M] is the sentinel), skips i when y[q] == b
+                int decided = 0;
+#pragma unroll
+                for (int cc = 0; cc < CH; ++cc) {
+                    if (cc < c || decided) continue;
+                    const int q = wbase + 64 * cc + lane;
+                    unsigned long long ms = __ballot(q <= M && dI[cc] > thr), my = __ballot(q < M && yI[cc] == b);
+                    if (cc == c) { const unsigned long long above = (src == 63) ? 0ULL : (~0ULL << (src + 1)); ms &= above; my &= above; }
+                    const unsigned long long any = ms | my;
+                    if (any) decided = ((ms >> (__ffsll((long long)any) - 1)) & 1ULL) ? 2 : 1;
+                }
+                if (!decided) decided = coop_walk4<PACKED>(a, d, wbase + 64 * CH, +1, thr, b, M) ? 1 : 2;
+                if (decided == 1 && lane == src) rep[c] = false;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        if (rep[c]) {
+            const int len = k - min(dI[c], dN[c]);          // (d[i] < d[i+1]) ? k - d[i] : k - d[i+1]   (pbwtMatch.c:131)
+            if (len < 0 || len >= g.histlen) atomicExch(g.err, 1);
+            else if (len < HIST_LBINS) atomicAdd(&s_hist[len], 1u);
+            else atomicAdd(g.hist + len, 1ULL);
+        }
+    }
+    }
+    __syncthreads();
+    unsigned long long *rep = g.hist_rep + (size_t)((blockIdx.x + 7 * blockIdx.y) % HIST_REP) * HIST_LBINS;
+    for (int x = threadIdx.x; x < HIST_LBINS; x += BLOCK) { const unsigned v = s_hist[x]; if (v) atomicAdd(rep + x, (unsigned long long)v); }
+}
+
 // matchLongWithin2 (pbwtMatch.c:85-113, -longWithin L) over ring slots: positions are cut into
 // blocks wherever d[i] > k-L; every pair ia < ib inside a CLOSED block with different alleles is
 // reported with start = max d over (ia, ib].  One thread per ia walks to the end of its block.
@@ -1866,7 +2071,8 @@ __global__ __launch_bounds__(BLOCK) void tags_to_bits_kernel(const int *A, size_
 // owns 64-position words; a run is emitted by the word in which it ENDS.
 // bytes for a run of length n (pack3Add, pbwtCore.c:240-252)
 __device__ __forceinline__ int p3_nbytes(int n) {
-    int c = n / 63488; n -= c * 63488;
+    int c = 0;
+    if (n >= 63488) { c = n / 63488; n -= c * 63488; }       // rare: keep the division off the common path
     if (n >= 2048) { ++c; n &= 0x7ff; }
     if (n >= 64) { ++c; n &= 0x3f; }
     if (n) ++c;
@@ -1955,6 +2161,101 @@ __global__ __launch_bounds__(NT) void pack3_kernel(const unsigned long long *yco
         __syncthreads();
     }
     if (MODE == 0 && threadIdx.x == 0) colBytes[col] = (unsigned long long)s_carry_bytes;
+}
+
+// pack3 encode, wave-regional: a wave owns a contiguous region of 64*IT words of the column and walks it 64 words
+// (= one coalesced 512-byte load) at a time; all IT loads are issued up front.  Inside the wave the start of the run open
+// at a word is an exclusive max-scan over the lanes (DPP) carried across the iterations — no barrier; across the waves of
+// the column ONE LDS exchange of (first / last transition, bytes) fixes the run open at each region's start and the byte
+// bases.  A run is emitted by the word in which it ends; its value is the last bit of the previous word and alternates from
+// there.  (pack3_kernel above does the same with a barrier chain per 1024-word chunk: 16 chunks x 5 barriers at M = 1 M.)
+template <int MODE, int NT, int IT>
+__global__ __launch_bounds__(NT) void pack3v2_kernel(const unsigned long long *ycols, int wpc64, int M,
+                                                       unsigned long long *colBytes, uint8_t *out) {
+    constexpr int NWV = NT / 64;
+    __shared__ int s_last[NWV], s_first[NWV], s_inner[NWV];
+    const int col = blockIdx.x, lane = lane_id(), wv = wave_id();
+    const unsigned long long *y = ycols + (size_t)col * wpc64;
+    const int nw = (M + 63) / 64, base = wv * 64 * IT;
+    unsigned long long cur[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) { const int wd = base + i * 64 + lane; cur[i] = (wd < nw) ? y[wd] : 0ULL; }
+    const int hi0 = (base > 0 && base <= nw) ? (int)(y[base - 1] >> 32) : 0;      // the word before the region (its last bit matters)
+    // transitions of word i of this lane: bit p set = position 64 wd + p starts a new run.  prevHi carries the previous
+    // iteration's last word across the loop.
+    auto transitions = [&](int i, int &prevHi) -> unsigned long long {
+        const int wd = base + i * 64 + lane;
+        const int hi = (int)(cur[i] >> 32);
+        const int ph = lane_shr1(hi, prevHi);
+        prevHi = __builtin_amdgcn_readlane(hi, 63);
+        unsigned long long tr = cur[i] ^ ((cur[i] << 1) | (unsigned long long)((unsigned)ph >> 31));
+        if (wd == 0) tr &= ~1ULL;                            // position 0 opens the first run, closes nothing
+        const int nbits = M - wd * 64;
+        if (nbits <= 0) tr = 0; else if (nbits < 64) tr &= (1ULL << nbits) - 1ULL;
+        return tr;
+    };
+    // ---- pass A: first / last transition of the region, bytes of the runs that start at a transition of the region and end in it
+    int carryT = -1, firstT = -1, inner = 0, prevHi = hi0;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int wd = base + i * 64 + lane;
+        unsigned long long tr = transitions(i, prevHi);
+        const int tl = tr ? wd * 64 + 63 - __clzll(tr) : -1, tf = tr ? wd * 64 + __ffsll((long long)tr) - 1 : -1;
+        const int inc = wave_iscan_max(tl + 1);             // 1 + last transition up to and including this lane (0 = none)
+        int st = max(lane_shr1(inc, 0) - 1, carryT);        // start of the run open at this word; -1 = it began before the region
+        int bytes = 0;
+        for (; tr; tr &= tr - 1) { const int pz = wd * 64 + __ffsll((long long)tr) - 1; if (st >= 0) bytes += p3_nbytes(pz - st); st = pz; }
+        inner += wave_sum(bytes);
+        const unsigned long long has = __ballot(tf >= 0);
+        if (has) {
+            if (firstT < 0) firstT = __builtin_amdgcn_readlane(tf, __ffsll((long long)has) - 1);
+            carryT = __builtin_amdgcn_readlane(inc, 63) - 1;
+        }
+    }
+    if (lane == 0) { s_last[wv] = carryT; s_first[wv] = firstT; s_inner[wv] = inner; }
+    __syncthreads();
+    // ---- the waves before this one: run open at the region's start, byte base
+    int openW = 0, baseB = 0, total = 0;
+    {
+        int open = 0;                                        // start of the run open at wave q's region (position 0 opens the first run)
+#pragma unroll
+        for (int q = 0; q < NWV; ++q) {
+            const int lq = s_last[q], fq = s_first[q];
+            const bool ownsLast = (q * 64 * IT < nw) && ((q + 1) * 64 * IT >= nw);
+            const int wb = (fq >= 0 ? p3_nbytes(fq - open) : 0) + s_inner[q] + (ownsLast ? p3_nbytes(M - (lq >= 0 ? lq : open)) : 0);
+            if (q == wv) { openW = open; baseB = total; }
+            total += wb;
+            if (lq >= 0) open = lq;
+        }
+    }
+    if (MODE == 0) { if (threadIdx.x == 0) colBytes[col] = (unsigned long long)total; return; }
+    // ---- pass B: emit.  The run open at the region's start now has a known start (openW).
+    uint8_t *obase = out + colBytes[col] + baseB;
+    carryT = openW; prevHi = hi0;
+    int done = 0;                                            // bytes emitted so far by this wave
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int wd = base + i * 64 + lane;
+        const int hiPrevIter = prevHi;                       // transitions() advances prevHi: the value of the run open at this word is needed too
+        unsigned long long tr = transitions(i, prevHi);
+        const int tl = tr ? wd * 64 + 63 - __clzll(tr) : -1;
+        const int inc = wave_iscan_max(tl + 1);
+        int st = max(lane_shr1(inc, 0) - 1, carryT);
+        const bool lastWord = (wd == nw - 1);
+        int bytes = 0;
+        { int s2 = st; for (unsigned long long t2 = tr; t2; t2 &= t2 - 1) { const int pz = wd * 64 + __ffsll((long long)t2) - 1; bytes += p3_nbytes(pz - s2); s2 = pz; } if (lastWord) bytes += p3_nbytes(M - s2); }
+        const int incB = wave_iscan_sum(bytes);
+        const int ph = lane_shr1((int)(cur[i] >> 32), hiPrevIter);   // cross-lane: outside the divergent branch below
+        if (bytes) {
+            uint8_t *o = obase + done + incB - bytes;
+            unsigned v = (wd == 0) ? (unsigned)(cur[i] & 1ULL) : ((unsigned)ph >> 31);   // value of the run open at this word = last bit before it
+            for (; tr; tr &= tr - 1) { const int pz = wd * 64 + __ffsll((long long)tr) - 1; o = p3_emit(o, v, pz - st); st = pz; v ^= 1u; }
+            if (lastWord) p3_emit(o, v, M - st);
+        }
+        done += __builtin_amdgcn_readlane(incB, 63);
+        const int wl = __builtin_amdgcn_readlane(inc, 63) - 1;
+        if (wl >= 0) carryT = wl;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -119,3 +119,24 @@ def test_wider_than_2_20_haplotypes(gpu_lib, orc):
     sw = eng.sweep_AD(o["yz"], N)
     s = orc.sweep_AD(o["yz"], M, N)
     assert np.array_equal(sw["csum_a"], s["csum_a"]) and np.array_equal(sw["csum_d"], s["csum_d"])
+
+
+def test_bench_north_star_width_path(gpu_lib, orc):
+    """bench.py's `north_star_width` measurement (1 M haplotypes, the bench option set, 8192-site advances) run on a
+    short panel: the histogram total it reports and the bytes it packs are the oracle's — the published 1 M-wide number
+    rests on verified output"""
+    import sys
+    import torch
+    sys.path.insert(0, __import__("conftest").ROOT)
+    import bench
+    amd = gpu_lib
+    sites, batch = 1024, 512
+    opts = amd.OPT_WITH_D | amd.OPT_WITHIN_HIST | amd.OPT_PACK3
+    r = bench.north_star_width(torch, amd, torch.device("cuda", 0), opts, kind=0, sites=sites, batch=batch, step=768, want_hist=True)
+    N = sites + batch
+    bits = r["panel"].cpu().numpy().view(np.uint32)
+    o = orc.build_bitcols(bits, 1000000, with_d=True, want_csum=False)
+    want = orc.max_within_hist(o["yz"], 1000000, N)[: N + 1]
+    assert np.array_equal(r["hist"], want) and r["within_reports_hist_total"] == int(want.sum())
+    assert np.array_equal(r["packed"], o["yz"])
+    assert r["roofline"]["sites_per_launch"] > 2.5 and 0 < r["roofline"]["frac"] < 1
