@@ -94,6 +94,11 @@ int pbwtamd_cursor_at(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, c
  * (0/1) of haplotype h at site k, recovered by a forward sweep of the packed panel */
 int pbwtamd_haplotypes(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart, uint8_t *out);
 
+/* the same, streamed: sink(k0, nsites, rows, ctx) is called on the calling thread with the alleles of sites k0 .. k0+nsites-1
+ * (nsites rows of M bytes), batch after batch in site order — pbwtWriteHaplotypes without an N x M matrix on the host */
+int pbwtamd_haplotypes_stream(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart,
+                              void (*sink)(int k0, int nsites, const uint8_t *rows, void *ctx), void *ctx);
+
 /* matchMaximalWithin (pbwtMatch.c:115-142): all set-maximal matches within the panel.
  * Exactly one of the three sinks is used:
  *   report   : called synchronously on the calling thread, in the reference's order (k, then i,
@@ -141,6 +146,18 @@ int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, int64_t pnz
                                int Mq, const uint8_t *qz, int64_t qnz, const int32_t *qStart, int nSparse,
                                pbwtamd_report5_fn report, pbwtamd_match5 **recs_out, int64_t *nrecs_out,
                                int64_t *n_nomatch, int64_t *tot);
+
+/* Panel transforms — the "x[a[j]] = y[j]; y'[j] = x[a'[j]]; pbwtCursorWriteForwards" loops of pbwtBuildReverse
+ * (pbwtCore.c:151-191), pbwtSubSample (pbwtSample.c:59-93), pbwtSubRange (pbwtCore.c:111-148), pbwtSelectSites /
+ * pbwtRemoveSites (pbwtCore.c:623-732) — as one device pass: decode, regather, rebuild.  The new panel has
+ *   n_out sites : output site j = input site site_order[j]   (NULL = all N sites in order)
+ *   M_out haps  : output haplotype h = input haplotype hap_select[h]   (NULL = all M in order)
+ *   start order aStart_out (NULL = identity);  outputs: packed columns (malloc()ed), final order aFend_out[M_out],
+ *   and optionally the INPUT panel's final order aFend_fwd[M] (what pbwtBuildReverse starts the reverse cursor from).
+ * BuildReverse: site_order = N-1..0, aStart_out = aFend_fwd of a first call (or the panel's stored aFend). */
+int pbwtamd_regather(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart,
+                     const int32_t *site_order, int n_out, const int32_t *hap_select, int M_out, const int32_t *aStart_out,
+                     uint8_t **yz_out, int64_t *nz_out, int32_t *aFend_out, int32_t *aFend_fwd);
 
 /* pack3 codec on the device (pbwtCore.c:254-305): N columns <-> packed bytes.
  * unpack returns sorted-order bit columns (N*wpc words, caller buffer). */

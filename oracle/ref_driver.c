@@ -321,6 +321,32 @@ int ref_build_reverse(const char *pbwt_in, const char *rev_out)
     return 0;
 }
 
+/* panel transforms of the reference (pbwtSubRange pbwtCore.c:111, pbwtSelectSites :682, pbwtRemoveSites :686, pbwtSubSample
+ * pbwtSample.c:59) on a .pbwt + .sites pair, written back as files: op 0 subrange [i0, i1), 1 selectSites(list file),
+ * 2 removeSites(list file), 3 subsample with the haplotype list select[0..nsel) */
+int ref_transform(const char *pbwt_in, const char *sites_in, int op, int i0, int i1, const char *list_file,
+                  const int32_t *select, int nsel, const char *pbwt_out, const char *sites_out)
+{
+    ref_init();
+    FILE *fp = fopen(pbwt_in, "r"); if (!fp) return -1;
+    PBWT *p = pbwtRead(fp); fclose(fp);
+    if (sites_in) { fp = fopen(sites_in, "r"); if (!fp) return -2; pbwtReadSites(p, fp); fclose(fp); }
+    if (op == 0) p = pbwtSubRange(p, i0, i1);
+    else if (op == 1 || op == 2) {
+        fp = fopen(list_file, "r"); if (!fp) return -3;
+        char *chr = 0; Array sites = pbwtReadSitesFile(fp, &chr); fclose(fp);
+        p = (op == 1) ? pbwtSelectSites(p, sites, FALSE) : pbwtRemoveSites(p, sites, FALSE);
+    } else {
+        Array sel = arrayCreate(nsel, int);
+        for (int i = 0; i < nsel; ++i) array(sel, i, int) = select[i];
+        p = pbwtSubSample(p, sel);
+    }
+    FILE *fo = fopen(pbwt_out, "w"); if (!fo) return -4;
+    pbwtWrite(p, fo); fclose(fo);
+    if (sites_out && p->sites) { FILE *fs = fopen(sites_out, "w"); if (!fs) return -5; pbwtWriteSites(p, fs); fclose(fs); }
+    return 0;
+}
+
 size_t ref_pack3(uint8_t *y_with_sentinel, int M, uint8_t *out) { ref_init(); return pack3(y_with_sentinel, M, out); }
 size_t ref_unpack3(uint8_t *z, int M, uint8_t *y, int *n0) { ref_init(); return unpack3(z, M, y, n0); }
 void ref_free(void *p) { free(p); }

@@ -262,6 +262,22 @@ class Engine:
         self._L.pbwtamd_free(rp)
         return out
 
+    def regather(self, yz, N, site_order=None, hap_select=None, aFstart=None, aStart_out=None, want_fwd_end=False):
+        """panel transform on the device: returns dict(yz, aFend[, aFend_fwd]) of the new panel"""
+        yz = np.ascontiguousarray(yz, dtype=np.uint8)
+        so, hs, aF, aS = _i32(site_order), _i32(hap_select), _i32(aFstart), _i32(aStart_out)
+        n_out = N if so is None else so.size
+        M_out = self.M if hs is None else hs.size
+        aFend = np.zeros(M_out, np.int32)
+        fwd = np.zeros(self.M, np.int32) if want_fwd_end else None
+        yzp = C.POINTER(C.c_uint8)(); nz = C.c_int64(0)
+        self._chk(self._L.pbwtamd_regather(self._h, _p(yz, C.c_uint8), C.c_int64(yz.size), C.c_int(N), _p(aF, C.c_int32),
+                                           _p(so, C.c_int32), C.c_int(n_out), _p(hs, C.c_int32), C.c_int(M_out), _p(aS, C.c_int32),
+                                           C.byref(yzp), C.byref(nz), _p(aFend, C.c_int32), _p(fwd, C.c_int32)))
+        out = np.ctypeslib.as_array(yzp, shape=(max(nz.value, 1),))[: nz.value].copy()
+        self._L.pbwtamd_free(yzp)
+        return dict(yz=out, aFend=aFend, aFend_fwd=fwd)
+
     def pack3(self, sorted_bitcols):
         sb = np.ascontiguousarray(sorted_bitcols, dtype=np.uint32)
         N, wpc = sb.shape

@@ -174,7 +174,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     if (const char *s = getenv("PBWTAMD_PAIR1024")) e->pair1024 = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_SKEL")) e->skel = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_SKN")) e->skn = atoi(s) != 0;
-    if (M > (1 << 20)) e->skel = false;                    // skeleton tables: <= 1024 tiles of 1024; fill: <= 4096 tile summaries per thread block
+    if (M > (1 << 21)) e->skel = false;                    // skeleton: <= 2048 tiles of 1024 positions (one lane / one workgroup slot per 32 tiles in the tile scans)
     int prLow = 0, prHigh = 0;
     (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);  // numerically: low >= high
     if (const char *s = getenv("PBWTAMD_NO_PRIO")) { if (atoi(s)) prLow = prHigh = 0; }
@@ -1284,6 +1284,99 @@ extern "C" int pbwtamd_haplotypes(pbwtamd_engine *e, const uint8_t *yz, int64_t 
     return pbwtamd_pass_end(e, PBWTAMD_OPT_SORTED);
 }
 
+// Panel transforms on the device: decode the packed panel with a forward sweep (original-order alleles of every batch of sites),
+// gather the selected haplotypes of the selected sites into the new panel's bit columns (kept in HBM), and run the build chain
+// over them.  One entry point covers pbwtBuildReverse (site_order = N-1 .. 0, start order = the forward panel's final order),
+// pbwtSubSample (hap_select), pbwtSubRange / pbwtSelectSites / pbwtRemoveSites (site_order = the kept sites, increasing).
+extern "C" int pbwtamd_regather(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart,
+                                const int32_t *site_order, int n_out, const int32_t *hap_select, int M_out, const int32_t *aStart_out,
+                                uint8_t **yz_out, int64_t *nz_out, int32_t *aFend_out, int32_t *aFend_fwd) {
+    HIPCHK(hipSetDevice(e->device));
+    const int M = e->M;
+    if (!hap_select) M_out = M;
+    if (!site_order) n_out = N;
+    if (M_out < 1 || n_out < 0) return fail("pbwtamd_regather: M_out %d, n_out %d", M_out, n_out);
+    std::vector<int> inv((size_t)N + 1, -1);                // input site -> output column
+    int last_needed = -1;
+    for (int j = 0; j < n_out; ++j) {
+        const int sIn = site_order ? site_order[j] : j;
+        if (sIn < 0 || sIn >= N) return fail("pbwtamd_regather: site_order[%d] = %d outside 0..%d", j, sIn, N - 1);
+        if (inv[(size_t)sIn] >= 0) return fail("pbwtamd_regather: input site %d selected twice", sIn);
+        inv[(size_t)sIn] = j; last_needed = std::max(last_needed, sIn);
+    }
+    if (hap_select) for (int h = 0; h < M_out; ++h) if (hap_select[h] < 0 || hap_select[h] >= M) return fail("pbwtamd_regather: hap_select[%d] = %d outside 0..%d", h, hap_select[h], M - 1);
+    const int wpc_out = wpc_for(M_out), wpc64_out = wpc_out / 2;
+    const int n_sweep = aFend_fwd ? N : last_needed + 1;     // the forward order at the end needs the whole sweep
+    DevBufs bufs;
+    Packed pk;
+    unsigned long long *cols_out; int *d_inv, *d_sel = nullptr; unsigned char *dout;
+    CHK(bufs.alloc(&cols_out, (size_t)std::max(n_out, 1) * wpc64_out + 2 * (size_t)wpc64_out));
+    CHK(bufs.alloc(&d_inv, (size_t)N + 1));
+    CHK(bufs.alloc(&dout, (size_t)e->B * M));
+    HIPCHK(hipMemcpyAsync(d_inv, inv.data(), sizeof(int) * ((size_t)N + 1), hipMemcpyHostToDevice, e->stream));
+    if (hap_select) { CHK(bufs.alloc(&d_sel, (size_t)M_out)); HIPCHK(hipMemcpyAsync(d_sel, hap_select, sizeof(int) * (size_t)M_out, hipMemcpyHostToDevice, e->stream)); }
+    HIPCHK(hipMemsetAsync(cols_out, 0, ((size_t)std::max(n_out, 1) * wpc64_out + 2 * (size_t)wpc64_out) * sizeof(unsigned long long), e->stream));
+    CHK(packed_upload(e, e->stream, M, yz, nz, N, pk));
+    // ---- phase A: forward sweep (A only), alleles of each batch back in original order, gathered into the new columns
+    CHK(pbwtamd_pass_begin(e, aFstart, 0, N));
+    for (int done = 0; done < n_sweep;) {
+        const int nb = std::min(e->B, n_sweep - done), navail = std::min(nb + 1, N - done);
+        CHK(packed_expand(e, e->stream, pk, M, done, navail, (unsigned long long *)e->cols_stage, e->wpc64));
+        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, PBWTAMD_OPT_SORTED | OPT_INTERNAL_KEEP_STATES));
+        CHK(pbwtamd_sync(e));                              // every state of the batch is in the ring (incl. the fill of the skeleton path)
+        const int *A = ringA(e, e->ring ^ 1);
+        dim3 gu(std::min(64, (M + BLOCK - 1) / BLOCK), nb);
+        hipLaunchKernelGGL(unsort_alleles_kernel, gu, dim3(BLOCK), 0, e->stream, A, e->strideA, M, dout);
+        dim3 gg(std::min(64, (wpc64_out + WAVES - 1) / WAVES), nb);
+        hipLaunchKernelGGL(regather_kernel, gg, dim3(BLOCK), 0, e->stream, (const unsigned char *)dout, M, (const int *)(d_inv + done), (const int *)d_sel, M_out, cols_out, wpc64_out);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(e->stream));
+        done += nb;
+    }
+    if (aFend_fwd) CHK(pbwtamd_get_state(e, aFend_fwd, nullptr));
+    e->pass_open = false;
+    CHK(pbwtamd_sync(e));
+    // ---- phase B: the build chain over the new columns (already resident)
+    pbwtamd_engine *eb = e;
+    struct EngGuard { pbwtamd_engine *p = nullptr; ~EngGuard() { if (p) pbwtamd_engine_destroy(p); } } guard;
+    if (M_out != M) { CHK(pbwtamd_engine_create(&eb, e->device, M_out, e->B, nullptr)); guard.p = eb; }
+    CHK(pbwtamd_pass_begin(eb, aStart_out, 0, n_out));
+    const unsigned opts = yz_out ? PBWTAMD_OPT_PACK3 : 0u;
+    if (n_out) CHK(pbwtamd_pass_advance(eb, cols_out, wpc_out, n_out, n_out, opts));
+    CHK(pbwtamd_pass_end(eb, opts));
+    if (aFend_out) CHK(pbwtamd_get_state(eb, aFend_out, nullptr));
+    if (yz_out) CHK(pbwtamd_get_packed(eb, yz_out, nz_out));
+    return 0;
+}
+
+// pbwtWriteHaplotypes without the N x M host matrix: `sink` receives the alleles of consecutive sites, nsites rows of M bytes
+// (0/1, original haplotype order) at a time, on the calling thread, in site order
+extern "C" int pbwtamd_haplotypes_stream(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart,
+                                         void (*sink)(int k0, int nsites, const uint8_t *rows, void *ctx), void *ctx) {
+    HIPCHK(hipSetDevice(e->device));
+    Packed pk;
+    CHK(packed_upload(e, e->stream, e->M, yz, nz, N, pk));
+    CHK(pbwtamd_pass_begin(e, aFstart, 0, N));
+    DevBufs bufs;
+    unsigned char *dout;
+    CHK(bufs.alloc(&dout, (size_t)e->B * e->M));
+    std::vector<uint8_t> rows((size_t)e->B * e->M);
+    for (int done = 0; done < N;) {
+        const int nb = std::min(e->B, N - done), navail = std::min(nb + 1, N - done);
+        CHK(packed_expand(e, e->stream, pk, e->M, done, navail, (unsigned long long *)e->cols_stage, e->wpc64));
+        CHK(pbwtamd_pass_advance(e, e->cols_stage, e->wpc, nb, navail, PBWTAMD_OPT_SORTED | OPT_INTERNAL_KEEP_STATES));
+        CHK(pbwtamd_sync(e));
+        dim3 grid(std::min(64, (e->M + BLOCK - 1) / BLOCK), nb);
+        hipLaunchKernelGGL(unsort_alleles_kernel, grid, dim3(BLOCK), 0, e->stream, (const int *)ringA(e, e->ring ^ 1), e->strideA, e->M, dout);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(rows.data(), dout, (size_t)nb * e->M, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        sink(done, nb, rows.data(), ctx);
+        done += nb;
+    }
+    return pbwtamd_pass_end(e, PBWTAMD_OPT_SORTED);
+}
+
 // -longWithin L: matchLongWithin2 (pbwtMatch.c:85-113) over a packed panel
 extern "C" int pbwtamd_long_within(pbwtamd_engine *e, const uint8_t *yz, int64_t nz, int N, const int32_t *aFstart, int L,
                                    pbwtamd_report_fn report, pbwtamd_match **recs_out, int64_t *nrecs_out) {
@@ -1453,6 +1546,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     unsigned char *xq; int *invq, *rankdir, *fst[2], *dst[2], *fss[2], *dss[2]; unsigned long long *cnt, *tot; Rec5 *recs = nullptr; size_t recsCap = 0;
     const size_t BQ = (size_t)e->B * Mq;
     CHK(bufs.alloc(&xq, BQ)); CHK(bufs.alloc(&invq, BQ)); CHK(bufs.alloc(&cnt, 2 * std::max(BQ, (size_t)Mq)));
+    int2 *evt; CHK(bufs.alloc(&evt, 2 * BQ));
     CHK(bufs.alloc(&rankdir, (size_t)e->B * (wpc64 + 1)));
     for (int i = 0; i < 2; ++i) {
         CHK(bufs.alloc(&fst[i], (size_t)Mq)); CHK(bufs.alloc(&dst[i], (size_t)Mq));
@@ -1537,7 +1631,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         g.f_in = fst[cur]; g.dq_in = dst[cur]; g.f_out = fst[cur ^ 1]; g.dq_out = dst[cur ^ 1];
         g.fs_in = fss[cur]; g.ds_in = dss[cur]; g.fs_out = fss[cur ^ 1]; g.ds_out = dss[cur ^ 1];
         g.cnt = cnt; g.recs = nullptr; g.tot = tot;
-        g.nm_ev = nm_ev; g.nm_n = nm_n; g.nm_cap = NM_CAP;
+        g.nm_ev = nm_ev; g.nm_n = nm_n; g.nm_cap = NM_CAP; g.evt = evt;
         hipLaunchKernelGGL((qss_sweep_kernel<0>), dim3(qwaves), dim3(BLOCK), 0, st, g);
         scan_u64(st, cnt, 2 * (size_t)nb * Mq, tot + 3, bsum);
         HIPCHK(hipGetLastError());
@@ -1546,8 +1640,12 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         HIPCHK(hipStreamSynchronize(st));
         if (total) {
             CHK(ensure_recs((size_t)total));
-            g.recs = recs;
-            hipLaunchKernelGGL((qss_sweep_kernel<1>), dim3(qwaves), dim3(BLOCK), 0, st, g);
+            QssEmitArgs em;                                 // expand the event descriptors of the counting pass (the walks are not repeated)
+            em.off = cnt; em.total = tot + 3; em.evt = evt; em.nslots = 2 * (size_t)nb * Mq;
+            em.dense = g.dense; em.sparse = dviews; em.nS = std::max(nS, 1);
+            em.AQ = AQ; em.strideAQ = eq->strideA; em.Mq = Mq; em.kbase = done; em.recs = recs;
+            const size_t ewaves = (em.nslots + 63) / 64;
+            hipLaunchKernelGGL(qss_emit_kernel, dim3((unsigned)((ewaves + WAVES - 1) / WAVES)), dim3(BLOCK), 0, st, em);
             HIPCHK(hipGetLastError());
             CHK(deliver((size_t)total));
         }

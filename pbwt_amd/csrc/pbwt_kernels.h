@@ -1144,7 +1144,7 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     { const int2 v = sv[(size_t)w * SKK + t]; s_bH[SKK + t] = v.x; s_cH[SKK + t] = v.y; s_tH[SKK + t] = reinterpret_cast<const int *>(sv + (size_t)g.W * SKK)[t]; }
 #pragma unroll
     for (int c = 0; c < NC; ++c) { s_rawH[c][SKK + t] = 0; s_lastH[c][SKK + t] = -1; }
-    __syncthreads();
+    lds_barrier();
     // ballot refinement bit by bit: after bit j-1 the mask of same-j-key lanes
     short rk[EPT][8], pl[EPT][8];                           // [.][j]: rank inside the chunk, previous same-j-key position in the chunk (-1)
     const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     constexpr int NSTEP = (NL - 1 > SKB - 1) ? NL - 1 : SKB - 1;
 #pragma unroll
     for (int l = 1; l <= NSTEP; ++l) {
-        __syncthreads();
+        lds_barrier();
         if (l < NL) {
 #pragma unroll
             for (int r = 0; r < EPT; ++r) {
@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     // (i) every level entry (heap index 2..255): exclusive scan over the chunks, in place (count -> base, last -> previous)
     if (t >= 2) {
         int base = 0, last = -1;
@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
         else if (wv == 2) { level_scan(4); level_scan(2); }
         else { level_scan(3); level_scan(7); }
     }
-    __syncthreads();
+    lds_barrier();
     // all seven levels, no barrier in between: positions, divergences, scatter
 #pragma unroll
     for (int j = SKB - 1; j >= 1; --j) {
@@ -1843,16 +1843,31 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
     const int M = g.M, lane = lane_id();
     for (int x = threadIdx.x; x < HIST_LBINS; x += BLOCK) s_hist[x] = 0;
     __syncthreads();
+    // branch-free loads: every address is clamped into [0, M] (index M holds the sentinel d[M]); words of positions beyond M
+    // are never used as anything but a right neighbour of an invalid position
+    auto WD = [&](int x) -> int {
+        const int xc = min(max(x, 0), M);
+        return PACKED ? __builtin_nontemporal_load(d + xc) : (__builtin_nontemporal_load(d + xc) | (__builtin_nontemporal_load(a + min(xc, M - 1)) & (int)0x80000000));
+    };
+    // the words of a group (own 4 chunks + the two halo words, wave-uniform addresses) are requested one iteration ahead of their use
+    int nw_[CH], nhl = 0, nhr = 0;
+    auto request = [&](int it) {
+        const int wb = ((blockIdx.x * g.iters + it) * WAVES + wave_id()) * (64 * CH);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) nw_[c] = WD(wb + 64 * c + lane);
+        nhl = WD(wb - 1);
+        nhr = WD(wb + 64 * CH);
+    };
+    request(0);
     for (int it = 0; it < g.iters; ++it) {
     const int wv = (blockIdx.x * g.iters + it) * WAVES + wave_id();
     const int wbase = wv * (64 * CH);
-    if (wbase > M) break;
-    auto WD = [&](int x) -> int { return PACKED ? __builtin_nontemporal_load(d + x) : (__builtin_nontemporal_load(d + x) | ((x < M) ? (__builtin_nontemporal_load(a + x) & (int)0x80000000) : 0)); };
     int w[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) { const int p = wbase + 64 * c + lane; w[c] = (p <= M) ? WD(p) : 0; }   // index M: the sentinel d[M], as a right neighbour
-    const int hl = (lane == 0 && wbase > 0) ? WD(wbase - 1) : 0;
-    const int hr = (lane == 63 && wbase + 64 * CH <= M) ? WD(wbase + 64 * CH) : 0;
+    for (int c = 0; c < CH; ++c) w[c] = nw_[c];
+    const int hl = nhl, hr = nhr;
+    request(it + 1);
+    if (wbase > M) break;
     int dI[CH], dN[CH]; unsigned yI[CH];
     bool pendUp[CH], pendDn[CH], rep[CH];
     unsigned long long mPendUp = 0, mPendDn = 0;             // any pending lane in the wave (per chunk bit sets are re-balloted below)
@@ -1860,7 +1875,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
     for (int c = 0; c < CH; ++c) {
         const int p = wbase + 64 * c + lane;
         const int fillL = (c > 0) ? __builtin_amdgcn_readlane(w[c > 0 ? c - 1 : 0], 63) : __builtin_amdgcn_readfirstlane(hl);
-        const int fillR = (c < CH - 1) ? __builtin_amdgcn_readlane(w[c < CH - 1 ? c + 1 : c], 0) : __builtin_amdgcn_readlane(hr, 63);
+        const int fillR = (c < CH - 1) ? __builtin_amdgcn_readlane(w[c < CH - 1 ? c + 1 : c], 0) : __builtin_amdgcn_readfirstlane(hr);
         const int wl = lane_shr1(w[c], fillL);
         const int wr = __builtin_amdgcn_update_dpp(fillR, w[c], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
         const bool valid = p < M;
@@ -2231,13 +2246,27 @@ __global__ __launch_bounds__(NT) void pack3v2_kernel(const unsigned long long *y
     if (MODE == 0) { if (threadIdx.x == 0) colBytes[col] = (unsigned long long)total; return; }
     // ---- pass B: emit.  The run open at the region's start now has a known start (openW).
     uint8_t *obase = out + colBytes[col] + baseB;
+    // (a rolled loop over freshly reloaded, L2-hot words: keeping all IT words live through the emission code spills registers)
     carryT = openW; prevHi = hi0;
     int done = 0;                                            // bytes emitted so far by this wave
-#pragma unroll
+    unsigned long long nxt = (base + lane < nw) ? y[base + lane] : 0ULL;
+#pragma unroll 1
     for (int i = 0; i < IT; ++i) {
         const int wd = base + i * 64 + lane;
-        const int hiPrevIter = prevHi;                       // transitions() advances prevHi: the value of the run open at this word is needed too
-        unsigned long long tr = transitions(i, prevHi);
+        if (base + i * 64 >= nw) break;
+        const unsigned long long cw = nxt;
+        nxt = (wd + 64 < nw && i + 1 < IT) ? y[wd + 64] : 0ULL;
+        const int hiPrevIter = prevHi;                       // the value of the run open at this word = the last bit before it
+        unsigned long long tr;
+        {
+            const int hi = (int)(cw >> 32);
+            const int ph0 = lane_shr1(hi, prevHi);
+            prevHi = __builtin_amdgcn_readlane(hi, 63);
+            tr = cw ^ ((cw << 1) | (unsigned long long)((unsigned)ph0 >> 31));
+            if (wd == 0) tr &= ~1ULL;
+            const int nbits = M - wd * 64;
+            if (nbits <= 0) tr = 0; else if (nbits < 64) tr &= (1ULL << nbits) - 1ULL;
+        }
         const int tl = tr ? wd * 64 + 63 - __clzll(tr) : -1;
         const int inc = wave_iscan_max(tl + 1);
         int st = max(lane_shr1(inc, 0) - 1, carryT);
@@ -2245,10 +2274,10 @@ __global__ __launch_bounds__(NT) void pack3v2_kernel(const unsigned long long *y
         int bytes = 0;
         { int s2 = st; for (unsigned long long t2 = tr; t2; t2 &= t2 - 1) { const int pz = wd * 64 + __ffsll((long long)t2) - 1; bytes += p3_nbytes(pz - s2); s2 = pz; } if (lastWord) bytes += p3_nbytes(M - s2); }
         const int incB = wave_iscan_sum(bytes);
-        const int ph = lane_shr1((int)(cur[i] >> 32), hiPrevIter);   // cross-lane: outside the divergent branch below
+        const int ph = lane_shr1((int)(cw >> 32), hiPrevIter);   // cross-lane: outside the divergent branch below
         if (bytes) {
             uint8_t *o = obase + done + incB - bytes;
-            unsigned v = (wd == 0) ? (unsigned)(cur[i] & 1ULL) : ((unsigned)ph >> 31);   // value of the run open at this word = last bit before it
+            unsigned v = (wd == 0) ? (unsigned)(cw & 1ULL) : ((unsigned)ph >> 31);
             for (; tr; tr &= tr - 1) { const int pz = wd * 64 + __ffsll((long long)tr) - 1; o = p3_emit(o, v, pz - st); st = pz; v ^= 1u; }
             if (lastWord) p3_emit(o, v, M - st);
         }
@@ -2425,6 +2454,7 @@ struct QssArgs {
     Rec5 *recs;
     unsigned long long *tot;                                 // [0] nTot [1] totLen [2] no-match events
     int4 *nm_ev; unsigned *nm_n; unsigned nm_cap;            // the no-match events themselves: {site k, query rank, query jj, x | isSparse << 1}
+    int2 *evt;                                               // per slot with reports: {first panel position f, reported start} — what qss_emit_kernel expands
 };
 
 // reportAndUpdate (pbwtMatch.c:452-499) for one query at one site against one cursor state, executed by a whole
@@ -2436,7 +2466,7 @@ template <int MODE>
 __device__ __forceinline__ void qss_update(const int *a, const int *d, const unsigned long long *yc, int M, unsigned x, int jj, int k,
                                            int kend, int nS, int isSparse, int &f, int &dq, unsigned long long *cntslot, Rec5 *recs,
                                            unsigned long long &nTot, unsigned long long &totLen, unsigned long long &nomatch,
-                                           int rank, int4 *nm_ev, unsigned *nm_n, unsigned nm_cap) {
+                                           int rank, int4 *nm_ev, unsigned *nm_n, unsigned nm_cap, int2 *evt) {
     const int lane = lane_id();
 #define PY(i) ((unsigned)((yc[(i) >> 6] >> ((i) & 63)) & 1ULL))
     if (PY(f) == x) return;
@@ -2455,7 +2485,7 @@ __device__ __forceinline__ void qss_update(const int *a, const int *d, const uns
     if (found) { f = iPlus; return; }
     const int n = iPlus - f;                                 // these matches end here (pbwtMatch.c:459-461)
     const int dj = isSparse ? nS * dq + k % nS : dq;
-    if (MODE == 0) { if (lane == 0) *cntslot = (unsigned long long)n; nTot += n; totLen += (unsigned long long)(k - dj) * n; }
+    if (MODE == 0) { if (lane == 0) { *cntslot = (unsigned long long)n; if (evt) *evt = make_int2(f, dj); } nTot += n; totLen += (unsigned long long)(k - dj) * n; }
     else {
         Rec5 *o = recs + *cntslot;
         for (int i = f + lane; i < iPlus; i += 64) { Rec5 r; r.ai = jj; r.bi = a[i] & AMASK; r.start = dj; r.end = k; r.sparse = isSparse; o[i - f] = r; }
@@ -2537,7 +2567,7 @@ __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
                 f = x ? c0 + f - uf : uf;
                 if (f == M) f = 0;
             } else {
-                qss_update<MODE>(a, d, yc, M, x, jj, k, k, nS, 0, f, dq, g.cnt + slot, g.recs, nTot, totLen, nomatch, qrank, g.nm_ev, g.nm_n, g.nm_cap);
+                qss_update<MODE>(a, d, yc, M, x, jj, k, k, nS, 0, f, dq, g.cnt + slot, g.recs, nTot, totLen, nomatch, qrank, g.nm_ev, g.nm_n, g.nm_cap, g.evt ? g.evt + slot : nullptr);
                 f = qss_lfmap(yc, rd, g.wpc64, M, x, f);
             }
         }
@@ -2552,7 +2582,7 @@ __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
             if (MODE == 0) { fsl = g.fs_out[ix]; dsl = g.ds_out[ix]; }
             else if (s < nS) { fsl = g.fs_in[ix]; dsl = g.ds_in[ix]; }
             else { fsl = g.fs_out[sx]; dsl = g.ds_out[sx]; }
-            qss_update<MODE>(a, d, yc, M, x, jj, k, k / nS, nS, 1, fsl, dsl, g.cnt + slot + 1, g.recs, nTot, totLen, nomatch, qrank, g.nm_ev, g.nm_n, g.nm_cap);
+            qss_update<MODE>(a, d, yc, M, x, jj, k, k / nS, nS, 1, fsl, dsl, g.cnt + slot + 1, g.recs, nTot, totLen, nomatch, qrank, g.nm_ev, g.nm_n, g.nm_cap, g.evt ? g.evt + slot + 1 : nullptr);
             fsl = qss_lfmap(yc, v.rankdir + (size_t)t * (g.wpc64 + 1), g.wpc64, M, x, fsl);
             if (lane == 0) {
                 if (MODE == 0) { g.fs_out[ix] = fsl; g.ds_out[ix] = dsl; }
@@ -2566,6 +2596,41 @@ __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
         g.f_out[jj] = f; g.dq_out[jj] = dq;
         if (nTot) { atomicAdd(g.tot, nTot); atomicAdd(g.tot + 1, totLen); }
         if (nomatch) atomicAdd(g.tot + 2, nomatch);
+    }
+}
+
+// records of a batch from the counting pass's event descriptors: slot (site s, query rank r, dense / sparse) with n reports
+// -> (query AQ[s][r], a[f + i], start, k, isSparse) for i < n, at the slot's scanned offset.  Replaces a second run of the whole
+// sweep in emit mode (the walks are done once).  A wave takes 64 consecutive slots; the non-empty ones are expanded cooperatively.
+struct QssEmitArgs {
+    const unsigned long long *off; const unsigned long long *total;   // exclusive offsets per slot (scan of the counts), their total
+    const int2 *evt; size_t nslots;
+    QsView dense; const QsView *sparse; int nS;
+    const int *AQ; size_t strideAQ;                              // query cursor: position r of site s holds the query index
+    int Mq, kbase;
+    Rec5 *recs;
+};
+__global__ __launch_bounds__(BLOCK) void qss_emit_kernel(QssEmitArgs g) {
+    const size_t base = ((size_t)blockIdx.x * WAVES + wave_id()) * 64;
+    const int lane = lane_id();
+    if (base >= g.nslots) return;
+    const size_t slot = base + lane;
+    unsigned long long off = 0, nxt = 0;
+    if (slot < g.nslots) { off = g.off[slot]; nxt = (slot + 1 < g.nslots) ? g.off[slot + 1] : *g.total; }
+    const int n = (int)(nxt - off);
+    for (unsigned long long pend = __ballot(n > 0); pend; pend &= pend - 1) {
+        const int src = __ffsll((long long)pend) - 1;
+        const size_t sl = base + src;
+        const int cntN = __builtin_amdgcn_readlane(n, src);
+        const unsigned long long o0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(off >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)off, src);
+        const int2 ev = g.evt[sl];
+        const int sparse = (int)(sl & 1), r = (int)((sl >> 1) % (size_t)g.Mq), s = (int)((sl >> 1) / (size_t)g.Mq);
+        const int k = g.kbase + s;
+        const int jj = g.AQ[(size_t)s * g.strideAQ + r] & AMASK;
+        const int *a;
+        if (sparse) { const QsView v = g.sparse[k % g.nS]; a = v.A + (size_t)(k / g.nS - v.sbase) * v.strideA; }
+        else a = g.dense.A + (size_t)s * g.dense.strideA;
+        for (int i = lane; i < cntN; i += 64) { Rec5 rr; rr.ai = jj; rr.bi = a[ev.x + i] & AMASK; rr.start = ev.y; rr.end = k; rr.sparse = sparse; g.recs[o0 + i] = rr; }
     }
 }
 
@@ -2599,6 +2664,24 @@ __global__ void cursor_y_u_kernel(const unsigned long long *yc, const int *rd, i
     const unsigned long long w = (i < M || bo) ? yc[wd] : 0ULL;
     if (i < M) y[i] = (unsigned char)((w >> bo) & 1ULL);
     u[i] = (i < M || bo) ? rd[wd] + (bo - __popcll(w & ((1ULL << bo) - 1ULL))) : rd[wd];
+}
+
+// panel transforms (pbwtBuildReverse pbwtCore.c:151-191, pbwtSubSample pbwtSample.c:59-93, pbwtSubRange pbwtCore.c:111-148,
+// pbwtSelectSites pbwtCore.c:623-682) are all "x[a[j]] = y[j]; y'[j] = x[a'[j]]" loops: the first half is
+// unsort_alleles_kernel (alleles of a batch of sites back in original haplotype order), this is the gather half — the
+// bit column of output site inv[s] = the selected haplotypes of input site s, in the new panel's haplotype order.
+// grid (ceil(wpc64_out / WAVES), sites of the batch); one wave builds one 64-haplotype word with a ballot.
+__global__ __launch_bounds__(BLOCK) void regather_kernel(const unsigned char *alleles, int M_in, const int *site_to_out, const int *hap_select,
+                                                        int M_out, unsigned long long *cols_out, int wpc64_out) {
+    const int s = blockIdx.y, j = site_to_out[s];
+    if (j < 0) return;                                       // site dropped
+    const unsigned char *x = alleles + (size_t)s * M_in;
+    for (int wd = blockIdx.x * WAVES + wave_id(); wd < wpc64_out; wd += gridDim.x * WAVES) {
+        const int h = wd * 64 + lane_id();
+        const bool one = (h < M_out) && x[hap_select ? hap_select[h] : h] != 0;
+        const unsigned long long mk = __ballot(one);
+        if (lane_id() == 0) cols_out[(size_t)j * wpc64_out + wd] = mk;
+    }
 }
 
 // bytes (0/1 per haplotype, original order) -> bit column words; grid (words/4, sites)

@@ -1,7 +1,7 @@
 /* pbwt_cli.c — `pbwt` command interpreter for the hot-path subset of the reference's CLI
  * (pbwtMain.c:276-494): a sequence of "-command args" applied in order to one current panel.
  * Supported: -check -stats -log -checkpoint -read -readSites -readAll -readMacs -write -writeSites -writeAll
- * -haps -maxWithin -longWithin -matchDynamic -siteInfo -subsample -buildReverse -writeReverse -readReverse.  Everything else: "not on the accelerated
+ * -haps -maxWithin -longWithin -matchDynamic -siteInfo -subsample -subrange -selectSites -removeSites -buildReverse -writeReverse -readReverse.  Everything else: "not on the accelerated
  * path of this build". */
 #include "pbwt_host.h"
 #include <stdlib.h>
@@ -23,7 +23,8 @@ int main (int argc, char *argv[])
     { fprintf (stderr, "Program: pbwt (MI355X hot-path build, pbwt_amd)\nUsage: pbwt [ -<command> [options]* ]+\n"
 	       "Commands: -check -stats -log <file> -checkpoint <n> -read <file> -readSites <file> -readAll <root> -readMacs <file>\n"
 	       "          -write <file> -writeSites <file> -writeAll <root> -haps <file> -maxWithin -longWithin <L>\n"
-	       "          -matchDynamic <file> -siteInfo <file> <kmin> <kmax> -subsample <start> <n>\n"
+	       "          -matchDynamic <file> -siteInfo <file> <kmin> <kmax> -subsample <start> <n> -subrange <start> <end>\n"
+	       "          -selectSites <file> -removeSites <file>\n"
 	       "          -buildReverse -writeReverse <file> -readReverse <file>\n") ;
       return 0 ;
     }
@@ -69,6 +70,12 @@ int main (int argc, char *argv[])
 	{ NEEDP ; fp = openOrDie (argv[1], "siteInfo", "w") ; panelSiteInfo (p, fp, atoi (argv[2]), atoi (argv[3])) ; fclose (fp) ; argc -= 4 ; argv += 4 ; }
       else if (!strcmp (argv[0], "-subsample") && argc > 2)
 	{ NEEDP ; p = panelSubSampleInterval (p, atoi (argv[1]), atoi (argv[2])) ; argc -= 3 ; argv += 3 ; }
+      else if (!strcmp (argv[0], "-subrange") && argc > 2)
+	{ NEEDP ; p = panelSubRange (p, atoi (argv[1]), atoi (argv[2])) ; argc -= 3 ; argv += 3 ; }
+      else if (!strcmp (argv[0], "-selectSites") && argc > 1)
+	{ NEEDP ; fp = openOrDie (argv[1], "selectSites", "r") ; p = panelSelectSites (p, fp) ; fclose (fp) ; argc -= 2 ; argv += 2 ; }
+      else if (!strcmp (argv[0], "-removeSites") && argc > 1)
+	{ NEEDP ; fp = openOrDie (argv[1], "removeSites", "r") ; p = panelRemoveSites (p, fp) ; fclose (fp) ; argc -= 2 ; argv += 2 ; }
       else
 	die ("unrecognised command %s (or missing arguments): not on the accelerated path of this build\nType pbwt without arguments for help", *argv) ;
       timeUpdate (logFile) ;

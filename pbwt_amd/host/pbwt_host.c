@@ -174,7 +174,11 @@ void panelReadSites (Panel *p, FILE *fp)
     }
   free (line) ;
   if (ferror (fp)) die ("error reading sites file") ;
-  fprintf (logFile, "read %zu sites on chromosome %s from file\n", n, p->chrom ? p->chrom : "(null)") ;
+  /* the reference's reader runs its chromosome match once more at end of file (pbwtIO.c:240-241 with fgetword returning ""
+     there), which leaves a panel whose sites all say "." with chrom = "" rather than unset: -writeSites then prints an
+     empty first column.  Kept, so that files round-trip byte for byte. */
+  if (!p->chrom) p->chrom = strdup ("") ;
+  fprintf (logFile, "read %zu sites on chromosome %s from file\n", n, p->chrom) ;
   if ((int) n != p->N) die ("sites file contains %zu sites not %d as in pbwt", n, p->N) ;
   p->sites = sites ;
 }
@@ -284,16 +288,21 @@ Panel *panelReadMacs (FILE *fp)
   return p ;
 }
 
+/* -haps (pbwtWriteHaplotypes, pbwtIO.c:839-857): the device hands over the alleles a batch of sites at a time */
+typedef struct { FILE *fp ; int M ; char *line ; } HapSink ;
+static void writeHapRows (int k0, int nsites, const uint8_t *rows, void *ctx)
+{ HapSink *h = (HapSink*) ctx ; (void) k0 ;
+  for (int i = 0 ; i < nsites ; ++i)
+    { for (int j = 0 ; j < h->M ; ++j) h->line[j] = rows[(size_t) i * h->M + j] ? '1' : '0' ;
+      h->line[h->M] = '\n' ; fwrite (h->line, 1, (size_t) h->M + 1, h->fp) ;
+    }
+}
+
 void panelWriteHaplotypes (FILE *fp, Panel *p)
 {
-  uint8_t *hap = xalloc ((size_t) p->N * p->M) ;
-  if (pbwtamd_haplotypes (engineFor (p->M), p->yz, p->nz, p->N, p->aFstart, hap)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
-  char *line = xalloc ((size_t) p->M + 2) ;
-  for (int i = 0 ; i < p->N ; ++i)
-    { for (int j = 0 ; j < p->M ; ++j) line[j] = hap[(size_t) i * p->M + j] ? '1' : '0' ;
-      line[p->M] = '\n' ; fwrite (line, 1, (size_t) p->M + 1, fp) ;
-    }
-  free (line) ; free (hap) ;
+  HapSink h = { fp, p->M, xalloc ((size_t) p->M + 2) } ;
+  if (pbwtamd_haplotypes_stream (engineFor (p->M), p->yz, p->nz, p->N, p->aFstart, writeHapRows, &h)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+  free (h.line) ;
   fprintf (logFile, "written haplotype file: %d rows of %d\n", p->N, p->M) ;
 }
 
@@ -364,27 +373,24 @@ void panelMatchDynamic (Panel *p, FILE *fp)
   panelDestroy (q) ;
 }
 
-/* reverse PBWT (pbwtCore.c:151-191): the same build loop over the sites in reverse order, started
- * from the forward pass's final order aFend (computed by a forward sweep when the file lacks it) */
+/* reverse PBWT (pbwtCore.c:151-191): the same build loop over the sites in reverse order, started from the forward
+ * pass's final order aFend — decode, regather and rebuild all on the device (pbwtamd_regather) */
 void panelBuildReverse (Panel *p)
 {
-  uint8_t *hap = decodeHaps (p) ;
   pbwtamd_engine *e = engineFor (p->M) ;
-  const int wpc = pbwtamd_engine_wpc (e) ;
+  int *order = xalloc (sizeof (int) * ((size_t) p->N + 1)) ;
+  for (int k = 0 ; k < p->N ; ++k) order[k] = p->N - 1 - k ;	/* column k of the reverse panel = site N-1-k */
   if (!p->aFend)			/* run forwards to the end first (pbwtCore.c:160-165) */
     { p->aFend = xalloc (sizeof (int) * p->M) ;
       int last = p->N ;
       if (pbwtamd_sweep_AD (e, p->yz, p->nz, p->N, p->aFstart, 0, 0, 0, &last, 1, p->aFend, 0, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
     }
-  uint32_t *cols = xalloc ((size_t) p->N * wpc * sizeof (uint32_t)) ;
-  for (int k = 0 ; k < p->N ; ++k)		/* column k of the reverse panel = site N-1-k */
-    for (int h = 0 ; h < p->M ; ++h)
-      if (hap[(size_t) (p->N - 1 - k) * p->M + h]) cols[(size_t) k * wpc + (h >> 5)] |= 1u << (h & 31) ;
   free (p->zz) ; free (p->aRstart) ; free (p->aRend) ;
   p->aRstart = xalloc (sizeof (int) * p->M) ; memcpy (p->aRstart, p->aFend, sizeof (int) * p->M) ;
   p->aRend = xalloc (sizeof (int) * p->M) ;
-  if (pbwtamd_build (e, cols, wpc, p->N, 0, p->aRstart, &p->zz, &p->nzz, p->aRend, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
-  free (cols) ; free (hap) ;
+  if (pbwtamd_regather (e, p->yz, p->nz, p->N, p->aFstart, order, p->N, 0, p->M, p->aRstart, &p->zz, &p->nzz, p->aRend, 0))
+    die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+  free (order) ;
   fprintf (logFile, "built reverse PBWT - size %ld\n", (long) p->nzz) ;
 }
 
@@ -444,27 +450,128 @@ void panelSiteInfo (Panel *p, FILE *fp, int f1, int f2)
   fprintf (logFile, "%d rows exported with allele count f, %d <= f < %d\n", n, f1, f2) ;
 }
 
-/* pbwtSubSample over a contiguous interval (pbwtSample.c:59-108): decode, keep the selected
- * haplotypes in their original relative order, rebuild */
-Panel *panelSubSampleInterval (Panel *p, int start, int Mnew)
+/* site i of p -> a fresh copy for another panel */
+static HostSite copySite (const HostSite *s)
+{ HostSite c ; c.x = s->x ; c.var = s->var ? strdup (s->var) : 0 ; return c ; }
+
+/* the shared tail of the panel transforms: a new panel of Mnew haplotypes (select[h] of the old ones, or all) over the
+ * sites order[0..nOut) of the old one, rebuilt on the device; consumes p like the reference's transforms do */
+static Panel *regathered (Panel *p, const int *order, int nOut, const int *select, int Mnew)
 {
-  if (start < 0 || Mnew <= 0 || start + Mnew > p->M) die ("bad start %d, Mnew %d in subsample", start, Mnew) ;
-  uint8_t *hap = decodeHaps (p) ;
-  Panel *q = panelCreate (Mnew, p->N) ;
-  pbwtamd_engine *e = engineFor (Mnew) ;
-  const int wpc = pbwtamd_engine_wpc (e) ;
-  uint32_t *cols = xalloc ((size_t) p->N * wpc * sizeof (uint32_t)) ;
-  for (int k = 0 ; k < p->N ; ++k)
-    for (int h = 0 ; h < Mnew ; ++h)
-      if (hap[(size_t) k * p->M + start + h]) cols[(size_t) k * wpc + (h >> 5)] |= 1u << (h & 31) ;
+  Panel *q = panelCreate (Mnew, nOut) ;
   q->aFend = xalloc (sizeof (int) * Mnew) ;
-  if (pbwtamd_build (e, cols, wpc, q->N, 0, q->aFstart, &q->yz, &q->nz, q->aFend, 0)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
+  if (pbwtamd_regather (engineFor (p->M), p->yz, p->nz, p->N, p->aFstart, order, nOut, select, Mnew, q->aFstart, &q->yz, &q->nz, q->aFend, 0))
+    die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
   if (p->chrom) q->chrom = strdup (p->chrom) ;
   if (p->sites)
-    { q->sites = xalloc (sizeof (HostSite) * (size_t) p->N) ;
-      for (int i = 0 ; i < p->N ; ++i) { q->sites[i].x = p->sites[i].x ; q->sites[i].var = p->sites[i].var ? strdup (p->sites[i].var) : 0 ; }
+    { q->sites = xalloc (sizeof (HostSite) * ((size_t) nOut + 1)) ;
+      for (int i = 0 ; i < nOut ; ++i) q->sites[i] = copySite (&p->sites[order ? order[i] : i]) ;
     }
-  free (cols) ; free (hap) ;
   panelDestroy (p) ;
   return q ;
 }
+
+/* pbwtSubSample (pbwtSample.c:59-93): select[i] is the position in old of the i'th haplotype in new */
+Panel *panelSubSample (Panel *p, const int *select, int Mnew)
+{
+  if (!p || !p->yz) die ("subSample called without valid pbwt") ;
+  return regathered (p, 0, p->N, select, Mnew) ;
+}
+
+Panel *panelSubSampleInterval (Panel *p, int start, int Mnew)	/* pbwtSample.c:95-108 */
+{
+  if (start < 0 || Mnew <= 0 || start + Mnew > p->M) die ("bad start %d, Mnew %d in subsample", start, Mnew) ;
+  int *select = xalloc (sizeof (int) * (size_t) Mnew) ;
+  for (int i = 0 ; i < Mnew ; ++i) select[i] = start + i ;
+  Panel *q = panelSubSample (p, select, Mnew) ;
+  free (select) ;
+  return q ;
+}
+
+Panel *panelSubRange (Panel *p, int start, int end)		/* pbwtSubRange, pbwtCore.c:111-148 */
+{
+  if (!p || !p->yz) die ("subrange without an existing pbwt") ;
+  if (start < 0 || end > p->N || end <= start) die ("subrange invalid start %d, end %d", start, end) ;
+  int *order = xalloc (sizeof (int) * (size_t) (end - start)) ;
+  for (int i = start ; i < end ; ++i) order[i - start] = i ;
+  Panel *q = regathered (p, order, end - start, 0, p->M) ;
+  free (order) ;
+  return q ;
+}
+
+/* a sites file as a list (pbwtReadSitesFile, pbwtIO.c:232-267) */
+static HostSite *readSitesList (FILE *fp, char **chrom, int *n)
+{
+  Panel tmp ; memset (&tmp, 0, sizeof tmp) ;
+  size_t cap = 1024, cnt = 0, len = 0 ; char *line = 0 ; ssize_t got ;
+  HostSite *v = xalloc (cap * sizeof (HostSite)) ;
+  while ((got = getline (&line, &len, fp)) > 0)
+    { while (got > 0 && (line[got-1] == '\n' || line[got-1] == '\r')) line[--got] = 0 ;
+      if (!got) continue ;
+      char *tab = strchr (line, '\t') ; if (!tab) tab = strchr (line, ' ') ;
+      if (!tab) die ("bad position line %zu in sites file", cnt + 1) ;
+      *tab = 0 ;
+      if (strcmp (line, "."))				/* readMatchChrom, pbwtIO.c:219-230 */
+	{ if (!*chrom) *chrom = strdup (line) ;
+	  else if (strcmp (*chrom, line)) die ("failed to match chromosome in sites file: line %zu", cnt + 1) ;
+	}
+      char *q = tab + 1 ;
+      if (!isdigit ((unsigned char) *q)) die ("bad position line %zu in sites file", cnt + 1) ;
+      if (cnt == cap) { v = xrealloc (v, cap * sizeof (HostSite), 2 * cap * sizeof (HostSite)) ; cap *= 2 ; }
+      v[cnt].x = 0 ; while (isdigit ((unsigned char) *q)) v[cnt].x = v[cnt].x * 10 + (*q++ - '0') ;
+      while (*q && isspace ((unsigned char) *q)) ++q ;
+      v[cnt].var = *q ? strdup (q) : 0 ;
+      ++cnt ;
+    }
+  free (line) ;
+  if (!*chrom) *chrom = strdup ("") ;			/* as panelReadSites: the reference's end-of-file chromosome match */
+  *n = (int) cnt ;
+  return v ;
+}
+
+/* the reference orders variations by their index in the global variation dictionary (first-come order of the strings it has
+ * seen: the panel's sites first, then the list's): the same numbering here */
+typedef struct { char **name ; int n, cap ; } VarDict ;
+static int varIndex (VarDict *d, const char *s)
+{ if (!s) s = "" ;
+  for (int i = 0 ; i < d->n ; ++i) if (!strcmp (d->name[i], s)) return i ;
+  if (d->n == d->cap) { d->name = xrealloc (d->name, sizeof (char*) * (size_t) d->cap, sizeof (char*) * (size_t) (2 * d->cap + 16)) ; d->cap = 2 * d->cap + 16 ; }
+  d->name[d->n] = strdup (s) ; return d->n++ ;
+}
+static int noAlt (const char *s) { size_t n = s ? strlen (s) : 0 ; return n && s[n-1] == '.' ; }
+
+/* pbwtSelectSites / pbwtRemoveSites (pbwtCore.c:623-732): the merge of the panel's sites with the list by position, then
+ * by variation unless one of the two has no ALT; keep (or drop) the matches */
+static Panel *selectOrRemove (Panel *p, FILE *fp, int keepMatches)
+{
+  if (!p || !p->sites) die ("%s called without sites", keepMatches ? "selectSites" : "removeSites") ;
+  char *chr = 0 ; int nList = 0 ;
+  HostSite *list = readSitesList (fp, &chr, &nList) ;
+  if (p->chrom && chr && strcmp (chr, p->chrom)) die ("chromosome mismatch in %s", keepMatches ? "selectSites" : "removeSites") ;
+  VarDict dict = { 0, 0, 0 } ;
+  int *vp = xalloc (sizeof (int) * ((size_t) p->N + 1)), *vl = xalloc (sizeof (int) * ((size_t) nList + 1)) ;
+  for (int i = 0 ; i < p->N ; ++i) vp[i] = varIndex (&dict, p->sites[i].var) ;
+  for (int i = 0 ; i < nList ; ++i) vl[i] = varIndex (&dict, list[i].var) ;
+  int *order = xalloc (sizeof (int) * ((size_t) p->N + 1)), nOut = 0, ip = 0, ia = 0 ;
+  while (ip < p->N && ia < nList)
+    { if (p->sites[ip].x < list[ia].x) { if (!keepMatches) order[nOut++] = ip ; ++ip ; }
+      else if (p->sites[ip].x > list[ia].x) ++ia ;
+      else
+	{ int na = keepMatches && (noAlt (list[ia].var) || noAlt (p->sites[ip].var)) ;	/* pbwtRemoveSites compares the variations always */
+	  if (!na && vp[ip] < vl[ia]) { if (!keepMatches) order[nOut++] = ip ; ++ip ; }
+	  else if (!na && vp[ip] > vl[ia]) ++ia ;
+	  else { if (keepMatches) order[nOut++] = ip ; ++ip ; ++ia ; }
+	}
+    }
+  /* (pbwtRemoveSites stops with the list, pbwtCore.c:700: panel sites beyond the list's last position are not carried over) */
+  const int Nold = p->N, M = p->M ;
+  Panel *q = regathered (p, order, nOut, 0, M) ;
+  fprintf (logFile, "%d sites selected from %d, pbwt size for %d haplotypes is %ld\n", nOut, Nold, M, (long) q->nz) ;
+  for (int i = 0 ; i < nList ; ++i) free (list[i].var) ;
+  for (int i = 0 ; i < dict.n ; ++i) free (dict.name[i]) ;
+  free (dict.name) ; free (list) ; free (chr) ; free (vp) ; free (vl) ; free (order) ;
+  return q ;
+}
+
+Panel *panelSelectSites (Panel *p, FILE *fp) { return selectOrRemove (p, fp, 1) ; }
+Panel *panelRemoveSites (Panel *p, FILE *fp) { return selectOrRemove (p, fp, 0) ; }

@@ -43,6 +43,10 @@ void panelLongMatches (Panel *p, int L) ;	/* pbwtLongMatches, pbwtMatch.c:148-18
 void panelMatchDynamic (Panel *p, FILE *fp) ;	/* matchSequencesDynamic, pbwtMatch.c:352-357 */
 void panelSiteInfo (Panel *p, FILE *fp, int f1, int f2) ;	/* exportSiteInfo, pbwtMain.c:82-100 */
 Panel *panelSubSampleInterval (Panel *p, int start, int Mnew) ;	/* pbwtSubSampleInterval, pbwtSample.c:95-108 */
+Panel *panelSubSample (Panel *p, const int *select, int Mnew) ;	/* pbwtSubSample, pbwtSample.c:59-93 */
+Panel *panelSubRange (Panel *p, int start, int end) ;		/* pbwtSubRange, pbwtCore.c:111-148 */
+Panel *panelSelectSites (Panel *p, FILE *fp) ;			/* -selectSites: pbwtReadSitesFile + pbwtSelectSites, pbwtCore.c:623-682 */
+Panel *panelRemoveSites (Panel *p, FILE *fp) ;			/* -removeSites: pbwtRemoveSites, pbwtCore.c:686-732 */
 void panelBuildReverse (Panel *p) ;		/* pbwtBuildReverse, pbwtCore.c:151-191 */
 void panelWriteReverse (Panel *p, FILE *fp) ;	/* pbwtWriteReverse, pbwtIO.c:121-132 */
 void panelReadReverse (Panel *p, FILE *fp) ;	/* pbwtReadReverse, pbwtIO.c:392-404 */

@@ -134,6 +134,33 @@ def macs_small():
     print("wrote macs_small.*")
 
 
+def transforms():
+    """panel transforms of the reference on macs_small (.pbwt + .sites): -subrange 17 93, -selectSites / -removeSites with a
+    list holding every third site plus a position the panel lacks, pbwtSubSample with a 10-haplotype selection"""
+    P = os.path.join(HERE, "macs_small.pbwt").encode(); S = os.path.join(HERE, "macs_small.sites").encode()
+    sites = open(os.path.join(HERE, "macs_small.sites")).read().splitlines()
+    lst = [sites[i] for i in range(0, len(sites), 3)]
+    chrom = sites[0].split("\t")[0]
+    lst.insert(5, "%s\t%d\t%s" % (chrom, int(sites[14].split("\t")[1]) + 1, sites[14].split("\t", 2)[2]))
+    lst = sorted(lst, key=lambda l: int(l.split("\t")[1]))
+    open(os.path.join(HERE, "macs_small.select.sites"), "w").write("\n".join(lst) + "\n")
+    ref.ref_transform.restype = C.c_int
+
+    def run(op, i0=0, i1=0, lf=None, sel=None, tag=""):
+        sel_a = np.asarray(sel if sel is not None else [0], np.int32)
+        rc = ref.ref_transform(P, S, C.c_int(op), C.c_int(i0), C.c_int(i1), lf.encode() if lf else None, sel_a.ctypes.data_as(C.c_void_p),
+                               C.c_int(len(sel_a)), os.path.join(HERE, "macs_small.%s.pbwt" % tag).encode(),
+                               os.path.join(HERE, "macs_small.%s.out.sites" % tag).encode())
+        assert rc == 0, (tag, rc)
+    run(0, 17, 93, tag="subrange")
+    run(1, lf=os.path.join(HERE, "macs_small.select.sites"), tag="selected")
+    run(2, lf=os.path.join(HERE, "macs_small.select.sites"), tag="removed")
+    sel = [59, 3, 4, 40, 7, 22, 0, 31, 58, 12]
+    run(3, sel=sel, tag="subsample10")
+    np.save(os.path.join(HERE, "macs_small.subsample10.select.npy"), np.asarray(sel, np.int32))
+    print("wrote macs_small.{subrange,selected,removed,subsample10}.*")
+
+
 if __name__ == "__main__":
     macs_small()      # first: the reference's global variation dict must still be empty (fresh-process behaviour)
     merge1()
@@ -142,3 +169,4 @@ if __name__ == "__main__":
     mosaic(300, 400, 5, 0, 40)       # founder mosaic
     mosaic(1100, 260, 6, 0, 100)     # spans two 1024-position tiles
     sparse_sweep()                   # needs the mosaic goldens above
+    transforms()                     # needs macs_small.*

@@ -191,3 +191,32 @@ def test_stats_after_longWithin_and_writeAll_reverse(cli, tmp_path):
     assert open(str(root) + ".reverse", "rb").read() == open(os.path.join(GOLDEN, "macs_small.reverse.pbwt"), "rb").read()
     run(cli, "-readAll", root, "-writeReverse", tmp_path / "again.reverse")
     assert open(tmp_path / "again.reverse", "rb").read() == open(os.path.join(GOLDEN, "macs_small.reverse.pbwt"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_panel_transforms_match_reference_bytes(cli, gpu_lib, tmp_path):
+    """-subrange / -selectSites / -removeSites (incl. its stop-with-the-list quirk) and pbwtSubSample with an arbitrary
+    selection: decode, regather and rebuild on the device (pbwtamd_regather); .pbwt and .sites bytes are the reference's"""
+    P, S = os.path.join(GOLDEN, "macs_small.pbwt"), os.path.join(GOLDEN, "macs_small.sites")
+    lst = os.path.join(GOLDEN, "macs_small.select.sites")
+    for tag, args in (("subrange", ["-subrange", 17, 93]), ("selected", ["-selectSites", lst]), ("removed", ["-removeSites", lst])):
+        out, outs = tmp_path / (tag + ".pbwt"), tmp_path / (tag + ".sites")
+        run(cli, "-read", P, "-readSites", S, *args, "-write", out, "-writeSites", outs)
+        assert open(out, "rb").read() == open(os.path.join(GOLDEN, "macs_small.%s.pbwt" % tag), "rb").read(), tag
+        assert open(outs).read() == open(os.path.join(GOLDEN, "macs_small.%s.out.sites" % tag)).read(), tag
+    # the general selection goes through the ABI (the CLI only has the interval form)
+    M, N, aFstart, aFend, yz = parse_pbwt(P)
+    sel = np.load(os.path.join(GOLDEN, "macs_small.subsample10.select.npy"))
+    eng = gpu_lib.Engine(M, batch_sites=32)
+    r = eng.regather(yz, N, hap_select=sel, aFstart=aFstart)
+    M2, N2, a0, a1, yz2 = parse_pbwt(os.path.join(GOLDEN, "macs_small.subsample10.pbwt"))
+    assert (M2, N2) == (len(sel), N) and np.array_equal(r["yz"], yz2) and np.array_equal(r["aFend"], a1)
+    # the interval form of the CLI against the same ABI call
+    run(cli, "-read", P, "-subsample", 20, 25, "-write", tmp_path / "ss.pbwt")
+    M3, N3, b0, b1, yz3 = parse_pbwt(tmp_path / "ss.pbwt")
+    r3 = eng.regather(yz, N, hap_select=np.arange(20, 45), aFstart=aFstart)
+    assert M3 == 25 and np.array_equal(r3["yz"], yz3) and np.array_equal(r3["aFend"], b1)
+    # reverse panel through the same entry point: site order N-1..0, started from the forward panel's final order
+    rev = eng.regather(yz, N, site_order=np.arange(N - 1, -1, -1), aFstart=aFstart, aStart_out=aFend, want_fwd_end=True)
+    Mr, Nr, r0, r1, zz = parse_pbwt(os.path.join(GOLDEN, "macs_small.reverse.pbwt"))
+    assert np.array_equal(rev["aFend_fwd"], aFend) and np.array_equal(rev["yz"], zz) and np.array_equal(rev["aFend"], r1)

@@ -103,10 +103,11 @@ def test_config4_shape_million_haplotypes(gpu_lib, orc, kind, Q):
     assert len(recs) == len(wrecs) and np.array_equal(recs, wrecs)
 
 
-def test_wider_than_2_20_haplotypes(gpu_lib, orc):
-    """M > 2^20: the skeleton's tables stop at 1 048 576 positions; the wide chain (2048-position tiles) takes over"""
+@pytest.mark.parametrize("M,N", [(1100000, 40), (2200000, 24)])
+def test_wider_than_2_20_haplotypes(gpu_lib, orc, M, N):
+    """M > 2^20: up to 2^21 haplotypes the skeleton chain runs with 1024-position tiles (2048 of them) and the two-level
+    tile scan; beyond that its tables stop and the wide fallback chain (2048-position tiles, two sites per launch) takes over"""
     amd = gpu_lib
-    M, N = 1100000, 40
     eng = amd.Engine(M, batch_sites=16)
     buf = device_panel(eng, N, seed=21)
     bits = buf.cpu().numpy().view(np.uint32)
