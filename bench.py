@@ -125,6 +125,45 @@ def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=65536, b
     return out
 
 
+def match_dynamic(torch, pbwt_amd, dev, kind, M=1000000, Q=10000, sites=8192, batch=512):
+    """configs[4]'s second half: `-matchDynamic` of a Q-haplotype query panel against an M-wide panel (pbwtamd_match_sweep,
+    matchSequencesSweep pbwtMatch.c:363-443), host-buffer entry point: packed panels in, records out.  Panel and queries
+    are the two parts of ONE synthetic panel (shared founders: matches run for many sites, as with real data).
+    Secondary measurement; the record stream at this shape is pinned to the oracle by tests/test_gpu_configs.py."""
+    assert M % 32 == 0
+    full = pbwt_amd.Engine(M + Q, batch_sites=batch, device=dev.index)
+    cols = torch.empty((sites, full.wpc), dtype=torch.int32, device=dev)
+    full.synth_device(cols.data_ptr(), 0, sites, seed=0x3D, kind=kind)
+    full.sync(); full.close()
+    ep = pbwt_amd.Engine(M, batch_sites=batch, device=dev.index)
+    eq = pbwt_amd.Engine(Q, batch_sites=batch, device=dev.index)
+    pc = torch.zeros((sites, ep.wpc), dtype=torch.int32, device=dev); pc[:, : M // 32] = cols[:, : M // 32]
+    nqw = (Q + 31) // 32
+    qc = torch.zeros((sites, eq.wpc), dtype=torch.int32, device=dev); qc[:, :nqw] = cols[:, M // 32: M // 32 + nqw]
+    if Q % 32:
+        qc[:, nqw - 1] &= (1 << (Q % 32)) - 1
+    del cols
+    torch.cuda.synchronize()
+    packed = []
+    for eng, c in ((ep, pc), (eq, qc)):
+        eng.pass_begin(sites); eng.pass_advance(c.data_ptr(), sites, sites, pbwt_amd.OPT_PACK3); eng.pass_end(pbwt_amd.OPT_PACK3)
+        packed.append(eng.get_packed())
+    del pc, qc
+    eq.close()
+    pz, qz = packed
+    best = None
+    for _ in range(2):                                       # first call pays the allocations
+        t0 = time.perf_counter()
+        recs, nom, tot = ep.match_sweep(pz, sites, qz, Q)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    ep.close()
+    alg = (ALG_BYTES_PER_SITEHAP * (M + Q) * sites + 16.0 * len(recs)) / best / 1e9      # SURVEY §8(d): panel step + query step + 16 B per report
+    return {"haplotypes": M, "queries": Q, "sites": sites, "us_per_site": 1e6 * best / sites, "records": int(len(recs)), "no_match_events": int(nom),
+            "value": M * sites / best, "unit": "panel site*haps/s", "achieved_GBps": alg, "frac_of_hbm_peak": alg / HBM_PEAK_GBPS,
+            "note": "host-buffer entry point (packed panels in host memory in, records out), best of 2 calls"}
+
+
 def host_entry_points(torch, pbwt_amd, panel, M, sites=16384, batch=512):
     """PCIe-inclusive rates of the host-buffer entry points on the first `sites` columns of the same panel (reported
     next to the headline, never part of `value`): pbwtamd_build (columns in host memory -> .pbwt bytes) and the read side
@@ -296,6 +335,8 @@ def main():
         del panel
         torch.cuda.empty_cache()
         out["north_star_width"] = north_star_width(torch, pbwt_amd, dev, opts, args.kind)
+        torch.cuda.empty_cache()
+        out["match_dynamic"] = match_dynamic(torch, pbwt_amd, dev, args.kind)
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args, first)
     if rank == 0:

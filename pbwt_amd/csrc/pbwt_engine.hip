@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -1547,6 +1548,9 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     const size_t BQ = (size_t)e->B * Mq;
     CHK(bufs.alloc(&xq, BQ)); CHK(bufs.alloc(&invq, BQ)); CHK(bufs.alloc(&cnt, 2 * std::max(BQ, (size_t)Mq)));
     int2 *evt; CHK(bufs.alloc(&evt, 2 * BQ));
+    int *a0P, *a0Q; CHK(bufs.alloc(&a0P, (size_t)e->strideA)); CHK(bufs.alloc(&a0Q, (size_t)eq->strideA));   // first rows of a batch, kept for the emission pass
+    std::vector<int *> a0S((size_t)nS, nullptr);
+    for (int kk = 0; kk < nS; ++kk) CHK(bufs.alloc(&a0S[kk], (size_t)e->strideA));
     CHK(bufs.alloc(&rankdir, (size_t)e->B * (wpc64 + 1)));
     for (int i = 0; i < 2; ++i) {
         CHK(bufs.alloc(&fst[i], (size_t)Mq)); CHK(bufs.alloc(&dst[i], (size_t)Mq));
@@ -1561,7 +1565,8 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     std::vector<unsigned long long *> ycS((size_t)nS, nullptr); std::vector<int *> rdS((size_t)nS, nullptr);
     for (int kk = 0; kk < nS; ++kk) { CHK(bufs.alloc(&ycS[kk], (size_t)(Bs + 2) * wpc64)); CHK(bufs.alloc(&rdS[kk], (size_t)(Bs + 2) * (wpc64 + 1))); }
     QsView *dviews = nullptr; CHK(bufs.alloc(&dviews, (size_t)std::max(nS, 1)));
-    std::vector<QsView> hviews((size_t)std::max(nS, 1));
+    std::vector<QsView> hviews_buf[2] = {std::vector<QsView>((size_t)std::max(nS, 1)), std::vector<QsView>((size_t)std::max(nS, 1))};   // per batch parity: the async upload of one batch's views may still be reading while the next batch's are filled in
+    int hv_par = 0;
     hipStream_t st = e->s2;
     HIPCHK(hipMemsetAsync(fst[0], 0, sizeof(int) * (size_t)Mq, st));       // calloc'ed f[], d[], ff[][], dd[][] (pbwtMatch.c:512-523)
     HIPCHK(hipMemsetAsync(dst[0], 0, sizeof(int) * (size_t)Mq, st));
@@ -1584,32 +1589,55 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         if (report) { for (size_t r = old; r < old + total; ++r) report(all[r].ai, all[r].bi, all[r].start, all[r].end, all[r].sparse); all.resize(old); }
         return 0;
     };
+    unsigned long long *h_total = nullptr; hipEvent_t evTotal = nullptr;      // the batch's record count comes back through pinned memory + an event
+    HIPCHK(hipHostMalloc((void **)&h_total, sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&evTotal, hipEventDisableTiming));
+    hipEvent_t evCols = nullptr; HIPCHK(hipEventCreateWithFlags(&evCols, hipEventDisableTiming));
+    struct TotGuard { unsigned long long *p; hipEvent_t ev, ev2; ~TotGuard() { if (ev) (void)hipEventDestroy(ev); if (ev2) (void)hipEventDestroy(ev2); if (p) (void)hipHostFree(p); } } totGuard{h_total, evTotal, evCols};
     int cur = 0;
+    static const bool trace_qs = getenv("PBWTAMD_TRACE_QS") != nullptr;
+    double tph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+    double tmark = now();
+    auto lap = [&](int i) { if (trace_qs) { const double t = now(); tph[i] += t - tmark; tmark = t; } };
     const int qblocks = (Mq + BLOCK - 1) / BLOCK;          // thread per query (qs_unsort)
     const int qwaves = (Mq + WAVES - 1) / WAVES;            // wave per query (sweep, tails)
-    for (int done = 0; done < N;) {
-        const int nb = std::min(Bd, N - done);
-        const int navail = std::min(nb + 1, N - done);
-        CHK(packed_expand(e, e->stream, pk, Mp, done, navail, (unsigned long long *)e->cols_stage, wpc64));
-        CHK(packed_expand(eq, eq->stream, qk, Mq, done, navail, (unsigned long long *)eq->cols_stage, eq->wpc64));
+    // the chains of the batch starting at site `at` (panel, queries, sparse cursors): enqueued only — batch b+1's chains run
+    // while batch b's query sweep does (the sweep's stream records the consumer events the chains wait for before they
+    // overwrite the ring the sweep reads)
+    auto enqueue_chains = [&](int at) -> int {
+        const int nb = std::min(Bd, N - at);
+        const int navail = std::min(nb + 1, N - at);
+        CHK(packed_expand(e, e->stream, pk, Mp, at, navail, (unsigned long long *)e->cols_stage, wpc64));
+        CHK(packed_expand(eq, eq->stream, qk, Mq, at, navail, (unsigned long long *)eq->cols_stage, eq->wpc64));
         CHK(pbwtamd_pass_advance(e, e->cols_stage, wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES));
         CHK(pbwtamd_pass_advance(eq, eq->cols_stage, eq->wpc, nb, navail, PBWTAMD_OPT_SORTED | OPT_INTERNAL_KEEP_STATES));
         for (int kk = 0; kk < nS; ++kk) {                  // the sparse cursors' steps that fall into this batch
             const int ns = nb > kk ? (nb - kk + nS - 1) / nS : 0;
-            hviews[kk] = QsView{nullptr, nullptr, 0, 0, nullptr, nullptr, done / nS};
             if (!ns) continue;
             pbwtamd_engine *s = es[kk];
-            const int left = nTotS[kk] - done / nS;        // sparse sites from this batch's first one on
+            const int left = nTotS[kk] - at / nS;          // sparse sites from this batch's first one on
             const int nav = std::min(std::min(ns + 8, left), s->B + 8);
-            HIPCHK(hipMemcpy2DAsync(s->cols_stage, (size_t)wpc * 4, orig + (size_t)(done + kk) * wpc, (size_t)nS * wpc * 4, (size_t)wpc * 4, (size_t)nav,
+            HIPCHK(hipMemcpy2DAsync(s->cols_stage, (size_t)wpc * 4, orig + (size_t)(at + kk) * wpc, (size_t)nS * wpc * 4, (size_t)wpc * 4, (size_t)nav,
                                     hipMemcpyDeviceToDevice, s->stream));
             CHK(pbwtamd_pass_advance(s, s->cols_stage, wpc, ns, nav, PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES));
         }
+        return 0;
+    };
+    if (N > 0) CHK(enqueue_chains(0));
+    for (int done = 0; done < N;) {
+        const int nb = std::min(Bd, N - done);
+        std::vector<QsView> &hviews = hviews_buf[hv_par]; hv_par ^= 1;
+        for (int kk = 0; kk < nS; ++kk) hviews[kk] = QsView{nullptr, nullptr, 0, 0, nullptr, nullptr, done / nS, nullptr};
+        lap(0);
         CHK(pbwtamd_sync(e));
         CHK(pbwtamd_sync(eq));
+        lap(1);
         const int *A = ringA(e, e->ring ^ 1), *D = ringD(e, e->ring ^ 1), *AQ = ringA(eq, eq->ring ^ 1);
-        dim3 g1(std::min(64, (wpc64 + WAVES - 1) / WAVES), nb);
-        hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, st, A, e->strideA, Mp, e->ycols, wpc64);
+        // the panel's sorted bit columns of this batch are the decoded input columns themselves (read side): a copy out of the
+        // staging buffer (the next batch's decode overwrites it) instead of a pass over the tags of A
+        HIPCHK(hipMemcpyAsync(e->ycols, e->cols_stage, (size_t)nb * wpc64 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipEventRecord(evCols, st));                  // the next batch's decode (chain stream) must not overwrite the staging buffer before this copy has read it
         hipLaunchKernelGGL(qs_rankdir_kernel, dim3(nb), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, wpc64, Mp, rankdir);
         hipLaunchKernelGGL(qs_unsort_kernel, dim3(std::min(qblocks, 64), nb), dim3(BLOCK), 0, st, AQ, eq->strideA, Mq, xq, invq);
         for (int kk = 0; kk < nS; ++kk) {
@@ -1621,37 +1649,60 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
             dim3 gs(std::min(64, (wpc64 + WAVES - 1) / WAVES), ns);
             hipLaunchKernelGGL(tags_to_bits_kernel, gs, dim3(BLOCK), 0, st, As, s->strideA, Mp, ycS[kk], wpc64);
             hipLaunchKernelGGL(qs_rankdir_kernel, dim3(ns), dim3(BLOCK), 0, st, (const unsigned long long *)ycS[kk], wpc64, Mp, rdS[kk]);
-            hviews[kk] = QsView{As, Ds, s->strideA, s->strideD, ycS[kk], rdS[kk], done / nS};
+            HIPCHK(hipMemcpyAsync(a0S[kk], As, sizeof(int) * (size_t)Mp, hipMemcpyDeviceToDevice, st));
+            hviews[kk] = QsView{As, Ds, s->strideA, s->strideD, ycS[kk], rdS[kk], done / nS, a0S[kk]};
         }
         if (nS) HIPCHK(hipMemcpyAsync(dviews, hviews.data(), sizeof(QsView) * (size_t)nS, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * 2 * (size_t)nb * Mq, st));
         QssArgs g;
-        g.dense = QsView{A, D, e->strideA, e->strideD, e->ycols, rankdir, 0}; g.sparse = dviews; g.wpc64 = wpc64; g.nS = nS;
+        HIPCHK(hipMemcpyAsync(a0P, A, sizeof(int) * (size_t)Mp, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(a0Q, AQ, sizeof(int) * (size_t)Mq, hipMemcpyDeviceToDevice, st));
+        g.dense = QsView{A, D, e->strideA, e->strideD, e->ycols, rankdir, 0, a0P}; g.sparse = dviews; g.wpc64 = wpc64; g.nS = nS;
         g.xq = xq; g.invq = invq; g.Mp = Mp; g.Mq = Mq; g.kbase = done; g.nsites = nb;
         g.f_in = fst[cur]; g.dq_in = dst[cur]; g.f_out = fst[cur ^ 1]; g.dq_out = dst[cur ^ 1];
         g.fs_in = fss[cur]; g.ds_in = dss[cur]; g.fs_out = fss[cur ^ 1]; g.ds_out = dss[cur ^ 1];
         g.cnt = cnt; g.recs = nullptr; g.tot = tot;
         g.nm_ev = nm_ev; g.nm_n = nm_n; g.nm_cap = NM_CAP; g.evt = evt;
-        hipLaunchKernelGGL((qss_sweep_kernel<0>), dim3(qwaves), dim3(BLOCK), 0, st, g);
+        // a wave lives for the whole batch here (one query, site after site): at full occupancy the next batch's chain kernels,
+        // enqueued below to run beside it, would find no wave slot until it ends.  26 KB of (unused) dynamic LDS per workgroup
+        // holds the sweep to 6 of the 8 wave slots per SIMD.
+        static const int qs_lds_kb = getenv("PBWTAMD_QS_LDS") ? atoi(getenv("PBWTAMD_QS_LDS")) : 26;
+        hipLaunchKernelGGL((qss_sweep_kernel<0>), dim3(qwaves), dim3(BLOCK), (size_t)qs_lds_kb * 1024, st, g);
         scan_u64(st, cnt, 2 * (size_t)nb * Mq, tot + 3, bsum);
         HIPCHK(hipGetLastError());
-        unsigned long long total = 0;
-        HIPCHK(hipMemcpyAsync(&total, tot + 3, sizeof total, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpyAsync(h_total, tot + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));   // read back before the next batch's fill queues on this stream
+        HIPCHK(hipEventRecord(evTotal, st));
+        {   // this batch's rings are read by the kernels just enqueued on `st`: the next batch's chains wait for them
+            auto mark = [&](pbwtamd_engine *x) -> int { const int r = x->ring ^ 1; HIPCHK(hipEventRecord(x->evCons[r], st)); x->consRecorded[r] = true; return 0; };
+            CHK(mark(e)); CHK(mark(eq));
+            for (int kk = 0; kk < nS; ++kk) if (hviews[kk].A) CHK(mark(es[kk]));
+        }
+        if (done + nb < N) {                                 // runs beside the sweep; ring pointers of THIS batch were taken above
+            HIPCHK(hipStreamWaitEvent(e->stream, evCols, 0));
+            CHK(enqueue_chains(done + nb));
+            CHK(flush_pending(e)); CHK(flush_pending(eq));      // their fills queue behind the sweep on the consumer stream instead of waiting for the next sync
+            for (int kk = 0; kk < nS; ++kk) CHK(flush_pending(es[kk]));
+        }
+        lap(2);
+        HIPCHK(hipEventSynchronize(evTotal));
+        const unsigned long long total = *h_total;
+        lap(3);
         if (total) {
             CHK(ensure_recs((size_t)total));
             QssEmitArgs em;                                 // expand the event descriptors of the counting pass (the walks are not repeated)
             em.off = cnt; em.total = tot + 3; em.evt = evt; em.nslots = 2 * (size_t)nb * Mq;
             em.dense = g.dense; em.sparse = dviews; em.nS = std::max(nS, 1);
-            em.AQ = AQ; em.strideAQ = eq->strideA; em.Mq = Mq; em.kbase = done; em.recs = recs;
+            em.AQ = AQ; em.strideAQ = eq->strideA; em.AQ0 = a0Q; em.Mq = Mq; em.kbase = done; em.recs = recs;
             const size_t ewaves = (em.nslots + 63) / 64;
             hipLaunchKernelGGL(qss_emit_kernel, dim3((unsigned)((ewaves + WAVES - 1) / WAVES)), dim3(BLOCK), 0, st, em);
             HIPCHK(hipGetLastError());
             CHK(deliver((size_t)total));
         }
+        lap(4);
         cur ^= 1;
         done += nb;
     }
+    if (trace_qs) fprintf(stderr, "pbwt_amd query sweep host phases (s): enqueue chains %.4f  wait chains+fill %.4f  enqueue sweep %.4f  wait count %.4f  emit+deliver %.4f\n", tph[0], tph[1], tph[2], tph[3], tph[4]);
     // ---- matches still open at N: the panel cursor for every query, then each sparse cursor in turn (pbwtMatch.c:577-594) ----
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipStreamSynchronize(eq->stream));

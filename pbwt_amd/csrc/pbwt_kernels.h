@@ -2245,7 +2245,12 @@ __global__ __launch_bounds__(NT) void pack3v2_kernel(const unsigned long long *y
     }
     if (MODE == 0) { if (threadIdx.x == 0) colBytes[col] = (unsigned long long)total; return; }
     // ---- pass B: emit.  The run open at the region's start now has a known start (openW).
-    uint8_t *obase = out + colBytes[col] + baseB;
+    // Scattered single-byte stores to HBM are slow (partial-sector writes): a column of up to P3_STAGE bytes — all but iid-like
+    // columns of wide panels — is assembled in LDS and copied out with consecutive lanes writing consecutive bytes.
+    constexpr int P3_STAGE = 32768;
+    __shared__ uint8_t s_stage[MODE == 1 ? P3_STAGE : 1];
+    const bool staged = total <= P3_STAGE;
+    uint8_t *obase = (staged ? s_stage : out + colBytes[col]) + baseB;
     // (a rolled loop over freshly reloaded, L2-hot words: keeping all IT words live through the emission code spills registers)
     carryT = openW; prevHi = hi0;
     int done = 0;                                            // bytes emitted so far by this wave
@@ -2284,6 +2289,11 @@ __global__ __launch_bounds__(NT) void pack3v2_kernel(const unsigned long long *y
         done += __builtin_amdgcn_readlane(incB, 63);
         const int wl = __builtin_amdgcn_readlane(inc, 63) - 1;
         if (wl >= 0) carryT = wl;
+    }
+    if (staged) {
+        __syncthreads();
+        uint8_t *dst = out + colBytes[col];
+        for (int x = threadIdx.x; x < total; x += NT) dst[x] = s_stage[x];
     }
 }
 
@@ -2442,6 +2452,8 @@ struct QsView {                                              // one cursor's sta
     const int *A; const int *D; size_t strideA, strideD;
     const unsigned long long *ycols; const int *rankdir;    // sorted bit columns, zero-prefix directory [slot][wpc64+1]
     int sbase;                                               // sparse cursors: index of the cursor's first step in this batch
+    const int *A0;                                           // a copy of the batch's FIRST a[] row for the emission pass: the next batch's chain, which runs
+                                                             // beside it, ends by writing its own first state into that ring slot
 };
 struct QssArgs {
     QsView dense; const QsView *sparse;                      // sparse[nS] in device memory
@@ -2471,13 +2483,21 @@ __device__ __forceinline__ void qss_update(const int *a, const int *d, const uns
 #define PY(i) ((unsigned)((yc[(i) >> 6] >> ((i) & 63)) & 1ULL))
     if (PY(f) == x) return;
     // downward scan from `from` while d <= thr: the first position that either fails the test (or is M) or carries x
+    // (256 positions per trip to memory: the four 64-position sub-steps' loads are issued together, then tested in order — a query
+    // whose allele is rare around its match walks thousands of positions here, one dependent round trip per step)
     auto scan_down = [&](int from, int thr, bool &found) -> int {
-        for (int base = from;; base += 64) {
-            const int i = base + lane;
-            const bool bound = (i >= M) || (d[i] > thr);
-            const bool same = !bound && PY(i) == x;
-            const unsigned long long mb = __ballot(bound), ms = __ballot(same), any = mb | ms;
-            if (any) { const int first = __ffsll((long long)any) - 1; found = (ms >> first) & 1ULL; return base + first; }
+        for (int base = from;; base += 256) {
+            int dv[4]; unsigned long long yw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int i = base + 64 * q + lane; dv[q] = (i < M) ? d[i] : 0x7fffffff; yw[q] = (i < M) ? yc[i >> 6] : 0ULL; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = base + 64 * q + lane;
+                const bool bound = dv[q] > thr;
+                const bool same = !bound && (unsigned)((yw[q] >> (i & 63)) & 1ULL) == x;
+                const unsigned long long mb = __ballot(bound), ms = __ballot(same), any = mb | ms;
+                if (any) { const int first = __ffsll((long long)any) - 1; found = (ms >> first) & 1ULL; return base + 64 * q + first; }
+            }
         }
     };
     bool found = false;
@@ -2497,15 +2517,21 @@ __device__ __forceinline__ void qss_update(const int *a, const int *d, const uns
         if (dMinus <= dPlus) {
             // while (d[iMinus] <= dMinus) if (y[--iMinus] == x) hit = iMinus;   d[0] = kend+1 stops it; the LOWEST hit counts
             int hit = -1;
-            for (int base = iMinus;; base -= 64) {
-                const int j = base - lane;
-                const bool stop = (j < 0) || (d[j] > dMinus);
-                const unsigned long long mstop = __ballot(stop);
-                const int nlive = mstop ? __ffsll((long long)mstop) - 1 : 64;     // lanes 0..nlive-1 passed the test: candidates j-1
-                const bool cand = (lane < nlive) && (j - 1 >= 0) && PY(j - 1) == x;
-                const unsigned long long mc = __ballot(cand);
-                if (mc) hit = base - (63 - __clzll(mc)) - 1;                       // highest lane = lowest index
-                if (mstop) { iMinus = base - nlive; break; }
+            for (int base4 = iMinus, go = 1; go; base4 -= 256) {
+                int dv[4]; unsigned long long yw[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int j = base4 - 64 * q - lane; dv[q] = (j >= 0) ? d[j] : 0x7fffffff; yw[q] = (j - 1 >= 0) ? yc[(j - 1) >> 6] : 0ULL; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!go) continue;
+                    const int base = base4 - 64 * q, j = base - lane;
+                    const unsigned long long mstop = __ballot(dv[q] > dMinus);
+                    const int nlive = mstop ? __ffsll((long long)mstop) - 1 : 64;     // lanes 0..nlive-1 passed the test: candidates j-1
+                    const bool cand = (lane < nlive) && (j - 1 >= 0) && (unsigned)((yw[q] >> ((j - 1) & 63)) & 1ULL) == x;
+                    const unsigned long long mc = __ballot(cand);
+                    if (mc) hit = base - (63 - __clzll(mc)) - 1;                       // highest lane = lowest index
+                    if (mstop) { iMinus = base - nlive; go = 0; }
+                }
             }
             if (hit >= 0) { f = hit; dq = dMinus; return; }
             dMinus = d[iMinus];
@@ -2606,7 +2632,7 @@ struct QssEmitArgs {
     const unsigned long long *off; const unsigned long long *total;   // exclusive offsets per slot (scan of the counts), their total
     const int2 *evt; size_t nslots;
     QsView dense; const QsView *sparse; int nS;
-    const int *AQ; size_t strideAQ;                              // query cursor: position r of site s holds the query index
+    const int *AQ; size_t strideAQ; const int *AQ0;              // query cursor: position r of site s holds the query index (AQ0: copy of row 0, see QsView::A0)
     int Mq, kbase;
     Rec5 *recs;
 };
@@ -2626,10 +2652,10 @@ __global__ __launch_bounds__(BLOCK) void qss_emit_kernel(QssEmitArgs g) {
         const int2 ev = g.evt[sl];
         const int sparse = (int)(sl & 1), r = (int)((sl >> 1) % (size_t)g.Mq), s = (int)((sl >> 1) / (size_t)g.Mq);
         const int k = g.kbase + s;
-        const int jj = g.AQ[(size_t)s * g.strideAQ + r] & AMASK;
+        const int jj = (s ? g.AQ[(size_t)s * g.strideAQ + r] : g.AQ0[r]) & AMASK;
         const int *a;
-        if (sparse) { const QsView v = g.sparse[k % g.nS]; a = v.A + (size_t)(k / g.nS - v.sbase) * v.strideA; }
-        else a = g.dense.A + (size_t)s * g.dense.strideA;
+        if (sparse) { const QsView v = g.sparse[k % g.nS]; const int t = k / g.nS - v.sbase; a = t ? v.A + (size_t)t * v.strideA : v.A0; }
+        else a = s ? g.dense.A + (size_t)s * g.dense.strideA : g.dense.A0;
         for (int i = lane; i < cntN; i += 64) { Rec5 rr; rr.ai = jj; rr.bi = a[ev.x + i] & AMASK; rr.start = ev.y; rr.end = k; rr.sparse = sparse; g.recs[o0 + i] = rr; }
     }
 }

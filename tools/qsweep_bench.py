@@ -17,8 +17,8 @@ def pack(h):
 ep = amd.Engine(M, batch_sites=512); eq = amd.Engine(Mq, batch_sites=512)
 pz = ep.build(pack(hap[:, :M]), with_d=False)["yz"]; qz = eq.build(pack(hap[:, M:]), with_d=False)["yz"]
 for rep in range(2):
-    t0 = time.perf_counter()
+    t0 = time.perf_counter(); tc0 = time.process_time()
     recs, nom, tot = ep.match_sweep(pz, N, qz, Mq)
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0; print("host cpu time %.3f s of %.3f wall" % (time.process_time() - tc0, dt))
     print("matchDynamic %d x %d queries x %d sites: %.1f ms = %.2f us/site, %d records, %.3e panel site*haps/s" % (M, Mq, N, 1e3 * dt, 1e6 * dt / N, len(recs), M * N / dt))
 np.savez("/tmp/qsweep_case.npz", pz=pz, qz=qz) if os.path.isdir("/tmp") and os.environ.get("QS_SAVE") else None
