@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/profile_round.sh <tag> — rocprofv3 evidence for one round, written under gpurun_out/<tag>/
-# (kernel-trace stats and the two PMC passes are separate runs, as the pool requires)
-tag=${1:-r01}
+# (kernel-trace stats and the PMC passes are separate runs, as the pool requires)
+tag=${1:-r02}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -12,5 +12,13 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o 
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_sq -o bench -- $BENCH > $out/pmc_sq.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/calib_fetch -o calib -- ./tools/pmc_calib > $out/calib_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/calib_write -o calib -- ./tools/pmc_calib > $out/calib_write.log 2>&1
-find $out -name "*.csv" | head -20
+# the north-star width (1 M haplotypes), same option set: kernel stats, traffic and SQ counters of chain + consumers
+WIDE="python tools/wide_bench.py 1000000 2048 hp"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/wide_trace -o wide -- $WIDE > $out/wide_trace.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/wide_fetch -o wide -- $WIDE > $out/wide_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/wide_write -o wide -- $WIDE > $out/wide_write.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/wide_sq -o wide -- $WIDE > $out/wide_sq.log 2>&1
+# -matchDynamic, 10 000 queries against 1 M haplotypes
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/qs_trace -o qs -- python tools/qsweep_bench.py 1000000 10000 4096 > $out/qs_trace.log 2>&1
+find $out -name "*.csv" | head -40
 du -sh $out

@@ -1,14 +1,27 @@
-"""Condense gpurun_out/<tag>/ (tools/profile_round.sh) into profiles/<tag>_*.  Usage: summarize_profile.py r01"""
+"""Condense gpurun_out/<tag>/ (tools/profile_round.sh) into profiles/<tag>_*.  Usage: summarize_profile.py r02"""
 import collections
 import csv
+import json
 import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
-shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join("profiles", tag + "_kernel_stats.csv"))
+
+
+def copy_stats(sub, stem, dst):
+    p = os.path.join(src, sub, stem + "_kernel_stats.csv")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join("profiles", dst))
+        return True
+    return False
+
+
+copy_stats("trace", "bench", tag + "_kernel_stats.csv")                 # bench.py --steps 2 --warmup 1 (configs[2] width)
+copy_stats("wide_trace", "wide", tag + "_wide_kernel_stats.csv")        # tools/wide_bench.py 1000000 2048 hp (north-star width)
+copy_stats("qs_trace", "qs", tag + "_matchdynamic_kernel_stats.csv")    # tools/qsweep_bench.py 1000000 10000 4096
 
 
 def agg(path):
@@ -19,63 +32,87 @@ def agg(path):
 
 
 rows = []
-for name in ("calib_fetch/calib", "calib_write/calib", "pmc_fetch/bench", "pmc_write/bench", "pmc_sq/bench"):
-    if not os.path.exists(os.path.join(src, name + "_counter_collection.csv")):
+for name in ("calib_fetch/calib", "calib_write/calib", "pmc_fetch/bench", "pmc_write/bench", "pmc_sq/bench", "wide_fetch/wide", "wide_write/wide", "wide_sq/wide"):
+    p = os.path.join(src, name + "_counter_collection.csv")
+    if not os.path.exists(p):
         continue
-    for (k, c), v in sorted(agg(os.path.join(src, name + "_counter_collection.csv")).items(), key=lambda kv: -sum(kv[1])):
+    for (k, c), v in sorted(agg(p).items(), key=lambda kv: -sum(kv[1])):
         rows.append((name.split("/")[0], k, c, len(v), sum(v) / len(v)))
 with open(os.path.join("profiles", tag + "_pmc_summary.csv"), "w") as f:
-    f.write("pass,kernel,counter,dispatches,mean_value_KiB\n")
+    f.write("pass,kernel,counter,dispatches,mean_value\n")
     for r in rows:
         f.write('%s,"%s",%s,%d,%.3f\n' % r)
-# calibration factors: known bytes / reported
 cal = {}
 for p, k, c, n, m in rows:
     if k.startswith("calib_copy4"):
-        cal[c] = (256 << 20) * 4 / 1024.0 / m
-import json
-CHAIN = ("void pbwtk::skel_hist_kernel", "void pbwtk::skel_k2_kernel", "void pbwtk::skel_rank_kernel")
+        cal[c] = (256 << 20) * 4 / 1024.0 / m                      # known bytes (1 GiB copy, 4 B/lane) / reported KiB
+cf, cw = cal.get("FETCH_SIZE", 2.0), cal.get("WRITE_SIZE", 1.0)
+CHAIN = ("skel_hist_kernel", "skel_k2_kernel", "skel_k2_wide_kernel", "skel_rank_kernel")
+CONS = ("skel_fill_kernel", "sweep_hist_kernel", "pack3v2_kernel", "transpose32_kernel")
 
 
-def chain_counter(counter, passname):
-    """mean per dispatch of each chain kernel (hist, k2, rank) for one counter"""
+def counters(passname, counter, names):
     out = {}
     for p, k, c, n, m in rows:
         if p == passname and c == counter:
-            for ck in CHAIN:
-                if k.startswith(ck):
-                    out[ck.split("::")[1]] = m
+            for nm in names:
+                if ("::" + nm) in k:
+                    out[nm] = out.get(nm, 0.0) + m * n          # total over the dispatches of the run
+                    out[nm + "#n"] = out.get(nm + "#n", 0) + n
     return out
 
 
-fetch_k, write_k = chain_counter("FETCH_SIZE", "pmc_fetch"), chain_counter("WRITE_SIZE", "pmc_write")
-print("calibration (true/reported): ", cal)
-cf, cw = cal.get("FETCH_SIZE", 1), cal.get("WRITE_SIZE", 1)
-per_round = sum(fetch_k.values()) * cf * 1024 + sum(write_k.values()) * cw * 1024
-per_launch = per_round / max(len(fetch_k), 1)
 with open(os.path.join("profiles", tag + "_traffic.txt"), "w") as f:
     f.write("rocprofv3 PMC, separate passes (FETCH_SIZE, WRITE_SIZE), units KiB; calibration on tools/pmc_calib.hip\n")
-    f.write("(1 GiB copy with 4 B/lane coalesced accesses): true/reported = %s\n" % cal)
-    f.write("skeleton chain, one round = 8 sites = %d launches (M = 100000):\n" % len(fetch_k))
-    for kname in fetch_k:
-        f.write("  %-20s FETCH_SIZE %9.1f KiB x %.3f   WRITE_SIZE %9.1f KiB x %.3f\n" % (kname, fetch_k[kname], cf, write_k.get(kname, 0), cw))
-    f.write("=> %.0f bytes HBM-side traffic per round, %.0f per launch (algorithmic: 16.125 B x M x 8 sites = %.0f per round)\n"
-            % (per_round, per_launch, 16.125 * 100000 * 8))
-print(open(os.path.join("profiles", tag + "_traffic.txt")).read())
-json.dump({"100000": {"with_d": True, "kernel": "skeleton chain (skel_hist/k2/rank), mean over the launches of a round",
-                      "bytes_per_launch": int(per_launch),
-                      "source": "profiles/%s_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x%.1f per the calibration kernel tools/pmc_calib.hip)" % (tag, cf)}},
-          open(os.path.join("profiles", "traffic.json"), "w"), indent=1)
-sq_rows = [(k, c, m) for p, k, c, n, m in rows if p == "pmc_sq" and any(k.startswith(ck) for ck in CHAIN)]
-if sq_rows:
-    with open(os.path.join("profiles", tag + "_sq.txt"), "w") as f:
-        f.write("rocprofv3 PMC (SQ block), chain kernels, mean per dispatch:\n")
-        for ck in CHAIN:
-            sq = {c: m for k, c, m in sq_rows if k.startswith(ck)}
-            if not sq.get("SQ_WAVES"):
+    f.write("(1 GiB copy with 4 B/lane coalesced accesses): true/reported = %s  (FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md says)\n\n" % cal)
+    result = {}
+    for label, fp, wp, M, sites in (("configs[2] width, bench.py --steps 2 --warmup 1 (M = 100000, 3 x 8192 sites)", "pmc_fetch", "pmc_write", 100000, 3 * 8192),
+                                    ("north-star width, tools/wide_bench.py (M = 1000000, 512 + 2048 sites)", "wide_fetch", "wide_write", 1000000, 2560)):
+        fe, wr = counters(fp, "FETCH_SIZE", CHAIN + CONS), counters(wp, "WRITE_SIZE", CHAIN + CONS)
+        if not fe:
+            continue
+        f.write(label + "\n")
+        tot = 0.0
+        chain_bytes, chain_launches = 0.0, 0
+        for nm in CHAIN + CONS:
+            if nm not in fe:
                 continue
-            w = sq["SQ_WAVES"]
-            f.write("%s: waves %.0f; per wave: VALU %.0f  SALU %.0f  LDS %.0f instructions; wave-cycles (quad-cycle units) %.0f, of which waiting %.0f (%.0f%%), issuing %.0f\n"
-                    % (ck.split("::")[1], w, sq.get("SQ_INSTS_VALU", 0) / w, sq.get("SQ_INSTS_SALU", 0) / w, sq.get("SQ_INSTS_LDS", 0) / w, sq.get("SQ_WAVE_CYCLES", 0) / w,
+            b = (fe[nm] * cf + wr.get(nm, 0.0) * cw) * 1024
+            tot += b
+            if nm in CHAIN:
+                chain_bytes += b; chain_launches += fe[nm + "#n"]
+            f.write("  %-22s %6d dispatches  fetch %12.0f KiB x %.2f  write %12.0f KiB x %.2f  = %8.1f MB\n"
+                    % (nm, fe[nm + "#n"], fe[nm], cf, wr.get(nm, 0.0), cw, b / 1e6))
+        alg = 16.125 * M * sites
+        f.write("  => %.1f MB HBM-side traffic for %d sites = %.2f MB/site; algorithmic 16.125 B x M = %.2f MB/site: ratio %.2f\n"
+                % (tot / 1e6, sites, tot / 1e6 / sites, 16.125 * M / 1e6, tot / alg))
+        if chain_launches:
+            f.write("  chain: %.0f bytes per launch (%d launches)\n\n" % (chain_bytes / chain_launches, chain_launches))
+            result[str(M)] = {"with_d": True, "kernel": "skeleton chain (skel_hist/k2/rank), mean over the launches of a round",
+                              "bytes_per_launch": int(chain_bytes / chain_launches),
+                              "source": "profiles/%s_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x%.1f per the calibration kernel tools/pmc_calib.hip)" % (tag, cf)}
+    if result:
+        json.dump(result, open(os.path.join("profiles", "traffic.json"), "w"), indent=1)
+print(open(os.path.join("profiles", tag + "_traffic.txt")).read())
+
+with open(os.path.join("profiles", tag + "_sq.txt"), "w") as f:
+    f.write("rocprofv3 PMC (SQ block), mean per dispatch; wave-cycles in the counter's quad-cycle units\n")
+    for label, pn in (("configs[2] width (M = 100000)", "pmc_sq"), ("north-star width (M = 1000000)", "wide_sq")):
+        d = collections.defaultdict(dict)
+        for p, k, c, n, m in rows:
+            if p == pn:
+                d[k][c] = m
+        if not d:
+            continue
+        f.write("\n" + label + "\n")
+        for k in sorted(d):
+            if not any(("::" + nm) in k for nm in CHAIN + CONS):
+                continue
+            sq = d[k]
+            w = sq.get("SQ_WAVES", 0)
+            if not w:
+                continue
+            f.write("%-64s waves %9.0f; per wave: VALU %6.0f SALU %6.0f LDS %5.0f; wave-cycles %8.0f, waiting %8.0f (%.0f%%), issuing %7.0f\n"
+                    % (k[:64], w, sq.get("SQ_INSTS_VALU", 0) / w, sq.get("SQ_INSTS_SALU", 0) / w, sq.get("SQ_INSTS_LDS", 0) / w, sq.get("SQ_WAVE_CYCLES", 0) / w,
                        sq.get("SQ_WAIT_ANY", 0) / w, 100.0 * sq.get("SQ_WAIT_ANY", 0) / max(sq.get("SQ_WAVE_CYCLES", 1), 1), sq.get("SQ_ACTIVE_INST_ANY", 0) / w))
-    print(open(os.path.join("profiles", tag + "_sq.txt")).read())
+print(open(os.path.join("profiles", tag + "_sq.txt")).read())
