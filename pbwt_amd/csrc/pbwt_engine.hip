@@ -649,7 +649,7 @@ static int flush_pending(pbwtamd_engine *e) {
 #endif
         f.pack_y = packed ? 1 : 0;
         dim3 grid(e->Wt, p.nb / 8);
-        const size_t dyn = 0;
+        static const size_t dyn = getenv("PBWTAMD_FILL_PAD_KB") ? (size_t)atoi(getenv("PBWTAMD_FILL_PAD_KB")) * 1024 : 0;   // occupancy probe (results unchanged)
 #define FILL(EP) do { if (packed) hipLaunchKernelGGL((skel_fill_kernel<EP, true>), grid, dim3(BLOCK), dyn, e->s2, f); \
                       else hipLaunchKernelGGL((skel_fill_kernel<EP, false>), grid, dim3(BLOCK), dyn, e->s2, f); } while (0)
         if (e->skEPT == 1) FILL(1); else if (e->skEPT == 2) FILL(2); else FILL(4);
@@ -698,7 +698,9 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
         const int nwg = (W + 31) / 32;
         e->k2epoch += (unsigned)nwg; kw.target = e->k2epoch;
         hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, e->stream, kw);
-        hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
+        static const bool rank_r4 = !(getenv("PBWTAMD_RANK_R4") && !atoi(getenv("PBWTAMD_RANK_R4")));
+        if (rank_r4) hipLaunchKernelGGL((skel_rank_kernel<EPT, 0, true>), dim3(W), dim3(BLOCK), 0, e->stream, g);    // more tiles than one round of the chip: occupancy counts
+        else hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         return;
     }
     Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = W;

@@ -939,13 +939,16 @@ __global__ __launch_bounds__(SKK) void skel_k2_wide_kernel(Sk2WArgs g) {
 // table: W coalesced 8-byte loads per thread, issued first and consumed last, behind the
 // ballot refinement and the sparse table.  TR == 0: before/carry/total come from skel_k2_kernel.
 constexpr int SKN_MAXW = 128;
-template <int EPT, int TR>
+// R4 (wide panels: more tiles than fit the chip at once): the range maxima come from a radix-4 sparse table (windows 1, 4, 16, 64,
+// 256; <= 4 reads per query instead of 2) — 10 KB instead of 18 at T = 512, 22 KB per workgroup instead of 30: 7 workgroups per
+// CU instead of 5, so the 1954 tiles of M = 1 M almost fit in one round (1792 resident) instead of needing two (1280).
+template <int EPT, int TR, bool R4 = false>
 __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
 #endif
     constexpr int T = BLOCK * EPT, NC = EPT * WAVES;        // positions per tile, 64-position chunks per tile
-    constexpr int NL = (EPT == 4) ? 10 : (EPT == 2) ? 9 : 8;   // sparse table levels: windows 1 .. T/2
+    constexpr int NL = R4 ? ((EPT == 1) ? 4 : 5) : ((EPT == 4) ? 10 : (EPT == 2) ? 9 : 8);   // sparse table levels: windows 1 .. T/2 (radix 2) or 1 .. 4^(NL-1) (radix 4)
     __shared__ short s_cnt[NC][SKK];                        // per chunk: count -> base (exclusive over chunks)
     __shared__ short s_lastp[NC][SKK];                      // per chunk: last local position of the key -> previous one before the chunk
     __shared__ int s_tbl[NL][T];                            // s_tbl[l][i] = max d over (i-2^l, i]
@@ -1009,8 +1012,18 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
         lds_barrier();
 #pragma unroll
         for (int r = 0; r < EPT; ++r) {
-            const int i = r * BLOCK + t, j = i - (1 << (l - 1));
-            s_tbl[l][i] = (j >= 0) ? max(s_tbl[l - 1][i], s_tbl[l - 1][j]) : s_tbl[l - 1][i];
+            const int i = r * BLOCK + t;
+            if (R4) {
+                const int wq = 1 << (2 * (l - 1));
+                int m = s_tbl[l - 1][i];
+                if (i - wq >= 0) m = max(m, s_tbl[l - 1][i - wq]);
+                if (i - 2 * wq >= 0) m = max(m, s_tbl[l - 1][i - 2 * wq]);
+                if (i - 3 * wq >= 0) m = max(m, s_tbl[l - 1][i - 3 * wq]);
+                s_tbl[l][i] = m;
+            } else {
+                const int j = i - (1 << (l - 1));
+                s_tbl[l][i] = (j >= 0) ? max(s_tbl[l - 1][i], s_tbl[l - 1][j]) : s_tbl[l - 1][i];
+            }
         }
     }
     if constexpr (TR > 0) {   // thread q = key: scan of the tiles (keys before this tile, carry = max d since the key's last earlier occurrence, total)
@@ -1040,8 +1053,15 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
         const int rank = s_cnt[c][ky] + rk[r];
         const int p = (pl[r] >= 0) ? pl[r] : s_lastp[c][ky];        // previous same-key position in the tile, or -1
         // range max of d over (p, l]  (p = -1: the whole prefix): two windows of 2^lv >= len/2
-        const int len = l - p, lv = min(31 - __clz(len), NL - 1);
-        const int rm = max(s_tbl[lv][l], s_tbl[lv][p + (1 << lv)]);
+        const int len = l - p;
+        int rm;
+        if (R4) {
+            const int lv = min((31 - __clz(len)) >> 1, NL - 1), wq = 1 << (2 * lv);
+            rm = max(max(s_tbl[lv][l], s_tbl[lv][p + wq]), max(s_tbl[lv][len > 2 * wq ? l - wq : l], s_tbl[lv][len > 3 * wq ? l - 2 * wq : l]));
+        } else {
+            const int lv = min(31 - __clz(len), NL - 1);
+            rm = max(s_tbl[lv][l], s_tbl[lv][p + (1 << lv)]);
+        }
         int dd;
         if (p >= 0) dd = rm;
         else if (s_carry[ky] >= 0) dd = max(s_carry[ky], rm);
@@ -1119,12 +1139,23 @@ struct SkFillArgs {
 template <int EPT, bool PACKY>
 __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     constexpr int T = BLOCK * EPT, NC = EPT * WAVES;
-    constexpr int NL = (EPT == 4) ? 10 : (EPT == 2) ? 9 : 8;
-    // heap layout: level j (keys of j bits) lives at [2^j, 2^(j+1)), the rank kernel's level 8 at [256, 512)
-    __shared__ short s_rawH[NC][2 * SKK], s_lastH[NC][2 * SKK];  // per chunk: count / last local position (-1) -> levels 1..7 become base / previous position (exclusive over the chunks)
-    __shared__ int s_tbl[NL][T];
+    // Range maxima of d_k through a RADIX-4 sparse table: level e holds max d over (i - 4^e, i], windows 1, 4, 16, 64 (, 256): a
+    // range of len positions is covered by <= 4 windows of the largest level with 4^e <= len (a radix-2 table answers with 2 reads
+    // but costs 18 KB at T = 512).  This kernel is occupancy-bound — measured: 2 instead of 4 workgroups per CU takes 1.73x
+    // as long — so LDS is what counts.  The per-chunk tables of the 8-bit keys are dead after the first fold step and the
+    // sparse-table levels >= 2 are born after it: they share storage.  26 KB at T = 512: 6 workgroups per CU (was 40 KB, 4).
+    constexpr int NL4 = (EPT == 1) ? 4 : 5;
+    // heap layout: level j (keys of j bits) lives at [2^j, 2^(j+1)); levels 1..7 in s_rawH / s_lastH, the rank kernel's level 8 in s_raw8 / s_last8
+    __shared__ short s_rawH[NC][SKK], s_lastH[NC][SKK];      // per chunk: count / last local position (-1) -> base / previous position (exclusive over the chunks)
+    constexpr int UBYTES = (2 * NC * SKK * 2 > (NL4 - 2) * T * 4) ? 2 * NC * SKK * 2 : (NL4 - 2) * T * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char s_u[UBYTES];
+    short (*const s_raw8)[SKK] = reinterpret_cast<short (*)[SKK]>(s_u);                      // until fold step 1
+    short (*const s_last8)[SKK] = reinterpret_cast<short (*)[SKK]>(s_u + NC * SKK * 2);
+    int (*const s_tblU)[T] = reinterpret_cast<int (*)[T]>(s_u);                              // sparse levels 2 .. NL4-1, from step 2 on
+    __shared__ int s_tbl01[2][T];                                                            // sparse levels 0, 1
+    auto TBL = [&](int lv) -> int * { return lv < 2 ? s_tbl01[lv] : s_tblU[lv - 2]; };
     __shared__ int s_bH[2 * SKK], s_cH[2 * SKK], s_tH[2 * SKK];
-    int *const s_GH = &s_bH[SKK], *const s_lowH = &s_cH[SKK];   // the level-8 halves are dead once level 7 is folded: 40 KB in all, 4 workgroups per CU
+    int *const s_GH = &s_bH[SKK], *const s_lowH = &s_cH[SKK];   // the level-8 halves are dead once level 7 is folded
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x, b = blockIdx.y;
     const int S = w * T, k = g.kbase + 8 * b;
     const int *a_in = g.A + (size_t)(8 * b) * g.strideA;
@@ -1138,12 +1169,12 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
         const bool valid = i < g.M;
         av[r] = PACKY ? 0 : (a_in[i] & AMASK); key[r] = valid ? (int)keys[i] : -1;
         const int dv = valid ? d_in[i] : 0;
-        s_tbl[0][l] = dv;
+        s_tbl01[0][l] = dv;
         if (PACKY && valid) d_in[i] = dv | (int)(((unsigned)key[r] & 1u) << 31);   // the skeleton slot itself, in the packed form of the other seven
     }
     { const int2 v = sv[(size_t)w * SKK + t]; s_bH[SKK + t] = v.x; s_cH[SKK + t] = v.y; s_tH[SKK + t] = reinterpret_cast<const int *>(sv + (size_t)g.W * SKK)[t]; }
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { s_rawH[c][SKK + t] = 0; s_lastH[c][SKK + t] = -1; }
+    for (int c = 0; c < NC; ++c) { s_raw8[c][t] = 0; s_last8[c][t] = -1; }
     lds_barrier();
     // ballot refinement bit by bit: after bit j-1 the mask of same-j-key lanes
     short rk[EPT][8], pl[EPT][8];                           // [.][j]: rank inside the chunk, previous same-j-key position in the chunk (-1)
@@ -1158,19 +1189,25 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
             same &= ((key[r] >> bb) & 1) ? bal : ~bal;
             const unsigned long long before = same & lt;
             if (bb < SKB - 1) { rk[r][bb + 1] = (short)__popcll(before); pl[r][bb + 1] = before ? (short)(c * 64 + (63 - __clzll(before))) : (short)-1; }
-            else if (key[r] >= 0 && !before) { s_rawH[c][SKK + key[r]] = (short)__popcll(same); s_lastH[c][SKK + key[r]] = (short)(c * 64 + (63 - __clzll(same))); }
+            else if (key[r] >= 0 && !before) { s_raw8[c][key[r]] = (short)__popcll(same); s_last8[c][key[r]] = (short)(c * 64 + (63 - __clzll(same))); }
         }
     }
-    // one barrier per step: sparse-table level l and, beside it, the fold of level 8-l out of level 9-l (bit 8-l folded away)
-    constexpr int NSTEP = (NL - 1 > SKB - 1) ? NL - 1 : SKB - 1;
+    // one barrier per step: sparse-table level l (radix 4: steps 1 .. NL4-1) and, beside it, the fold of level 8-l out of level 9-l
+    constexpr int NSTEP = SKB - 1;
 #pragma unroll
     for (int l = 1; l <= NSTEP; ++l) {
         lds_barrier();
-        if (l < NL) {
+        if (l < NL4) {
+            const int wq = 1 << (2 * (l - 1));              // window of the level below
+            const int *lo = TBL(l - 1); int *hi = TBL(l);
 #pragma unroll
             for (int r = 0; r < EPT; ++r) {
-                const int i = r * BLOCK + t, jn = i - (1 << (l - 1));
-                s_tbl[l][i] = (jn >= 0) ? max(s_tbl[l - 1][i], s_tbl[l - 1][jn]) : s_tbl[l - 1][i];
+                const int i = r * BLOCK + t;
+                int m = lo[i];
+                if (i - wq >= 0) m = max(m, lo[i - wq]);
+                if (i - 2 * wq >= 0) m = max(m, lo[i - 2 * wq]);
+                if (i - 3 * wq >= 0) m = max(m, lo[i - 3 * wq]);
+                hi[i] = m;                                  // windows are clipped at the tile's first position
             }
         }
         const int j = SKB - l;
@@ -1178,8 +1215,13 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
             const int K = 1 << j;
             for (int e = t; e < (NC << j); e += BLOCK) {
                 const int c = e >> j, kj = e & (K - 1);
-                s_rawH[c][K + kj] = (short)(s_rawH[c][2 * K + kj] + s_rawH[c][3 * K + kj]);
-                s_lastH[c][K + kj] = (short)max((int)s_lastH[c][2 * K + kj], (int)s_lastH[c][3 * K + kj]);
+                if (j == SKB - 1) {                          // out of the 8-bit keys' tables (their storage becomes sparse levels >= 2 after this step)
+                    s_rawH[c][K + kj] = (short)(s_raw8[c][kj] + s_raw8[c][K + kj]);
+                    s_lastH[c][K + kj] = (short)max((int)s_last8[c][kj], (int)s_last8[c][K + kj]);
+                } else {
+                    s_rawH[c][K + kj] = (short)(s_rawH[c][2 * K + kj] + s_rawH[c][3 * K + kj]);
+                    s_lastH[c][K + kj] = (short)max((int)s_lastH[c][2 * K + kj], (int)s_lastH[c][3 * K + kj]);
+                }
             }
             if (t < K) {
                 const int c0 = s_cH[2 * K + t], c1 = s_cH[3 * K + t];
@@ -1231,8 +1273,10 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
             const int l = r * BLOCK + t, c = r * 4 + wv, kj = key[r] & (K - 1), h = K + kj;
             const int rank = s_rawH[c][h] + rk[r][j];
             const int p = (pl[r][j] >= 0) ? pl[r][j] : s_lastH[c][h];
-            const int len = l - p, lv = min(31 - __clz(len), NL - 1);
-            const int rm = max(s_tbl[lv][l], s_tbl[lv][p + (1 << lv)]);
+            // max d over (p, l]: windows of 4^lv ending at l and at p + 4^lv, and two more in between when the range is longer than 2 / 3 windows
+            const int len = l - p, lv = min((31 - __clz(len)) >> 1, NL4 - 1), wq = 1 << (2 * lv);
+            const int *tb = TBL(lv);
+            const int rm = max(max(tb[l], tb[p + wq]), max(tb[len > 2 * wq ? l - wq : l], tb[len > 3 * wq ? l - 2 * wq : l]));
             int dd;
             if (p >= 0) dd = rm;
             else if (s_cH[h] >= 0) dd = max(s_cH[h], rm);
