@@ -1,7 +1,8 @@
 mkdir -p gpurun_out/p1m; cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_configs.py -x -q -m gpu 2>&1 | tail -3
 for i in 1 2; do
-echo "R4=1"; timeout 300 python tools/wide_bench.py 1000000 4096 none; timeout 300 python tools/wide_bench.py 1000000 4096 hp
-echo "R4=0"; PBWTAMD_RANK_R4=0 timeout 300 python tools/wide_bench.py 1000000 4096 none; PBWTAMD_RANK_R4=0 timeout 300 python tools/wide_bench.py 1000000 4096 hp
+echo base; timeout 300 python tools/wide_bench.py 100000 16384 hp
+echo "chain on 160-255"; PBWTAMD_CHAIN_CU_LO=160 timeout 300 python tools/wide_bench.py 100000 16384 hp
+echo "chain on 128-255, consumers 0-127"; PBWTAMD_CHAIN_CU_LO=128 PBWTAMD_S2_CUS=128 timeout 300 python tools/wide_bench.py 100000 16384 hp
+echo "chain on 192-255, consumers 0-191"; PBWTAMD_CHAIN_CU_LO=192 PBWTAMD_S2_CUS=192 timeout 300 python tools/wide_bench.py 100000 16384 hp
 done
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p1m/t2 -o w -- python tools/wide_bench.py 1000000 2048 none > gpurun_out/p1m/t2.log 2>&1; grep "skel_" gpurun_out/p1m/t2/w_kernel_stats.csv | cut -c1-150
+echo "chain-only masks"; timeout 300 python tools/wide_bench.py 100000 16384 none; PBWTAMD_CHAIN_CU_LO=160 timeout 300 python tools/wide_bench.py 100000 16384 none; PBWTAMD_CHAIN_CU_LO=192 timeout 300 python tools/wide_bench.py 100000 16384 none
