@@ -260,7 +260,7 @@ extern "C" int pbwtamd_sync(pbwtamd_engine *e) {
     HIPCHK(hipStreamSynchronize(e->s2));
     int err = 0;
     HIPCHK(hipMemcpy(&err, e->ctl + 2, sizeof(int), hipMemcpyDeviceToHost));
-    if (err) return fail("pbwtamd: device-side error flag %d (1=histogram range, 2/3=malformed packed column, 4=yz buffer overflow)", err);
+    if (err) return fail("pbwtamd: device-side error flag %d (1=histogram range, 2/3=malformed packed column, 4=yz buffer overflow, 5=tile scan of a wide panel timed out waiting for its workgroups)", err);
     return 0;
 }
 
@@ -694,7 +694,7 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
     }
     static const bool k2_wide = !(getenv("PBWTAMD_K2_WIDE") && !atoi(getenv("PBWTAMD_K2_WIDE")));
     if (W > 512 && W <= 64 * 32 && k2_wide) {              // two-level scan in one launch: <= 64 co-resident workgroups of 32 tiles
-        Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = W; kw.agg = e->k2agg; kw.counter = e->k2cnt;
+        Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = W; kw.agg = e->k2agg; kw.counter = e->k2cnt; kw.err = e->ctl + 2;
         const int nwg = (W + 31) / 32;
         e->k2epoch += (unsigned)nwg; kw.target = e->k2epoch;
         hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, e->stream, kw);

@@ -891,7 +891,7 @@ __global__ __launch_bounds__(KPW * 64) void skel_k2_kernel(Sk2Args g) {
 // All of them are resident at once (W / TPW <= 64 workgroups).  Cross-workgroup visibility: 8-byte agent-scope relaxed
 // atomics on both sides (write-through stores, L1-bypassing loads), `s_waitcnt vmcnt(0)` before the arrival — the
 // granule form of MI355X_MICROARCH.md "Workgroup dispatch ... inter-workgroup visibility".
-struct Sk2WArgs { const int2 *tbl; int2 *scan; int *total; int W; unsigned long long *agg; unsigned *counter; unsigned target; };
+struct Sk2WArgs { const int2 *tbl; int2 *scan; int *total; int W; unsigned long long *agg; unsigned *counter; unsigned target; int *err; };
 template <int TPW>
 __global__ __launch_bounds__(SKK) void skel_k2_wide_kernel(Sk2WArgs g) {
 #ifndef PBWT_NO_SETPRIO
@@ -912,7 +912,13 @@ __global__ __launch_bounds__(SKK) void skel_k2_wide_kernel(Sk2WArgs g) {
     __syncthreads();
     if (t == 0) {
         __hip_atomic_fetch_add(g.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((int)(__hip_atomic_load(g.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.target) < 0) __builtin_amdgcn_s_sleep(1);
+        // bounded wait (~1 s): if an earlier launch of this chain never ran, the arrivals it owes never come — flag it (device
+        // error 5, reported at the next pbwtamd_sync) instead of hanging the GPU
+        int spins = 0;
+        while ((int)(__hip_atomic_load(g.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 25)) { atomicExch(g.err, 5); break; }
+        }
     }
     __syncthreads();
     int ec = 0, et = 0;                                      // prefix over the workgroups before this one: every load in flight at once

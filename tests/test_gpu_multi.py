@@ -104,3 +104,47 @@ def test_restart_from_checkpoint(gpu_lib, orc):
     assert np.array_equal(head + e2.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
     with pytest.raises(amd.PbwtAmdError, match="sentinels"):
         e2.pass_begin(N, k0=k0, aInit=a); e2.pass_set_d(np.zeros(M + 1, np.int32))
+
+
+SHARD_WORKER = textwrap.dedent("""
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    import torch
+    from pbwt_amd import dist as pd
+    from pbwt_amd.sharded import sharded_step_AD, owner_ranges
+    import oracle
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))     # RCCL; one rank: the collectives run, on device tensors
+    rank, world = dist.get_rank(), dist.get_world_size()
+    M, N = 5000, 48
+    bits = oracle.synth_bitcols(M, N, seed=99, kind=0)
+    hap = torch.from_numpy(oracle.unpack_bitcols(bits, M).astype(np.int64)).cuda()
+    want = oracle.build_bitcols(bits, M, with_d=True, dump_sites=range(N + 1))
+    b = owner_ranges(M, world)
+    lo, hi = b[rank], b[rank + 1]
+    a = torch.arange(lo, hi, dtype=torch.int64, device="cuda")
+    d = torch.zeros(hi - lo, dtype=torch.int64, device="cuda")
+    if rank == 0: d[0] = 1
+    ok = True
+    for k in range(N):
+        a, d = sharded_step_AD(a, d, hap[k][a], k, M)
+        ok &= a.is_cuda and bool(np.array_equal(a.cpu().numpy(), want["a_dump"][k + 1][lo:hi])) and bool(np.array_equal(d.cpu().numpy(), want["d_dump"][k + 1][lo:hi]))
+    json.dump({"ok": bool(ok)}, open(os.path.join(os.environ["OUT_DIR"], "ps.json"), "w"))
+    pd.finish()
+""") % ROOT
+
+
+def test_position_sharded_step_on_device_tensors_over_rccl(tmp_path):
+    """pbwt_amd/sharded.py with DEVICE tensors and the RCCL backend ("nccl") on the GPU box: the same function the gloo tests
+    drive at world_size 2 and 3 on the CPU.  One rank here (the box has one GPU; RCCL refuses two ranks on one device), so the
+    all-gather and the all-to-all run degenerate but through RCCL, and every site's a/d equals the oracle's."""
+    script = tmp_path / "ps_worker.py"
+    script.write_text(SHARD_WORKER)
+    env = dict(os.environ, OUT_DIR=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert json.load(open(tmp_path / "ps.json"))["ok"]
