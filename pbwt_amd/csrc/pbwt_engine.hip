@@ -73,6 +73,7 @@ struct pbwtamd_engine {
     uint32_t *cols_stage = nullptr;         // (B+1) columns, for the host-buffer entry points
     unsigned long long *ycols = nullptr;    // (B+1) sorted bit columns (wpc64 words each)
     unsigned long long *colBytes = nullptr; // B+2
+    P3Region *p3regs = nullptr;             // (B+2) x regions per column: the region-parallel pack3 encoder's per-region results
     unsigned long long *blockCount = nullptr; size_t blockCountCap = 0;
     unsigned long long *scal = nullptr;     // [0]=record total of the batch  [1]=yz bytes so far
     unsigned long long *hist = nullptr; int histlen = 0;
@@ -124,6 +125,7 @@ extern "C" int pbwtamd_engine_wpc(const pbwtamd_engine *e) { return e->wpc; }
 extern "C" int pbwtamd_engine_batch(const pbwtamd_engine *e) { return e->B; }
 
 static int wpc_for(int M) { return ((M + 31) / 32 + 3) / 4 * 4; }
+static inline int p3_regions(int M) { return ((M + 63) / 64 + 63) / 64; }   // regions of 64 words per column (region-parallel pack3 encoder)
 
 extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (!e) return;
@@ -136,7 +138,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->rankdirS, (void *)e->skT, (void *)e->k2agg, (void *)e->k2cnt, e->cols_stage, e->ycols, e->colBytes,
+    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->rankdirS, (void *)e->skT, (void *)e->k2agg, (void *)e->k2cnt, e->cols_stage, e->ycols, e->colBytes, (void *)e->p3regs,
                     e->blockCount, e->scal, e->hist, e->hist_rep, e->csum, e->recs, e->yz};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -196,6 +198,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     ALLOC(e->cols_stage, 2 * (slots + 6) * e->wpc * sizeof(uint32_t));   // two halves of B+8 columns: batch + look-ahead, double-buffered by the host entry points
     ALLOC(e->ycols, slots * e->wpc64 * sizeof(unsigned long long));
     ALLOC(e->colBytes, (slots + 1) * sizeof(unsigned long long));
+    ALLOC(e->p3regs, slots * (size_t)p3_regions(M) * sizeof(P3Region));
     ALLOC(e->scal, 8 * sizeof(unsigned long long));
     ALLOC(e->hist_rep, (size_t)HIST_REP * HIST_LBINS * sizeof(unsigned long long));
     if (e->skel) {
@@ -541,12 +544,25 @@ __global__ void pack3_offsets_kernel(unsigned long long *colBytes, size_t n, con
     (void)acc;
 }
 // pack3v2_kernel<MODE, NT, IT>: NT/64 waves of 64*IT words each cover the column
+// region-parallel encoder (p3r_*): sizes of nsites columns into colBytes, then (after the caller's scan over the columns) the bytes
+static void launch_p3r_sizes(hipStream_t st, int nsites, const unsigned long long *ycols, int wpc64, int M, P3Region *regs, unsigned long long *colBytes) {
+    const int R = p3_regions(M);
+    hipLaunchKernelGGL((p3r_scan_kernel<1>), dim3((R + WAVES - 1) / WAVES, nsites), dim3(BLOCK), 0, st, ycols, wpc64, M, R, regs);
+    hipLaunchKernelGGL(p3r_combine_kernel, dim3((nsites + WAVES - 1) / WAVES), dim3(BLOCK), 0, st, M, R, 64, nsites, regs, colBytes);
+}
+static void launch_p3r_emit(hipStream_t st, int nsites, const unsigned long long *ycols, int wpc64, int M, const P3Region *regs, const unsigned long long *colOff, uint8_t *out) {
+    const int R = p3_regions(M);
+    hipLaunchKernelGGL((p3r_emit_kernel<1>), dim3((R + WAVES - 1) / WAVES, nsites), dim3(BLOCK), 0, st, ycols, wpc64, M, R, regs, colOff, out);
+}
+
 template <int MODE>
 static void launch_pack3v2(hipStream_t st, int nsites, const unsigned long long *ycols, int wpc64, int M, unsigned long long *colBytes, uint8_t *out) {
     const int nw = (M + 63) / 64;
 #define P3(NT, IT) hipLaunchKernelGGL((pack3v2_kernel<MODE, NT, IT>), dim3(nsites), dim3(NT), 0, st, ycols, wpc64, M, colBytes, out)
-    if (nw <= 256 * 2) P3(256, 2); else if (nw <= 256 * 8) P3(256, 8); else if (nw <= 1024 * 4) P3(1024, 4);
-    else if (nw <= 1024 * 16) P3(1024, 16); else P3(1024, 64);
+    // as many waves and as few 64-word iterations per wave as the column allows: a wave's iterations are a serial instruction
+    // stream with nothing to hide its latency behind (measured at M = 100 k: 4 waves x 8 iterations 32 + 91 us per batch)
+    if (nw <= 256) P3(256, 1); else if (nw <= 512) P3(256, 2); else if (nw <= 1024) P3(1024, 1); else if (nw <= 2048) P3(1024, 2);
+    else if (nw <= 4096) P3(1024, 4); else if (nw <= 8192) P3(1024, 8); else if (nw <= 16384) P3(1024, 16); else P3(1024, 64);
 #undef P3
 }
 
@@ -555,7 +571,9 @@ static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites
     if (!have_ycols) hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, st, A, e->strideA, e->M, e->ycols, e->wpc64);   // else: emitted by the maxWithin sweep
     const bool wide = e->wpc64 > 2048;                      // > 131072 haplotypes: 1024 threads per column
     static const bool old_pack3 = getenv("PBWTAMD_OLD_PACK3") != nullptr;   // the chunk-loop encoder (A/B runs)
-    if (!old_pack3) launch_pack3v2<0>(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
+    static const int p3_form = getenv("PBWTAMD_PACK3_FORM") ? atoi(getenv("PBWTAMD_PACK3_FORM")) : 3;   // 3 = region-parallel, 2 = one workgroup per column
+    if (!old_pack3 && p3_form == 3) launch_p3r_sizes(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->p3regs, e->colBytes);
+    else if (!old_pack3) launch_pack3v2<0>(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
     else if (wide) hipLaunchKernelGGL((pack3_kernel<0, 1024>), dim3(nsites), dim3(1024), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
     else hipLaunchKernelGGL((pack3_kernel<0>), dim3(nsites), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
     // exclusive offsets inside the batch; batch total -> scal[2]
@@ -581,7 +599,8 @@ static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites
     }
     hipLaunchKernelGGL(pack3_offsets_kernel, dim3((nsites + 255) / 256), dim3(256), 0, st, e->colBytes, (size_t)nsites, (const unsigned long long *)(e->scal + 1),
                        e->scal + 2, e->scal + 1, (unsigned long long)e->yzCap, e->ctl + 2);
-    if (!old_pack3) launch_pack3v2<1>(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
+    if (!old_pack3 && p3_form == 3) launch_p3r_emit(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->p3regs, e->colBytes, e->yz);
+    else if (!old_pack3) launch_pack3v2<1>(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
     else if (wide) hipLaunchKernelGGL((pack3_kernel<1, 1024>), dim3(nsites), dim3(1024), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
     else hipLaunchKernelGGL((pack3_kernel<1>), dim3(nsites), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
     hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->scal + 1, (const unsigned long long *)(e->scal + 2), (unsigned long long)e->yzCap, e->ctl + 2);
@@ -1408,14 +1427,14 @@ extern "C" int pbwtamd_pack3(pbwtamd_engine *e, const uint32_t *sorted_bitcols, 
     for (int done = 0; done < N; done += e->B) {
         const int nb = std::min(e->B, N - done);
         HIPCHK(hipMemcpyAsync(e->ycols, sorted_bitcols + (size_t)done * wpc, (size_t)nb * wpc * 4, hipMemcpyHostToDevice, e->stream));
-        launch_pack3v2<0>(e->stream, nb, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
+        launch_p3r_sizes(e->stream, nb, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->p3regs, e->colBytes);
         hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, e->stream, e->colBytes, (size_t)nb, e->scal + 2, 0ULL);
         HIPCHK(hipGetLastError());
         unsigned long long tot = 0;
         HIPCHK(hipMemcpyAsync(&tot, e->scal + 2, sizeof tot, hipMemcpyDeviceToHost, e->stream));
         HIPCHK(hipStreamSynchronize(e->stream));
         CHK(ensure_yz(e, e->stream, (size_t)tot + 16));
-        launch_pack3v2<1>(e->stream, nb, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
+        launch_p3r_emit(e->stream, nb, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->p3regs, e->colBytes, e->yz);
         HIPCHK(hipGetLastError());
         const size_t old = all.size();
         all.resize(old + tot);

@@ -2347,6 +2347,124 @@ __global__ __launch_bounds__(NT) void pack3v2_kernel(const unsigned long long *y
     }
 }
 
+// pack3 encode, region-parallel (three launches per batch of columns): a column is cut into REGIONS of 64*IT words, one wave
+// each, and no wave waits for another.
+//   p3r_scan_kernel    per region: first / last transition, bytes of the runs that start and end inside it
+//   p3r_combine_kernel per column (one wave): the run open at each region's start (max-scan over the regions' last transitions),
+//                      the regions' byte bases (sum-scan), the column's size
+//   p3r_emit_kernel    per region: emission at the column's offset + the region's base
+// pack3v2_kernel does the same inside one workgroup per column; its 16 waves x 16 serial iterations at M = 1 M are a latency
+// chain (0.27 ms per 512 columns) where this form runs 245 single-iteration waves per column.
+struct P3Region { int firstT, lastT, inner, pad; };           // after combine: {openW, baseB, -, -}
+
+template <int IT>
+__device__ __forceinline__ unsigned long long p3r_transitions(const unsigned long long (&cur)[IT], int i, int base, int lane, int M, int &prevHi) {
+    const int wd = base + i * 64 + lane;
+    const int hi = (int)(cur[i] >> 32);
+    const int ph = lane_shr1(hi, prevHi);                    // previous word's high half (lane 0: the last word before this iteration)
+    prevHi = __builtin_amdgcn_readlane(hi, 63);
+    unsigned long long tr = cur[i] ^ ((cur[i] << 1) | (unsigned long long)((unsigned)ph >> 31));
+    if (wd == 0) tr &= ~1ULL;                                // position 0 opens the first run, closes nothing
+    const int nbits = M - wd * 64;
+    if (nbits <= 0) tr = 0; else if (nbits < 64) tr &= (1ULL << nbits) - 1ULL;
+    return tr;
+}
+
+template <int IT>
+__global__ __launch_bounds__(BLOCK) void p3r_scan_kernel(const unsigned long long *ycols, int wpc64, int M, int R, P3Region *regs) {
+    const int col = blockIdx.y, reg = blockIdx.x * WAVES + wave_id(), lane = lane_id();
+    if (reg >= R) return;
+    const unsigned long long *y = ycols + (size_t)col * wpc64;
+    const int nw = (M + 63) / 64, base = reg * 64 * IT;
+    unsigned long long cur[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) { const int wd = base + i * 64 + lane; cur[i] = (wd < nw) ? y[wd] : 0ULL; }
+    int prevHi = (base > 0 && base <= nw) ? (int)(y[base - 1] >> 32) : 0;
+    int carryT = -1, firstT = -1, inner = 0;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int wd = base + i * 64 + lane;
+        unsigned long long tr = p3r_transitions<IT>(cur, i, base, lane, M, prevHi);
+        const int tl = tr ? wd * 64 + 63 - __clzll(tr) : -1, tf = tr ? wd * 64 + __ffsll((long long)tr) - 1 : -1;
+        const int inc = wave_iscan_max(tl + 1);             // 1 + last transition up to and including this lane (0 = none)
+        int st = max(lane_shr1(inc, 0) - 1, carryT);        // start of the run open at this word; -1 = it began before the region
+        int bytes = 0;
+        for (; tr; tr &= tr - 1) { const int pz = wd * 64 + __ffsll((long long)tr) - 1; if (st >= 0) bytes += p3_nbytes(pz - st); st = pz; }
+        inner += wave_sum(bytes);
+        const unsigned long long has = __ballot(tf >= 0);
+        if (has) {
+            if (firstT < 0) firstT = __builtin_amdgcn_readlane(tf, __ffsll((long long)has) - 1);
+            carryT = __builtin_amdgcn_readlane(inc, 63) - 1;
+        }
+    }
+    if (lane == 0) regs[(size_t)col * R + reg] = P3Region{firstT, carryT, inner, 0};
+}
+
+// one wave per column: lanes = regions, 64 at a time with carries
+__global__ __launch_bounds__(BLOCK) void p3r_combine_kernel(int M, int R, int words_per_region, int ncols, P3Region *regs, unsigned long long *colBytes) {
+    const int col = blockIdx.x * WAVES + wave_id(), lane = lane_id();
+    if (col >= ncols) return;
+    P3Region *rg = regs + (size_t)col * R;
+    const int nw = (M + 63) / 64;
+    int openCarry = 0, byteCarry = 0;                        // position 0 opens the first run
+    for (int r0 = 0; r0 < R; r0 += 64) {
+        const int r = r0 + lane;
+        const P3Region v = (r < R) ? rg[r] : P3Region{-1, -1, 0, 0};
+        const int inc = wave_iscan_max(v.lastT + 1);
+        const int prevLast = lane_shr1(inc, 0) - 1;          // last transition in the earlier regions of this group of 64, -1 = none
+        const int open = (prevLast >= 0) ? prevLast : openCarry;
+        const bool ownsLast = (r < R) && (r * words_per_region < nw) && ((r + 1) * words_per_region >= nw);
+        const int wb = (r < R) ? (v.firstT >= 0 ? p3_nbytes(v.firstT - open) : 0) + v.inner + (ownsLast ? p3_nbytes(M - (v.lastT >= 0 ? v.lastT : open)) : 0) : 0;
+        const int incB = wave_iscan_sum(wb);
+        if (r < R) rg[r] = P3Region{open, byteCarry + incB - wb, 0, 0};
+        const int lastAll = __builtin_amdgcn_readlane(inc, 63) - 1;
+        if (lastAll >= 0) openCarry = lastAll;
+        byteCarry += __builtin_amdgcn_readlane(incB, 63);
+    }
+    if (lane == 0) colBytes[col] = (unsigned long long)byteCarry;
+}
+
+template <int IT>
+__global__ __launch_bounds__(BLOCK) void p3r_emit_kernel(const unsigned long long *ycols, int wpc64, int M, int R, const P3Region *regs,
+                                                           const unsigned long long *colOff, uint8_t *out) {
+    const int col = blockIdx.y, reg = blockIdx.x * WAVES + wave_id(), lane = lane_id();
+    if (reg >= R) return;
+    const unsigned long long *y = ycols + (size_t)col * wpc64;
+    const int nw = (M + 63) / 64, base = reg * 64 * IT;
+    if (base >= nw) return;
+    unsigned long long cur[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) { const int wd = base + i * 64 + lane; cur[i] = (wd < nw) ? y[wd] : 0ULL; }
+    const P3Region rg = regs[(size_t)col * R + reg];
+    uint8_t *obase = out + colOff[col] + rg.lastT;           // .lastT holds the region's byte base after the combine
+    int prevHi = (base > 0) ? (int)(y[base - 1] >> 32) : 0;
+    int carryT = rg.firstT;                                  // .firstT holds the start of the run open at the region's start
+    int done = 0;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int wd = base + i * 64 + lane;
+        const int hiPrevIter = prevHi;
+        unsigned long long tr = p3r_transitions<IT>(cur, i, base, lane, M, prevHi);
+        const int tl = tr ? wd * 64 + 63 - __clzll(tr) : -1;
+        const int inc = wave_iscan_max(tl + 1);
+        int st = max(lane_shr1(inc, 0) - 1, carryT);
+        const bool lastWord = (wd == nw - 1);
+        int bytes = 0;
+        { int s2 = st; for (unsigned long long t2 = tr; t2; t2 &= t2 - 1) { const int pz = wd * 64 + __ffsll((long long)t2) - 1; bytes += p3_nbytes(pz - s2); s2 = pz; } if (lastWord) bytes += p3_nbytes(M - s2); }
+        const int incB = wave_iscan_sum(bytes);
+        const int ph = lane_shr1((int)(cur[i] >> 32), hiPrevIter);   // cross-lane: outside the divergent branch below
+        if (bytes) {
+            uint8_t *o = obase + done + incB - bytes;
+            unsigned v = (wd == 0) ? (unsigned)(cur[i] & 1ULL) : ((unsigned)ph >> 31);   // value of the run open at this word = the last bit before it
+            for (; tr; tr &= tr - 1) { const int pz = wd * 64 + __ffsll((long long)tr) - 1; o = p3_emit(o, v, pz - st); st = pz; v ^= 1u; }
+            if (lastWord) p3_emit(o, v, M - st);
+        }
+        done += __builtin_amdgcn_readlane(incB, 63);
+        const int wl = __builtin_amdgcn_readlane(inc, 63) - 1;
+        if (wl >= 0) carryT = wl;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // pack3 decode (unpack3, pbwtCore.c:279-305).
 __device__ __forceinline__ int p3_len(uint8_t b) {

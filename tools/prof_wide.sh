@@ -1,8 +1,6 @@
 mkdir -p gpurun_out/p1m; cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for i in 1 2; do
-echo base; timeout 300 python tools/wide_bench.py 100000 16384 hp
-echo "chain on 160-255"; PBWTAMD_CHAIN_CU_LO=160 timeout 300 python tools/wide_bench.py 100000 16384 hp
-echo "chain on 128-255, consumers 0-127"; PBWTAMD_CHAIN_CU_LO=128 PBWTAMD_S2_CUS=128 timeout 300 python tools/wide_bench.py 100000 16384 hp
-echo "chain on 192-255, consumers 0-191"; PBWTAMD_CHAIN_CU_LO=192 PBWTAMD_S2_CUS=192 timeout 300 python tools/wide_bench.py 100000 16384 hp
-done
-echo "chain-only masks"; timeout 300 python tools/wide_bench.py 100000 16384 none; PBWTAMD_CHAIN_CU_LO=160 timeout 300 python tools/wide_bench.py 100000 16384 none; PBWTAMD_CHAIN_CU_LO=192 timeout 300 python tools/wide_bench.py 100000 16384 none
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -3
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p1m/t3 -o w -- python tools/wide_bench.py 100000 8192 hp > gpurun_out/p1m/t3.log 2>&1; grep "us/site" gpurun_out/p1m/t3.log; grep "fill\|sweep_hist\|pack3\|p3r" gpurun_out/p1m/t3/w_kernel_stats.csv | cut -c1-150
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p1m/t2 -o w -- python tools/wide_bench.py 1000000 2048 hp > gpurun_out/p1m/t2.log 2>&1; grep "us/site" gpurun_out/p1m/t2.log; grep "pack3\|p3r" gpurun_out/p1m/t2/w_kernel_stats.csv | cut -c1-150
+timeout 300 python tools/wide_bench.py 100000 16384 hp
+timeout 300 python tools/wide_bench.py 1000000 4096 hp
