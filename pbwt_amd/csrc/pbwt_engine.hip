@@ -749,7 +749,7 @@ static int skel_prepare(pbwtamd_engine *e, int r, const uint32_t *cols, int nb, 
     } else {
         skel_transpose(e, e->stream, e->xTr[r], cols, nb, nvalid);
         if (!e->keys_ready[r])
-            hipLaunchKernelGGL(skel_keys_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, ringA(e, r), (const uint32_t *)e->xTr[r], 0, e->M, e->keysR[r]);
+            hipLaunchKernelGGL(skel_keys_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, ringA(e, r), (const unsigned char *)e->xTr[r], e->M, e->keysR[r]);
     }
     e->keys_ready[r] = false;
     HIPCHK(hipGetLastError());
@@ -778,7 +778,7 @@ static int skel_rounds(pbwtamd_engine *e, int r, const uint32_t *cols, bool sort
         int2 *sv = e->saveR[r] + (size_t)s8 * e->strideS;  // this round's per-key scan over the tiles, kept for the fill
         g.scan = sv; g.total = reinterpret_cast<int *>(sv + (size_t)W * SKK);
         g.has_next = (e->k_cur + site + 8 < e->n_total) && (site + 8 < nvalid);
-        g.xTnext = xT + (size_t)((site + 8) / 32) * e->strideX; g.shift_next = (site + 8) % 32;
+        g.kbnext = reinterpret_cast<const unsigned char *>(xT) + (size_t)((site + 8) / 8) * e->strideX;   // byte plane of sites site+8 .. site+15
         g.ycnext = sorted ? (const unsigned long long *)cols + (size_t)(site + 8) * e->wpc64 : nullptr;
         g.k = e->k_cur + site;
         if (e->skEPT == 1) launch_skel_round<1>(e, g, two); else if (e->skEPT == 2) launch_skel_round<2>(e, g, two); else launch_skel_round<4>(e, g, two);

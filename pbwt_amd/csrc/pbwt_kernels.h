@@ -739,10 +739,21 @@ __global__ __launch_bounds__(BLOCK) void transpose32_kernel(const uint32_t *cols
             r[k + j] ^= tt; r[k] ^= tt << j;
         }
     }
-    uint32_t (&o)[32] = r;
-    uint32_t *dst = xT + (size_t)blk * strideX + (size_t)wd * 32;
+    // four BYTE planes per 32-site block: plane 4 blk + q holds, per haplotype, the alleles of sites 32 blk + 8 q .. + 7 = the 8-bit
+    // key of one radix step.  A round gathers its next keys from ONE plane: Mpad bytes (1 MB at M = 1 M, L2-resident) instead of
+    // 4-byte words of a 4 MB array — the rank kernel's gather was 42 of its 61 MB of HBM-side traffic per launch at that width.
+    if (wd * 32 >= Mpad) return;
+    unsigned char *base = reinterpret_cast<unsigned char *>(xT) + (size_t)blk * 4 * strideX + (size_t)wd * 32;   // strideX = Mpad: bytes per plane
 #pragma unroll
-    for (int i = 0; i < 32; ++i) if (wd * 32 + i < Mpad) dst[i] = o[i];
+    for (int q = 0; q < 4; ++q) {
+        uint32_t pk[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            pk[j] = ((r[4 * j] >> (8 * q)) & 0xffu) | (((r[4 * j + 1] >> (8 * q)) & 0xffu) << 8) | (((r[4 * j + 2] >> (8 * q)) & 0xffu) << 16) | (((r[4 * j + 3] >> (8 * q)) & 0xffu) << 24);
+        uint4 *dst = reinterpret_cast<uint4 *>(base + (size_t)q * strideX);
+        dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+    }
 }
 
 // HIST (K1): per tile of T = 256*EPT positions — count the 8-bit keys, and the max of d_k after each
@@ -755,7 +766,7 @@ struct SkArgs {
     int *a_out; int *d_out; unsigned char *keys_out;
     int2 *tbl;                                                  // hist -> scan: [W][256] {count, tail}
     int2 *scan; int *total;                                     // scan -> rank (kept for the fill): [W][256] {keys before the tile, carry}, total[256]
-    const uint32_t *xTnext; int shift_next; int has_next;
+    const unsigned char *kbnext; int has_next;                  // byte plane of the NEXT round's keys by haplotype (transpose32_kernel)
     const unsigned long long *ycnext;                           // read side: sorted bit column of the OUTPUT state's site (tag by position); keys are precomputed
     int M, W, k;                                                // k = site of the input state
 };
@@ -985,7 +996,7 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
         const bool valid = S + l < g.M;
         av[r] &= AMASK; if (!valid) { dv[r] = 0; key[r] = -1; }
         s_tbl[0][l] = dv[r];
-        nk[r] = (g.has_next && valid && !g.ycnext) ? ((g.xTnext[av[r]] >> g.shift_next) & 0xffu) : 0u;   // next round's key (bit 0 = the output state's tag)
+        nk[r] = (g.has_next && valid && !g.ycnext) ? (unsigned)g.kbnext[av[r]] : 0u;   // next round's key (bit 0 = the output state's tag)
     }
     int rk[EPT], pl[EPT];
     const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
@@ -1118,9 +1129,9 @@ __global__ void skel_tag_sorted_kernel(int *a, const unsigned long long *yc, int
 }
 
 // keys (and tags) of a state from the transposed panel: start of a batch
-__global__ void skel_keys_kernel(int *a, const uint32_t *xT, int shift, int M, unsigned char *keys) {
+__global__ void skel_keys_kernel(int *a, const unsigned char *kb, int M, unsigned char *keys) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M) { const int v = a[i] & AMASK; const unsigned kk = (xT[v] >> shift) & 0xffu; a[i] = v | (int)((kk & 1u) << 31); keys[i] = (unsigned char)kk; }
+    if (i < M) { const int v = a[i] & AMASK; const unsigned kk = kb[v]; a[i] = v | (int)((kk & 1u) << 31); keys[i] = (unsigned char)kk; }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -31,7 +31,7 @@ static void run(int M, float p1, int reps) {
     SkArgs g;
     g.a = dA; g.d = dD; g.keys = dK; g.a_out = dA2; g.d_out = dD2; g.keys_out = dK2;
     g.tbl = (int2 *)tab; g.scan = (int2 *)tab + (size_t)(Wp + 8) * SKK; g.total = tab + (size_t)5 * (Wp + 8) * SKK;
-    g.xTnext = dX; g.shift_next = 8; g.has_next = 1; g.M = M; g.W = W; g.k = 100;
+    g.kbnext = (const unsigned char *)dX; g.has_next = 1; g.M = M; g.W = W; g.k = 100;
     Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = W;
     hipStream_t s;
     if (getenv("KB_PRIO")) { int lo, hi; CK(hipDeviceGetStreamPriorityRange(&lo, &hi)); CK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, atoi(getenv("KB_PRIO")) ? hi : 0)); printf("stream: nonblocking, prio %s\n", getenv("KB_PRIO")); }
@@ -69,7 +69,7 @@ static void run(int M, float p1, int reps) {
             SkArgs h = g;
             h.a = rA + (size_t)slot * Mpad; h.d = rD + (size_t)slot * (Mpad + 64); h.keys = rK + (size_t)slot * Mpad;
             h.a_out = rA + (size_t)(slot + 1) * Mpad; h.d_out = rD + (size_t)(slot + 1) * (Mpad + 64); h.keys_out = rK + (size_t)(slot + 1) * Mpad;
-            h.shift_next = (slot % 4) * 8;
+            h.kbnext = (const unsigned char *)dX + (size_t)(slot % 4) * 4096;
             hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, s, h); k2l(); hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, s, h);
             slot = (slot + 1) % NS;
             if (slot == 0) { CK(hipMemcpyAsync(rA, rA + (size_t)NS * Mpad, Mpad * 4, hipMemcpyDeviceToDevice, s)); CK(hipMemcpyAsync(rD, rD + (size_t)NS * (Mpad + 64), (Mpad + 64) * 4, hipMemcpyDeviceToDevice, s)); CK(hipMemcpyAsync(rK, rK + (size_t)NS * Mpad, Mpad, hipMemcpyDeviceToDevice, s)); }
@@ -82,7 +82,7 @@ static void run(int M, float p1, int reps) {
             SkArgs h = g;
             h.a = rA + (size_t)sl * Mpad; h.d = rD + (size_t)sl * (Mpad + 64); h.keys = rK + (size_t)sl * Mpad;
             h.a_out = rA + (size_t)(sl + 1) * Mpad; h.d_out = rD + (size_t)(sl + 1) * (Mpad + 64); h.keys_out = rK + (size_t)(sl + 1) * Mpad;
-            h.shift_next = (sl % 4) * 8;
+            h.kbnext = (const unsigned char *)dX + (size_t)(sl % 4) * 4096;
             hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, s, h); k2l(); hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, s, h);
         }
         CK(hipMemcpyAsync(rA, rA + (size_t)NS * Mpad, Mpad * 4, hipMemcpyDeviceToDevice, s)); CK(hipMemcpyAsync(rD, rD + (size_t)NS * (Mpad + 64), (Mpad + 64) * 4, hipMemcpyDeviceToDevice, s)); CK(hipMemcpyAsync(rK, rK + (size_t)NS * Mpad, Mpad, hipMemcpyDeviceToDevice, s));
