@@ -202,7 +202,10 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     ALLOC(e->scal, 8 * sizeof(unsigned long long));
     ALLOC(e->hist_rep, (size_t)HIST_REP * HIST_LBINS * sizeof(unsigned long long));
     if (e->skel) {
-        e->skEPT = (M <= 40000) ? 1 : 2;                       // measured: smaller tiles = shorter per-workgroup latency chains, and the fill fits 4 workgroups per CU (T = 1024: 2)
+        // measured: smaller tiles = shorter per-workgroup latency chains while the chain is alone on the critical path; from ~250 k
+        // haplotypes on, where the consumers weigh as much as the chain, half as many workgroups of 1024 positions win end to end
+        // (1 M: 7.25 -> 6.78 us/site, 600 k: 5.03 -> 4.82, 300 k: 3.35 -> 3.29) although the chain alone is 3 % slower
+        e->skEPT = (M <= 40000) ? 1 : (M <= 250000) ? 2 : 4;
         if (const char *sv = getenv("PBWTAMD_SKT")) e->skEPT = (atoi(sv) == 256) ? 1 : (atoi(sv) == 512) ? 2 : 4;
 
         if (M > 256 * e->skEPT * 2048) e->skEPT = 4;           // skel_k2_kernel scans at most 2048 tiles per key
