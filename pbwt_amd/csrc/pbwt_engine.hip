@@ -202,10 +202,10 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     ALLOC(e->scal, 8 * sizeof(unsigned long long));
     ALLOC(e->hist_rep, (size_t)HIST_REP * HIST_LBINS * sizeof(unsigned long long));
     if (e->skel) {
-        // measured: smaller tiles = shorter per-workgroup latency chains while the chain is alone on the critical path; from ~250 k
-        // haplotypes on, where the consumers weigh as much as the chain, half as many workgroups of 1024 positions win end to end
-        // (1 M: 7.25 -> 6.78 us/site, 600 k: 5.03 -> 4.82, 300 k: 3.35 -> 3.29) although the chain alone is 3 % slower
-        e->skEPT = (M <= 40000) ? 1 : (M <= 250000) ? 2 : 4;
+        // measured: smaller tiles = shorter per-workgroup latency chains, and every chain workgroup must fit into the hole a retiring
+        // consumer workgroup leaves on a CU (LDS is allocated contiguously: a 41 KB rank workgroup of 1024 positions starves beside
+        // 26 KB fill workgroups).  1 M, T = 512 vs 1024: 6.25 vs 6.84 us/site; 500 k: 3.99 vs 4.32
+        e->skEPT = (M <= 40000) ? 1 : 2;
         if (const char *sv = getenv("PBWTAMD_SKT")) e->skEPT = (atoi(sv) == 256) ? 1 : (atoi(sv) == 512) ? 2 : 4;
 
         if (M > 256 * e->skEPT * 2048) e->skEPT = 4;           // skel_k2_kernel scans at most 2048 tiles per key
@@ -645,6 +645,9 @@ static int ensure_prepared(pbwtamd_engine *e, const uint32_t *col, bool sorted, 
     return 0;
 }
 
+// XCD-contiguous tile placement (xcd_tile): bit 0 fill, bit 1 rank, bit 2 hist.  Measured at M = 100 k: 1.600 -> 1.539 us/site.
+static int xcd_flags() { static const int v = getenv("PBWTAMD_XCD") ? atoi(getenv("PBWTAMD_XCD")) : 7; return v; }
+
 // batch consumers (checksums, maxWithin sweep, pack3) of the pending batch, on the second stream so
 // they overlap the next batch's launch chain (which occupies only ~W of the 256 CUs)
 static int flush_pending(pbwtamd_engine *e) {
@@ -670,6 +673,7 @@ static int flush_pending(pbwtamd_engine *e) {
         static const int dbg_nowrite = getenv("PBWTAMD_DEBUG_FILL_NOWRITE") ? 1 : 0; f.dbg_nowrite = dbg_nowrite;
 #endif
         f.pack_y = packed ? 1 : 0;
+        f.xcd = xcd_flags() & 1;
         dim3 grid(e->Wt, p.nb / 8);
         static const size_t dyn = getenv("PBWTAMD_FILL_PAD_KB") ? (size_t)atoi(getenv("PBWTAMD_FILL_PAD_KB")) * 1024 : 0;   // occupancy probe (results unchanged)
 #define FILL(EP) do { if (packed) hipLaunchKernelGGL((skel_fill_kernel<EP, true>), grid, dim3(BLOCK), dyn, e->s2, f); \
@@ -719,7 +723,9 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
         Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = W; kw.agg = e->k2agg; kw.counter = e->k2cnt; kw.err = e->ctl + 2;
         const int nwg = (W + 31) / 32;
         e->k2epoch += (unsigned)nwg; kw.target = e->k2epoch;
-        hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, e->stream, kw);
+        static const bool k2_light = !(getenv("PBWTAMD_K2_LIGHT") && !atoi(getenv("PBWTAMD_K2_LIGHT")));
+        if (k2_light) hipLaunchKernelGGL((skel_k2_wide_kernel<32, true>), dim3(nwg), dim3(SKK), 0, e->stream, kw);
+        else hipLaunchKernelGGL((skel_k2_wide_kernel<32, false>), dim3(nwg), dim3(SKK), 0, e->stream, kw);
         static const bool rank_r4 = !(getenv("PBWTAMD_RANK_R4") && !atoi(getenv("PBWTAMD_RANK_R4")));
         if (rank_r4) hipLaunchKernelGGL((skel_rank_kernel<EPT, 0, true>), dim3(W), dim3(BLOCK), 0, e->stream, g);    // more tiles than one round of the chip: occupancy counts
         else hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
@@ -770,7 +776,7 @@ static int skel_rounds(pbwtamd_engine *e, int r, const uint32_t *cols, bool sort
     const bool two = skel_two_launch(e);
     SkArgs g;
     g.tbl = (int2 *)e->skT;
-    g.M = e->M; g.W = W;
+    g.M = e->M; g.W = W; g.xcd = xcd_flags();
     for (int s8 = s_from; s8 < s_to; ++s8) {
         const int site = 8 * s8;                           // relative to the batch
         const bool last = direct && s8 == nb / 8 - 1;
@@ -844,8 +850,8 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
             e->xT = e->xTr[r];
             CHK(skel_prepare(e, r, bc, nb, left, sorted));
             // the other stream's work is enqueued once all but the last round of this batch are (measured: better than right away)
-            static const bool early_flush = getenv("PBWTAMD_EARLY_FLUSH") != nullptr;
-            const int nr = nb / 8, head = early_flush ? std::min(4, nr - 1) : nr - 1;
+            static const int flush_at = getenv("PBWTAMD_FLUSH_AT") ? atoi(getenv("PBWTAMD_FLUSH_AT")) : -1;   // rounds enqueued before the consumers (-1: all but the last)
+            const int nr = nb / 8, head = (flush_at >= 0) ? std::min(flush_at, nr - 1) : nr - 1;
             CHK(skel_rounds(e, r, bc, sorted, nb, left, 0, head, true));
             // consumers of the PREVIOUS batch (other ring) are enqueued now, beside this batch's chain
             CHK(flush_pending(e));

@@ -761,6 +761,14 @@ __global__ __launch_bounds__(BLOCK) void transpose32_kernel(const uint32_t *cols
 // kernel of the previous round scattered them), so this reads 1 + 4 bytes per position.  Threads own
 // positions in REVERSE blocked order so that a forward scan over threads is a suffix scan over
 // positions.  Output: tbl[tile][key] {count, tail}.
+// Workgroups are dealt to the 8 XCDs round-robin by linear id (observed: block b runs on XCD b % 8) and every XCD has its own
+// L2.  xcd_tile gives XCD x a CONTIGUOUS range of logical tiles, so that neighbouring tiles — which write neighbouring
+// destinations of the same bucket — complete their 64-B lines in one L2 instead of eight.  Placement is for speed only.
+__device__ __forceinline__ int xcd_tile(int lin, int n) {
+    const int q = n >> 3, r = n & 7, x = lin & 7, idx = lin >> 3;
+    return x * q + min(x, r) + idx;
+}
+
 struct SkArgs {
     const int *a; const int *d; const unsigned char *keys;     // input state and its 8-bit keys
     int *a_out; int *d_out; unsigned char *keys_out;
@@ -769,6 +777,7 @@ struct SkArgs {
     const unsigned char *kbnext; int has_next;                  // byte plane of the NEXT round's keys by haplotype (transpose32_kernel)
     const unsigned long long *ycnext;                           // read side: sorted bit column of the OUTPUT state's site (tag by position); keys are precomputed
     int M, W, k;                                                // k = site of the input state
+    int xcd;                                                    // bit 1: rank, bit 2: hist — XCD-contiguous tiles (xcd_tile)
 };
 
 template <int EPT>
@@ -780,7 +789,7 @@ __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
     __shared__ int h_cnt[SKK], h_last[SKK];
     __shared__ int s_suf[T];
     __shared__ int s_w[WAVES];
-    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x;
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = (g.xcd & 4) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
     const int rb = BLOCK - 1 - t;
     const int l0 = rb * EPT, i0 = w * T + l0;
     unsigned packed;
@@ -903,21 +912,40 @@ __global__ __launch_bounds__(KPW * 64) void skel_k2_kernel(Sk2Args g) {
 // atomics on both sides (write-through stores, L1-bypassing loads), `s_waitcnt vmcnt(0)` before the arrival — the
 // granule form of MI355X_MICROARCH.md "Workgroup dispatch ... inter-workgroup visibility".
 struct Sk2WArgs { const int2 *tbl; int2 *scan; int *total; int W; unsigned long long *agg; unsigned *counter; unsigned target; int *err; };
-template <int TPW>
+// LIGHT (default): 16 rows / 32 aggregates in flight per lane and the rows read a second time (from L2) for the output pass,
+// instead of 32 rows + 64 aggregates held in 200 VGPRs.  A 200-VGPR wave fits on no SIMD while a consumer kernel is at full
+// occupancy (sweep: 8 waves x 56 VGPRs, fill: 6 x 56), and the 56 registers a retiring consumer workgroup frees go to the next
+// consumer workgroup: measured (rocprofv3 trace), the scan launch then waited for the END of the fill, 1.1-1.4 ms, and the chain
+// stood still beside fill + sweep.  This form (44 VGPRs, no LDS) fits into the slot any retiring consumer workgroup leaves:
+// 9.3 us alone instead of 8.0, 14 us beside the fill instead of 185; end to end at 1 M with 512-position tiles 7.25 -> 6.25 us/site.
+template <int TPW, bool LIGHT>
 __global__ __launch_bounds__(SKK) void skel_k2_wide_kernel(Sk2WArgs g) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
     const int t = threadIdx.x, j = blockIdx.x, w0 = j * TPW;
-    int c[TPW], tl[TPW];
-#pragma unroll
-    for (int x = 0; x < TPW; ++x) {
-        const int2 v = (w0 + x < g.W) ? g.tbl[(size_t)(w0 + x) * SKK + t] : make_int2(0, 0);
-        c[x] = v.x; tl[x] = v.y;
-    }
+    constexpr int CH = LIGHT ? 16 : TPW;                     // rows in flight
+    constexpr int PCH = LIGHT ? 32 : 64;                     // aggregates in flight
+    int c[LIGHT ? 1 : TPW], tl[LIGHT ? 1 : TPW];
     int ac = 0, at = 0;                                      // this workgroup's aggregate for key t
+    if constexpr (LIGHT) {
+#pragma unroll 1
+        for (int x0 = 0; x0 < TPW; x0 += CH) {
+            int2 v[CH];
 #pragma unroll
-    for (int x = 0; x < TPW; ++x) { at = c[x] ? tl[x] : max(at, tl[x]); ac += c[x]; }
+            for (int x = 0; x < CH; ++x) v[x] = (w0 + x0 + x < g.W) ? g.tbl[(size_t)(w0 + x0 + x) * SKK + t] : make_int2(0, 0);
+#pragma unroll
+            for (int x = 0; x < CH; ++x) { at = v[x].x ? v[x].y : max(at, v[x].y); ac += v[x].x; }
+        }
+    } else {
+#pragma unroll
+        for (int x = 0; x < TPW; ++x) {
+            const int2 v = (w0 + x < g.W) ? g.tbl[(size_t)(w0 + x) * SKK + t] : make_int2(0, 0);
+            c[x] = v.x; tl[x] = v.y;
+        }
+#pragma unroll
+        for (int x = 0; x < TPW; ++x) { at = c[x] ? tl[x] : max(at, tl[x]); ac += c[x]; }
+    }
     __hip_atomic_store(g.agg + (size_t)j * SKK + t, ((unsigned long long)(unsigned)at << 32) | (unsigned)ac, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -932,19 +960,36 @@ __global__ __launch_bounds__(SKK) void skel_k2_wide_kernel(Sk2WArgs g) {
         }
     }
     __syncthreads();
-    int ec = 0, et = 0;                                      // prefix over the workgroups before this one: every load in flight at once
-    unsigned long long pv[64];
+    int ec = 0, et = 0;                                      // prefix over the workgroups before this one, PCH loads in flight at once
+#pragma unroll 1
+    for (int i0 = 0; i0 < (LIGHT ? j : 1); i0 += PCH) {
+        unsigned long long pv[PCH];
 #pragma unroll
-    for (int i = 0; i < 64; ++i) pv[i] = (i < j) ? __hip_atomic_load(g.agg + (size_t)i * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+        for (int i = 0; i < PCH; ++i) pv[i] = (i0 + i < j) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-        const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32);     // beyond j: (0, 0), the identity
-        et = vc ? vt : max(et, vt); ec += vc;
+        for (int i = 0; i < PCH; ++i) {
+            const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32);     // beyond j: (0, 0), the identity
+            et = vc ? vt : max(et, vt); ec += vc;
+        }
     }
+    if constexpr (LIGHT) {
+#pragma unroll 1
+        for (int x0 = 0; x0 < TPW; x0 += CH) {
+            int2 v[CH];
 #pragma unroll
-    for (int x = 0; x < TPW; ++x) {
-        if (w0 + x < g.W) g.scan[(size_t)(w0 + x) * SKK + t] = make_int2(ec, ec ? et : -1);
-        et = c[x] ? tl[x] : max(et, tl[x]); ec += c[x];
+            for (int x = 0; x < CH; ++x) v[x] = (w0 + x0 + x < g.W) ? g.tbl[(size_t)(w0 + x0 + x) * SKK + t] : make_int2(0, 0);
+#pragma unroll
+            for (int x = 0; x < CH; ++x) {
+                if (w0 + x0 + x < g.W) g.scan[(size_t)(w0 + x0 + x) * SKK + t] = make_int2(ec, ec ? et : -1);
+                et = v[x].x ? v[x].y : max(et, v[x].y); ec += v[x].x;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int x = 0; x < TPW; ++x) {
+            if (w0 + x < g.W) g.scan[(size_t)(w0 + x) * SKK + t] = make_int2(ec, ec ? et : -1);
+            et = c[x] ? tl[x] : max(et, tl[x]); ec += c[x];
+        }
     }
     if (j == (int)gridDim.x - 1) g.total[t] = ec;
 }
@@ -971,7 +1016,7 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
     __shared__ int s_tbl[NL][T];                            // s_tbl[l][i] = max d over (i-2^l, i]
     __shared__ int s_before[SKK], s_carry[SKK], s_G[SKK], s_lower[SKK];
     __shared__ int s_gw[WAVES], s_lw[WAVES];
-    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x;
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = (g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
     const int S = w * T;
     int av[EPT], dv[EPT], key[EPT];
     unsigned nk[EPT];
@@ -1150,6 +1195,7 @@ struct SkFillArgs {
     int dbg_nowrite;                                        // measurement builds only (results WRONG): no stores
 #endif
     int pack_y;                                             // write d | y << 31 only (no a): for consumers that need (d, y) but not the haplotype ids
+    int xcd;                                                // XCD-contiguous (round, tile) pairs (xcd_tile)
 };
 
 // PACKY: the consumers need (d, y) of every site but not the haplotype ids — a[] is neither read nor written
@@ -1173,7 +1219,9 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     auto TBL = [&](int lv) -> int * { return lv < 2 ? s_tbl01[lv] : s_tblU[lv - 2]; };
     __shared__ int s_bH[2 * SKK], s_cH[2 * SKK], s_tH[2 * SKK];
     int *const s_GH = &s_bH[SKK], *const s_lowH = &s_cH[SKK];   // the level-8 halves are dead once level 7 is folded
-    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = blockIdx.x, b = blockIdx.y;
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
+    int w = blockIdx.x, b = blockIdx.y;
+    if (g.xcd) { const int lg = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y); b = lg / g.W; w = lg - b * g.W; }
     const int S = w * T, k = g.kbase + 8 * b;
     const int *a_in = g.A + (size_t)(8 * b) * g.strideA;
     int *d_in = g.D + (size_t)(8 * b) * g.strideD;

@@ -1,4 +1,5 @@
 mkdir -p gpurun_out/p1m; cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_configs.py tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q -m gpu 2>&1 | tail -3
-echo "100k"; timeout 300 python tools/wide_bench.py 100000 16384 hp; PBWTAMD_SKT=1024 timeout 300 python tools/wide_bench.py 100000 16384 hp
-echo "200k"; timeout 300 python tools/wide_bench.py 200000 8192 hp; PBWTAMD_SKT=1024 timeout 300 python tools/wide_bench.py 200000 8192 hp
+for i in $(seq 1 4); do
+timeout 900 python -m pytest tests -x -q -s -m gpu > gpurun_out/p1m/loop.log 2>&1 || { echo "FAILED at iteration $i"; grep -v "^  File" gpurun_out/p1m/loop.log | cut -c1-400 | tail -40; cp gpurun_out/p1m/loop.log gpurun_out/p1m/loop_fail.log; break; }
+done
+echo "done $i"; tail -2 gpurun_out/p1m/loop.log
