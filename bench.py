@@ -83,7 +83,7 @@ def cpu_baseline(args, first_cols):
 def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=65536, batch=512, step=8192, want_hist=False):
     """the same hot path at the north-star width (1 M haplotypes) over `sites` sites, device-resident, with its own
     roofline object.  A secondary measurement (the headline `value` stays BASELINE configs[2]); its histogram total is
-    pinned to the oracle by tests/test_gpu_configs.py::test_bench_north_star_width_path (same function, a prefix)."""
+    pinned to the oracle by tests/test_gpu_z_configs.py::test_bench_north_star_width_path (same function, a prefix)."""
     eng = pbwt_amd.Engine(M, batch_sites=batch, device=dev.index)
     n_total = sites + batch
     panel = torch.empty((n_total, eng.wpc), dtype=torch.int32, device=dev)
@@ -129,7 +129,7 @@ def match_dynamic(torch, pbwt_amd, dev, kind, M=1000000, Q=10000, sites=8192, ba
     """configs[4]'s second half: `-matchDynamic` of a Q-haplotype query panel against an M-wide panel (pbwtamd_match_sweep,
     matchSequencesSweep pbwtMatch.c:363-443), host-buffer entry point: packed panels in, records out.  Panel and queries
     are the two parts of ONE synthetic panel (shared founders: matches run for many sites, as with real data).
-    Secondary measurement; the record stream at this shape is pinned to the oracle by tests/test_gpu_configs.py."""
+    Secondary measurement; the record stream at this shape is pinned to the oracle by tests/test_gpu_z_configs.py."""
     assert M % 32 == 0
     full = pbwt_amd.Engine(M + Q, batch_sites=batch, device=dev.index)
     cols = torch.empty((sites, full.wpc), dtype=torch.int32, device=dev)

@@ -13,6 +13,8 @@
 #include <ctime>
 #include <string>
 #include <vector>
+#include <unordered_map>
+#include <mutex>
 
 using namespace pbwtk;
 
@@ -32,14 +34,59 @@ static int fail(const char *fmt, ...) {
     } while (0)
 #define CHK(expr) do { int _r = (expr); if (_r) return _r; } while (0)
 
+
+// ------------------------------------------------------------------------------------ device memory
+// PBWTAMD_GUARD=1 (debugging): every device buffer is mapped through the virtual-memory API so that it ENDS (to within its 256-byte
+// alignment) at the end of its mapping with an unmapped granule behind it (=2: STARTS at the mapping's first byte, an unmapped
+// granule before it): an access past a buffer faults at once instead of reading a neighbour.  Off: plain hipMalloc / hipFree.
+struct GuardRec { void *va; size_t reserved; size_t mapped; void *mapAt; hipMemGenericAllocationHandle_t h; };
+static std::unordered_map<void *, GuardRec> g_guard;
+static std::mutex g_guard_mu;
+static int guard_mode() { static const int v = getenv("PBWTAMD_GUARD") ? atoi(getenv("PBWTAMD_GUARD")) : 0; return v; }
+static hipError_t dev_alloc(void **out, size_t n) {
+    // PBWTAMD_POISON=<byte> (debugging): fresh buffers are filled with that byte instead of whatever the allocator hands out
+    // (in practice zeros): a kernel that depends on memory it never wrote shows up in the parity tests
+    static const int poison = getenv("PBWTAMD_POISON") ? atoi(getenv("PBWTAMD_POISON")) : -1;
+    if (!guard_mode()) {
+        hipError_t r0 = hipMalloc(out, n);
+        if (r0 == hipSuccess && poison >= 0) { r0 = hipMemset(*out, poison, n); (void)hipDeviceSynchronize(); }   // (the null stream does not order with the engine's)
+        return r0;
+    }
+    int dev = 0; hipError_t r = hipGetDevice(&dev); if (r != hipSuccess) return r;
+    hipMemAllocationProp prop = {}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+    size_t gran = 0; r = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum); if (r != hipSuccess) return r;
+    n = std::max<size_t>(n, 1);
+    GuardRec g; g.mapped = (n + gran - 1) / gran * gran; g.reserved = g.mapped + 2 * gran;
+    r = hipMemAddressReserve(&g.va, g.reserved, gran, nullptr, 0); if (r != hipSuccess) return r;
+    g.mapAt = (char *)g.va + gran;
+    r = hipMemCreate(&g.h, g.mapped, &prop, 0); if (r != hipSuccess) return r;
+    r = hipMemMap(g.mapAt, g.mapped, 0, g.h, 0); if (r != hipSuccess) return r;
+    hipMemAccessDesc ad = {}; ad.location = prop.location; ad.flags = hipMemAccessFlagsProtReadWrite;
+    r = hipMemSetAccess(g.mapAt, g.mapped, &ad, 1); if (r != hipSuccess) return r;
+    const size_t back = (guard_mode() == 2) ? 0 : (g.mapped - (n + 255) / 256 * 256);
+    *out = (char *)g.mapAt + back;
+    if (poison >= 0) { r = hipMemset(g.mapAt, poison, g.mapped); (void)hipDeviceSynchronize(); if (r != hipSuccess) return r; }
+    std::lock_guard<std::mutex> lk(g_guard_mu); g_guard[*out] = g;
+    return hipSuccess;
+}
+static hipError_t dev_free(void *p) {
+    if (!p) return hipSuccess;
+    if (!guard_mode()) return hipFree(p);
+    GuardRec g;
+    { std::lock_guard<std::mutex> lk(g_guard_mu); auto it = g_guard.find(p); if (it == g_guard.end()) return hipFree(p); g = it->second; g_guard.erase(it); }
+    (void)hipDeviceSynchronize();
+    (void)hipMemUnmap(g.mapAt, g.mapped); (void)hipMemRelease(g.h);
+    return hipMemAddressFree(g.va, g.reserved);
+}
+
 // ------------------------------------------------------------------------------------ engine
 // small RAII holder for temporary device buffers
 struct DevBufs {
     std::vector<void *> v;
-    ~DevBufs() { for (void *p : v) if (p) (void)hipFree(p); }
+    ~DevBufs() { for (void *p : v) if (p) (void)dev_free(p); }
     template <typename T> int alloc(T **out, size_t n) {
         void *p = nullptr;
-        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return fail("hipMalloc(%zu) failed", n * sizeof(T));
+        if (dev_alloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return fail("hipMalloc(%zu) failed", n * sizeof(T));
         v.push_back(p); *out = (T *)p; return 0;
     }
 };
@@ -140,7 +187,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->rankdirS, (void *)e->skT, (void *)e->k2agg, (void *)e->k2cnt, e->cols_stage, e->ycols, e->colBytes, (void *)e->p3regs,
                     e->blockCount, e->scal, e->hist, e->hist_rep, e->csum, e->recs, e->yz};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) (void)dev_free(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -186,7 +233,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     e->strideA = (size_t)e->Mpad;
     e->strideD = (size_t)e->Mpad + 64;
     const size_t slots = (size_t)e->B + 2;
-#define ALLOC(ptr, bytes) do { hipError_t _e = hipMalloc((void **)&(ptr), (bytes)); if (_e != hipSuccess) { int r = fail("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(_e)); pbwtamd_engine_destroy(e); return r; } } while (0)
+#define ALLOC(ptr, bytes) do { hipError_t _e = dev_alloc((void **)&(ptr), (bytes)); if (_e != hipSuccess) { int r = fail("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(_e)); pbwtamd_engine_destroy(e); return r; } } while (0)
     ALLOC(e->A, 2 * slots * e->strideA * sizeof(int));
     ALLOC(e->D, 2 * slots * e->strideD * sizeof(int));
     ALLOC(e->summ, (size_t)3 * e->wpad * 3 * sizeof(int4));
@@ -389,15 +436,15 @@ extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k
     HIPCHK(hipMemsetAsync(e->scal, 0, 8 * sizeof(unsigned long long), e->stream));
     const int nsites = n_total - k0 + 1;
     if (nsites > e->csum_sites) {
-        if (e->csum) HIPCHK(hipFree(e->csum));
-        HIPCHK(hipMalloc((void **)&e->csum, (size_t)3 * nsites * sizeof(unsigned long long)));
+        if (e->csum) HIPCHK(dev_free(e->csum));
+        HIPCHK(dev_alloc((void **)&e->csum, (size_t)3 * nsites * sizeof(unsigned long long)));
         e->csum_sites = nsites;
     }
     HIPCHK(hipMemsetAsync(e->csum, 0, (size_t)3 * e->csum_sites * sizeof(unsigned long long), e->stream));
     const int hl = n_total + 2;
     if (hl > e->histlen) {
-        if (e->hist) HIPCHK(hipFree(e->hist));
-        HIPCHK(hipMalloc((void **)&e->hist, (size_t)hl * sizeof(unsigned long long)));
+        if (e->hist) HIPCHK(dev_free(e->hist));
+        HIPCHK(dev_alloc((void **)&e->hist, (size_t)hl * sizeof(unsigned long long)));
         e->histlen = hl;
     }
     HIPCHK(hipMemsetAsync(e->hist, 0, (size_t)e->histlen * sizeof(unsigned long long), e->stream));
@@ -410,8 +457,8 @@ extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k
 
 static int ensure_blockcount(pbwtamd_engine *e, size_t n) {
     if (n <= e->blockCountCap) return 0;
-    if (e->blockCount) HIPCHK(hipFree(e->blockCount));
-    HIPCHK(hipMalloc((void **)&e->blockCount, n * sizeof(unsigned long long)));
+    if (e->blockCount) HIPCHK(dev_free(e->blockCount));
+    HIPCHK(dev_alloc((void **)&e->blockCount, n * sizeof(unsigned long long)));
     e->blockCountCap = n;
     return 0;
 }
@@ -459,9 +506,9 @@ static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int
         HIPCHK(hipMemcpyAsync(&total, e->scal, sizeof total, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (total > e->recsCap) {
-            if (e->recs) HIPCHK(hipFree(e->recs));
+            if (e->recs) HIPCHK(dev_free(e->recs));
             e->recsCap = (size_t)(total + total / 4 + 1024);
-            HIPCHK(hipMalloc((void **)&e->recs, e->recsCap * sizeof(int4)));
+            HIPCHK(dev_alloc((void **)&e->recs, e->recsCap * sizeof(int4)));
         }
         if (total) {
             g.recs = e->recs;
@@ -499,9 +546,9 @@ static int run_long(pbwtamd_engine *e, hipStream_t st, const int *A, const int *
     HIPCHK(hipMemcpyAsync(&total, e->scal, sizeof total, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (total > e->recsCap) {
-        if (e->recs) HIPCHK(hipFree(e->recs));
+        if (e->recs) HIPCHK(dev_free(e->recs));
         e->recsCap = (size_t)(total + total / 4 + 1024);
-        HIPCHK(hipMalloc((void **)&e->recs, e->recsCap * sizeof(int4)));
+        HIPCHK(dev_alloc((void **)&e->recs, e->recsCap * sizeof(int4)));
     }
     if (total) {
         g.recs = e->recs;
@@ -524,11 +571,11 @@ static int run_long(pbwtamd_engine *e, hipStream_t st, const int *A, const int *
 static int ensure_yz(pbwtamd_engine *e, hipStream_t st, size_t cap) {
     if (cap <= e->yzCap) return 0;
     uint8_t *n = nullptr;
-    HIPCHK(hipMalloc((void **)&n, cap));
+    HIPCHK(dev_alloc((void **)&n, cap));
     if (e->yz) {
         HIPCHK(hipStreamSynchronize(st));
         HIPCHK(hipMemcpy(n, e->yz, e->yzCap, hipMemcpyDeviceToDevice));
-        HIPCHK(hipFree(e->yz));
+        HIPCHK(dev_free(e->yz));
     }
     e->yz = n; e->yzCap = cap;
     return 0;
@@ -692,7 +739,7 @@ static int flush_pending(pbwtamd_engine *e) {
     if (p.opts & PBWTAMD_OPT_LONG_RECS) {
         CHK(run_long(e, e->s2, A, D, nullptr, p.kbase, p.nb, -1));
         // keep the batch's last state (before site kbase+nb-1): it is the stale allele column if the panel ends here
-        if (!e->ystale) HIPCHK(hipMalloc((void **)&e->ystale, sizeof(int) * e->strideA));
+        if (!e->ystale) HIPCHK(dev_alloc((void **)&e->ystale, sizeof(int) * e->strideA));
         HIPCHK(hipMemcpyAsync(e->ystale, A + (size_t)(p.nb - 1) * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->s2));
     }
     static const bool no_fuse = getenv("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
@@ -1082,16 +1129,16 @@ extern "C" int pbwtamd_build(pbwtamd_engine *e, const uint32_t *bitcols, int wpc
 // decode state for packed panels on the device
 struct Packed {
     uint8_t *z = nullptr; long long *colStart = nullptr; unsigned long long *blockSum = nullptr;
-    ~Packed() { if (z) (void)hipFree(z); if (colStart) (void)hipFree(colStart); if (blockSum) (void)hipFree(blockSum); }
+    ~Packed() { if (z) (void)dev_free(z); if (colStart) (void)dev_free(colStart); if (blockSum) (void)dev_free(blockSum); }
 };
 
 static int packed_upload(pbwtamd_engine *e, hipStream_t st, int M, const uint8_t *yz, int64_t nz, int N, Packed &pk) {
     if (nz <= 0 && N > 0) return fail("pbwtamd: empty packed panel for N=%d", N);
-    HIPCHK(hipMalloc((void **)&pk.z, (size_t)std::max<int64_t>(nz, 1)));
+    HIPCHK(dev_alloc((void **)&pk.z, (size_t)std::max<int64_t>(nz, 1)));
     HIPCHK(hipMemcpyAsync(pk.z, yz, (size_t)nz, hipMemcpyHostToDevice, st));
     const size_t nblk = ((size_t)nz + DEC_CHUNK - 1) / DEC_CHUNK;
-    HIPCHK(hipMalloc((void **)&pk.blockSum, (nblk + 1) * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc((void **)&pk.colStart, ((size_t)N + 2) * sizeof(long long)));
+    HIPCHK(dev_alloc((void **)&pk.blockSum, (nblk + 1) * sizeof(unsigned long long)));
+    HIPCHK(dev_alloc((void **)&pk.colStart, ((size_t)N + 2) * sizeof(long long)));
     HIPCHK(hipMemsetAsync(pk.colStart, 0xff, ((size_t)N + 2) * sizeof(long long), st));
     if (nblk) {
         hipLaunchKernelGGL(dec_sum_kernel, dim3((unsigned)nblk), dim3(BLOCK), 0, st, (const uint8_t *)pk.z, (size_t)nz, pk.blockSum);

@@ -7,7 +7,9 @@ checksum on a second pass.
 configs[4] shape (1 000 000 haplotypes, build + -maxWithin + -matchDynamic with a 10 000-haplotype
 query panel): 512 sites, histogram + packed bytes + final state, the records of a window of sites,
 and the query sweep's records / no-match count / totals against the oracle.
-One M > 2^20 case (the wide fallback chain: step2_kernel / step_kernel with 2048-position tiles)."""
+One M > 2^20 case (the wide fallback chain: step2_kernel / step_kernel with 2048-position tiles).
+
+(File name: these tests allocate and free tens of GB; they sort after the rest of the -m gpu suite.)"""
 import numpy as np
 import pytest
 

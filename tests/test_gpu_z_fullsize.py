@@ -6,7 +6,7 @@ configs[2] scale (100k haplotypes): size-independent properties that tie indepen
 together — the build-side chain (two sites per launch, gather mode) and the read-side chain (one site
 per launch, sorted mode) must produce the same a/d at every site, decode(encode(panel)) == panel,
 a[] stays a permutation, the divergence sentinels hold.  (configs[2] and configs[4] against the oracle at their own
-width: tests/test_gpu_configs.py.)"""
+width: tests/test_gpu_z_configs.py.)"""
 import os
 
 import numpy as np
