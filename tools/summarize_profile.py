@@ -22,6 +22,9 @@ def copy_stats(sub, stem, dst):
 copy_stats("trace", "bench", tag + "_kernel_stats.csv")                 # bench.py --steps 2 --warmup 1 (configs[2] width)
 copy_stats("wide_trace", "wide", tag + "_wide_kernel_stats.csv")        # tools/wide_bench.py 1000000 2048 hp (north-star width)
 copy_stats("qs_trace", "qs", tag + "_matchdynamic_kernel_stats.csv")    # tools/qsweep_bench.py 1000000 10000 4096
+copy_stats("wide_alone", "wide", tag + "_wide_chain_alone_kernel_stats.csv")   # tools/wide_bench.py 1000000 4096 none
+if os.path.exists(os.path.join(src, "overlap.txt")):
+    shutil.copy(os.path.join(src, "overlap.txt"), os.path.join("profiles", tag + "_overlap.txt"))
 
 
 def agg(path):
@@ -48,7 +51,7 @@ for p, k, c, n, m in rows:
         cal[c] = (256 << 20) * 4 / 1024.0 / m                      # known bytes (1 GiB copy, 4 B/lane) / reported KiB
 cf, cw = cal.get("FETCH_SIZE", 2.0), cal.get("WRITE_SIZE", 1.0)
 CHAIN = ("skel_hist_kernel", "skel_k2_kernel", "skel_k2_wide_kernel", "skel_rank_kernel")
-CONS = ("skel_fill_kernel", "sweep_hist_kernel", "pack3v2_kernel", "transpose32_kernel")
+CONS = ("skel_fill_kernel", "sweep_hist_kernel", "p3r_scan_kernel", "p3r_combine_kernel", "p3r_emit_kernel", "transpose32_kernel")
 
 
 def counters(passname, counter, names):
