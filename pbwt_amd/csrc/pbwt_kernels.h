@@ -918,14 +918,15 @@ struct Sk2WArgs { const int2 *tbl; int2 *scan; int *total; int W; unsigned long 
 // consumer workgroup: measured (rocprofv3 trace), the scan launch then waited for the END of the fill, 1.1-1.4 ms, and the chain
 // stood still beside fill + sweep.  This form (44 VGPRs, no LDS) fits into the slot any retiring consumer workgroup leaves:
 // 9.3 us alone instead of 8.0, 14 us beside the fill instead of 185; end to end at 1 M with 512-position tiles 7.25 -> 6.25 us/site.
-template <int TPW, bool LIGHT>
+// Measured around the shipped (rows, aggregates) = (16, 32): (8, 32) 6.21, (32, 32) 6.25, (16, 64) 6.93, (32, 64) 7.12 us/site against 6.12.
+template <int TPW, bool LIGHT, int LCH = 16, int LPCH = 32>
 __global__ __launch_bounds__(SKK) void skel_k2_wide_kernel(Sk2WArgs g) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
     const int t = threadIdx.x, j = blockIdx.x, w0 = j * TPW;
-    constexpr int CH = LIGHT ? 16 : TPW;                     // rows in flight
-    constexpr int PCH = LIGHT ? 32 : 64;                     // aggregates in flight
+    constexpr int CH = LIGHT ? LCH : TPW;                    // rows in flight
+    constexpr int PCH = LIGHT ? LPCH : 64;                   // aggregates in flight
     int c[LIGHT ? 1 : TPW], tl[LIGHT ? 1 : TPW];
     int ac = 0, at = 0;                                      // this workgroup's aggregate for key t
     if constexpr (LIGHT) {
