@@ -770,9 +770,7 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
         Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = W; kw.agg = e->k2agg; kw.counter = e->k2cnt; kw.err = e->ctl + 2;
         const int nwg = (W + 31) / 32;
         e->k2epoch += (unsigned)nwg; kw.target = e->k2epoch;
-        static const bool k2_light = !(getenv("PBWTAMD_K2_LIGHT") && !atoi(getenv("PBWTAMD_K2_LIGHT")));
-        if (k2_light) hipLaunchKernelGGL((skel_k2_wide_kernel<32, true>), dim3(nwg), dim3(SKK), 0, e->stream, kw);
-        else hipLaunchKernelGGL((skel_k2_wide_kernel<32, false>), dim3(nwg), dim3(SKK), 0, e->stream, kw);
+        hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, e->stream, kw);
         static const bool rank_r4 = !(getenv("PBWTAMD_RANK_R4") && !atoi(getenv("PBWTAMD_RANK_R4")));
         if (rank_r4) hipLaunchKernelGGL((skel_rank_kernel<EPT, 0, true>), dim3(W), dim3(BLOCK), 0, e->stream, g);    // more tiles than one round of the chip: occupancy counts
         else hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);

@@ -912,40 +912,27 @@ __global__ __launch_bounds__(KPW * 64) void skel_k2_kernel(Sk2Args g) {
 // atomics on both sides (write-through stores, L1-bypassing loads), `s_waitcnt vmcnt(0)` before the arrival — the
 // granule form of MI355X_MICROARCH.md "Workgroup dispatch ... inter-workgroup visibility".
 struct Sk2WArgs { const int2 *tbl; int2 *scan; int *total; int W; unsigned long long *agg; unsigned *counter; unsigned target; int *err; };
-// LIGHT (default): 16 rows / 32 aggregates in flight per lane and the rows read a second time (from L2) for the output pass,
-// instead of 32 rows + 64 aggregates held in 200 VGPRs.  A 200-VGPR wave fits on no SIMD while a consumer kernel is at full
-// occupancy (sweep: 8 waves x 56 VGPRs, fill: 6 x 56), and the 56 registers a retiring consumer workgroup frees go to the next
-// consumer workgroup: measured (rocprofv3 trace), the scan launch then waited for the END of the fill, 1.1-1.4 ms, and the chain
-// stood still beside fill + sweep.  This form (44 VGPRs, no LDS) fits into the slot any retiring consumer workgroup leaves:
-// 9.3 us alone instead of 8.0, 14 us beside the fill instead of 185; end to end at 1 M with 512-position tiles 7.25 -> 6.25 us/site.
-// Measured around the shipped (rows, aggregates) = (16, 32): (8, 32) 6.21, (32, 32) 6.25, (16, 64) 6.93, (32, 64) 7.12 us/site against 6.12.
-template <int TPW, bool LIGHT, int LCH = 16, int LPCH = 32>
+// 16 rows / 32 aggregates in flight per lane, and the rows are read a second time (from L2) for the output pass.  The first
+// form of this kernel held all 32 rows + 64 aggregates in 200 VGPRs (one round trip each, 8.0 us alone).  A 200-VGPR wave fits
+// on no SIMD while a consumer kernel is at full occupancy (sweep: 8 waves x 56 VGPRs, fill: 6 x 56), and the 56 registers a
+// retiring consumer workgroup frees go to the next consumer workgroup: measured (rocprofv3 trace), that launch waited for the
+// END of the fill, 1.1-1.4 ms, and the chain stood still beside fill + sweep.  This form (44 VGPRs, no LDS) fits into the slot
+// any retiring consumer workgroup leaves: 9.3 us alone, 14 us beside the fill instead of 185; end to end at 1 M 7.25 -> 6.25
+// us/site.  Around the shipped (rows, aggregates) = (16, 32): (8, 32) 6.21, (32, 32) 6.25, (16, 64) 6.93, (32, 64) 7.12 against 6.12.
+template <int TPW, int CH = 16, int PCH = 32>                // rows / aggregates in flight per lane
 __global__ __launch_bounds__(SKK) void skel_k2_wide_kernel(Sk2WArgs g) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
     const int t = threadIdx.x, j = blockIdx.x, w0 = j * TPW;
-    constexpr int CH = LIGHT ? LCH : TPW;                    // rows in flight
-    constexpr int PCH = LIGHT ? LPCH : 64;                   // aggregates in flight
-    int c[LIGHT ? 1 : TPW], tl[LIGHT ? 1 : TPW];
     int ac = 0, at = 0;                                      // this workgroup's aggregate for key t
-    if constexpr (LIGHT) {
 #pragma unroll 1
-        for (int x0 = 0; x0 < TPW; x0 += CH) {
-            int2 v[CH];
+    for (int x0 = 0; x0 < TPW; x0 += CH) {
+        int2 v[CH];
 #pragma unroll
-            for (int x = 0; x < CH; ++x) v[x] = (w0 + x0 + x < g.W) ? g.tbl[(size_t)(w0 + x0 + x) * SKK + t] : make_int2(0, 0);
+        for (int x = 0; x < CH; ++x) v[x] = (w0 + x0 + x < g.W) ? g.tbl[(size_t)(w0 + x0 + x) * SKK + t] : make_int2(0, 0);
 #pragma unroll
-            for (int x = 0; x < CH; ++x) { at = v[x].x ? v[x].y : max(at, v[x].y); ac += v[x].x; }
-        }
-    } else {
-#pragma unroll
-        for (int x = 0; x < TPW; ++x) {
-            const int2 v = (w0 + x < g.W) ? g.tbl[(size_t)(w0 + x) * SKK + t] : make_int2(0, 0);
-            c[x] = v.x; tl[x] = v.y;
-        }
-#pragma unroll
-        for (int x = 0; x < TPW; ++x) { at = c[x] ? tl[x] : max(at, tl[x]); ac += c[x]; }
+        for (int x = 0; x < CH; ++x) { at = v[x].x ? v[x].y : max(at, v[x].y); ac += v[x].x; }
     }
     __hip_atomic_store(g.agg + (size_t)j * SKK + t, ((unsigned long long)(unsigned)at << 32) | (unsigned)ac, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -961,9 +948,9 @@ __global__ __launch_bounds__(SKK) void skel_k2_wide_kernel(Sk2WArgs g) {
         }
     }
     __syncthreads();
-    int ec = 0, et = 0;                                      // prefix over the workgroups before this one, PCH loads in flight at once
+    int ec = 0, et = 0;                                      // prefix over the workgroups before this one
 #pragma unroll 1
-    for (int i0 = 0; i0 < (LIGHT ? j : 1); i0 += PCH) {
+    for (int i0 = 0; i0 < j; i0 += PCH) {
         unsigned long long pv[PCH];
 #pragma unroll
         for (int i = 0; i < PCH; ++i) pv[i] = (i0 + i < j) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
@@ -973,23 +960,15 @@ __global__ __launch_bounds__(SKK) void skel_k2_wide_kernel(Sk2WArgs g) {
             et = vc ? vt : max(et, vt); ec += vc;
         }
     }
-    if constexpr (LIGHT) {
 #pragma unroll 1
-        for (int x0 = 0; x0 < TPW; x0 += CH) {
-            int2 v[CH];
+    for (int x0 = 0; x0 < TPW; x0 += CH) {                   // output pass: the rows again (L2), the running prefix written in front of each
+        int2 v[CH];
 #pragma unroll
-            for (int x = 0; x < CH; ++x) v[x] = (w0 + x0 + x < g.W) ? g.tbl[(size_t)(w0 + x0 + x) * SKK + t] : make_int2(0, 0);
+        for (int x = 0; x < CH; ++x) v[x] = (w0 + x0 + x < g.W) ? g.tbl[(size_t)(w0 + x0 + x) * SKK + t] : make_int2(0, 0);
 #pragma unroll
-            for (int x = 0; x < CH; ++x) {
-                if (w0 + x0 + x < g.W) g.scan[(size_t)(w0 + x0 + x) * SKK + t] = make_int2(ec, ec ? et : -1);
-                et = v[x].x ? v[x].y : max(et, v[x].y); ec += v[x].x;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int x = 0; x < TPW; ++x) {
-            if (w0 + x < g.W) g.scan[(size_t)(w0 + x) * SKK + t] = make_int2(ec, ec ? et : -1);
-            et = c[x] ? tl[x] : max(et, tl[x]); ec += c[x];
+        for (int x = 0; x < CH; ++x) {
+            if (w0 + x0 + x < g.W) g.scan[(size_t)(w0 + x0 + x) * SKK + t] = make_int2(ec, ec ? et : -1);
+            et = v[x].x ? v[x].y : max(et, v[x].y); ec += v[x].x;
         }
     }
     if (j == (int)gridDim.x - 1) g.total[t] = ec;
