@@ -157,10 +157,22 @@ def match_dynamic(torch, pbwt_amd, dev, kind, M=1000000, Q=10000, sites=8192, ba
         recs, nom, tot = ep.match_sweep(pz, sites, qz, Q)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
+    # one rank's share when the QUERIES are sharded over G GPUs (pbwt_amd/queryshard.py; every rank repeats the panel side):
+    # the job's wall time at G ranks is the time of Q / G queries here — measured, not modelled, but on this one GPU
+    from pbwt_amd import queryshard as qsh
+    shard = {}
+    for G in (2, 4, 8):
+        lo, hi = qsh.plan_ranges(Q, G)[0]
+        t0 = time.perf_counter()
+        qsh.run_range(ep, pz, sites, qz, Q, lo, hi)
+        shard[str(G)] = {"us_per_site": 1e6 * (time.perf_counter() - t0) / sites, "queries_per_rank": hi - lo}
+    for G in shard:
+        shard[G]["speedup_vs_1"] = 1e6 * best / sites / shard[G]["us_per_site"]
     ep.close()
     alg = (ALG_BYTES_PER_SITEHAP * (M + Q) * sites + 16.0 * len(recs)) / best / 1e9      # panel step + query step + 16 B per report
     return {"haplotypes": M, "queries": Q, "sites": sites, "us_per_site": 1e6 * best / sites, "records": int(len(recs)), "no_match_events": int(nom),
             "value": M * sites / best, "unit": "panel site*haps/s", "achieved_GBps": alg, "frac_of_hbm_peak": alg / HBM_PEAK_GBPS,
+            "query_sharding_one_rank_share": shard,
             "note": "host-buffer entry point (packed panels in host memory in, records out), best of 2 calls"}
 
 

@@ -147,6 +147,15 @@ int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, int64_t pnz
                                pbwtamd_report5_fn report, pbwtamd_match5 **recs_out, int64_t *nrecs_out,
                                int64_t *n_nomatch, int64_t *tot);
 
+/* Query sharding across GPUs for matchSequencesSweep / -matchDynamic (queries are independent given the panel state:
+ * pbwtMatch.c:376-414 touches f[jj], d[jj] of one query at a time).  After this call the query sweeps of `e` process the
+ * queries lo <= jj < hi only (original indices in the query panel).  Every record's `sparse` field (and the isSparse column
+ * of pbwtamd_get_nomatch_events) then carries, above bit 0, the query's rank in the query panel's PBWT order at the
+ * record's site: (end, rank, isSparse) is the reference's emission order (k ascending, then uq->a order, dense before
+ * sparse), so the streams of several ranks merge into exactly the reference's stream.  nTot / totLen / n_nomatch are this
+ * range's share.  lo < 0: all queries again, plain `sparse` field.  Host side: pbwt_amd/queryshard.py. */
+int pbwtamd_set_query_range(pbwtamd_engine *e, int lo, int hi);
+
 /* Panel transforms — the "x[a[j]] = y[j]; y'[j] = x[a'[j]]; pbwtCursorWriteForwards" loops of pbwtBuildReverse
  * (pbwtCore.c:151-191), pbwtSubSample (pbwtSample.c:59-93), pbwtSubRange (pbwtCore.c:111-148), pbwtSelectSites /
  * pbwtRemoveSites (pbwtCore.c:623-732) — as one device pass: decode, regather, rebuild.  The new panel has

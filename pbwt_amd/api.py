@@ -216,6 +216,10 @@ class Engine:
             self._L.pbwtamd_free(rp)
         return out, nom.value, (tot[0], tot[1])
 
+    def set_query_range(self, lo, hi=0):
+        """query sweeps process the queries lo <= jj < hi only and tag records with the query's PBWT rank (sparse >> 1); lo < 0: all"""
+        self._chk(self._L.pbwtamd_set_query_range(self._h, C.c_int(lo), C.c_int(hi)))
+
     def nomatch_events(self):
         """(jj, x, k, isSparse) rows of the last query sweep's "no match to query" events, in the reference's log order"""
         ev = C.POINTER(C.c_int32)(); n = C.c_int64(0)

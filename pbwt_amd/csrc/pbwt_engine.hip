@@ -147,6 +147,7 @@ struct pbwtamd_engine {
     hipEvent_t tev[16] = {}; long long tev_n = 0; int thr_rounds = 28, thr_depth = 2;   // host throttle: an event every thr_rounds rounds, host at most thr_depth events ahead
     int *rankdirS = nullptr;                // read-side skeleton: zero-prefix directories of the batch's sorted columns [B+2][wpc64+1]
     bool keys_ready[2] = {false, false};     // slot-0 keys of the ring delivered by the previous batch's last round
+    int q_lo = 0, q_hi = 0x7fffffff; bool q_part = false;   // query sweeps: only queries q_lo <= jj < q_hi (pbwtamd_set_query_range)
     int Wt = 0, skEPT = 4;                  // skeleton tiles: 256*skEPT positions, Wt of them; PBWTAMD_SKT=512|1024
     int skn_maxw = 16;                      // two-launch round (rank scans the tile table itself) up to this many tiles; PBWTAMD_SKN_MAXW
     bool summ_pair = false;                 // format of the current tile summaries (two-site keys or single site)
@@ -1523,6 +1524,17 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
                                           pbwtamd_report5_fn report, pbwtamd_match5 **recs_out, int64_t *nrecs_out,
                                           int64_t *n_nomatch, int64_t *tot_out);
 
+// Query sharding across GPUs ("for matchDynamic shard queries": queries are independent given the panel state,
+// pbwtMatch.c:376-414).  After this call the query sweeps of `e` report for the queries lo <= jj < hi only (original indices of
+// the query panel); every record's `sparse` field then carries, above bit 0, the query's rank in the query panel's order at the
+// record's site — (end, rank, isSparse) is the reference's emission order, so per-rank streams merge exactly.  lo < 0: all queries.
+extern "C" int pbwtamd_set_query_range(pbwtamd_engine *e, int lo, int hi) {
+    if (lo < 0) { e->q_lo = 0; e->q_hi = 0x7fffffff; e->q_part = false; return 0; }
+    if (hi < lo) return fail("pbwtamd_set_query_range: [%d, %d)", lo, hi);
+    e->q_lo = lo; e->q_hi = hi; e->q_part = true;
+    return 0;
+}
+
 // matchSequencesSweep (pbwtMatch.c:363-443) = the sparse sweep without sparse cursors (same kernels: one wave per query)
 static thread_local pbwtamd_report_fn g_report4 = nullptr;
 static void report4_thunk(int ai, int bi, int start, int end, int) { g_report4(ai, bi, start, end); }
@@ -1738,6 +1750,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         g.fs_in = fss[cur]; g.ds_in = dss[cur]; g.fs_out = fss[cur ^ 1]; g.ds_out = dss[cur ^ 1];
         g.cnt = cnt; g.recs = nullptr; g.tot = tot;
         g.nm_ev = nm_ev; g.nm_n = nm_n; g.nm_cap = NM_CAP; g.evt = evt;
+        g.q_lo = e->q_lo; g.q_hi = e->q_hi;
         // a wave lives for the whole batch here (one query, site after site): at full occupancy the next batch's chain kernels,
         // enqueued below to run beside it, would find no wave slot until it ends.  26 KB of (unused) dynamic LDS per workgroup
         // holds the sweep to 6 of the 8 wave slots per SIMD.
@@ -1767,7 +1780,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
             QssEmitArgs em;                                 // expand the event descriptors of the counting pass (the walks are not repeated)
             em.off = cnt; em.total = tot + 3; em.evt = evt; em.nslots = 2 * (size_t)nb * Mq;
             em.dense = g.dense; em.sparse = dviews; em.nS = std::max(nS, 1);
-            em.AQ = AQ; em.strideAQ = eq->strideA; em.AQ0 = a0Q; em.Mq = Mq; em.kbase = done; em.recs = recs;
+            em.AQ = AQ; em.strideAQ = eq->strideA; em.AQ0 = a0Q; em.Mq = Mq; em.kbase = done; em.recs = recs; em.emit_rank = e->q_part ? 1 : 0;
             const size_t ewaves = (em.nslots + 63) / 64;
             hipLaunchKernelGGL(qss_emit_kernel, dim3((unsigned)((ewaves + WAVES - 1) / WAVES)), dim3(BLOCK), 0, st, em);
             HIPCHK(hipGetLastError());
@@ -1786,14 +1799,14 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         if (c >= 0) CHK(pbwtamd_sync(s));
         const int *A = ringA(s, s->ring), *D = ringD(s, s->ring), *AQ = ringA(eq, eq->ring);
         const int *fp = c < 0 ? fst[cur] : fss[cur] + (size_t)c * Mq, *dp = c < 0 ? dst[cur] : dss[cur] + (size_t)c * Mq;
-        hipLaunchKernelGGL((qss_tail_kernel<0>), dim3(qwaves), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, nS, std::max(c, 0), c >= 0 ? 1 : 0, fp, dp, cnt, (Rec5 *)nullptr, tot);
+        hipLaunchKernelGGL((qss_tail_kernel<0>), dim3(qwaves), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, nS, std::max(c, 0), c >= 0 ? 1 : 0, fp, dp, cnt, (Rec5 *)nullptr, tot, e->q_lo, e->q_hi, e->q_part ? 1 : 0);
         hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, cnt, (size_t)Mq, tot + 3, 0ULL);
         HIPCHK(hipGetLastError());
         unsigned long long total = 0;
         HIPCHK(hipMemcpyAsync(&total, tot + 3, sizeof total, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         CHK(ensure_recs((size_t)total));
-        hipLaunchKernelGGL((qss_tail_kernel<1>), dim3(qwaves), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, nS, std::max(c, 0), c >= 0 ? 1 : 0, fp, dp, cnt, recs, tot);
+        hipLaunchKernelGGL((qss_tail_kernel<1>), dim3(qwaves), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, nS, std::max(c, 0), c >= 0 ? 1 : 0, fp, dp, cnt, recs, tot, e->q_lo, e->q_hi, e->q_part ? 1 : 0);
         HIPCHK(hipGetLastError());
         CHK(deliver((size_t)total));
     }
@@ -1808,7 +1821,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         std::vector<int4> ev(nev);
         if (nev) HIPCHK(hipMemcpy(ev.data(), nm_ev, sizeof(int4) * nev, hipMemcpyDeviceToHost));
         std::sort(ev.begin(), ev.end(), [](const int4 &a, const int4 &b) { return a.x != b.x ? a.x < b.x : a.y != b.y ? a.y < b.y : (a.w >> 1) < (b.w >> 1); });
-        for (const int4 &v : ev) { e->nomatch_events.push_back(v.z); e->nomatch_events.push_back(v.w & 1); e->nomatch_events.push_back(v.x); e->nomatch_events.push_back(v.w >> 1); }
+        for (const int4 &v : ev) { e->nomatch_events.push_back(v.z); e->nomatch_events.push_back(v.w & 1); e->nomatch_events.push_back(v.x); e->nomatch_events.push_back((v.w >> 1) | (e->q_part ? (v.y << 1) : 0)); }
     }
     CHK(pbwtamd_pass_end(e, 0));
     CHK(pbwtamd_pass_end(eq, 0));

@@ -2674,6 +2674,7 @@ struct QssArgs {
     unsigned long long *tot;                                 // [0] nTot [1] totLen [2] no-match events
     int4 *nm_ev; unsigned *nm_n; unsigned nm_cap;            // the no-match events themselves: {site k, query rank, query jj, x | isSparse << 1}
     int2 *evt;                                               // per slot with reports: {first panel position f, reported start} — what qss_emit_kernel expands
+    int q_lo, q_hi;                                          // only the queries q_lo <= jj < q_hi are swept (query sharding across GPUs: pbwtamd_set_query_range)
 };
 
 // reportAndUpdate (pbwtMatch.c:452-499) for one query at one site against one cursor state, executed by a whole
@@ -2769,7 +2770,7 @@ __device__ __forceinline__ int qss_lfmap(const unsigned long long *yc, const int
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
     const int jj = blockIdx.x * WAVES + wave_id(), lane = lane_id();
-    if (jj >= g.Mq) return;
+    if (jj >= g.Mq || jj < g.q_lo || jj >= g.q_hi) return;   // another rank's query: its count slots stay zero
     const int M = g.Mp, nS = g.nS;
     int f = g.f_in[jj], dq = g.dq_in[jj];
     unsigned long long nTot = 0, totLen = 0, nomatch = 0;
@@ -2842,6 +2843,7 @@ struct QssEmitArgs {
     const int *AQ; size_t strideAQ; const int *AQ0;              // query cursor: position r of site s holds the query index (AQ0: copy of row 0, see QsView::A0)
     int Mq, kbase;
     Rec5 *recs;
+    int emit_rank;                                           // query sharding: the query's rank r in the query panel's order at the site goes into sparse >> 1 (the merge key)
 };
 __global__ __launch_bounds__(BLOCK) void qss_emit_kernel(QssEmitArgs g) {
     const size_t base = ((size_t)blockIdx.x * WAVES + wave_id()) * 64;
@@ -2863,7 +2865,7 @@ __global__ __launch_bounds__(BLOCK) void qss_emit_kernel(QssEmitArgs g) {
         const int *a;
         if (sparse) { const QsView v = g.sparse[k % g.nS]; const int t = k / g.nS - v.sbase; a = t ? v.A + (size_t)t * v.strideA : v.A0; }
         else a = s ? g.dense.A + (size_t)s * g.dense.strideA : g.dense.A0;
-        for (int i = lane; i < cntN; i += 64) { Rec5 rr; rr.ai = jj; rr.bi = a[ev.x + i] & AMASK; rr.start = ev.y; rr.end = k; rr.sparse = sparse; g.recs[o0 + i] = rr; }
+        for (int i = lane; i < cntN; i += 64) { Rec5 rr; rr.ai = jj; rr.bi = a[ev.x + i] & AMASK; rr.start = ev.y; rr.end = k; rr.sparse = sparse | (g.emit_rank ? (r << 1) : 0); g.recs[o0 + i] = rr; }
     }
 }
 
@@ -2871,10 +2873,12 @@ __global__ __launch_bounds__(BLOCK) void qss_emit_kernel(QssEmitArgs g) {
 // order; sparse cursor kk: start nS*d + kk, totLen with the cursor's own d (as the reference).  One wave per query.
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void qss_tail_kernel(const int *A, const int *D, const int *AQ, int Mp, int Mq, int N, int nS, int kk, int isSparse,
-                                                        const int *f, const int *dq, unsigned long long *cnt, Rec5 *recs, unsigned long long *tot) {
+                                                        const int *f, const int *dq, unsigned long long *cnt, Rec5 *recs, unsigned long long *tot,
+                                                        int q_lo, int q_hi, int emit_rank) {
     const int j = blockIdx.x * WAVES + wave_id(), lane = lane_id();
     if (j >= Mq) return;
     const int jj = AQ[j] & AMASK;
+    if (jj < q_lo || jj >= q_hi) { if (MODE == 0 && lane == 0) cnt[j] = 0; return; }   // another rank's query
     const int f0 = f[jj], d0 = dq[jj];
     int i = f0 + 1;                                          // for (i = f; ++i < M && d[i] <= dq; )
     for (;; i += 64) {
@@ -2885,7 +2889,7 @@ __global__ __launch_bounds__(BLOCK) void qss_tail_kernel(const int *A, const int
     const int n = i - f0;
     const int dj = isSparse ? nS * d0 + kk : d0;
     if (MODE == 0) { if (lane == 0) { cnt[j] = (unsigned long long)n; atomicAdd(tot, (unsigned long long)n); atomicAdd(tot + 1, (unsigned long long)(N - d0) * n); } }
-    else { Rec5 *o = recs + cnt[j]; for (int q = f0 + lane; q < i; q += 64) { Rec5 r; r.ai = jj; r.bi = A[q] & AMASK; r.start = dj; r.end = N; r.sparse = isSparse; o[q - f0] = r; } }
+    else { Rec5 *o = recs + cnt[j]; for (int q = f0 + lane; q < i; q += 64) { Rec5 r; r.ai = jj; r.bi = A[q] & AMASK; r.start = dj; r.end = N; r.sparse = isSparse | (emit_rank ? (j << 1) : 0); o[q - f0] = r; } }
 }
 
 // PbwtCursor view of one sorted bit column (pbwt.h:78-83): y[i] as bytes, u[i] = zeros in y[0..i) for i = 0..M

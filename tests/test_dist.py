@@ -164,3 +164,80 @@ def test_site_block_combine_gloo(world, tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     assert all(json.load(open(tmp_path / ("blk%d.json" % rk)))["ok"] for rk in range(world))
+
+
+QS_MERGE_WORKER = textwrap.dedent("""
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    from pbwt_amd import dist as pd
+    from pbwt_amd import queryshard as qs
+    rank, world = pd.init("gloo")
+    z = np.load(os.environ["QS_IN"])
+    N, nS, Mq = int(z["N"]), int(z["nS"]), int(z["Mq"])
+    lo, hi = qs.plan_ranges(Mq, world)[rank]
+    tagged = z["tagged"]                                   # the full stream, rank-tagged as a device would tag it
+    mine = tagged[(tagged[:, 0] >= lo) & (tagged[:, 0] < hi)]            # this rank's share, in its own emission order
+    parts = qs._gather_rows(mine)
+    streams = []
+    for a in parts:
+        s = np.zeros(len(a), qs.MERGED_DTYPE)
+        for i, f in enumerate(("ai", "bi", "start", "end", "sparse")):
+            s[f] = a[:, i]
+        streams.append(s)
+    merged = qs.merge_streams(streams, N, nS)
+    want = z["want"]
+    ok = len(merged) == len(want) and all(np.array_equal(merged[f], want[:, i]) for i, f in enumerate(("ai", "bi", "start", "end", "sparse")))
+    total = pd.sum_over_ranks(len(mine))
+    with open(os.path.join(os.environ["OUT_DIR"], "qs" + str(rank) + ".json"), "w") as f:
+        json.dump({"rank": rank, "ok": bool(ok), "total": total, "n": len(want)}, f)
+    pd.finish()
+""") % ROOT
+
+
+@pytest.mark.parametrize("world,nS", [(2, 0), (3, 3)])
+def test_query_shard_merge_gloo(world, nS, tmp_path):
+    """the host side of -matchDynamic sharded by queries (pbwt_amd/queryshard.py) under gloo: every rank contributes the
+    records of its query range tagged with the query's PBWT rank, the all-gather + one stable sort give back exactly
+    the oracle's stream — dense and sparse reports, tails at N cursor by cursor"""
+    import json
+    import numpy as np
+    import oracle as orc
+    Mp, Mq, N = 60, 17, 50
+    rng = np.random.default_rng(5 + world)
+    hap = (rng.random((N, Mp + Mq)) < 0.35).astype(np.uint8)
+    for k in range(1, N):                                  # some linkage, so that matches have length
+        keep = rng.random(Mp + Mq) < 0.7
+        hap[k, keep] = hap[k - 1, keep]
+    pz = orc.build_bitcols(orc.pack_bitcols(hap[:, :Mp]), Mp, with_d=False)["yz"]
+    qb = orc.build_bitcols(orc.pack_bitcols(hap[:, Mp:]), Mq, with_d=False, dump_sites=range(N))
+    want, _, _ = orc.match_sweep_sparse(pz, Mp, qb["yz"], Mq, N, nS)
+    assert len(want) > 50
+    # the query's rank in the query panel's order at the record's site (the final order for the tails at N)
+    pos = np.zeros((N + 1, Mq), np.int64)
+    for k in range(N):
+        pos[k, qb["a_dump"][k]] = np.arange(Mq)
+    pos[N, qb["a_final"]] = np.arange(Mq)
+    w = np.stack([want[f] for f in ("ai", "bi", "start", "end", "sparse")], axis=1).astype(np.int32)
+    tagged = w.copy()
+    tagged[:, 4] |= (pos[w[:, 3], w[:, 0]] << 1).astype(np.int32)
+    np.savez(tmp_path / "in.npz", want=w, tagged=tagged, N=N, nS=nS, Mq=Mq)
+    script = tmp_path / "qs_merge_worker.py"
+    script.write_text(QS_MERGE_WORKER)
+    env = dict(os.environ, OUT_DIR=str(tmp_path), QS_IN=str(tmp_path / "in.npz"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = [json.load(open(tmp_path / ("qs%d.json" % rk))) for rk in range(world)]
+    assert all(x["ok"] for x in res) and all(x["total"] == len(want) for x in res)
+
+
+def test_query_shard_plan():
+    from pbwt_amd import queryshard as qs
+    for Mq, world in ((10000, 8), (7, 3), (2, 4), (0, 2)):
+        r = qs.plan_ranges(Mq, world)
+        assert len(r) == world and r[0][0] == 0 and r[-1][1] == Mq
+        assert all(r[g][1] == r[g + 1][0] for g in range(world - 1))
+        sizes = [hi - lo for lo, hi in r]
+        assert max(sizes) - min(sizes) <= 1

@@ -148,3 +148,68 @@ def test_position_sharded_step_on_device_tensors_over_rccl(tmp_path):
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert json.load(open(tmp_path / "ps.json"))["ok"]
+
+
+QS_WORKER = textwrap.dedent("""
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    from pbwt_amd import dist as pd
+    from pbwt_amd import queryshard as qs
+    import pbwt_amd as amd
+    rank, world = pd.init("gloo")
+    z = np.load(os.environ["QS_IN"])
+    Mp, Mq, N, nS = int(z["Mp"]), int(z["Mq"]), int(z["N"]), int(z["nS"])
+    eng = amd.Engine(Mp, batch_sites=int(z["batch"]), device=0)
+    recs, ev, nom, tot = qs.match_sweep_sharded(eng, z["pz"], N, z["qz"], Mq, nS)
+    if rank == 0:
+        np.savez(os.path.join(os.environ["OUT_DIR"], "merged.npz"), recs=recs, ev=ev, nom=nom, tot=np.array(tot, dtype=np.int64))
+    pd.finish()
+""") % ROOT
+
+
+@pytest.mark.parametrize("world,Mp,Mq,N,kind,nS,batch", [(2, 3000, 50, 200, 0, 0, 64), (3, 2500, 31, 130, 1, 4, 128), (2, 20000, 300, 260, 0, 0, 512)])
+def test_query_sharding_ranks_one_gpu(world, Mp, Mq, N, kind, nS, batch, tmp_path, orc):
+    """-matchDynamic with the QUERIES sharded over `world` ranks (pbwt_amd/queryshard.py): every rank sweeps its range of
+    queries on the device, the rank-tagged streams merge into exactly the oracle's stream; counts and totals add up"""
+    bits = orc.synth_bitcols(Mp + Mq, N, seed=Mp * 7 + N, kind=kind)
+    hap = orc.unpack_bitcols(bits, Mp + Mq)
+    pz = orc.build_bitcols(orc.pack_bitcols(hap[:, :Mp]), Mp, with_d=False)["yz"]
+    qz = orc.build_bitcols(orc.pack_bitcols(hap[:, Mp:]), Mq, with_d=False)["yz"]
+    want, nomatch, tot = orc.match_sweep_sparse(pz, Mp, qz, Mq, N, nS)
+    np.savez(tmp_path / "in.npz", pz=pz, qz=qz, Mp=Mp, Mq=Mq, N=N, nS=nS, batch=batch)
+    script = tmp_path / "qs_worker.py"
+    script.write_text(QS_WORKER)
+    env = dict(os.environ, OUT_DIR=str(tmp_path), QS_IN=str(tmp_path / "in.npz"))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    m = np.load(tmp_path / "merged.npz")
+    got = m["recs"]
+    assert len(got) == len(want)
+    for f in ("ai", "bi", "start", "end", "sparse"):
+        assert np.array_equal(got[f], want[f]), f
+    assert int(m["nom"]) == nomatch and tuple(int(v) for v in m["tot"]) == tuple(tot)
+
+
+def test_query_range_events_and_reset(gpu_lib, orc):
+    """pbwtamd_set_query_range: the no-match events of the ranges merge into the full run's log order; resetting the range
+    gives the plain stream back (the reference's own golden with sites where no panel haplotype carries the query's allele)"""
+    import pbwt_amd as amd
+    from pbwt_amd import queryshard as qs
+    g = np.load(os.path.join(ROOT, "tests", "golden", "sparse_sweep.npz"))
+    Mp, Mq, N = (int(v) for v in g["nomatch_shape"])
+    eng = amd.Engine(Mp, batch_sites=8)
+    for nS in (1, 3):
+        full, fn, ft = eng.match_sweep_sparse(g["nomatch_pz"], N, g["nomatch_qz"], Mq, nS)
+        fev = eng.nomatch_events()
+        assert fn > 0 and np.array_equal(full, g["nomatch_s%d" % nS].view(full.dtype).reshape(-1))
+        parts = [qs.run_range(eng, g["nomatch_pz"], N, g["nomatch_qz"], Mq, lo, hi, nS) for lo, hi in qs.plan_ranges(Mq, 3)]
+        merged = qs.merge_streams([p[0] for p in parts], N, nS)
+        for f in ("ai", "bi", "start", "end", "sparse"):
+            assert np.array_equal(merged[f], full[f]), (nS, f)
+        assert sum(p[2] for p in parts) == fn and tuple(sum(p[3][i] for p in parts) for i in (0, 1)) == tuple(ft)
+        assert np.array_equal(qs.merge_events([p[1] for p in parts]), fev)
+        again, _, _ = eng.match_sweep_sparse(g["nomatch_pz"], N, g["nomatch_qz"], Mq, nS)     # range reset by run_range
+        assert np.array_equal(again, full)

@@ -1,3 +1,7 @@
 mkdir -p gpurun_out/p1m; cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/p1m/full_b.log 2>&1; tail -3 gpurun_out/p1m/full_b.log | cut -c1-200
-timeout 300 python tools/wide_bench.py 1000000 8192 hp
+python bench.py --steps 2 --warmup 1 --no-cpu > gpurun_out/p1m/bench_qs.json 2> gpurun_out/p1m/bench_qs.err; tail -3 gpurun_out/p1m/bench_qs.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/p1m/bench_qs.json').read().strip().splitlines()[-1])
+print(json.dumps(d.get("match_dynamic"), indent=1))
+PY
