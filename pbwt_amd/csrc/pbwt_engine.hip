@@ -148,6 +148,7 @@ struct pbwtamd_engine {
     int *rankdirS = nullptr;                // read-side skeleton: zero-prefix directories of the batch's sorted columns [B+2][wpc64+1]
     bool keys_ready[2] = {false, false};     // slot-0 keys of the ring delivered by the previous batch's last round
     int q_lo = 0, q_hi = 0x7fffffff; bool q_part = false;   // query sweeps: only queries q_lo <= jj < q_hi (pbwtamd_set_query_range)
+    bool prow = false; int W2 = 0;          // pair rows: skel_hist_kernel<4, true> + the scan on W2 = ceil(Wt / 2) rows
     int Wt = 0, skEPT = 4;                  // skeleton tiles: 256*skEPT positions, Wt of them; PBWTAMD_SKT=512|1024
     int skn_maxw = 16;                      // two-launch round (rank scans the tile table itself) up to this many tiles; PBWTAMD_SKN_MAXW
     bool summ_pair = false;                 // format of the current tile summaries (two-site keys or single site)
@@ -267,7 +268,12 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         for (int i = 0; i < 16; ++i) ECHK(hipEventCreateWithFlags(&e->tev[i], hipEventDisableTiming));
         {
             const int rounds = e->B / 8 + 1;
-            e->strideS = (size_t)SKK * e->Wt + SKK / 2;
+            // pair rows (wide panels at 512-position tiles): the scan over the tiles runs on 1024-position pairs — half the rows —
+            // and the rank / fill workgroup of an odd tile folds the first tile's row in.  Rows 512 < W2 <= 1024: the wide scan, <= 32 workgroups
+            static const bool pair_rows = !(getenv("PBWTAMD_PAIR_ROWS") && !atoi(getenv("PBWTAMD_PAIR_ROWS")));
+            e->W2 = (e->Wt + 1) / 2;
+            e->prow = pair_rows && e->skEPT == 2 && e->W2 > 512 && e->W2 <= 1024;
+            e->strideS = e->prow ? (size_t)SKK * e->W2 * 2 + SKK / 2 : (size_t)SKK * e->Wt + SKK / 2;
             for (int i = 0; i < 2; ++i) {
                 ALLOC(e->keysR[i], (size_t)(rounds + 1) * e->Mpad);
                 ALLOC(e->saveR[i], (size_t)rounds * e->strideS * sizeof(int2));
@@ -722,6 +728,7 @@ static int flush_pending(pbwtamd_engine *e) {
 #endif
         f.pack_y = packed ? 1 : 0;
         f.xcd = xcd_flags() & 1;
+        f.pair = e->prow ? 1 : 0; f.W2 = e->W2;
         dim3 grid(e->Wt, p.nb / 8);
         static const size_t dyn = getenv("PBWTAMD_FILL_PAD_KB") ? (size_t)atoi(getenv("PBWTAMD_FILL_PAD_KB")) * 1024 : 0;   // occupancy probe (results unchanged)
 #define FILL(EP) do { if (packed) hipLaunchKernelGGL((skel_fill_kernel<EP, true>), grid, dim3(BLOCK), dyn, e->s2, f); \
@@ -758,6 +765,16 @@ static inline bool skel_two_launch(const pbwtamd_engine *e) { return e->skn && e
 template <int EPT>
 static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
     const int W = g.W;
+    if (e->prow) {                                         // wide panels: hist and scan on PAIRS of tiles (half the rows), rank on tiles
+        SkArgs h = g; h.W = e->W2;
+        hipLaunchKernelGGL((skel_hist_kernel<4, true>), dim3(e->W2), dim3(BLOCK), 0, e->stream, h);
+        Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = e->W2; kw.agg = e->k2agg; kw.counter = e->k2cnt; kw.err = e->ctl + 2;
+        const int nwg = (e->W2 + 31) / 32;
+        e->k2epoch += (unsigned)nwg; kw.target = e->k2epoch;
+        hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, e->stream, kw);
+        hipLaunchKernelGGL((skel_rank_kernel<EPT, 0, true>), dim3(W), dim3(BLOCK), 0, e->stream, g);
+        return;
+    }
     hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, e->stream, g);
     if (two_launch) {
         if (W <= 16) hipLaunchKernelGGL((skel_rank_kernel<EPT, 16>), dim3(W), dim3(BLOCK), 0, e->stream, g);
@@ -831,7 +848,8 @@ static int skel_rounds(pbwtamd_engine *e, int r, const uint32_t *cols, bool sort
         g.d_out = last ? ringD(e, r ^ 1) : D + (size_t)(site + 8) * e->strideD;
         g.keys_out = last ? e->keysR[r ^ 1] : kb + (size_t)(s8 + 1) * e->Mpad;
         int2 *sv = e->saveR[r] + (size_t)s8 * e->strideS;  // this round's per-key scan over the tiles, kept for the fill
-        g.scan = sv; g.total = reinterpret_cast<int *>(sv + (size_t)W * SKK);
+        const size_t nrow = e->prow ? (size_t)e->W2 : (size_t)W;
+        g.scan = sv; g.total = reinterpret_cast<int *>(sv + nrow * SKK); g.tbl0 = sv + nrow * SKK + SKK / 2; g.pair = e->prow ? 1 : 0;
         g.has_next = (e->k_cur + site + 8 < e->n_total) && (site + 8 < nvalid);
         g.kbnext = reinterpret_cast<const unsigned char *>(xT) + (size_t)((site + 8) / 8) * e->strideX;   // byte plane of sites site+8 .. site+15
         g.ycnext = sorted ? (const unsigned long long *)cols + (size_t)(site + 8) * e->wpc64 : nullptr;

@@ -773,6 +773,8 @@ struct SkArgs {
     const int *a; const int *d; const unsigned char *keys;     // input state and its 8-bit keys
     int *a_out; int *d_out; unsigned char *keys_out;
     int2 *tbl;                                                  // hist -> scan: [W][256] {count, tail}
+    int2 *tbl0;                                                 // pair rows: the same pair for the FIRST HALF of every hist tile (kept beside the scan)
+    int pair;                                                   // rank: the scan rows are per PAIR of tiles (row w / 2); odd tiles fold tbl0[w / 2] in
     int2 *scan; int *total;                                     // scan -> rank (kept for the fill): [W][256] {keys before the tile, carry}, total[256]
     const unsigned char *kbnext; int has_next;                  // byte plane of the NEXT round's keys by haplotype (transpose32_kernel)
     const unsigned long long *ycnext;                           // read side: sorted bit column of the OUTPUT state's site (tag by position); keys are precomputed
@@ -780,7 +782,11 @@ struct SkArgs {
     int xcd;                                                    // bit 1: rank, bit 2: hist — XCD-contiguous tiles (xcd_tile)
 };
 
-template <int EPT>
+// HALF (pair rows, wide panels): the workgroup covers a PAIR of the rank kernel's tiles and also emits the (count, tail) row of its
+// first half; the scan over the tiles then runs on half as many rows (the scan launch is what a wide panel pays most for beside
+// the consumers: 22.7 us per round at 1954 rows, 14 at 977), and the rank / fill workgroup of an odd tile folds the first half's
+// row into its pair's prefix (skel_k2_kernel's combine).  Waves 2, 3 hold the first half.
+template <int EPT, bool HALF = false>
 __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
@@ -789,6 +795,7 @@ __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
     __shared__ int h_cnt[SKK], h_last[SKK];
     __shared__ int s_suf[T];
     __shared__ int s_w[WAVES];
+    __shared__ int h_cnt0[HALF ? SKK : 1], h_last0[HALF ? SKK : 1], s_suf0[HALF ? T / 2 : 1];
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = (g.xcd & 4) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
     const int rb = BLOCK - 1 - t;
     const int l0 = rb * EPT, i0 = w * T + l0;
@@ -806,6 +813,7 @@ __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
         packed = g.keys[i0]; dv[0] = g.d[i0];
     }
     h_cnt[t] = 0; h_last[t] = -1;
+    if (HALF) { h_cnt0[t] = 0; h_last0[t] = -1; }
     int key[EPT];
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -823,6 +831,7 @@ __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
         for (int b = 0; b < SKB; ++b) { const unsigned long long bal = __ballot((key[e] >> b) & 1); same &= ((key[e] >> b) & 1) ? bal : ~bal; }
         if (key[e] >= 0 && (same & ((lane == 0) ? 0ULL : (~0ULL >> (64 - lane)))) == 0) {
             atomicAdd(&h_cnt[key[e]], __popcll(same)); atomicMax(&h_last[key[e]], l0 + e);
+            if (HALF && wv >= 2) { atomicAdd(&h_cnt0[key[e]], __popcll(same)); atomicMax(&h_last0[key[e]], l0 + e); }
         }
     }
     int own = dv[0];
@@ -832,15 +841,23 @@ __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
     if (lane == 63) s_w[wv] = inc;
     const int excl_lane = lane_shr1(inc, 0);
     lds_barrier();
-    int later = excl_lane;
+    int later = excl_lane, later0 = excl_lane;
     for (int q = 0; q < wv; ++q) later = max(later, s_w[q]);
+    if (HALF && wv == 3) later0 = max(later0, s_w[2]);
 #pragma unroll
-    for (int e = EPT - 1; e >= 0; --e) { s_suf[l0 + e] = later; later = max(later, dv[e]); }   // s_suf[l] = max d over positions > l
+    for (int e = EPT - 1; e >= 0; --e) {                   // s_suf[l] = max d over positions > l (s_suf0: inside the first half)
+        s_suf[l0 + e] = later; later = max(later, dv[e]);
+        if (HALF && wv >= 2) { s_suf0[l0 + e] = later0; later0 = max(later0, dv[e]); }
+    }
     int tilemax = 0;
     for (int q = 0; q < WAVES; ++q) tilemax = max(tilemax, s_w[q]);
     lds_barrier();
     const int c = h_cnt[t], tl = c ? s_suf[h_last[t]] : tilemax;
     g.tbl[(size_t)w * SKK + t] = make_int2(c, tl);         // row-major: one coalesced 2 KB row per tile
+    if (HALF) {
+        const int c0 = h_cnt0[t], tl0 = c0 ? s_suf0[h_last0[t]] : max(s_w[2], s_w[3]);
+        g.tbl0[(size_t)w * SKK + t] = make_int2(c0, tl0);
+    }
 }
 
 // SCAN (K2): exclusive scan over the W tiles, per key, of the pair (count, max d since the key's last
@@ -1011,7 +1028,12 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
 #pragma unroll
         for (int r = 0; r < TR; ++r) row[r] = (r < g.W) ? g.tbl[(size_t)r * SKK + t] : make_int2(0, 0);
     } else {
-        const int2 sv = g.scan[(size_t)w * SKK + t];
+        int2 sv = g.scan[(size_t)(g.pair ? (w >> 1) : w) * SKK + t];
+        if (g.pair && (w & 1)) {                            // second tile of its pair: fold the first one's row in
+            const int2 r0 = g.tbl0[(size_t)(w >> 1) * SKK + t];
+            sv.y = r0.x ? r0.y : (sv.x ? max(sv.y, r0.y) : -1);
+            sv.x += r0.x;
+        }
         bq = sv.x; cq = sv.y; tq = g.total[t];
     }
     for (int x = t; x < NC * SKK / 2; x += BLOCK) { reinterpret_cast<int *>(&s_cnt[0][0])[x] = 0; reinterpret_cast<int *>(&s_lastp[0][0])[x] = -1; }
@@ -1176,6 +1198,7 @@ struct SkFillArgs {
 #endif
     int pack_y;                                             // write d | y << 31 only (no a): for consumers that need (d, y) but not the haplotype ids
     int xcd;                                                // XCD-contiguous (round, tile) pairs (xcd_tile)
+    int pair, W2;                                           // pair rows: scan[W2][256], total, then the first halves' rows tbl0[W2][256] per round
 };
 
 // PACKY: the consumers need (d, y) of every site but not the haplotype ids — a[] is neither read nor written
@@ -1217,7 +1240,16 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
         s_tbl01[0][l] = dv;
         if (PACKY && valid) d_in[i] = dv | (int)(((unsigned)key[r] & 1u) << 31);   // the skeleton slot itself, in the packed form of the other seven
     }
-    { const int2 v = sv[(size_t)w * SKK + t]; s_bH[SKK + t] = v.x; s_cH[SKK + t] = v.y; s_tH[SKK + t] = reinterpret_cast<const int *>(sv + (size_t)g.W * SKK)[t]; }
+    {
+        const int nrow = g.pair ? g.W2 : g.W;
+        int2 v = sv[(size_t)(g.pair ? (w >> 1) : w) * SKK + t];
+        if (g.pair && (w & 1)) {                            // second tile of its pair: fold the first one's row in (skel_k2_kernel's combine)
+            const int2 r0 = (sv + (size_t)nrow * SKK + SKK / 2)[(size_t)(w >> 1) * SKK + t];
+            v.y = r0.x ? r0.y : (v.x ? max(v.y, r0.y) : -1);
+            v.x += r0.x;
+        }
+        s_bH[SKK + t] = v.x; s_cH[SKK + t] = v.y; s_tH[SKK + t] = reinterpret_cast<const int *>(sv + (size_t)nrow * SKK)[t];
+    }
 #pragma unroll
     for (int c = 0; c < NC; ++c) { s_raw8[c][t] = 0; s_last8[c][t] = -1; }
     lds_barrier();

@@ -1,6 +1,3 @@
 mkdir -p gpurun_out/p1m; cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-run() { echo "== $*"; env "$@" timeout 300 python tools/wide_bench.py 1000000 8192 hp; env "$@" timeout 300 python tools/wide_bench.py 1000000 8192 none; }
-run PBWTAMD_K2_TPW=32
-run PBWTAMD_K2_TPW=64
-run PBWTAMD_K2_TPW=6432
-run PBWTAMD_K2_TPW=32
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/p1m/full_c.log 2>&1; tail -3 gpurun_out/p1m/full_c.log | cut -c1-200
+PBWTAMD_POISON=77 timeout 600 python -m pytest tests/test_gpu_z_configs.py tests/test_gpu_parity.py -x -q -m gpu -k "config4 or north_star or 300000 or wider" 2>&1 | tail -2

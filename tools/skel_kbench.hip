@@ -31,7 +31,7 @@ static void run(int M, float p1, int reps) {
     SkArgs g;
     g.a = dA; g.d = dD; g.keys = dK; g.a_out = dA2; g.d_out = dD2; g.keys_out = dK2;
     g.tbl = (int2 *)tab; g.scan = (int2 *)tab + (size_t)(Wp + 8) * SKK; g.total = tab + (size_t)5 * (Wp + 8) * SKK;
-    g.kbnext = (const unsigned char *)dX; g.has_next = 1; g.M = M; g.W = W; g.xcd = 0; g.k = 100;
+    g.kbnext = (const unsigned char *)dX; g.has_next = 1; g.M = M; g.W = W; g.xcd = 0; g.pair = 0; g.tbl0 = nullptr; g.k = 100;
     Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = W;
     hipStream_t s;
     if (getenv("KB_PRIO")) { int lo, hi; CK(hipDeviceGetStreamPriorityRange(&lo, &hi)); CK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, atoi(getenv("KB_PRIO")) ? hi : 0)); printf("stream: nonblocking, prio %s\n", getenv("KB_PRIO")); }
