@@ -290,9 +290,11 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     ECHK(hipMemsetAsync(e->D, 0, 2 * slots * e->strideD * sizeof(int), e->stream));
     {   // consumers yield to the dependent chain: low priority; and while the chain is the bottleneck (narrow panels) they run on
         // the first 5/8 of the CUs only, so the chain's workgroups find whole shader arrays without scattered-store traffic in
-        // their memory pipelines (measured +3 % at M = 100 k with 160 of 256 CUs; at M = 1 M the consumers are the bottleneck: no mask)
+        // their memory pipelines (measured +3 % at M = 100 k and +13 % at 250 k with 160 of 256 CUs; at M = 1 M the consumers are the bottleneck: no mask)
         int ncu_dev = 0; (void)hipDeviceGetAttribute(&ncu_dev, hipDeviceAttributeMultiprocessorCount, device);
-        int ncus = (M <= 150000 && ncu_dev >= 64 && ncu_dev <= 256) ? ncu_dev * 5 / 8 : 0;
+        // re-measured with the register-light tile scan (us/site, none / 160 / 192 CUs): 150 k 2.13 / 1.88 / 1.91, 200 k 2.40 / 2.11 / 2.15,
+        // 250 k 2.69 / 2.35 / 2.40, 300 k 2.99 / 2.97 / 2.97, 400 k 3.43 / 3.39 / 3.35, 500 k 3.83 / . / 3.78, 700 k 4.66 / . / 4.66, 1 M 5.84 / . / 6.56
+        int ncus = (ncu_dev < 64 || ncu_dev > 256) ? 0 : (M <= 270000) ? ncu_dev * 5 / 8 : (M <= 600000) ? ncu_dev * 3 / 4 : 0;
         if (const char *s = getenv("PBWTAMD_S2_CUS")) ncus = atoi(s);
         if (ncus > 0) {
             uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
