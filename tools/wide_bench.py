@@ -6,7 +6,7 @@ import torch, pbwt_amd as amd
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 sites = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 what = sys.argv[3] if len(sys.argv) > 3 else "hp"
-B = 512
+B = int(os.environ.get("WB_BATCH", "512"))
 eng = amd.Engine(M, batch_sites=B)
 N = sites + B
 panel = torch.empty((N, eng.wpc), dtype=torch.int32, device="cuda")
