@@ -1,4 +1,3 @@
-mkdir -p gpurun_out/p1m; cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for i in 1 2; do
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/p1m/full_d$i.log 2>&1; tail -2 gpurun_out/p1m/full_d$i.log | cut -c1-200
-done
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for G in 1 0; do echo "GRAPH=$G"; for M in 10000 100000 250000; do PBWTAMD_SKEL_GRAPH=$G python tools/hostrate.py $M 8192; for O in none hp; do PBWTAMD_SKEL_GRAPH=$G timeout 300 python tools/wide_bench.py $M 16384 $O; done; done; done
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -3
