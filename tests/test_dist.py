@@ -241,3 +241,51 @@ def test_query_shard_plan():
         assert all(r[g][1] == r[g + 1][0] for g in range(world - 1))
         sizes = [hi - lo for lo, hi in r]
         assert max(sizes) - min(sizes) <= 1
+
+
+ROUND8_WORKER = textwrap.dedent("""
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    from pbwt_amd import dist as pd
+    from pbwt_amd.sharded import sharded_round8, owner_ranges
+    import oracle
+    import torch
+    rank, world = pd.init("gloo")
+    M, N, kind = int(os.environ["SH_M"]), int(os.environ["SH_N"]), int(os.environ["SH_KIND"])
+    bits = oracle.synth_bitcols(M, N, seed=777, kind=kind)
+    hap = oracle.unpack_bitcols(bits, M).astype(np.int64)
+    want = oracle.build_bitcols(bits, M, with_d=True, dump_sites=range(0, N + 1, 8))
+    b = owner_ranges(M, world)
+    lo, hi = b[rank], b[rank + 1]
+    a = torch.arange(lo, hi, dtype=torch.int64)
+    d = torch.zeros(hi - lo, dtype=torch.int64)
+    if rank == 0 and hi > lo:
+        d[0] = 1
+    ok = True
+    for k in range(0, N, 8):
+        key_by_hap = sum(hap[k + j] << j for j in range(8))             # every rank holds the panel's columns (replicated, M / 8 bytes per site)
+        key = torch.from_numpy(key_by_hap)[a]
+        a, d = sharded_round8(a, d, key, k, M)
+        r = k // 8 + 1
+        ok &= bool(np.array_equal(a.numpy(), want["a_dump"][r][lo:hi])) and bool(np.array_equal(d.numpy(), want["d_dump"][r][lo:hi]))
+    with open(os.path.join(os.environ["OUT_DIR"], "r8_" + str(rank) + ".json"), "w") as f:
+        json.dump({"rank": rank, "ok": ok, "n": int(hi - lo)}, f)
+    pd.finish()
+""") % ROOT
+
+
+@pytest.mark.parametrize("world,M,N,kind", [(2, 101, 64, 1), (3, 400, 80, 0), (2, 64, 40, 0), (3, 5, 16, 1)])
+def test_position_sharded_round_of_eight_sites_gloo(world, M, N, kind, tmp_path):
+    """the skeleton round with a rank in the role of a tile (pbwt_amd/sharded.py::sharded_round8): one all-gather of the
+    per-key rows + one all-to-all per EIGHT sites reproduce the oracle's a[] and d[] after every round on every shard"""
+    import json
+    script = tmp_path / "r8_worker.py"
+    script.write_text(ROUND8_WORKER)
+    env = dict(os.environ, OUT_DIR=str(tmp_path), SH_M=str(M), SH_N=str(N), SH_KIND=str(kind))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    outs = [json.load(open(tmp_path / ("r8_%d.json" % rk))) for rk in range(world)]
+    assert all(o["ok"] for o in outs) and sum(o["n"] for o in outs) == M

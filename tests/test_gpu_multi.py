@@ -131,7 +131,17 @@ SHARD_WORKER = textwrap.dedent("""
     for k in range(N):
         a, d = sharded_step_AD(a, d, hap[k][a], k, M)
         ok &= a.is_cuda and bool(np.array_equal(a.cpu().numpy(), want["a_dump"][k + 1][lo:hi])) and bool(np.array_equal(d.cpu().numpy(), want["d_dump"][k + 1][lo:hi]))
-    json.dump({"ok": bool(ok)}, open(os.path.join(os.environ["OUT_DIR"], "ps.json"), "w"))
+    # the skeleton round with a rank in the role of a tile: two collectives per EIGHT sites
+    from pbwt_amd.sharded import sharded_round8
+    a = torch.arange(lo, hi, dtype=torch.int64, device="cuda")
+    d = torch.zeros(hi - lo, dtype=torch.int64, device="cuda")
+    if rank == 0: d[0] = 1
+    ok8 = True
+    for k in range(0, N, 8):
+        key = sum(hap[k + j] << j for j in range(8))[a]
+        a, d = sharded_round8(a, d, key, k, M)
+        ok8 &= a.is_cuda and bool(np.array_equal(a.cpu().numpy(), want["a_dump"][k + 8][lo:hi])) and bool(np.array_equal(d.cpu().numpy(), want["d_dump"][k + 8][lo:hi]))
+    json.dump({"ok": bool(ok), "ok8": bool(ok8)}, open(os.path.join(os.environ["OUT_DIR"], "ps.json"), "w"))
     pd.finish()
 """) % ROOT
 
@@ -147,7 +157,8 @@ def test_position_sharded_step_on_device_tensors_over_rccl(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert json.load(open(tmp_path / "ps.json"))["ok"]
+    res = json.load(open(tmp_path / "ps.json"))
+    assert res["ok"] and res["ok8"]
 
 
 QS_WORKER = textwrap.dedent("""
