@@ -150,7 +150,7 @@ struct pbwtamd_engine {
     int q_lo = 0, q_hi = 0x7fffffff; bool q_part = false;   // query sweeps: only queries q_lo <= jj < q_hi (pbwtamd_set_query_range)
     bool prow = false; int W2 = 0;          // pair rows: skel_hist_kernel<4, true> + the scan on W2 = ceil(Wt / 2) rows
     int Wt = 0, skEPT = 4;                  // skeleton tiles: 256*skEPT positions, Wt of them; PBWTAMD_SKT=512|1024
-    int skn_maxw = 16;                      // two-launch round (rank scans the tile table itself) up to this many tiles; PBWTAMD_SKN_MAXW
+    int skn_maxw = 48;                      // two-launch round (rank scans the tile table itself) up to this many tiles (measured: 5 k -28 %, 8 k -26 %, 10 k -9 %, 12 k -6 %, 16 k 0); PBWTAMD_SKN_MAXW
     bool summ_pair = false;                 // format of the current tile summaries (two-site keys or single site)
     uint32_t *zerocol = nullptr; long long sites_done = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0; long long launches = 0;
