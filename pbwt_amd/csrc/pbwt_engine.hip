@@ -254,7 +254,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         // measured: smaller tiles = shorter per-workgroup latency chains, and every chain workgroup must fit into the hole a retiring
         // consumer workgroup leaves on a CU (LDS is allocated contiguously: a 41 KB rank workgroup of 1024 positions starves beside
         // 26 KB fill workgroups).  1 M, T = 512 vs 1024: 6.25 vs 6.84 us/site; 500 k: 3.99 vs 4.32
-        e->skEPT = (M <= 40000) ? 1 : 2;
+        e->skEPT = (M <= 56000) ? 1 : 2;                       // 256- against 512-position tiles, end to end: 50 k 1.33 vs 1.37 us/site, 70 k 1.52 vs 1.45
         if (const char *sv = getenv("PBWTAMD_SKT")) e->skEPT = (atoi(sv) == 256) ? 1 : (atoi(sv) == 512) ? 2 : 4;
 
         if (M > 256 * e->skEPT * 2048) e->skEPT = 4;           // skel_k2_kernel scans at most 2048 tiles per key
