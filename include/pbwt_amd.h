@@ -230,6 +230,30 @@ int pbwtamd_get_packed(pbwtamd_engine *e, uint8_t **yz_out, int64_t *nz_out);
 int pbwtamd_get_chain_timing(pbwtamd_engine *e, double *ms_total, int64_t *launches);
 int pbwtamd_get_chain_sites(pbwtamd_engine *e, int64_t *sites);   /* sites those launches advanced (2 per launch on the build path) */
 
+/* ======================================================================================
+ * Position sharding of ONE panel across the GPUs of a node (BASELINE configs[3]): the recurrence of
+ * pbwtCursorForwardsAD (pbwtCore.c:485-508) itself is split — rank g owns a contiguous range of positions of the sorted
+ * order a_k, d_k.  Per round of 8 sites the ranks exchange one row of 256 (count, carry) pairs each (the exclusive scan of
+ * the local 0/1 counts, for 8 sites at once) and every element of the new order is stored straight into its owner's memory
+ * (the all-to-all, as peer stores over xGMI through hipIpc mappings).  The consumers (maxWithin sweep, pack3, checksums) are
+ * sharded by site inside every batch.  One process per GPU:
+ *     pbwtamd_engine_create(&e, device, M, batch, stream)          same M and batch on every rank
+ *     pbwtamd_shard_init(e, rank, world, handles)                   -> PBWTAMD_SHARD_HANDLE_BYTES bytes to all-gather
+ *     pbwtamd_shard_connect(e, all_handles)                         world blobs in rank order (after the all-gather)
+ *     pbwtamd_pass_begin / pbwtamd_pass_advance / pbwtamd_pass_end  as on one GPU, with the SAME columns on every rank,
+ *                                                                   original-order columns only
+ * Afterwards every rank holds the complete final state (pbwtamd_get_state); the histogram and the per-site checksums of a
+ * rank cover the sites it consumed — sum them over the ranks; the pack3 bytes of a rank are the blocks of sites
+ * pbwtamd_shard_blocks lists, which concatenate in site order into PBWT.yz.  Several ranks may share one device (tests). */
+#define PBWTAMD_SHARD_HANDLE_BYTES 320
+int pbwtamd_shard_init(pbwtamd_engine *e, int rank, int world, void *handles_out);
+int pbwtamd_shard_connect(pbwtamd_engine *e, const void *all_handles);
+/* positions [*pos_lo, *pos_hi) of the sorted order that `rank` owns */
+int pbwtamd_shard_range(const pbwtamd_engine *e, int rank, int *pos_lo, int *pos_hi);
+/* the blocks of sites whose packed columns this rank wrote since pass_begin, in order: first site, sites, and the offset in
+ * pbwtamd_get_packed's buffer at which the block ENDS.  *n = number of blocks (call with cap = 0 to size the arrays). */
+int pbwtamd_shard_blocks(pbwtamd_engine *e, int64_t *site0, int64_t *nsites, int64_t *byte_end, int cap, int *n);
+
 /* diagnostics: with PBWTAMD_PROFILE=1 in the environment at engine creation the step kernel
  * stamps wall_clock64() (100 MHz) at its phase boundaries for every tile of the LAST launch:
  * out[tile*8 + phase], phases 0..6.  Returns the number of tiles copied, or < 0 on error. */

@@ -78,6 +78,19 @@ void matchLongWithin2 (PBWT *p, int T, void (*report)(int ai, int bi, int start,
     die ("pbwt_amd: %s", pbwtamd_last_error()) ;
 }
 
+/* the "no match to query" lines the reference writes from inside its sweep (pbwtMatch.c:405-410, 489-494), in its order */
+static void noMatchLog (PBWT *p, int64_t nomatch)
+{
+  int32_t *ev = 0 ; int64_t nev = 0, i ;
+  if (!nomatch) return ;
+  if (pbwtamd_get_nomatch_events (engineFor(p->M), &ev, &nev)) die ("pbwt_amd: %s", pbwtamd_last_error()) ;
+  for (i = 0 ; i < nev ; ++i)
+    fprintf (logFile, "no match to query %d value %d at site %d\n", ev[4*i], ev[4*i+1], ev[4*i+2]) ;
+  if (nev < nomatch)		/* the library keeps a bounded number of events; the count is exact */
+    fprintf (logFile, "... %lld further no-match events not listed\n", (long long) (nomatch - nev)) ;
+  pbwtamd_free (ev) ;
+}
+
 static void sweepLog (PBWT *q, int64_t *tot)	/* pbwtMatch.c:438-439 */
 {
   fprintf (logFile, "Average number of best matches including alternates %.1f, Average length %.1f, Av number per position %.1f\n",
@@ -92,6 +105,7 @@ void matchSequencesSweep (PBWT *p, PBWT *q, void (*report)(int ai, int bi, int s
   if (pbwtamd_match_sweep (engineFor(p->M), PZ(p), p->N, p->aFstart,
 			   q->M, PZ(q), q->aFstart, report, 0, 0, &nomatch, tot))
     die ("pbwt_amd: %s", pbwtamd_last_error()) ;
+  noMatchLog (p, nomatch) ;
   sweepLog (q, tot) ;
 }
 
@@ -109,6 +123,7 @@ void matchSequencesSweepSparse (PBWT *p, PBWT *q, int nSparse,
   if (pbwtamd_match_sweep_sparse (engineFor(p->M), PZ(p), p->N, p->aFstart,
 				  q->M, PZ(q), q->aFstart, nSparse, sparseThunk, 0, 0, &nomatch, tot))
     die ("pbwt_amd: %s", pbwtamd_last_error()) ;
+  noMatchLog (p, nomatch) ;
   sweepLog (q, tot) ;
 }
 

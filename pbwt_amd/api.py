@@ -10,6 +10,7 @@ MATCH_DTYPE = np.dtype([("ai", "<i4"), ("bi", "<i4"), ("start", "<i4"), ("end", 
 MATCH5_DTYPE = np.dtype([("ai", "<i4"), ("bi", "<i4"), ("start", "<i4"), ("end", "<i4"), ("sparse", "<i4")])
 REPORT5_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
 REPORT_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_int, C.c_int)
+SHARD_HANDLE_BYTES = 320              # PBWTAMD_SHARD_HANDLE_BYTES
 
 
 class PbwtAmdError(RuntimeError):
@@ -353,6 +354,31 @@ class Engine:
         if n < 0:
             raise PbwtAmdError(self._L.pbwtamd_last_error().decode())
         return out[:n]
+
+    # ------------------------------------------------------------ position sharding (one rank of a panel; pbwt_amd/posshard.py)
+    def shard_init(self, rank, world):
+        """make this engine rank `rank` of `world`; returns the handle blob (bytes) the ranks all-gather"""
+        buf = C.create_string_buffer(SHARD_HANDLE_BYTES)
+        self._chk(self._L.pbwtamd_shard_init(self._h, C.c_int(rank), C.c_int(world), buf))
+        return buf.raw
+
+    def shard_connect(self, blobs):
+        """blobs: the ranks' handle blobs in rank order"""
+        allb = b"".join(blobs)
+        self._chk(self._L.pbwtamd_shard_connect(self._h, C.c_char_p(allb)))
+
+    def shard_range(self, rank):
+        lo, hi = C.c_int(0), C.c_int(0)
+        self._chk(self._L.pbwtamd_shard_range(self._h, C.c_int(rank), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def shard_blocks(self):
+        """(site0[], nsites[], byte_end[]) of the pack3 blocks this rank wrote since pass_begin"""
+        n = C.c_int(0)
+        self._chk(self._L.pbwtamd_shard_blocks(self._h, None, None, None, C.c_int(0), C.byref(n)))
+        s0 = np.zeros(max(n.value, 1), np.int64); ns = np.zeros(max(n.value, 1), np.int64); be = np.zeros(max(n.value, 1), np.int64)
+        self._chk(self._L.pbwtamd_shard_blocks(self._h, _p(s0, C.c_int64), _p(ns, C.c_int64), _p(be, C.c_int64), C.c_int(s0.size), C.byref(n)))
+        return s0[: n.value], ns[: n.value], be[: n.value]
 
     def chain_timing(self):
         ms = C.c_double(0)

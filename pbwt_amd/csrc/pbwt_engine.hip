@@ -95,7 +95,7 @@ struct DevBufs {
 constexpr unsigned OPT_INTERNAL_KEEP_STATES = 0x100u;
 
 struct GraphKey { int with_d, sorted, ring, pair; hipGraphExec_t exec; };
-struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; bool skel = false; };
+struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; bool skel = false; bool sharded = false; };
 
 // skeleton batches whose consumers need (d, y) of every site but not the haplotype ids (histogram sweep, pack3 through the
 // sweep's bit columns): the fill writes d | y << 31 and no a — half the consumer stream's bytes (they are what slows the chain)
@@ -104,6 +104,23 @@ static inline bool packed_fill(const Pending &p) {
     const unsigned ids = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_LONG_RECS | 0x100u /* OPT_INTERNAL_KEEP_STATES */;
     return !off && !no_fuse && p.skel && (p.opts & PBWTAMD_OPT_WITHIN_HIST) && !(p.opts & ids);
 }
+
+// one rank of a position-sharded panel (pbwt_shard.inc)
+struct ShardCtx {
+    int rank = 0, world = 1, w0 = 0, Wl = 0;
+    int tb[SHARD_MAX + 1] = {};                                 // tile boundaries
+    int pb[SHARD_MAX + 1] = {};                               // position boundaries; pb[world] = M, unused entries INT_MAX
+    ShardXch *xch = nullptr; bool xch_ext = false;            // own exchange block
+    ShardPeers peers = {};                                    // every rank's exchange block as mapped here (own = xch)
+    int *peerA[SHARD_MAX] = {}, *peerD[SHARD_MAX] = {}; unsigned char *peerK[2][SHARD_MAX] = {};   // ring bases of every rank (own = the engine's)
+    bool connected = false;
+    int2 *tbl = nullptr, *scan = nullptr; int *total = nullptr;              // chain scratch, rows indexed by global tile
+    unsigned long long *agg = nullptr; unsigned *cnt = nullptr; unsigned cntEpoch = 0;
+    unsigned e1 = 0, e2 = 0, e3 = 0;                          // epochs of f1 / f2 / f3
+    int2 *ctbl = nullptr; unsigned long long *cagg = nullptr; unsigned *ccnt = nullptr; unsigned cEpoch = 0;   // consumer stream: hist rows + two-level scan state
+    std::vector<long long> blkSite0, blkSites; unsigned long long *blkEnd = nullptr; size_t blkCap = 0;          // pack3 blocks this rank wrote
+    bool full_state = true;                                   // slot 0 of the current ring is complete on this rank (pass start, after a replicated batch)
+};
 
 struct pbwtamd_engine {
     int device = 0, M = 0, Mpad = 0, wpc = 0, wpc64 = 0, W = 0, wpad = 0, E = 4, T = 1024, B = 0;
@@ -159,6 +176,7 @@ struct pbwtamd_engine {
     int longL = 0;                          // L of the -longWithin consumer (PBWTAMD_OPT_LONG_RECS)
     int *ystale = nullptr;                  // copy of the previous state's tagged a, for the k == N quirk of -longWithin
     std::vector<int32_t> nomatch_events;    // (jj, x, k[, isSparse]) of the last query sweep, in the reference's log order
+    ShardCtx *sh = nullptr;          // position sharding across GPUs (pbwt_shard.inc): this engine is one rank of a panel
 };
 
 extern "C" int pbwtamd_abi_version(void) { return PBWTAMD_ABI_VERSION; }
@@ -176,11 +194,15 @@ extern "C" int pbwtamd_engine_batch(const pbwtamd_engine *e) { return e->B; }
 static int wpc_for(int M) { return ((M + 31) / 32 + 3) / 4 * 4; }
 static inline int p3_regions(int M) { return ((M + 63) / 64 + 63) / 64; }   // regions of 64 words per column (region-parallel pack3 encoder)
 
+static void shard_release(pbwtamd_engine *e);
+
 extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    if (e->s2) { (void)hipStreamSynchronize(e->s2); (void)hipStreamDestroy(e->s2); }
+    if (e->s2) (void)hipStreamSynchronize(e->s2);
+    shard_release(e);
+    if (e->s2) (void)hipStreamDestroy(e->s2);
     for (int i = 0; i < 16; ++i) if (e->tev[i]) (void)hipEventDestroy(e->tev[i]);
     for (int i = 0; i < 8; ++i) if (e->evUsed[i]) (void)hipEventDestroy(e->evUsed[i]);
     if (e->h_used) (void)hipHostFree(e->h_used);
@@ -322,7 +344,7 @@ extern "C" int pbwtamd_sync(pbwtamd_engine *e) {
     HIPCHK(hipStreamSynchronize(e->s2));
     int err = 0;
     HIPCHK(hipMemcpy(&err, e->ctl + 2, sizeof(int), hipMemcpyDeviceToHost));
-    if (err) return fail("pbwtamd: device-side error flag %d (1=histogram range, 2/3=malformed packed column, 4=yz buffer overflow, 5=tile scan of a wide panel timed out waiting for its workgroups)", err);
+    if (err) return fail("pbwtamd: device-side error flag %d (1=histogram range, 2/3=malformed packed column, 4=yz buffer overflow, 5=tile scan of a wide panel timed out waiting for its workgroups, 6/7=a position-sharded rank timed out waiting for its peers)", err);
     return 0;
 }
 
@@ -434,6 +456,8 @@ extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k
     e->pend.valid = false;
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipStreamSynchronize(e->s2));
+    if (e->k2cnt) { HIPCHK(hipMemsetAsync(e->k2cnt, 0, 64, e->stream)); e->k2epoch = 0; }   // arrival counter and host epoch restart together
+    if (e->sh) { e->sh->full_state = true; e->sh->blkSite0.clear(); e->sh->blkSites.clear(); }
     e->k0 = k0; e->k_cur = k0; e->n_total = n_total; e->prepared = false; e->pass_open = true;
     e->ring = 0; e->consRecorded[0] = e->consRecorded[1] = false; e->chainRecorded[0] = e->chainRecorded[1] = false;
     e->keys_ready[0] = e->keys_ready[1] = false;
@@ -706,13 +730,11 @@ static int xcd_flags() { static const int v = getenv("PBWTAMD_XCD") ? atoi(geten
 
 // batch consumers (checksums, maxWithin sweep, pack3) of the pending batch, on the second stream so
 // they overlap the next batch's launch chain (which occupies only ~W of the 256 CUs)
-static int flush_pending(pbwtamd_engine *e) {
-    if (!e->pend.valid) return 0;
-    const Pending p = e->pend;
-    e->pend.valid = false;
-    const int *A = ringA(e, p.ring), *D = ringD(e, p.ring);
+// consumers over the sites kbase+j0 .. kbase+j0+ns-1 of batch p (slots j0 .. j0+ns-1 of its ring; j0, ns multiples of 8 on the skeleton path)
+static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns) {
+    const int *A = ringA(e, p.ring) + (size_t)j0 * e->strideA, *D = ringD(e, p.ring) + (size_t)j0 * e->strideD;
+    const int kb = p.kbase + j0;
     const bool with_d = p.opts & PBWTAMD_OPT_WITH_D;
-    HIPCHK(hipStreamWaitEvent(e->s2, e->evChain[p.ring], 0));
 #ifdef PBWTAMD_MEASURE                                     // measurement builds only (-DPBWTAMD_MEASURE): these switches give WRONG results
     static const bool nofill = getenv("PBWTAMD_NOFILL") && atoi(getenv("PBWTAMD_NOFILL"));
 #else
@@ -722,16 +744,16 @@ static int flush_pending(pbwtamd_engine *e) {
     const bool packed = packed_fill(p);
     if (p.skel && !nofill && (p.opts & consumers)) {   // the 7 states between consecutive skeleton states: all blocks and tiles in one launch
         SkFillArgs f;
-        f.A = ringA(e, p.ring); f.D = ringD(e, p.ring); f.strideA = e->strideA; f.strideD = e->strideD;
-        f.keys = e->keysR[p.ring]; f.strideK = e->Mpad; f.scan = e->saveR[p.ring]; f.strideS = e->strideS;
-        f.M = e->M; f.W = e->Wt; f.kbase = p.kbase;
+        f.A = ringA(e, p.ring) + (size_t)j0 * e->strideA; f.D = ringD(e, p.ring) + (size_t)j0 * e->strideD; f.strideA = e->strideA; f.strideD = e->strideD;
+        f.keys = e->keysR[p.ring] + (size_t)(j0 / 8) * e->Mpad; f.strideK = e->Mpad; f.scan = e->saveR[p.ring] + (size_t)(j0 / 8) * e->strideS; f.strideS = e->strideS;
+        f.M = e->M; f.W = e->Wt; f.kbase = kb;
 #ifdef PBWTAMD_MEASURE
         static const int dbg_nowrite = getenv("PBWTAMD_DEBUG_FILL_NOWRITE") ? 1 : 0; f.dbg_nowrite = dbg_nowrite;
 #endif
         f.pack_y = packed ? 1 : 0;
         f.xcd = xcd_flags() & 1;
         f.pair = e->prow ? 1 : 0; f.W2 = e->W2;
-        dim3 grid(e->Wt, p.nb / 8);
+        dim3 grid(e->Wt, ns / 8);
         static const size_t dyn = getenv("PBWTAMD_FILL_PAD_KB") ? (size_t)atoi(getenv("PBWTAMD_FILL_PAD_KB")) * 1024 : 0;   // occupancy probe (results unchanged)
 #define FILL(EP) do { if (packed) hipLaunchKernelGGL((skel_fill_kernel<EP, true>), grid, dim3(BLOCK), dyn, e->s2, f); \
                       else hipLaunchKernelGGL((skel_fill_kernel<EP, false>), grid, dim3(BLOCK), dyn, e->s2, f); } while (0)
@@ -740,20 +762,32 @@ static int flush_pending(pbwtamd_engine *e) {
         HIPCHK(hipGetLastError());
     }
     if (p.opts & PBWTAMD_OPT_CHECKSUM) {
-        unsigned long long *ca = e->csum + (p.kbase - e->k0), *cd = ca + e->csum_sites, *cy = cd + e->csum_sites;
-        dim3 grid(std::min(64, (e->M + BLOCK) / BLOCK), p.nb);
-        hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, e->s2, A, D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, p.nb);
+        unsigned long long *ca = e->csum + (kb - e->k0), *cd = ca + e->csum_sites, *cy = cd + e->csum_sites;
+        dim3 grid(std::min(64, (e->M + BLOCK) / BLOCK), ns);
+        hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, e->s2, A, D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, ns);
         HIPCHK(hipGetLastError());
     }
-    if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, e->s2, A, D, p.kbase, p.nb, -1, p.opts, packed));
+    if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, e->s2, A, D, kb, ns, -1, p.opts, packed));
     if (p.opts & PBWTAMD_OPT_LONG_RECS) {
-        CHK(run_long(e, e->s2, A, D, nullptr, p.kbase, p.nb, -1));
+        CHK(run_long(e, e->s2, A, D, nullptr, kb, ns, -1));
         // keep the batch's last state (before site kbase+nb-1): it is the stale allele column if the panel ends here
         if (!e->ystale) HIPCHK(dev_alloc((void **)&e->ystale, sizeof(int) * e->strideA));
-        HIPCHK(hipMemcpyAsync(e->ystale, A + (size_t)(p.nb - 1) * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->s2));
+        HIPCHK(hipMemcpyAsync(e->ystale, A + (size_t)(ns - 1) * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->s2));
     }
     static const bool no_fuse = getenv("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
-    if (p.opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, e->s2, A, p.nb, !no_fuse && (p.opts & PBWTAMD_OPT_WITHIN_HIST) != 0));
+    if (p.opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, e->s2, A, ns, !no_fuse && (p.opts & PBWTAMD_OPT_WITHIN_HIST) != 0));
+    return 0;
+}
+
+static int shard_flush_pending(pbwtamd_engine *e);
+
+static int flush_pending(pbwtamd_engine *e) {
+    if (!e->pend.valid) return 0;
+    if (e->sh) return shard_flush_pending(e);
+    const Pending p = e->pend;
+    e->pend.valid = false;
+    HIPCHK(hipStreamWaitEvent(e->s2, e->evChain[p.ring], 0));
+    CHK(run_consumers(e, p, 0, p.nb));
     HIPCHK(hipEventRecord(e->evCons[p.ring], e->s2));
     e->consRecorded[p.ring] = true;
     return 0;
@@ -764,43 +798,51 @@ static int flush_pending(pbwtamd_engine *e) {
 static inline bool skel_two_launch(const pbwtamd_engine *e) { return e->skn && e->Wt <= e->skn_maxw; }
 
 // launch helpers for the skeleton kernels: EPT = positions per thread (tile = 256*EPT)
+// hist + the per-key scan over the tiles, into g.scan / g.total (and g.tbl0 with pair rows) on stream st; returns true when the
+// wide (two-level) scan ran.  agg / cnt / epoch: the two-level scan's aggregates and arrival counter (one set per stream).
+template <int EPT>
+static bool launch_skel_hist_scan(pbwtamd_engine *e, hipStream_t st, const SkArgs &g, unsigned long long *agg, unsigned *cnt, unsigned *epoch) {
+    const int W = g.W;
+    if (e->prow) {                                         // wide panels: hist and scan on PAIRS of tiles (half the rows), rank on tiles
+        SkArgs h = g; h.W = e->W2; h.Wtot = e->W2;
+        hipLaunchKernelGGL((skel_hist_kernel<4, true>), dim3(e->W2), dim3(BLOCK), 0, st, h);
+        Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = e->W2; kw.agg = agg; kw.counter = cnt; kw.err = e->ctl + 2;
+        const int nwg = (e->W2 + 31) / 32;
+        *epoch += (unsigned)nwg; kw.target = *epoch;
+        hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, st, kw);
+        return true;
+    }
+    hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, st, g);
+    static const bool k2_wide = !(getenv("PBWTAMD_K2_WIDE") && !atoi(getenv("PBWTAMD_K2_WIDE")));
+    if (W > 512 && W <= 64 * 32 && k2_wide) {              // two-level scan in one launch: <= 64 co-resident workgroups of 32 tiles
+        Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = W; kw.agg = agg; kw.counter = cnt; kw.err = e->ctl + 2;
+        const int nwg = (W + 31) / 32;
+        *epoch += (unsigned)nwg; kw.target = *epoch;
+        hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, st, kw);
+        return true;
+    }
+    Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = W;
+    if (W <= 256) hipLaunchKernelGGL((skel_k2_kernel<4, 4>), dim3(SKK / 4), dim3(BLOCK), 0, st, k2);   // one key per wave (16 / 8 keys per workgroup measured slower)
+    else if (W <= 1024) hipLaunchKernelGGL((skel_k2_kernel<4, 16>), dim3(SKK / 4), dim3(BLOCK), 0, st, k2);
+    else hipLaunchKernelGGL((skel_k2_kernel<2, 32>), dim3(SKK / 2), dim3(128), 0, st, k2);
+    return false;
+}
+
 template <int EPT>
 static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
     const int W = g.W;
-    if (e->prow) {                                         // wide panels: hist and scan on PAIRS of tiles (half the rows), rank on tiles
-        SkArgs h = g; h.W = e->W2;
-        hipLaunchKernelGGL((skel_hist_kernel<4, true>), dim3(e->W2), dim3(BLOCK), 0, e->stream, h);
-        Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = e->W2; kw.agg = e->k2agg; kw.counter = e->k2cnt; kw.err = e->ctl + 2;
-        const int nwg = (e->W2 + 31) / 32;
-        e->k2epoch += (unsigned)nwg; kw.target = e->k2epoch;
-        hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, e->stream, kw);
-        hipLaunchKernelGGL((skel_rank_kernel<EPT, 0, true>), dim3(W), dim3(BLOCK), 0, e->stream, g);
-        return;
-    }
-    hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, e->stream, g);
-    if (two_launch) {
+    if (two_launch && !e->prow) {
+        hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         if (W <= 16) hipLaunchKernelGGL((skel_rank_kernel<EPT, 16>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         else if (W <= 32) hipLaunchKernelGGL((skel_rank_kernel<EPT, 32>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         else if (W <= 64) hipLaunchKernelGGL((skel_rank_kernel<EPT, 64>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         else hipLaunchKernelGGL((skel_rank_kernel<EPT, SKN_MAXW>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         return;
     }
-    static const bool k2_wide = !(getenv("PBWTAMD_K2_WIDE") && !atoi(getenv("PBWTAMD_K2_WIDE")));
-    if (W > 512 && W <= 64 * 32 && k2_wide) {              // two-level scan in one launch: <= 64 co-resident workgroups of 32 tiles
-        Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = W; kw.agg = e->k2agg; kw.counter = e->k2cnt; kw.err = e->ctl + 2;
-        const int nwg = (W + 31) / 32;
-        e->k2epoch += (unsigned)nwg; kw.target = e->k2epoch;
-        hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, e->stream, kw);
-        static const bool rank_r4 = !(getenv("PBWTAMD_RANK_R4") && !atoi(getenv("PBWTAMD_RANK_R4")));
-        if (rank_r4) hipLaunchKernelGGL((skel_rank_kernel<EPT, 0, true>), dim3(W), dim3(BLOCK), 0, e->stream, g);    // more tiles than one round of the chip: occupancy counts
-        else hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
-        return;
-    }
-    Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = W;
-    if (W <= 256) hipLaunchKernelGGL((skel_k2_kernel<4, 4>), dim3(SKK / 4), dim3(BLOCK), 0, e->stream, k2);   // one key per wave (16 / 8 keys per workgroup measured slower)
-    else if (W <= 1024) hipLaunchKernelGGL((skel_k2_kernel<4, 16>), dim3(SKK / 4), dim3(BLOCK), 0, e->stream, k2);
-    else hipLaunchKernelGGL((skel_k2_kernel<2, 32>), dim3(SKK / 2), dim3(128), 0, e->stream, k2);
-    hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
+    const bool wide = launch_skel_hist_scan<EPT>(e, e->stream, g, e->k2agg, e->k2cnt, &e->k2epoch);
+    static const bool rank_r4 = !(getenv("PBWTAMD_RANK_R4") && !atoi(getenv("PBWTAMD_RANK_R4")));
+    if (wide && (e->prow || rank_r4)) hipLaunchKernelGGL((skel_rank_kernel<EPT, 0, true>), dim3(W), dim3(BLOCK), 0, e->stream, g);    // more tiles than one round of the chip: occupancy counts
+    else hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
 }
 
 // the skeleton chain of one batch: slot 8s -> slot 8s+8 with an 8-bit radix step (keys = the alleles
@@ -841,7 +883,7 @@ static int skel_rounds(pbwtamd_engine *e, int r, const uint32_t *cols, bool sort
     const bool two = skel_two_launch(e);
     SkArgs g;
     g.tbl = (int2 *)e->skT;
-    g.M = e->M; g.W = W; g.xcd = xcd_flags();
+    g.M = e->M; g.W = W; g.xcd = xcd_flags(); g.w0 = 0; g.Wtot = W;
     for (int s8 = s_from; s8 < s_to; ++s8) {
         const int site = 8 * s8;                           // relative to the batch
         const bool last = direct && s8 == nb / 8 - 1;
@@ -867,6 +909,8 @@ static int skel_rounds(pbwtamd_engine *e, int r, const uint32_t *cols, bool sort
     HIPCHK(hipGetLastError());
     return 0;
 }
+
+#include "pbwt_shard.inc"
 
 extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, int wpc, int ncols, int ncols_avail, unsigned opts) {
     HIPCHK(hipSetDevice(e->device));
@@ -896,6 +940,12 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         // the skeleton always carries d (A-only passes run it too: the divergences cost nothing on its critical path)
         const bool skel = e->skel && (nb % 8 == 0) && (sorted ? skel_read && left >= std::min(nb + 1, remaining) : left >= std::min(nb + 8, remaining));
         const bool pair = !skel && e->pair && !sorted && (e->T == 256 || e->T == 1024 || e->T == 2048 || e->T == 4096) && left >= std::min(2 * L + 2, remaining);
+        if (e->sh) {                                       // one rank of a position-sharded panel (pbwt_shard.inc)
+            if (sorted) return fail("pbwtamd: a position-sharded engine runs the build side only (original-order columns)");
+            if (!e->sh->connected) return fail("pbwtamd: pbwtamd_shard_connect has not been called");
+            if (skel) { CHK(shard_batch(e, bc, nb, left, opts)); done += nb; continue; }
+            CHK(shard_make_full(e));                       // a batch the skeleton cannot take: replicated on every rank
+        }
         if (!skel) {
             CHK(ensure_prepared(e, bc, sorted, with_d, pair, left));
             hipLaunchKernelGGL(set_ctl_kernel, dim3(1), dim3(256), 0, e->stream, e->ctlblk, e->k_cur, e->n_total, bc, (const uint32_t *)e->zerocol,
@@ -955,11 +1005,12 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
             CHK(flush_pending(e));
             // ---- carry the cursor into slot 0 of the other ring once its readers are done ----
             if (e->consRecorded[r ^ 1]) HIPCHK(hipStreamWaitEvent(e->stream, e->evCons[r ^ 1], 0));
+            if (e->sh) shard_wait_ring(e);                 // peers may still be pulling the other ring's slots
             HIPCHK(hipMemcpyAsync(ringA(e, r ^ 1), A + (size_t)nb * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->stream));
             if (with_d) HIPCHK(hipMemcpyAsync(ringD(e, r ^ 1), D + (size_t)nb * e->strideD, sizeof(int) * e->strideD, hipMemcpyDeviceToDevice, e->stream));
         }
         if (skel || (opts & (PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS))) {
-            e->pend.valid = true; e->pend.ring = r; e->pend.kbase = e->k_cur; e->pend.nb = nb; e->pend.opts = opts; e->pend.skel = skel;
+            e->pend.valid = true; e->pend.ring = r; e->pend.kbase = e->k_cur; e->pend.nb = nb; e->pend.opts = opts; e->pend.skel = skel; e->pend.sharded = false;
         }
         e->ring = r ^ 1;
         e->k_cur += nb;
@@ -974,8 +1025,13 @@ extern "C" int pbwtamd_pass_end(pbwtamd_engine *e, unsigned opts) {
     if (e->k_cur != e->n_total) return fail("pbwtamd_pass_end: at site %d of %d", e->k_cur, e->n_total);
     const bool with_d = opts & PBWTAMD_OPT_WITH_D;
     CHK(flush_pending(e));
+    if (e->sh) CHK(shard_make_full(e));                    // every rank ends with the complete final state
     HIPCHK(hipStreamSynchronize(e->stream));               // the final state sits in slot 0 of e->ring
     const int *A = ringA(e, e->ring), *D = ringD(e, e->ring);
+    if (e->sh) {                                           // the closing site belongs to the last rank; nobody leaves before every pull is done
+        shard_xbar(e, e->stream, 1, 3, ++e->sh->e2);
+        if (e->sh->rank != e->sh->world - 1) { e->pass_open = false; return pbwtamd_sync(e); }
+    }
     if (opts & PBWTAMD_OPT_CHECKSUM) {
         unsigned long long *ca = e->csum + (e->k_cur - e->k0), *cd = ca + e->csum_sites, *cy = cd + e->csum_sites;
         dim3 grid(std::min(64, (e->M + BLOCK) / BLOCK), 1);
@@ -994,6 +1050,7 @@ extern "C" int pbwtamd_pass_stop(pbwtamd_engine *e) {
     HIPCHK(hipSetDevice(e->device));
     if (!e->pass_open) return fail("pbwtamd_pass_stop without pass_begin");
     CHK(flush_pending(e));
+    if (e->sh) { CHK(shard_make_full(e)); shard_xbar(e, e->stream, 1, 3, ++e->sh->e2); }
     e->pass_open = false;
     return pbwtamd_sync(e);
 }

@@ -778,8 +778,19 @@ struct SkArgs {
     int2 *scan; int *total;                                     // scan -> rank (kept for the fill): [W][256] {keys before the tile, carry}, total[256]
     const unsigned char *kbnext; int has_next;                  // byte plane of the NEXT round's keys by haplotype (transpose32_kernel)
     const unsigned long long *ycnext;                           // read side: sorted bit column of the OUTPUT state's site (tag by position); keys are precomputed
-    int M, W, k;                                                // k = site of the input state
+    int M, W, k;                                                // k = site of the input state; W = tiles of this launch
     int xcd;                                                    // bit 1: rank, bit 2: hist — XCD-contiguous tiles (xcd_tile)
+    int w0, Wtot;                                               // position sharding: this launch covers tiles w0 .. w0+W-1 of Wtot (one GPU: 0, W)
+};
+
+// Position sharding: the ranks of one panel own contiguous ranges of TILES of the sorted order.  Every rank keeps
+// full-width ring slots; the chain of rank g reads and writes positions pb[g] .. pb[g+1]-1 of them only, and its rank kernel
+// stores each (a | tag, d', key) into the slot of the position's OWNER through the peers' mapped ring pointers (hipIpc).
+constexpr int SHARD_MAX = 8;
+struct SkShardOut {
+    int n;                                                      // ranks
+    int pb[SHARD_MAX + 1];                                      // first position of every rank's range; pb[n] = M (unused entries: INT_MAX)
+    int *a[SHARD_MAX]; int *d[SHARD_MAX]; unsigned char *k[SHARD_MAX];   // the OUTPUT slot (and its key row) in every rank's ring
 };
 
 // HALF (pair rows, wide panels): the workgroup covers a PAIR of the rank kernel's tiles and also emits the (count, tail) row of its
@@ -796,7 +807,7 @@ __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
     __shared__ int s_suf[T];
     __shared__ int s_w[WAVES];
     __shared__ int h_cnt0[HALF ? SKK : 1], h_last0[HALF ? SKK : 1], s_suf0[HALF ? T / 2 : 1];
-    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = (g.xcd & 4) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = g.w0 + ((g.xcd & 4) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x);
     const int rb = BLOCK - 1 - t;
     const int l0 = rb * EPT, i0 = w * T + l0;
     unsigned packed;
@@ -991,6 +1002,158 @@ __global__ __launch_bounds__(SKK) void skel_k2_wide_kernel(Sk2WArgs g) {
     if (j == (int)gridDim.x - 1) g.total[t] = ec;
 }
 
+// ---------------------------------------------------------------------------------------------
+// POSITION SHARDING across GPUs (pbwtCore.c:485-508 is what is sharded).  With the skeleton the per-site
+// "exclusive scan of local counts + all-to-all" of the north star becomes, per ROUND of 8 sites:
+//   (1) every rank publishes ONE row of 256 {count, tail} — its tiles' rows folded with the scan's own combine — into every
+//       peer's exchange block, and the scan of a rank starts from the fold of the rows of the ranks before it;
+//   (2) the rank kernel stores (a | tag, d', key) straight into the owner's ring slot (peer stores through hipIpc mappings),
+//       and a flag barrier closes the round.
+// The exchange block lives in device memory of its owner, mapped into every peer; everything in it is accessed with
+// system-scope atomics only (no cached copies), the bulk data only across kernel boundaries (tools/ipcprobe.hip measures both).
+struct alignas(256) ShardXch {
+    unsigned f1[64];                                        // [src] round whose row aggregate src has published here
+    unsigned f2[64];                                        // [src] chain barriers src has arrived at (scatter of a round complete)
+    unsigned f3[64];                                        // [src] batches whose consumers src has finished (ring reuse)
+    unsigned long long ragg[SHARD_MAX][SKK];                // [src][key] count | tail << 32 of src's tiles, current round
+};
+struct ShardPeers { ShardXch *x[SHARD_MAX]; int n, me; };
+
+__device__ __forceinline__ void shard_wait_flags(const unsigned *mine, int n, unsigned epoch, int *err, int code) {
+    const int t = threadIdx.x;
+    if (t < n) {                                            // bounded (seconds): a rank that died must not hang the others' GPUs
+        long spins = 0;
+        while ((int)(__hip_atomic_load(mine + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1L << 24)) { atomicExch(err, code); break; }
+        }
+    }
+}
+// which: 0 = f1, 1 = f2, 2 = f3.  mode bit 0: signal every rank (this one included), bit 1: wait for every rank
+__global__ __launch_bounds__(64) void shard_xbar_kernel(ShardPeers P, int which, int mode, unsigned epoch, int *err) {
+    const int t = threadIdx.x;
+    if ((mode & 1) && t < P.n) {
+        unsigned *f = which == 0 ? P.x[t]->f1 : which == 1 ? P.x[t]->f2 : P.x[t]->f3;
+        __hip_atomic_store(f + P.me, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (mode & 2) {
+        const unsigned *f = which == 0 ? P.x[P.me]->f1 : which == 1 ? P.x[P.me]->f2 : P.x[P.me]->f3;
+        shard_wait_flags(f, P.n, epoch, err, 6);
+    }
+}
+
+// SCAN of a shard, first half: workgroup j folds the rows of its TPW tiles per key (thread = key) and publishes the aggregate; the
+// last workgroup to arrive folds the workgroups' aggregates into the RANK's row, stores it into every rank's exchange block and
+// raises f1 there.  rows are indexed by global tile; this launch covers tiles w0 .. w0+Wl-1.
+struct Sk2SArgs { const int2 *tbl; int2 *scan; int *total; int w0, Wl; unsigned long long *agg; unsigned *counter; unsigned target; unsigned epoch; int *err; };
+template <int TPW, int CH = 16>
+__global__ __launch_bounds__(SKK) void skel_k2s_agg_kernel(Sk2SArgs g, ShardPeers P) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    __shared__ int s_last;
+    const int t = threadIdx.x, j = blockIdx.x, r0 = j * TPW;
+    int ac = 0, at = 0;
+#pragma unroll 1
+    for (int x0 = 0; x0 < TPW; x0 += CH) {
+        int2 v[CH];
+#pragma unroll
+        for (int x = 0; x < CH; ++x) v[x] = (r0 + x0 + x < g.Wl) ? g.tbl[(size_t)(g.w0 + r0 + x0 + x) * SKK + t] : make_int2(0, 0);
+#pragma unroll
+        for (int x = 0; x < CH; ++x) { at = v[x].x ? v[x].y : max(at, v[x].y); ac += v[x].x; }
+    }
+    __hip_atomic_store(g.agg + (size_t)j * SKK + t, ((unsigned long long)(unsigned)at << 32) | (unsigned)ac, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) s_last = (__hip_atomic_fetch_add(g.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == g.target) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    int rc = 0, rt = 0;
+    const int nwg = (int)gridDim.x;
+#pragma unroll 1
+    for (int i0 = 0; i0 < nwg; i0 += 32) {
+        unsigned long long pv[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) pv[i] = (i0 + i < nwg) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32); rt = vc ? vt : max(rt, vt); rc += vc; }
+    }
+    const unsigned long long row = ((unsigned long long)(unsigned)rt << 32) | (unsigned)rc;
+    for (int p = 0; p < P.n; ++p) __hip_atomic_store(&P.x[p]->ragg[P.me][t], row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __atomic_thread_fence(__ATOMIC_RELEASE);                // system scope: the row is out before the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t < P.n) __hip_atomic_store(&P.x[t]->f1[P.me], g.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// second half: once every rank's row is here — prefix = fold of the rows of the ranks before this one and of this rank's
+// workgroups before j; then the running prefix in front of each of the workgroup's tiles, and the totals over ALL ranks.
+template <int TPW, int CH = 16>
+__global__ __launch_bounds__(SKK) void skel_k2s_scan_kernel(Sk2SArgs g, ShardPeers P) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    const int t = threadIdx.x, j = blockIdx.x, r0 = j * TPW;
+    shard_wait_flags(P.x[P.me]->f1, P.n, g.epoch, g.err, 7);
+    __syncthreads();
+    int ec = 0, et = 0, tot = 0;
+    {
+        unsigned long long rv[SHARD_MAX];
+#pragma unroll
+        for (int r = 0; r < SHARD_MAX; ++r) rv[r] = (r < P.n) ? __hip_atomic_load(&P.x[P.me]->ragg[r][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ULL;
+#pragma unroll
+        for (int r = 0; r < SHARD_MAX; ++r) {
+            const int vc = (int)(unsigned)rv[r], vt = (int)(rv[r] >> 32);
+            tot += vc;
+            if (r < P.me) { et = vc ? vt : max(et, vt); ec += vc; }
+        }
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < j; i0 += 32) {
+        unsigned long long pv[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) pv[i] = (i0 + i < j) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32); et = vc ? vt : max(et, vt); ec += vc; }
+    }
+#pragma unroll 1
+    for (int x0 = 0; x0 < TPW; x0 += CH) {
+        int2 v[CH];
+#pragma unroll
+        for (int x = 0; x < CH; ++x) v[x] = (r0 + x0 + x < g.Wl) ? g.tbl[(size_t)(g.w0 + r0 + x0 + x) * SKK + t] : make_int2(0, 0);
+#pragma unroll
+        for (int x = 0; x < CH; ++x) {
+            if (r0 + x0 + x < g.Wl) g.scan[(size_t)(g.w0 + r0 + x0 + x) * SKK + t] = make_int2(ec, ec ? et : -1);
+            et = v[x].x ? v[x].y : max(et, v[x].y); ec += v[x].x;
+        }
+    }
+    if (j == 0) g.total[t] = tot;
+}
+
+// PULL: the consumer of rounds s0 .. s0+ns-1 of a batch completes ITS full-width skeleton slots 8s (and their key rows) with the
+// ranges the other ranks own, read from their rings.  grid (chunks, ns, ranks); 16 bytes per thread and array.
+struct ShardPullArgs {
+    const int *A[SHARD_MAX]; const int *D[SHARD_MAX]; const unsigned char *K[SHARD_MAX];   // slot 0 / key row 0 of the batch's ring in every rank
+    int *a; int *d; unsigned char *k;                                                      // the same in this rank
+    size_t strideA, strideD, strideK;                                                      // per slot (ints) / per key row (bytes)
+    int pb[SHARD_MAX + 1]; int n, me, M, s0, slot_step;                                    // slot of round s = s * slot_step (8; 0 rounds -> slot 0 only)
+};
+__global__ __launch_bounds__(BLOCK) void shard_pull_kernel(ShardPullArgs g) {
+    const int o = blockIdx.z, s = g.s0 + blockIdx.y;
+    if (o == g.me) return;
+    const int lo = g.pb[o], hi = g.pb[o + 1];               // multiples of 256 except the last rank's end (= M)
+    const size_t so = (size_t)s * g.slot_step;
+    const int4 *sa = reinterpret_cast<const int4 *>(g.A[o] + so * g.strideA), *sd = reinterpret_cast<const int4 *>(g.D[o] + so * g.strideD);
+    int4 *da = reinterpret_cast<int4 *>(g.a + so * g.strideA), *dd = reinterpret_cast<int4 *>(g.d + so * g.strideD);
+    const int hiD = (o == g.n - 1) ? hi + 1 : hi;           // d[M], the closing sentinel, lives with the last rank
+    for (int i = lo / 4 + blockIdx.x * BLOCK + threadIdx.x; i < (hiD + 3) / 4; i += gridDim.x * BLOCK) {
+        if (i < (hi + 3) / 4) da[i] = sa[i];
+        dd[i] = sd[i];
+    }
+    const uint4 *sk = reinterpret_cast<const uint4 *>(g.K[o] + (size_t)s * g.strideK);
+    uint4 *dk = reinterpret_cast<uint4 *>(g.k + (size_t)s * g.strideK);
+    for (int i = lo / 16 + blockIdx.x * BLOCK + threadIdx.x; i < (hi + 15) / 16; i += gridDim.x * BLOCK) dk[i] = sk[i];
+}
+
 // RANK (K3): per tile — stable rank of every position among its key (ballot refinement inside
 // 64-position chunks + a per-key scan over the chunks), previous same-key position, range max of d_k
 // through a sparse table in LDS, scatter of (a | next allele tag, d', next key).
@@ -1001,8 +1164,8 @@ constexpr int SKN_MAXW = 128;
 // R4 (wide panels: more tiles than fit the chip at once): the range maxima come from a radix-4 sparse table (windows 1, 4, 16, 64,
 // 256; <= 4 reads per query instead of 2) — 10 KB instead of 18 at T = 512, 22 KB per workgroup instead of 30: 7 workgroups per
 // CU instead of 5, so the 1954 tiles of M = 1 M almost fit in one round (1792 resident) instead of needing two (1280).
-template <int EPT, int TR, bool R4 = false>
-__global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
+template <int EPT, int TR, bool R4, bool SHARD>
+__device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut *so) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
 #endif
@@ -1013,8 +1176,11 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
     __shared__ int s_tbl[NL][T];                            // s_tbl[l][i] = max d over (i-2^l, i]
     __shared__ int s_before[SKK], s_carry[SKK], s_G[SKK], s_lower[SKK];
     __shared__ int s_gw[WAVES], s_lw[WAVES];
-    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = (g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
+    __shared__ int *s_pa[SHARD ? SHARD_MAX : 1], *s_pd[SHARD ? SHARD_MAX : 1]; __shared__ unsigned char *s_pk[SHARD ? SHARD_MAX : 1];
+    __shared__ int s_pb[SHARD ? SHARD_MAX : 1];
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = g.w0 + ((g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x);
     const int S = w * T;
+    if constexpr (SHARD) { if (t < SHARD_MAX) { s_pa[t] = so->a[t]; s_pd[t] = so->d[t]; s_pk[t] = so->k[t]; s_pb[t] = so->pb[t + 1]; } }   // visible after the barriers below
     int av[EPT], dv[EPT], key[EPT];
     unsigned nk[EPT];
 #pragma unroll
@@ -1133,7 +1299,14 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
         else dd = 0;
         const int pos = s_G[ky] + s_before[ky] + rank;
         if (pos == 0) dd = g.k + SKB + 1;                  // sentinel (pbwtCore.c:507 after the 8th site)
-        if (g.ycnext) {                                     // read side: the tag of a position is a bit of the sorted column, the keys were derived from the columns
+        if constexpr (SHARD) {                              // the owner of the destination: pb[o] <= pos < pb[o+1] (s_pb holds pb[1..]; unused entries INT_MAX)
+            int o = 0;
+#pragma unroll
+            for (int x = 0; x < SHARD_MAX - 1; ++x) o += (pos >= s_pb[x]) ? 1 : 0;
+            s_pa[o][pos] = av[r] | (int)((nk[r] & 1u) << 31);
+            s_pd[o][pos] = dd;
+            s_pk[o][pos] = (unsigned char)nk[r];
+        } else if (g.ycnext) {                              // read side: the tag of a position is a bit of the sorted column, the keys were derived from the columns
             const unsigned tg = g.has_next ? (unsigned)((g.ycnext[pos >> 6] >> (pos & 63)) & 1ULL) : 0u;
             g.a_out[pos] = av[r] | (int)(tg << 31);
             g.d_out[pos] = dd;
@@ -1143,8 +1316,16 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) {
             g.keys_out[pos] = (unsigned char)nk[r];
         }
     }
-    if (w == g.W - 1 && t == 0) g.d_out[g.M] = g.k + SKB + 1;
+    if (w == g.Wtot - 1 && t == 0) {
+        if constexpr (SHARD) so->d[so->n - 1][g.M] = g.k + SKB + 1;      // d[M] lives with the last rank
+        else g.d_out[g.M] = g.k + SKB + 1;
+    }
 }
+template <int EPT, int TR, bool R4 = false>
+__global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) { skel_rank_body<EPT, TR, R4, false>(g, nullptr); }
+// position-sharded form: tiles w0 .. w0+W-1, scatter through the owners' table
+template <int EPT, bool R4>
+__global__ __launch_bounds__(BLOCK) void skel_rank_shard_kernel(SkArgs g, SkShardOut so) { skel_rank_body<EPT, 0, R4, true>(g, &so); }
 
 // READ SIDE: the columns arrive in PBWT order (y_k by position), so the 8-bit key of position i of the
 // state before site k follows the LF-mapping through the 8 columns: bit j = y_{k+j}[p_j], p_0 = i,

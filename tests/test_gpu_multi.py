@@ -161,6 +161,27 @@ def test_position_sharded_step_on_device_tensors_over_rccl(tmp_path):
     assert res["ok"] and res["ok8"]
 
 
+@pytest.mark.parametrize("world,M,N,B,kind,step,csum", [
+    (2, 30000, 1024, 256, 0, 8192, 1),        # 512-position... 256-position tiles (M <= 56 k), two batches per advance call
+    (3, 5000, 520, 128, 1, 200, 1),           # iid panel, ragged advance calls: replicated (non-multiple-of-8) batches between sharded ones
+    (2, 100000, 1024, 512, 0, 8192, 0),       # configs[2]'s width on the bench option set (packed fill: no checksums)
+    (3, 70000, 776, 512, 0, 8192, 1),         # N not a multiple of 8: the tail runs replicated
+])
+def test_position_sharded_chain_ranks_one_gpu(world, M, N, B, kind, step, csum, tmp_path):
+    """BASELINE configs[3]'s device path at small widths: `world` processes on one GPU, each owning a range of positions of the
+    sorted order (hipIpc peer stores for the scatter, flag barriers per round), consumers sharded by site inside every batch;
+    every site's a/d checksum, the summed histogram, the interleaved pack3 bytes and the final state equal the oracle's"""
+    env = dict(os.environ, OUT_DIR=str(tmp_path), PS_M=str(M), PS_N=str(N), PS_B=str(B), PS_KIND=str(kind), PS_STEP=str(step), PS_CSUM=str(csum),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "posshard_worker.py")],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    outs = [json.load(open(tmp_path / ("ps%d.json" % rk))) for rk in range(world)]
+    assert all(o["ok"] for o in outs), outs
+    assert outs[0]["range"][0] == 0 and outs[-1]["range"][1] == M
+
+
 QS_WORKER = textwrap.dedent("""
     import json, os, sys
     import numpy as np
