@@ -15,6 +15,10 @@ so every step works on a realistic cursor state.
 Multi-GPU (⑤), two modes:
   --mode replicas (default): ranks process independent panels (different chromosomes = seeds) with no data-path
       collective: weak scaling, value = total site*haps over all ranks / max time.
+  --mode posshard: ONE panel of K*S sites with the RECURRENCE position-sharded over the ranks (BASELINE configs[3]: pbwt_amd/posshard.py,
+      csrc/pbwt_shard.inc): rank g owns a range of positions of the sorted order; per round of 8 sites one row exchange and the
+      scatter as peer stores over xGMI (hipIpc mappings), consumers sharded by site inside every batch; one all-reduce (RCCL) of
+      the histogram at the end, inside the timed region.  Strong scaling, value = M*K*S / max time.  Default M = 1,000,000.
   --mode siteblock: ONE panel of K*S sites sharded by site blocks (pbwt_amd/siteblock.py): every rank
       runs the chain alone up to its block, then the full hot path over its block; one all-reduce (RCCL) of the
       histogram at the end, inside the timed region.  Strong scaling, value = M*K*S / max time; bounded by
@@ -40,7 +44,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=122)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--haps", type=int, default=100000, help="M, haplotypes in the panel")
+    ap.add_argument("--haps", type=int, default=None, help="M, haplotypes in the panel (default 100000; 1000000 in --mode posshard)")
+    ap.add_argument("--backend", default=os.environ.get("PBWT_BENCH_BACKEND", "nccl"), help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share ONE GPU)")
     ap.add_argument("--sites-per-step", type=int, default=8192)
     ap.add_argument("--batch", type=int, default=512, help="sites per device batch (graph length)")
     ap.add_argument("--kind", type=int, default=0, help="0 founder mosaic, 1 iid")
@@ -50,10 +55,13 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-1m", action="store_true", help="skip the secondary measurement at the north-star width (1M haplotypes)")
     ap.add_argument("--own-stream", action="store_true", help="let the engine create its own (high-priority) chain stream instead of torch's current stream")
-    ap.add_argument("--mode", default=os.environ.get("PBWT_BENCH_MODE", "replicas"), choices=["replicas", "siteblock"],
+    ap.add_argument("--mode", default=os.environ.get("PBWT_BENCH_MODE", "replicas"), choices=["replicas", "siteblock", "posshard"],
                     help="multi-GPU mode: independent panels per rank (weak) or one panel sharded by site blocks (strong)")
     ap.add_argument("--panels", type=int, default=1, help="independent panels run concurrently on this GPU (throughput mode; default 1 = the named config)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.haps is None:
+        args.haps = 1000000 if args.mode == "posshard" else 100000
+    return args
 
 
 def cpu_baseline(args, first_cols):
@@ -231,17 +239,77 @@ def run_siteblock(args, torch, pdist, pbwt_amd, dev, rank, world):
     pdist.finish()
 
 
+def run_posshard(args, torch, pdist, pbwt_amd, dev, rank, world):
+    """--mode posshard: one panel, the recurrence position-sharded across the ranks (strong scaling; BASELINE configs[3])"""
+    from pbwt_amd import posshard as ps
+    M, S, K, Wm = args.haps, args.sites_per_step, args.steps, args.warmup
+    N = (K + Wm) * S
+    eng = pbwt_amd.Engine(M, batch_sites=args.batch, device=dev.index)
+    ps.setup(eng, rank, world)
+    if N * eng.wpc * 4 > 120e9:
+        raise SystemExit("bench.py --mode posshard keeps the panel's bit columns resident: %d sites x %d haplotypes = %.0f GB per rank; use fewer --steps"
+                         % (N, M, N * eng.wpc * 4 / 1e9))
+    panel = torch.empty((N, eng.wpc), dtype=torch.int32, device=dev)          # replicated: every rank holds the panel's columns
+    eng.synth_device(panel.data_ptr(), 0, N, seed=0x5EED0001, kind=args.kind)
+    eng.sync()
+    opts = pbwt_amd.OPT_WITH_D | (0 if args.no_within else pbwt_amd.OPT_WITHIN_HIST) | (0 if args.no_pack3 else pbwt_amd.OPT_PACK3)
+    col = lambda k: panel.data_ptr() + k * eng.wpc * 4
+    eng.pass_begin(N)
+    for i in range(Wm):                                       # untimed warm-up steps of the same pass
+        eng.pass_advance(col(i * S), S, min(S + 8, N - i * S), opts)
+    eng.sync()
+    ms0, n0 = eng.chain_timing(); s0 = eng.chain_sites()
+    pdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(Wm, Wm + K):
+        eng.pass_advance(col(i * S), S, min(S + 8, N - i * S), opts)
+    eng.pass_end(opts)
+    hist = ps.reduce_hist(eng.get_hist(N + 1), device=dev if args.backend == "nccl" else None)   # the one collective of the mode
+    pdist.barrier(); torch.cuda.synchronize()
+    dt = pdist.max_over_ranks(time.perf_counter() - t0, device=dev if args.backend == "nccl" else None)
+    ms1, n1 = eng.chain_timing(); s1 = eng.chain_sites()
+    us = 1e3 * (ms1 - ms0) / max(n1 - n0, 1); spl = (s1 - s0) / max(n1 - n0, 1)
+    lo, hi = eng.shard_range(rank)
+    ach = ALG_BYTES_PER_SITEHAP * (hi - lo) * spl / (us * 1e-6) / 1e9
+    out = {"metric": "sites*haplotypes/sec PBWT build + maxWithin", "value": M * K * S / dt, "unit": "site*haps/s",
+           "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1e3 * dt / K, "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+           "config": {"workload": "configs[3]: ONE panel of %d haplotypes x %d sites, build (ForwardsAD + pack3) + maxWithin (hist sink), "
+                                  "the recurrence position-sharded over %d ranks" % (M, K * S, world),
+                      "haplotypes": M, "sites_per_step": S, "sites_timed": K * S, "device_batch_sites": args.batch, "mode": "posshard",
+                      "positions_of_rank0": [lo, hi], "backend": args.backend,
+                      "exchange": "per round of 8 sites: one row of 256 (count, carry) per rank + the scatter as peer stores (hipIpc / xGMI), 2 flag barriers; "
+                                  "consumers sharded by site inside every batch (bulk pulls); one all-reduce of the histogram at the end"},
+           "roofline": {"bound": "hbm", "kernel": "sharded skeleton chain: skel_hist_kernel + skel_k2s_agg/scan_kernel + skel_rank_shard_kernel + shard_xbar_kernel, 5 launches per 8 sites",
+                        "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                        "us_per_launch": us, "sites_per_launch": spl, "note": "rank 0's chain over its own range of positions (launch gaps and peer waits included)"},
+           "whole_job_achieved_GBps": ALG_BYTES_PER_SITEHAP * M * K * S / dt / 1e9,
+           "whole_job_frac_of_hbm_peak": ALG_BYTES_PER_SITEHAP * M * K * S / dt / 1e9 / (HBM_PEAK_GBPS * world),
+           "within_reports_hist_total": int(hist.sum())}
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    pdist.finish()
+
+
 def main():
     args = parse()
     import torch
     from pbwt_amd import dist as pdist
     rank, local, world = pdist.env_world()
-    dev = torch.device("cuda", local if world > 1 else 0)
-    torch.cuda.set_device(dev)
-    pdist.init("nccl", device_id=dev)      # backend "nccl" is RCCL on ROCm; only barrier + max-reduce use it
+    if args.backend == "nccl":
+        dev = torch.device("cuda", local if world > 1 else 0)
+        torch.cuda.set_device(dev)
+        pdist.init("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm; only barrier + max-reduce (and the modes' one all-reduce) use it
+    else:                                  # gloo: several ranks may share one GPU (how the one-GPU test box runs the sharded modes)
+        dev = torch.device("cuda", local if (world > 1 and torch.cuda.device_count() > local) else 0)
+        torch.cuda.set_device(dev)
+        pdist.init(args.backend)
     import pbwt_amd
     if args.mode == "siteblock":
         return run_siteblock(args, torch, pdist, pbwt_amd, dev, rank, world)
+    if args.mode == "posshard":
+        return run_posshard(args, torch, pdist, pbwt_amd, dev, rank, world)
 
     M, S, K, Wm = args.haps, args.sites_per_step, args.steps, args.warmup
     n_total = (K + Wm) * S

@@ -112,8 +112,9 @@ struct ShardCtx {
     int pb[SHARD_MAX + 1] = {};                               // position boundaries; pb[world] = M, unused entries INT_MAX
     ShardXch *xch = nullptr; bool xch_ext = false;            // own exchange block
     ShardPeers peers = {};                                    // every rank's exchange block as mapped here (own = xch)
-    int *peerA[SHARD_MAX] = {}, *peerD[SHARD_MAX] = {}; unsigned char *peerK[2][SHARD_MAX] = {};   // ring bases of every rank (own = the engine's)
+    int *peerA[SHARD_MAX] = {}, *peerD[SHARD_MAX] = {}; unsigned char *peerK[2][SHARD_MAX] = {};   // skeleton rings and key rows of every rank (own = this rank's)
     bool connected = false;
+    int *SA = nullptr, *SD = nullptr; size_t nslot = 0;       // the skeleton ring: 2 rings of B/8+1 slots, a and d of the states 0, 8, 16, ... of a batch
     int2 *tbl = nullptr, *scan = nullptr; int *total = nullptr;              // chain scratch, rows indexed by global tile
     unsigned long long *agg = nullptr; unsigned *cnt = nullptr; unsigned cntEpoch = 0;
     unsigned e1 = 0, e2 = 0, e3 = 0;                          // epochs of f1 / f2 / f3

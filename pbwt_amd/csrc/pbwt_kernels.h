@@ -1129,29 +1129,30 @@ __global__ __launch_bounds__(SKK) void skel_k2s_scan_kernel(Sk2SArgs g, ShardPee
     if (j == 0) g.total[t] = tot;
 }
 
-// PULL: the consumer of rounds s0 .. s0+ns-1 of a batch completes ITS full-width skeleton slots 8s (and their key rows) with the
-// ranges the other ranks own, read from their rings.  grid (chunks, ns, ranks); 16 bytes per thread and array.
+// PULL: the consumer of rounds s0 .. s0+ns-1 of a batch copies those skeleton states (a, d, keys) out of every rank's skeleton
+// ring — the range each rank owns — into slots slot_step * s of its own full ring.  grid (chunks, ns, ranks); 16 bytes per
+// thread and array.  slot_step == 0 (with ns == 1): skeleton slot s0 into slot 0.
 struct ShardPullArgs {
-    const int *A[SHARD_MAX]; const int *D[SHARD_MAX]; const unsigned char *K[SHARD_MAX];   // slot 0 / key row 0 of the batch's ring in every rank
-    int *a; int *d; unsigned char *k;                                                      // the same in this rank
+    const int *A[SHARD_MAX]; const int *D[SHARD_MAX]; const unsigned char *K[SHARD_MAX];   // slot 0 of the batch's SKELETON ring / key row 0 in every rank
+    int *a; int *d; unsigned char *k;                                                      // slot 0 of the FULL ring / key row 0 in this rank
     size_t strideA, strideD, strideK;                                                      // per slot (ints) / per key row (bytes)
-    int pb[SHARD_MAX + 1]; int n, me, M, s0, slot_step;                                    // slot of round s = s * slot_step (8; 0 rounds -> slot 0 only)
+    int pb[SHARD_MAX + 1]; int n, me, M, s0, slot_step;
 };
 __global__ __launch_bounds__(BLOCK) void shard_pull_kernel(ShardPullArgs g) {
     const int o = blockIdx.z, s = g.s0 + blockIdx.y;
-    if (o == g.me) return;
     const int lo = g.pb[o], hi = g.pb[o + 1];               // multiples of 256 except the last rank's end (= M)
-    const size_t so = (size_t)s * g.slot_step;
-    const int4 *sa = reinterpret_cast<const int4 *>(g.A[o] + so * g.strideA), *sd = reinterpret_cast<const int4 *>(g.D[o] + so * g.strideD);
-    int4 *da = reinterpret_cast<int4 *>(g.a + so * g.strideA), *dd = reinterpret_cast<int4 *>(g.d + so * g.strideD);
+    const size_t dst = (size_t)s * g.slot_step;
+    const int4 *sa = reinterpret_cast<const int4 *>(g.A[o] + (size_t)s * g.strideA), *sd = reinterpret_cast<const int4 *>(g.D[o] + (size_t)s * g.strideD);
+    int4 *da = reinterpret_cast<int4 *>(g.a + dst * g.strideA), *dd = reinterpret_cast<int4 *>(g.d + dst * g.strideD);
     const int hiD = (o == g.n - 1) ? hi + 1 : hi;           // d[M], the closing sentinel, lives with the last rank
     for (int i = lo / 4 + blockIdx.x * BLOCK + threadIdx.x; i < (hiD + 3) / 4; i += gridDim.x * BLOCK) {
         if (i < (hi + 3) / 4) da[i] = sa[i];
         dd[i] = sd[i];
     }
+    if (g.slot_step == 0 && o != g.me) return;              // the keys of a pulled slot 0 are re-derived (pass start / replicated batch)
     const uint4 *sk = reinterpret_cast<const uint4 *>(g.K[o] + (size_t)s * g.strideK);
     uint4 *dk = reinterpret_cast<uint4 *>(g.k + (size_t)s * g.strideK);
-    for (int i = lo / 16 + blockIdx.x * BLOCK + threadIdx.x; i < (hi + 15) / 16; i += gridDim.x * BLOCK) dk[i] = sk[i];
+    if (o != g.me) for (int i = lo / 16 + blockIdx.x * BLOCK + threadIdx.x; i < (hi + 15) / 16; i += gridDim.x * BLOCK) dk[i] = sk[i];
 }
 
 // RANK (K3): per tile — stable rank of every position among its key (ballot refinement inside

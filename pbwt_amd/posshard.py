@@ -34,11 +34,16 @@ def setup(eng, rank=None, world=None):
         rank = dist.get_rank() if dist.is_initialized() else 0
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
+    import os, sys
+    tr = (lambda m: print("[posshard %d] %s" % (rank, m), file=sys.stderr, flush=True)) if os.environ.get("PBWTAMD_SHARD_TRACE") else (lambda m: None)
     blob = eng.shard_init(rank, world)
     if world > 1:
         blobs = [None] * world
+        tr("all-gather of the handle blobs")
         dist.all_gather_object(blobs, blob)
+        tr("connect")
         eng.shard_connect(blobs)
+        tr("connected")
     return rank, world
 
 

@@ -22,21 +22,27 @@ def main():
     M, N, B = int(os.environ["PS_M"]), int(os.environ["PS_N"]), int(os.environ.get("PS_B", "512"))
     kind, step = int(os.environ.get("PS_KIND", "0")), int(os.environ.get("PS_STEP", "8192"))
     with_csum = int(os.environ.get("PS_CSUM", "1"))
+    trace = (lambda m: print("[worker %d] %s" % (rank, m), file=sys.stderr, flush=True)) if os.environ.get("PS_TRACE") else (lambda m: None)
     eng = amd.Engine(M, batch_sites=B, device=0)
+    trace("engine up")
     ps.setup(eng, rank, world)
+    trace("shard connected")
     panel = torch.empty((N, eng.wpc), dtype=torch.int32, device="cuda:0")
     torch.cuda.synchronize()
     eng.synth_device(panel.data_ptr(), 0, N, seed=0x9051, kind=kind)       # every rank holds the same columns
     eng.sync()
+    trace("panel resident")
     opts = amd.OPT_WITH_D | amd.OPT_WITHIN_HIST | amd.OPT_PACK3 | (amd.OPT_CHECKSUM if with_csum else 0)
     pd.barrier()
     t0 = time.perf_counter()
     ps.run(eng, lambda k: panel.data_ptr() + k * eng.wpc * 4, N, opts, step=step)
     dt = time.perf_counter() - t0
+    trace("pass done in %.3f s" % dt)
     hist = ps.reduce_hist(eng.get_hist(N + 1))
     cs = ps.gather_checksums(eng, 0, N + 1) if with_csum else None
     yz = ps.gather_packed(eng)
     a, d = eng.get_state()
+    trace("results gathered")
     res = {"rank": rank, "range": list(eng.shard_range(rank)), "seconds": dt, "blocks": int(len(eng.shard_blocks()[0]))}
     if rank == 0:
         import oracle

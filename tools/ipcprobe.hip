@@ -190,6 +190,60 @@ static int run_vmm(Shared *sh, int rank, int G, int (*chan)[2]) {
     return (v[0] == 7 && v[1] == 7) ? 0 : 1;
 }
 
+// ---- 5. how large may an exported allocation be?  (the ring of a 1 M-haplotype engine is > 4 GiB)
+static int run_big(Shared *sh, int rank, int G) {
+    int phase = 56;
+    const double gbs[] = {1.0, 2.0, 3.9, 4.1, 6.0};
+    for (double gb : gbs) {
+        const size_t n = (size_t)(gb * (1ull << 30));
+        char *buf = nullptr; CK(hipMalloc((void **)&buf, n)); CK(hipMemset(buf, 0, 4096)); CK(hipDeviceSynchronize());
+        auto t0 = std::chrono::steady_clock::now();
+        CK(hipIpcGetMemHandle(&sh->hData[rank], buf));
+        double msg = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        host_barrier(sh, G, phase);
+        const int nx = (rank + 1) % G;
+        void *peer = nullptr;
+        t0 = std::chrono::steady_clock::now();
+        hipError_t e = hipIpcOpenMemHandle(&peer, sh->hData[nx], hipIpcMemLazyEnablePeerAccess);
+        double mso = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        printf("[r%d] %.1f GiB: get handle %.1f ms, open %.1f ms -> %s\n", rank, gb, msg, mso, hipGetErrorString(e));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(write_kernel, dim3(1), dim3(64), 0, 0, (int *)((char *)peer + n - 4096)); CK(hipDeviceSynchronize());
+            printf("[r%d] %.1f GiB: kernel write at the end of the peer mapping ok\n", rank, gb);
+            (void)hipIpcCloseMemHandle(peer);
+        } else (void)hipGetLastError();
+        host_barrier(sh, G, phase);
+        CK(hipFree(buf));
+        host_barrier(sh, G, phase);
+    }
+    return 0;
+}
+
+// ---- 6. several imported buffers held open at once: is there a limit on the TOTAL imported size?
+static int run_cumulative(Shared *sh, int rank, int G) {
+    int phase = 40;
+    const int NB = 5; const size_t n = 2ull << 30;
+    char *buf[NB]; void *peer[NB];
+    static hipIpcMemHandle_t *hs = nullptr;
+    for (int i = 0; i < NB; ++i) { CK(hipMalloc((void **)&buf[i], n)); CK(hipMemset(buf[i], 0, 4096)); }
+    CK(hipDeviceSynchronize());
+    const int nx = (rank + 1) % G;
+    for (int i = 0; i < NB; ++i) {
+        CK(hipIpcGetMemHandle(&sh->hData[rank], buf[i]));
+        host_barrier(sh, G, phase);
+        auto t0 = std::chrono::steady_clock::now();
+        printf("[r%d] opening buffer %d (%d GiB imported so far)\n", rank, i, 2 * i);
+        hipError_t e = hipIpcOpenMemHandle(&peer[i], sh->hData[nx], hipIpcMemLazyEnablePeerAccess);
+        double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        printf("[r%d] buffer %d open: %.1f ms -> %s\n", rank, i, ms, hipGetErrorString(e));
+        if (e != hipSuccess) return 1;
+        hipLaunchKernelGGL(write_kernel, dim3(1), dim3(64), 0, 0, (int *)((char *)peer[i] + n - 4096)); CK(hipDeviceSynchronize());
+        host_barrier(sh, G, phase);
+    }
+    (void)hs;
+    return 0;
+}
+
 int main(int argc, char **argv) {
     const int G = argc > 1 ? atoi(argv[1]) : 2, iters = argc > 2 ? atoi(argv[2]) : 2000;
     if (G < 2 || G > MAXG) return 2;
@@ -204,6 +258,8 @@ int main(int argc, char **argv) {
         if (pids[r] == 0) {
             int rc = 0;
             g_rank = r; setvbuf(stdout, nullptr, _IONBF, 0);
+            if (only == 4) { CK(hipSetDevice(0)); rc |= run_big(sh, r, G); }
+            if (only == 5) { CK(hipSetDevice(0)); rc |= run_cumulative(sh, r, G); }
             if (only == 3 || only < 0) { CK(hipSetDevice(0)); rc |= run_vmm(sh, r, G, chan); }
             for (int kind = 0; kind < 3; ++kind) if (only < 0 || only == kind) rc |= run_rank(sh, r, G, iters, kind);
             fflush(stdout);
