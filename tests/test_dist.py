@@ -289,3 +289,99 @@ def test_position_sharded_round_of_eight_sites_gloo(world, M, N, kind, tmp_path)
     assert r.returncode == 0, r.stderr[-3000:]
     outs = [json.load(open(tmp_path / ("r8_%d.json" % rk))) for rk in range(world)]
     assert all(o["ok"] for o in outs) and sum(o["n"] for o in outs) == M
+
+
+POSSHARD_WORKER = textwrap.dedent("""
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    from pbwt_amd import dist as pd
+    from pbwt_amd import posshard as ps
+    import oracle
+    rank, world = pd.init("gloo")
+    M, N, B = 700, int(os.environ["PS_N"]), 64
+    bits = oracle.synth_bitcols(M, N, seed=31, kind=0)
+    o = oracle.build_bitcols(bits, M, with_d=True)
+    # per-column byte offsets of the oracle's yz: decode run lengths column by column (pack3: every byte is one run, pbwtCore.c:232-238)
+    def runlen(b):
+        b &= 0x7f
+        return b if b < 64 else ((b - 64) << 6 if b < 96 else (b - 96) << 11)
+    off = [0]; acc = 0
+    for i, byte in enumerate(o["yz"]):
+        acc += runlen(int(byte))
+        if acc == M:
+            off.append(i + 1); acc = 0
+    assert len(off) == N + 1
+
+    class StubEngine:                       # the host-visible face of one rank of a sharded pass: what this rank's device consumed
+        def __init__(self):
+            self.blocks = []; self.connected = None
+            k = 0
+            while k < N:
+                nb = min(B, N - k)
+                if nb %% 8 == 0:
+                    lo, hi = ps.plan_rounds(nb // 8, world)[rank]
+                    if hi > lo: self.blocks.append((k + 8 * lo, 8 * (hi - lo)))
+                elif rank == world - 1:     # replicated batch: the last rank's
+                    self.blocks.append((k, nb))
+                k += nb
+        def shard_init(self, r, w): return bytes([r]) * 320
+        def shard_connect(self, blobs): self.connected = blobs
+        def shard_blocks(self):
+            ends, acc = [], 0
+            for s0, ns in self.blocks:
+                acc += off[s0 + ns] - off[s0]; ends.append(acc)
+            return np.array([b[0] for b in self.blocks], np.int64), np.array([b[1] for b in self.blocks], np.int64), np.array(ends, np.int64)
+        def get_packed(self):
+            return np.concatenate([o["yz"][off[s0]: off[s0 + ns]] for s0, ns in self.blocks] + [np.zeros(0, np.uint8)])
+        def get_checksums(self, k0, n):
+            mine = np.zeros(N + 1, bool)
+            for s0, ns in self.blocks: mine[s0: s0 + ns] = True
+            mine[N] = rank == world - 1
+            z = lambda v: np.where(mine, v, np.uint64(0))[k0: k0 + n]
+            return z(o["csum_a"]), z(o["csum_d"]), z(o["csum_a"])
+
+    eng = StubEngine()
+    ps.setup(eng, rank, world)
+    ok = eng.connected == [bytes([r]) * 320 for r in range(world)]
+    yz = ps.gather_packed(eng)
+    cs = ps.gather_checksums(eng, 0, N + 1)
+    hist = ps.reduce_hist(np.full(5, rank + 1, np.int64))
+    ok = ok and bool(np.array_equal(hist, np.full(5, world * (world + 1) // 2)))
+    if rank == 0:
+        ok = ok and bool(np.array_equal(yz, o["yz"])) and bool(np.array_equal(cs[0], o["csum_a"])) and bool(np.array_equal(cs[1], o["csum_d"]))
+    with open(os.path.join(os.environ["OUT_DIR"], "psd" + str(rank) + ".json"), "w") as f:
+        json.dump({"ok": bool(ok), "blocks": len(eng.blocks)}, f)
+    pd.finish()
+""") % ROOT
+
+
+@pytest.mark.parametrize("world,N", [(2, 200), (3, 333)])
+def test_position_shard_host_side_gloo(world, N, tmp_path):
+    """pbwt_amd/posshard.py under gloo at world_size 2 / 3: the handle all-gather, the interleaving of the ranks' pack3 blocks
+    (sharded batches by rounds, ragged batches on the last rank) into the oracle's yz, checksums and histograms adding up"""
+    import json
+    script = tmp_path / "psd_worker.py"
+    script.write_text(POSSHARD_WORKER)
+    env = dict(os.environ, OUT_DIR=str(tmp_path), PS_N=str(N))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    outs = [json.load(open(tmp_path / ("psd%d.json" % rk))) for rk in range(world)]
+    assert all(o["ok"] for o in outs), outs
+
+
+def test_position_shard_plans():
+    from pbwt_amd import posshard as ps
+    for world in (1, 2, 3, 8):
+        for n in (world, 7, 64, 1954):
+            tb = ps.tile_bounds(n, world)
+            assert tb[0] == 0 and tb[-1] == n and all(b >= a for a, b in zip(tb, tb[1:]))
+            if n >= world:
+                assert all(b > a for a, b in zip(tb, tb[1:]))          # every rank owns at least one tile
+            pr = ps.plan_rounds(n, world)
+            assert pr[0][0] == 0 and pr[-1][1] == n and all(a[1] == b[0] for a, b in zip(pr, pr[1:]))
+    import numpy as np
+    with pytest.raises(ValueError, match="tile the sites"):
+        ps.merge_packed([(np.array([0]), np.array([8]), np.array([3]), np.zeros(3, np.uint8)), (np.array([16]), np.array([8]), np.array([2]), np.zeros(2, np.uint8))])

@@ -162,10 +162,12 @@ def test_position_sharded_step_on_device_tensors_over_rccl(tmp_path):
 
 
 @pytest.mark.parametrize("world,M,N,B,kind,step,csum", [
-    (2, 30000, 1024, 256, 0, 8192, 1),        # 512-position... 256-position tiles (M <= 56 k), two batches per advance call
+    (2, 30000, 1024, 256, 0, 8192, 1),        # 256-position tiles (M <= 56 k), four batches: both rings reused
     (3, 5000, 520, 128, 1, 200, 1),           # iid panel, ragged advance calls: replicated (non-multiple-of-8) batches between sharded ones
     (2, 100000, 1024, 512, 0, 8192, 0),       # configs[2]'s width on the bench option set (packed fill: no checksums)
     (3, 70000, 776, 512, 0, 8192, 1),         # N not a multiple of 8: the tail runs replicated
+    (2, 1000000, 1024, 512, 0, 8192, 0),      # BASELINE configs[3]'s width (1 M haplotypes), bench option set, two ranks, two batches
+    (3, 1000000, 264, 128, 0, 8192, 1),       # the same width on three ranks with every site's checksum
 ])
 def test_position_sharded_chain_ranks_one_gpu(world, M, N, B, kind, step, csum, tmp_path):
     """BASELINE configs[3]'s device path at small widths: `world` processes on one GPU, each owning a range of positions of the
