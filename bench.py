@@ -37,6 +37,17 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_SITEHAP = 16.125        # r a,d + w a,d (4 B each) + 1 allele bit
 HBM_PEAK_GBPS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s HBM3E
+BOUNDARY_US = 1.54                    # measured cost of one dependent kernel boundary on MI355X, empty kernels (profiles/r01_probes.txt)
+
+
+def latency_bound(alg_bytes_per_launch, us_per_launch):
+    """site k+1 needs the whole order of site k, so every launch of the chain pays one device-wide dependency; the
+    reachable HBM fraction is bounded by (time the launch's algorithmic bytes take at the peak rate) / (one kernel boundary).
+    Reported next to the measured fraction: frac / latency_bound_frac says how much of what the dependency allows is reached."""
+    data_us = alg_bytes_per_launch / (HBM_PEAK_GBPS * 1e9) * 1e6
+    return {"boundary_us": BOUNDARY_US, "data_us_per_launch": data_us, "latency_bound_frac": min(1.0, data_us / BOUNDARY_US),
+            "measured_us_per_launch": us_per_launch,
+            "note": "upper bound on frac for a chain of dependent launches: data time of one launch at 8 TB/s / the 1.54 us a dependent kernel boundary costs"}
 
 
 def parse():
@@ -53,7 +64,8 @@ def parse():
     ap.add_argument("--no-pack3", action="store_true")
     ap.add_argument("--cpu-sites", type=int, default=32768, help="sites of the same panel timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-1m", action="store_true", help="skip the secondary measurement at the north-star width (1M haplotypes)")
+    ap.add_argument("--no-1m", action="store_true", help="skip the measurements at the north-star width (1M haplotypes)")
+    ap.add_argument("--ns-sites", type=int, default=1000000, help="sites of the north-star job (1M haplotypes x this many sites; the bit panel, 125 KB per site, is resident)")
     ap.add_argument("--own-stream", action="store_true", help="let the engine create its own (high-priority) chain stream instead of torch's current stream")
     ap.add_argument("--mode", default=os.environ.get("PBWT_BENCH_MODE", "replicas"), choices=["replicas", "siteblock", "posshard"],
                     help="multi-GPU mode: independent panels per rank (weak) or one panel sharded by site blocks (strong)")
@@ -88,10 +100,12 @@ def cpu_baseline(args, first_cols):
                       % (n, M, what, tb, tw)}
 
 
-def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=65536, batch=512, step=8192, want_hist=False):
-    """the same hot path at the north-star width (1 M haplotypes) over `sites` sites, device-resident, with its own
-    roofline object.  A secondary measurement (the headline `value` stays BASELINE configs[2]); its histogram total is
-    pinned to the oracle by tests/test_gpu_z_configs.py::test_bench_north_star_width_path (same function, a prefix)."""
+def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=1000000, batch=512, step=8192, want_hist=False):
+    """the north-star job itself: build + -maxWithin (histogram sink) + pack3 on 1 M haplotypes x `sites` sites (default: all
+    1 M sites; the 125 GB bit panel is resident in HBM before the timed region), with its own roofline object.  The headline
+    `value` stays BASELINE configs[2]; the histogram of a prefix is pinned to the oracle by
+    tests/test_gpu_z_configs.py::test_bench_north_star_width_path (this same function)."""
+    sites = (sites // batch) * batch
     eng = pbwt_amd.Engine(M, batch_sites=batch, device=dev.index)
     n_total = sites + batch
     panel = torch.empty((n_total, eng.wpc), dtype=torch.int32, device=dev)
@@ -117,13 +131,14 @@ def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=65536, b
     spl = (s1 - s0) / max(n1 - n0, 1)
     ach = ALG_BYTES_PER_SITEHAP * M * spl / (us * 1e-6) / 1e9
     hist = eng.get_hist(n_total + 1)
-    out = {"haplotypes": M, "sites_timed": sites, "value": M * sites / dt, "unit": "site*haps/s", "us_per_site": 1e6 * dt / sites,
+    alg_pl = ALG_BYTES_PER_SITEHAP * M * spl
+    out = {"haplotypes": M, "sites_timed": sites, "seconds": dt, "value": M * sites / dt, "unit": "site*haps/s", "us_per_site": 1e6 * dt / sites,
            "within_reports_hist_total": int(hist.sum()),
            "whole_job_achieved_GBps": ALG_BYTES_PER_SITEHAP * M * sites / dt / 1e9,
            "whole_job_frac_of_hbm_peak": ALG_BYTES_PER_SITEHAP * M * sites / dt / 1e9 / HBM_PEAK_GBPS,
            "roofline": {"bound": "hbm", "kernel": "skeleton chain: skel_hist_kernel + skel_k2_wide_kernel + skel_rank_kernel, 3 launches per 8 sites",
                         "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-                        "us_per_launch": us, "sites_per_launch": spl,
+                        "us_per_launch": us, "sites_per_launch": spl, "latency_bound": latency_bound(alg_pl, us),
                         "note": "chain launches only (HIP events around the dependent chain, launch gaps included); whole_job_* = the job's algorithmic bytes over wall time, consumers included"}}
     if want_hist:
         out["hist"] = hist
@@ -280,7 +295,7 @@ def run_posshard(args, torch, pdist, pbwt_amd, dev, rank, world):
                       "positions_of_rank0": [lo, hi], "backend": args.backend,
                       "exchange": "per round of 8 sites: one row of 256 (count, carry) per rank + the scatter as peer stores (hipIpc / xGMI), 2 flag barriers; "
                                   "consumers sharded by site inside every batch (bulk pulls); one all-reduce of the histogram at the end"},
-           "roofline": {"bound": "hbm", "kernel": "sharded skeleton chain: skel_hist_kernel + skel_k2s_agg/scan_kernel + skel_rank_shard_kernel + shard_xbar_kernel, 5 launches per 8 sites",
+           "roofline": {"bound": "hbm", "kernel": "sharded skeleton chain: skel_hist_kernel + skel_k2s_kernel + skel_rank_shard_kernel + shard_xbar_kernel, 4 launches per 8 sites",
                         "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
                         "us_per_launch": us, "sites_per_launch": spl, "note": "rank 0's chain over its own range of positions (launch gaps and peer waits included)"},
            "whole_job_achieved_GBps": ALG_BYTES_PER_SITEHAP * M * K * S / dt / 1e9,
@@ -406,6 +421,8 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "alg_bytes_per_launch": alg_bytes_per_launch, "us_per_launch": us_per_launch,
                      "launches": int(chain_n), "sites_per_launch": sites_per_launch,
+                     "latency_bound": latency_bound(alg_bytes_per_launch, us_per_launch),
+                     "latency_bound_frac": latency_bound(alg_bytes_per_launch, us_per_launch)["latency_bound_frac"],
                      "note": "one launch = sites_per_launch sites; duration = HIP-event time of the dependent launch chain / launches, i.e. including launch gaps"},
         "within_reports_hist_total": int(hist.sum()),
     }
@@ -414,7 +431,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_1m:
         del panel
         torch.cuda.empty_cache()
-        out["north_star_width"] = north_star_width(torch, pbwt_amd, dev, opts, args.kind)
+        free_b = torch.cuda.mem_get_info(dev)[0]
+        ns_sites = min(args.ns_sites, int((free_b - 24e9) // 125000) // 512 * 512)     # leave room for the engine's rings (~10 GB) and the query sweep
+        out["north_star_width"] = north_star_width(torch, pbwt_amd, dev, opts, args.kind, sites=max(ns_sites, 4096))
         torch.cuda.empty_cache()
         out["match_dynamic"] = match_dynamic(torch, pbwt_amd, dev, args.kind)
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -347,6 +347,26 @@ int ref_transform(const char *pbwt_in, const char *sites_in, int op, int i0, int
     return 0;
 }
 
+/* the log lines of `-read P -readSites S -selectSites L` (pbwtReadSitesFile's "read %ld sites on chromosome %s from file",
+ * pbwtIO.c:263, once per sites file) written to `log_out` */
+int ref_read_sites_log(const char *pbwt_in, const char *sites_in, const char *list_file, const char *log_out)
+{
+    ref_init();
+    FILE *fp = fopen(pbwt_in, "r"); if (!fp) return -1;
+    PBWT *p = pbwtRead(fp); fclose(fp);
+    FILE *saved = logFile;
+    logFile = fopen(log_out, "w");
+    if (!logFile) { logFile = saved; return -2; }
+    fp = fopen(sites_in, "r"); if (!fp) return -3;
+    pbwtReadSites(p, fp); fclose(fp);
+    fp = fopen(list_file, "r"); if (!fp) return -4;
+    char *chr = 0; Array sites = pbwtReadSitesFile(fp, &chr); fclose(fp);
+    arrayDestroy(sites);
+    fclose(logFile); logFile = saved;
+    pbwtDestroy(p);
+    return 0;
+}
+
 size_t ref_pack3(uint8_t *y_with_sentinel, int M, uint8_t *out) { ref_init(); return pack3(y_with_sentinel, M, out); }
 size_t ref_unpack3(uint8_t *z, int M, uint8_t *y, int *n0) { ref_init(); return unpack3(z, M, y, n0); }
 void ref_free(void *p) { free(p); }

@@ -1042,12 +1042,16 @@ __global__ __launch_bounds__(64) void shard_xbar_kernel(ShardPeers P, int which,
     }
 }
 
-// SCAN of a shard, first half: workgroup j folds the rows of its TPW tiles per key (thread = key) and publishes the aggregate; the
-// last workgroup to arrive folds the workgroups' aggregates into the RANK's row, stores it into every rank's exchange block and
-// raises f1 there.  rows are indexed by global tile; this launch covers tiles w0 .. w0+Wl-1.
+// SCAN of a shard, ONE launch (the two-level form of skel_k2_wide_kernel with the other ranks as a third level): workgroup j
+// folds the rows of its TPW tiles per key (thread = key) and publishes the aggregate; the last workgroup to arrive folds the
+// workgroups' aggregates into the RANK's row, stores it into every rank's exchange block and raises f1 there; every workgroup
+// then waits until all ranks' rows have arrived here — prefix = fold of the rows of the ranks before this one and of this rank's
+// workgroups before j — and writes the running prefix in front of each of its tiles, plus the totals over ALL ranks.
+// All <= 64 workgroups of the launch are co-resident (they wait for the last of them).  Rows are indexed by global tile; this
+// launch covers tiles w0 .. w0+Wl-1.
 struct Sk2SArgs { const int2 *tbl; int2 *scan; int *total; int w0, Wl; unsigned long long *agg; unsigned *counter; unsigned target; unsigned epoch; int *err; };
 template <int TPW, int CH = 16>
-__global__ __launch_bounds__(SKK) void skel_k2s_agg_kernel(Sk2SArgs g, ShardPeers P) {
+__global__ __launch_bounds__(SKK) void skel_k2s_kernel(Sk2SArgs g, ShardPeers P) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
@@ -1067,32 +1071,25 @@ __global__ __launch_bounds__(SKK) void skel_k2s_agg_kernel(Sk2SArgs g, ShardPeer
     __syncthreads();
     if (t == 0) s_last = (__hip_atomic_fetch_add(g.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == g.target) ? 1 : 0;
     __syncthreads();
-    if (!s_last) return;
-    int rc = 0, rt = 0;
     const int nwg = (int)gridDim.x;
+    if (s_last) {                                           // every workgroup's aggregate is out (agent scope): fold them into the rank's row
+        int rc = 0, rt = 0;
 #pragma unroll 1
-    for (int i0 = 0; i0 < nwg; i0 += 32) {
-        unsigned long long pv[32];
+        for (int i0 = 0; i0 < nwg; i0 += 32) {
+            unsigned long long pv[32];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) pv[i] = (i0 + i < nwg) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+            for (int i = 0; i < 32; ++i) pv[i] = (i0 + i < nwg) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) { const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32); rt = vc ? vt : max(rt, vt); rc += vc; }
+            for (int i = 0; i < 32; ++i) { const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32); rt = vc ? vt : max(rt, vt); rc += vc; }
+        }
+        const unsigned long long row = ((unsigned long long)(unsigned)rt << 32) | (unsigned)rc;
+        for (int p = 0; p < P.n; ++p) __hip_atomic_store(&P.x[p]->ragg[P.me][t], row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __atomic_thread_fence(__ATOMIC_RELEASE);            // system scope: the row is out before the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t < P.n) __hip_atomic_store(&P.x[t]->f1[P.me], g.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    const unsigned long long row = ((unsigned long long)(unsigned)rt << 32) | (unsigned)rc;
-    for (int p = 0; p < P.n; ++p) __hip_atomic_store(&P.x[p]->ragg[P.me][t], row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __atomic_thread_fence(__ATOMIC_RELEASE);                // system scope: the row is out before the flag
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t < P.n) __hip_atomic_store(&P.x[t]->f1[P.me], g.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// second half: once every rank's row is here — prefix = fold of the rows of the ranks before this one and of this rank's
-// workgroups before j; then the running prefix in front of each of the workgroup's tiles, and the totals over ALL ranks.
-template <int TPW, int CH = 16>
-__global__ __launch_bounds__(SKK) void skel_k2s_scan_kernel(Sk2SArgs g, ShardPeers P) {
-#ifndef PBWT_NO_SETPRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
-    const int t = threadIdx.x, j = blockIdx.x, r0 = j * TPW;
+    // every rank's row of this round (this rank's own among them: its flag is raised by the last arriver above)
     shard_wait_flags(P.x[P.me]->f1, P.n, g.epoch, g.err, 7);
     __syncthreads();
     int ec = 0, et = 0, tot = 0;

@@ -365,6 +365,8 @@ void panelMatchDynamic (Panel *p, FILE *fp)
       if (pbwtamd_get_nomatch_events (engineFor (p->M), &ev, &nev)) die ("pbwt_amd: %s", pbwtamd_last_error ()) ;
       for (int64_t i = 0 ; i < nev ; ++i)
 	fprintf (logFile, "no match to query %d value %d at site %d\n", ev[4*i], ev[4*i+1], ev[4*i+2]) ;
+      if (nev < nomatch)		/* the library keeps a bounded number of events (the count is exact) */
+	fprintf (logFile, "... %lld further no-match events not listed\n", (long long) (nomatch - nev)) ;
       pbwtamd_free (ev) ;
     }
   fprintf (logFile, "Average number of best matches including alternates %.1f, Average length %.1f, Av number per position %.1f\n",
@@ -526,6 +528,7 @@ static HostSite *readSitesList (FILE *fp, char **chrom, int *n)
   free (line) ;
   if (!*chrom) *chrom = strdup ("") ;			/* as panelReadSites: the reference's end-of-file chromosome match */
   *n = (int) cnt ;
+  fprintf (logFile, "read %ld sites on chromosome %s from file\n", (long) cnt, *chrom) ;	/* pbwtIO.c:263 */
   return v ;
 }
 

@@ -25,6 +25,22 @@ import torch.distributed as dist
 BIG = 1 << 32          # divergences are < 2^31: one segment's values never reach the next segment's offset
 
 
+
+def _check_counts(send_counts, recv_counts, group=None):
+    """PBWTAMD_SHARDED_CHECK=1 (debugging): all-gather every rank's send counts and compare them with the receive counts this
+    rank derived locally — a disagreement would otherwise hang the all-to-all instead of raising"""
+    import os
+    if not os.environ.get("PBWTAMD_SHARDED_CHECK"):
+        return
+    import torch.distributed as dist
+    allc = [None] * dist.get_world_size(group)
+    dist.all_gather_object(allc, list(send_counts), group=group)
+    me = dist.get_rank(group)
+    got = [allc[s][me] for s in range(len(allc))]
+    if got != list(recv_counts):
+        raise RuntimeError("sharded exchange: derived receive counts %s != the senders' counts %s" % (list(recv_counts), got))
+
+
 def owner_ranges(M, world):
     per, extra = divmod(M, world)
     lo = [r * per + min(r, extra) for r in range(world)]
@@ -111,6 +127,7 @@ def sharded_step_AD(a_loc, d_loc, y_loc, k, M, group=None):
             return max(0, min(a1, hi) - max(a0, lo))
         recv_counts.append(overlap(zb, zb + c0s) + overlap(C + ob, C + ob + c1s))
         zb += c0s
+    _check_counts(send_counts, recv_counts, group)
     recv = torch.zeros(3 * sum(recv_counts), dtype=torch.int64, device=dev)
     dist.all_to_all_single(recv, send, output_split_sizes=[3 * c for c in recv_counts],
                            input_split_sizes=[3 * c for c in send_counts], group=group)
@@ -248,6 +265,7 @@ def sharded_round8(a_loc, d_loc, key_loc, k, M, group=None):
     b0 = G.unsqueeze(0) + bef_all
     ov = torch.clamp(torch.minimum(b0 + cs, torch.full_like(b0, hi)) - torch.maximum(b0, torch.full_like(b0, lo)), min=0)
     recv_counts = ov.sum(1).cpu().tolist()
+    _check_counts(send_counts, recv_counts, group)
     recv = torch.zeros(3 * sum(recv_counts), dtype=torch.int64, device=dev)
     dist.all_to_all_single(recv, send, output_split_sizes=[3 * c for c in recv_counts],
                            input_split_sizes=[3 * c for c in send_counts], group=group)     # collective 2 of 2

@@ -158,6 +158,8 @@ def transforms():
     sel = [59, 3, 4, 40, 7, 22, 0, 31, 58, 12]
     run(3, sel=sel, tag="subsample10")
     np.save(os.path.join(HERE, "macs_small.subsample10.select.npy"), np.asarray(sel, np.int32))
+    # what the reference logs while it reads the two sites files of `-readSites S -selectSites L`
+    assert ref.ref_read_sites_log(P, S, os.path.join(HERE, "macs_small.select.sites").encode(), os.path.join(HERE, "macs_small.select.log").encode()) == 0
     print("wrote macs_small.{subrange,selected,removed,subsample10}.*")
 
 

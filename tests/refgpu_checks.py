@@ -98,6 +98,13 @@ def main():
             assert np.array_equal(oracle.ref_match_sweep_sparse(s["nomatch_pz"], Mp, s["nomatch_qz"], Mq, N, nS), s["nomatch_s%d" % nS]); nchk += 1
         g = np.load(os.path.join(GOLDEN, "mosaic_M300_N400_k0.npz"))
         assert np.array_equal(oracle.ref_match_sweep_sparse(g["pz"], 300 - int(g["Mq"]), g["qz"], int(g["Mq"]), 400, 3), s["mosaic_M300_s3"]); nchk += 1
+        # the reference's log of matchSequencesSweep on a panel with sites where no panel haplotype carries the query's allele: the
+        # binding writes the "no match to query" lines (pbwtMatch.c:405-410) from the library's event list, then the averages line
+        vp = lambda x: np.ascontiguousarray(x).ctypes.data_as(C.c_void_p)
+        logp = os.path.join(td, "nomatch.log")
+        assert r.ref_match_sweep_log_to_file(C.c_int(Mp), C.c_int(N), vp(s["nomatch_pz"]), C.c_long(len(s["nomatch_pz"])), None,
+                                             C.c_int(Mq), vp(s["nomatch_qz"]), C.c_long(len(s["nomatch_qz"])), None, logp.encode()) == 0
+        assert open(logp).read() == open(os.path.join(GOLDEN, "nomatch_dense.log")).read(); nchk += 1
     print("REFGPU_OK %d checks" % nchk)
 
 

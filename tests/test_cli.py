@@ -172,6 +172,11 @@ def test_log_lines_match_the_reference(cli, tmp_path):
     assert [ln for ln in log if ln.startswith("no match") or ln.startswith("Average number")] == want
     assert r.stdout == "".join("MATCH\t%d\t%d\t%d\t%d\t%d\n" % (m["ai"], m["bi"], m["start"], m["end"], m["end"] - m["start"])
                                for m in s["nomatch_dense"] if m["start"] != m["end"])
+    # the sites-file readers log one line per file (pbwtIO.c:263): -readSites and the list of -selectSites alike
+    P, S, lst = (os.path.join(GOLDEN, f) for f in ("macs_small.pbwt", "macs_small.sites", "macs_small.select.sites"))
+    run(cli, "-log", tmp_path / "log2.txt", "-read", P, "-readSites", S, "-selectSites", lst, "-write", tmp_path / "sel.pbwt")
+    got = [ln for ln in open(tmp_path / "log2.txt").read().splitlines() if ln.startswith("read ") and " sites on chromosome " in ln]
+    assert got == open(os.path.join(GOLDEN, "macs_small.select.log")).read().splitlines()
     timing = [ln for ln in log if ln.startswith("user\t")]
     assert len(timing) == 3 and all(re.fullmatch(r"user\t\d+\.\d{6}\tsystem\t\d+\.\d{6}\tmax_RSS\t-?\d+\tMemory\t\d+", ln) for ln in timing)
 
