@@ -95,7 +95,7 @@ struct DevBufs {
 constexpr unsigned OPT_INTERNAL_KEEP_STATES = 0x100u;
 
 struct GraphKey { int with_d, sorted, ring, pair; hipGraphExec_t exec; };
-struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; bool skel = false; bool sharded = false; };
+struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; bool skel = false; bool sharded = false; bool early = false; int flushed = 0; /* leading sites whose consumers are enqueued already */ const uint32_t *cols = nullptr; /* the batch's bit columns */ };
 
 // skeleton batches whose consumers need (d, y) of every site but not the haplotype ids (histogram sweep, pack3 through the
 // sweep's bit columns): the fill writes d | y << 31 and no a — half the consumer stream's bytes (they are what slows the chain)
@@ -128,6 +128,11 @@ struct pbwtamd_engine {
     hipStream_t stream = nullptr; bool own_stream = false;   // the launch chain
     hipStream_t s2 = nullptr;                                 // batch consumers
     hipEvent_t evChain[2] = {nullptr, nullptr}, evCons[2] = {nullptr, nullptr}; bool consRecorded[2] = {false, false}, chainRecorded[2] = {false, false};
+    int2 *qs_bsum[2] = {nullptr, nullptr}; int qs_nblk = 0;   // query sweep: per ring, block summaries of every state of the batch (qs_blocksum_kernel), written by the batch's consumers
+    int qs_bsum_sites[2] = {0, 0};          // ... and how many leading sites of the ring's batch they have summarised so far
+    hipEvent_t evPreKeys = nullptr;         // read side: the next skeleton batch's rank directories and keys were derived ahead of time on another stream (query sweep); wait for this event instead
+    int sub_rounds = 0; hipEvent_t evSub[8] = {}; long long evSub_n = 0;   // > 0: the consumers of a skeleton batch are enqueued every sub_rounds rounds, beside the rest of the batch's chain (query sweep)
+    hipEvent_t evRounds[2] = {nullptr, nullptr}; bool roundsRecorded[2] = {false, false};   // everything the batch's consumers read is done (the last round's scatter into the OTHER ring may still wait for that ring's consumers)
     int ring = 0; Pending pend;
     int *A = nullptr, *D = nullptr; size_t strideA = 0, strideD = 0;      // 2 rings of B+1 slots
     int4 *summ = nullptr;
@@ -206,8 +211,9 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (e->s2) (void)hipStreamDestroy(e->s2);
     for (int i = 0; i < 16; ++i) if (e->tev[i]) (void)hipEventDestroy(e->tev[i]);
     for (int i = 0; i < 8; ++i) if (e->evUsed[i]) (void)hipEventDestroy(e->evUsed[i]);
+    for (int i = 0; i < 8; ++i) if (e->evSub[i]) (void)hipEventDestroy(e->evSub[i]);
     if (e->h_used) (void)hipHostFree(e->h_used);
-    for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); }
+    for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); if (e->evRounds[i]) (void)hipEventDestroy(e->evRounds[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->rankdirS, (void *)e->skT, (void *)e->k2agg, (void *)e->k2cnt, e->cols_stage, e->ycols, e->colBytes, (void *)e->p3regs,
@@ -326,7 +332,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         }
         if (!e->s2) ECHK(hipStreamCreateWithPriority(&e->s2, hipStreamNonBlocking, prLow));
     }
-    for (int i = 0; i < 2; ++i) { ECHK(hipEventCreateWithFlags(&e->evChain[i], hipEventDisableTiming)); ECHK(hipEventCreateWithFlags(&e->evCons[i], hipEventDisableTiming)); }
+    for (int i = 0; i < 2; ++i) { ECHK(hipEventCreateWithFlags(&e->evChain[i], hipEventDisableTiming)); ECHK(hipEventCreateWithFlags(&e->evCons[i], hipEventDisableTiming)); ECHK(hipEventCreateWithFlags(&e->evRounds[i], hipEventDisableTiming)); }
     ECHK(hipMemsetAsync(e->ctl, 0, 16 * sizeof(int), e->stream));
     ECHK(hipMemsetAsync(e->scal, 0, 8 * sizeof(unsigned long long), e->stream));
     ECHK(hipMemsetAsync(e->zerocol, 0, (size_t)e->wpc * sizeof(uint32_t), e->stream));
@@ -460,7 +466,7 @@ extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k
     if (e->k2cnt) { HIPCHK(hipMemsetAsync(e->k2cnt, 0, 64, e->stream)); e->k2epoch = 0; }   // arrival counter and host epoch restart together
     if (e->sh) { e->sh->full_state = true; e->sh->blkSite0.clear(); e->sh->blkSites.clear(); }
     e->k0 = k0; e->k_cur = k0; e->n_total = n_total; e->prepared = false; e->pass_open = true;
-    e->ring = 0; e->consRecorded[0] = e->consRecorded[1] = false; e->chainRecorded[0] = e->chainRecorded[1] = false;
+    e->ring = 0; e->consRecorded[0] = e->consRecorded[1] = false; e->chainRecorded[0] = e->chainRecorded[1] = false; e->roundsRecorded[0] = e->roundsRecorded[1] = false;
     e->keys_ready[0] = e->keys_ready[1] = false;
     if (aInit) HIPCHK(hipMemcpyAsync(e->A, aInit, sizeof(int) * (size_t)e->M, hipMemcpyHostToDevice, e->stream));
     const int nb = (e->Mpad + 1 + 255) / 256;
@@ -762,6 +768,12 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns) {
 #undef FILL
         HIPCHK(hipGetLastError());
     }
+    if (e->qs_bsum[p.ring] && (p.opts & PBWTAMD_OPT_SORTED) && p.cols) {     // read side, for the query sweep: {max d, alleles present} per 256 positions of these states
+        hipLaunchKernelGGL(qs_blocksum_kernel, dim3((e->qs_nblk + 4 * WAVES - 1) / (4 * WAVES), ns), dim3(BLOCK), 0, e->s2, D, e->strideD,
+                           (const unsigned long long *)p.cols + (size_t)j0 * e->wpc64, e->wpc64, e->M, e->qs_nblk, e->qs_bsum[p.ring] + (size_t)j0 * e->qs_nblk);
+        HIPCHK(hipGetLastError());
+        if (j0 == e->qs_bsum_sites[p.ring]) e->qs_bsum_sites[p.ring] = j0 + ns;
+    }
     if (p.opts & PBWTAMD_OPT_CHECKSUM) {
         unsigned long long *ca = e->csum + (kb - e->k0), *cd = ca + e->csum_sites, *cy = cd + e->csum_sites;
         dim3 grid(std::min(64, (e->M + BLOCK) / BLOCK), ns);
@@ -787,8 +799,10 @@ static int flush_pending(pbwtamd_engine *e) {
     if (e->sh) return shard_flush_pending(e);
     const Pending p = e->pend;
     e->pend.valid = false;
-    HIPCHK(hipStreamWaitEvent(e->s2, e->evChain[p.ring], 0));
-    CHK(run_consumers(e, p, 0, p.nb));
+    // evRounds: everything the consumers READ is there while the batch's last rank launch may still be waiting for the other
+    // ring — not for the packed fill, which rewrites the skeleton slots' d in place (d | y << 31), the last round's input among them
+    HIPCHK(hipStreamWaitEvent(e->s2, (p.early && !packed_fill(p)) ? e->evRounds[p.ring] : e->evChain[p.ring], 0));
+    if (p.nb > p.flushed) CHK(run_consumers(e, p, p.flushed, p.nb - p.flushed));
     HIPCHK(hipEventRecord(e->evCons[p.ring], e->s2));
     e->consRecorded[p.ring] = true;
     return 0;
@@ -829,10 +843,13 @@ static bool launch_skel_hist_scan(pbwtamd_engine *e, hipStream_t st, const SkArg
     return false;
 }
 
+// part: 0 = the whole round; 1 = hist + tile scan only; 2 = the rank launch only (after a part-1 call with the same arguments).
+// Rounds of two launches (the rank scans the tile table itself) cannot be split: part 1 does nothing, part 2 the whole round.
 template <int EPT>
-static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
+static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch, int part = 0) {
     const int W = g.W;
     if (two_launch && !e->prow) {
+        if (part == 1) return;
         hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         if (W <= 16) hipLaunchKernelGGL((skel_rank_kernel<EPT, 16>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         else if (W <= 32) hipLaunchKernelGGL((skel_rank_kernel<EPT, 32>), dim3(W), dim3(BLOCK), 0, e->stream, g);
@@ -840,7 +857,10 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch) {
         else hipLaunchKernelGGL((skel_rank_kernel<EPT, SKN_MAXW>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         return;
     }
-    const bool wide = launch_skel_hist_scan<EPT>(e, e->stream, g, e->k2agg, e->k2cnt, &e->k2epoch);
+    static const bool k2_wide_on = !(getenv("PBWTAMD_K2_WIDE") && !atoi(getenv("PBWTAMD_K2_WIDE")));
+    bool wide = e->prow || (W > 512 && W <= 64 * 32 && k2_wide_on);
+    if (part != 2) wide = launch_skel_hist_scan<EPT>(e, e->stream, g, e->k2agg, e->k2cnt, &e->k2epoch);
+    if (part == 1) return;
     static const bool rank_r4 = !(getenv("PBWTAMD_RANK_R4") && !atoi(getenv("PBWTAMD_RANK_R4")));
     if (wide && (e->prow || rank_r4)) hipLaunchKernelGGL((skel_rank_kernel<EPT, 0, true>), dim3(W), dim3(BLOCK), 0, e->stream, g);    // more tiles than one round of the chip: occupancy counts
     else hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
@@ -859,9 +879,14 @@ static int skel_prepare(pbwtamd_engine *e, int r, const uint32_t *cols, int nb, 
     const int nvalid = std::min(navail, e->n_total - e->k_cur);
     if (sorted) {                                          // read side: keys of every round from the sorted columns (LF-mapping), slot 0 tagged by position
         const unsigned long long *yc = (const unsigned long long *)cols;
-        hipLaunchKernelGGL(qs_rankdir_kernel, dim3(nb), dim3(BLOCK), 0, e->stream, yc, e->wpc64, e->M, e->rankdirS);
-        hipLaunchKernelGGL(skel_keys_sorted_kernel, dim3((e->M + BLOCK - 1) / BLOCK, nb / 8), dim3(BLOCK), 0, e->stream, yc, e->wpc64,
-                           (const int *)e->rankdirS, e->M, e->keysR[r], (size_t)e->Mpad);
+        if (e->evPreKeys) {                                 // decoded columns and keysR[r] were prepared ahead of the chain (pbwtamd_match_sweep_sparse)
+            HIPCHK(hipStreamWaitEvent(e->stream, e->evPreKeys, 0));
+            e->evPreKeys = nullptr;
+        } else {
+            hipLaunchKernelGGL(qs_rankdir_kernel, dim3(nb), dim3(BLOCK), 0, e->stream, yc, e->wpc64, e->M, e->rankdirS);
+            hipLaunchKernelGGL(skel_keys_sorted_kernel, dim3((e->M + BLOCK - 1) / BLOCK, nb / 8), dim3(BLOCK), 0, e->stream, yc, e->wpc64,
+                               (const int *)e->rankdirS, e->M, e->keysR[r], (size_t)e->Mpad);
+        }
         if (!e->keys_ready[r]) hipLaunchKernelGGL(skel_tag_sorted_kernel, dim3((e->M + 255) / 256), dim3(256), 0, e->stream, ringA(e, r), yc, e->M);
     } else {
         skel_transpose(e, e->stream, e->xTr[r], cols, nb, nvalid);
@@ -875,7 +900,7 @@ static int skel_prepare(pbwtamd_engine *e, int r, const uint32_t *cols, int nb, 
 
 // rounds [s_from, s_to) of the batch; `direct`: the batch's last round scatters straight into slot 0
 // (and the slot-0 keys) of the other ring, where the next batch starts
-static int skel_rounds(pbwtamd_engine *e, int r, const uint32_t *cols, bool sorted, int nb, int navail, int s_from, int s_to, bool direct) {
+static int skel_rounds(pbwtamd_engine *e, int r, const uint32_t *cols, bool sorted, int nb, int navail, int s_from, int s_to, bool direct, int part = 0) {
     int *A = ringA(e, r), *D = ringD(e, r);
     const int nvalid = std::min(navail, e->n_total - e->k_cur);
     unsigned char *kb = e->keysR[r];
@@ -899,7 +924,8 @@ static int skel_rounds(pbwtamd_engine *e, int r, const uint32_t *cols, bool sort
         g.kbnext = reinterpret_cast<const unsigned char *>(xT) + (size_t)((site + 8) / 8) * e->strideX;   // byte plane of sites site+8 .. site+15
         g.ycnext = sorted ? (const unsigned long long *)cols + (size_t)(site + 8) * e->wpc64 : nullptr;
         g.k = e->k_cur + site;
-        if (e->skEPT == 1) launch_skel_round<1>(e, g, two); else if (e->skEPT == 2) launch_skel_round<2>(e, g, two); else launch_skel_round<4>(e, g, two);
+        if (e->skEPT == 1) launch_skel_round<1>(e, g, two, part); else if (e->skEPT == 2) launch_skel_round<2>(e, g, two, part); else launch_skel_round<4>(e, g, two, part);
+        if (part == 1) continue;
         if (last) e->keys_ready[r ^ 1] = g.has_next != 0;
         if (e->thr_rounds > 0 && (s8 + 1) % e->thr_rounds == 0) {   // a deep command queue slows the dependent chain down (measured): stay just ahead
             HIPCHK(hipEventRecord(e->tev[e->tev_n % 16], e->stream));
@@ -931,6 +957,7 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         const int nb = std::min(e->B, ncols - done);
         const uint32_t *bc = cols + (size_t)done * wpc;
         const int r = e->ring;
+        e->qs_bsum_sites[r] = 0;
         int *A = ringA(e, r), *D = ringD(e, r);
         // two sites per launch when the columns are in original order (the keys of the next pair are
         // gathered by haplotype) and the pair's successor columns are at hand
@@ -961,22 +988,47 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
             hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); e->ev.push_back({a, b});
         }
         HIPCHK(hipEventRecord(e->ev[e->ev_used].first, e->stream));
-        bool launched = false;
+        bool launched = false, early = false;
+        int flushed_sites = 0;
         if (skel) {
             // ring r's consumers (incl. the fill that read xTr[r], keysR[r], saveR[r]) were waited for before slot 0 of ring r was written
             e->xT = e->xTr[r];
             CHK(skel_prepare(e, r, bc, nb, left, sorted));
             // the other stream's work is enqueued once all but the last round of this batch are (measured: better than right away)
             static const int flush_at = getenv("PBWTAMD_FLUSH_AT") ? atoi(getenv("PBWTAMD_FLUSH_AT")) : -1;   // rounds enqueued before the consumers (-1: all but the last)
-            const int nr = nb / 8, head = (flush_at >= 0) ? std::min(flush_at, nr - 1) : nr - 1;
-            CHK(skel_rounds(e, r, bc, sorted, nb, left, 0, head, true));
+            const int nr = nb / 8;
+            int s_done = 0;
+            const unsigned cons_mask = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_PACK3 | OPT_INTERNAL_KEEP_STATES;
+            if (e->sub_rounds > 0 && nr > e->sub_rounds && (opts & cons_mask) && !(opts & (PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_LONG_RECS))) {
+                // sub-batches: the consumers of rounds [s, s + sub_rounds) go to the consumer stream as soon as those rounds are enqueued — the
+                // fill of the first rounds runs beside the chain of the later ones instead of after the whole batch
+                CHK(flush_pending(e));                     // the previous batch's consumers come first on that stream
+                Pending pt; pt.valid = true; pt.ring = r; pt.kbase = e->k_cur; pt.nb = nb; pt.opts = opts; pt.skel = true; pt.cols = bc;
+                while (s_done + e->sub_rounds <= nr - 1) {
+                    CHK(skel_rounds(e, r, bc, sorted, nb, left, s_done, s_done + e->sub_rounds, true));
+                    hipEvent_t &evs = e->evSub[e->evSub_n++ % 8];
+                    if (!evs) HIPCHK(hipEventCreateWithFlags(&evs, hipEventDisableTiming));
+                    HIPCHK(hipEventRecord(evs, e->stream));
+                    HIPCHK(hipStreamWaitEvent(e->s2, evs, 0));
+                    CHK(run_consumers(e, pt, 8 * s_done, 8 * e->sub_rounds));
+                    s_done += e->sub_rounds;
+                }
+                flushed_sites = 8 * s_done;
+            }
+            const int head = std::max(s_done, (flush_at >= 0) ? std::min(flush_at, nr - 1) : nr - 1);
+            CHK(skel_rounds(e, r, bc, sorted, nb, left, s_done, head, true));
             // consumers of the PREVIOUS batch (other ring) are enqueued now, beside this batch's chain
             CHK(flush_pending(e));
             // the last round scatters straight into slot 0 of the other ring, once its readers are done
             static const bool no_direct = getenv("PBWTAMD_NO_DIRECT") != nullptr;
             CHK(skel_rounds(e, r, bc, sorted, nb, left, head, nr - 1, !no_direct));
+            // the last round's hist + tile scan read this ring only: with them everything this batch's consumers need is done
+            // (evRounds) — only its rank launch, which scatters into the OTHER ring, has to wait for that ring's consumers
+            CHK(skel_rounds(e, r, bc, sorted, nb, left, nr - 1, nr, !no_direct, 1));
+            early = !skel_two_launch(e) || e->prow;
+            if (early) { HIPCHK(hipEventRecord(e->evRounds[r], e->stream)); e->roundsRecorded[r] = true; }
             if (e->consRecorded[r ^ 1]) HIPCHK(hipStreamWaitEvent(e->stream, e->evCons[r ^ 1], 0));
-            CHK(skel_rounds(e, r, bc, sorted, nb, left, nr - 1, nr, !no_direct));
+            CHK(skel_rounds(e, r, bc, sorted, nb, left, nr - 1, nr, !no_direct, 2));
             if (no_direct) {
                 HIPCHK(hipMemcpyAsync(ringA(e, r ^ 1), A + (size_t)nb * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->stream));
                 HIPCHK(hipMemcpyAsync(ringD(e, r ^ 1), D + (size_t)nb * e->strideD, sizeof(int) * e->strideD, hipMemcpyDeviceToDevice, e->stream));
@@ -1011,7 +1063,7 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
             if (with_d) HIPCHK(hipMemcpyAsync(ringD(e, r ^ 1), D + (size_t)nb * e->strideD, sizeof(int) * e->strideD, hipMemcpyDeviceToDevice, e->stream));
         }
         if (skel || (opts & (PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS))) {
-            e->pend.valid = true; e->pend.ring = r; e->pend.kbase = e->k_cur; e->pend.nb = nb; e->pend.opts = opts; e->pend.skel = skel; e->pend.sharded = false;
+            e->pend.valid = true; e->pend.ring = r; e->pend.kbase = e->k_cur; e->pend.nb = nb; e->pend.opts = opts; e->pend.skel = skel; e->pend.sharded = false; e->pend.early = early; e->pend.flushed = flushed_sites; e->pend.cols = bc;
         }
         e->ring = r ^ 1;
         e->k_cur += nb;
@@ -1673,7 +1725,14 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     const int Bd = nS ? (e->B / nS) * nS : e->B;             // dense batch: a whole number of sparse rounds
     const int Bs = nS ? Bd / nS : 0;
     pbwtamd_engine *eq = nullptr;
-    CHK(pbwtamd_engine_create(&eq, e->device, Mq, e->B, nullptr));
+    // the query cursor's chain on a stream of NORMAL priority: two high-priority streams share a hardware queue, where the panel's and
+    // the queries' dependent launches take turns (measured: 320 launches per batch one after the other); on a queue of its own the
+    // query chain runs beside the panel's
+    hipStream_t qchain = nullptr;
+    static const bool qs_own_queue = !(getenv("PBWTAMD_QS_QCHAIN") && !atoi(getenv("PBWTAMD_QS_QCHAIN")));
+    if (qs_own_queue) HIPCHK(hipStreamCreateWithPriority(&qchain, hipStreamNonBlocking, 0));
+    struct QcGuard { hipStream_t s; ~QcGuard() { if (s) (void)hipStreamDestroy(s); } } qcGuard{qchain};        // destroyed after the engine that runs on it
+    CHK(pbwtamd_engine_create(&eq, e->device, Mq, e->B, (void *)qchain));
     struct EngGuard { std::vector<pbwtamd_engine *> v; ~EngGuard() { for (auto *p : v) if (p) pbwtamd_engine_destroy(p); } } guard;
     guard.v.push_back(eq);
     std::vector<pbwtamd_engine *> es((size_t)nS, nullptr);
@@ -1705,6 +1764,11 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         CHK(pbwtamd_pass_end(e, PBWTAMD_OPT_SORTED));
     }
     // ---- phase B ----
+    // the panel's fill (1.3 ms per 512 sites at M = 1 M) in sub-batches of 16 rounds: it runs beside the batch's own chain and the previous
+    // batch's query sweep instead of between the two
+    struct SubGuard { pbwtamd_engine *p; int old; ~SubGuard() { p->sub_rounds = old; } } subGuard{e, e->sub_rounds};
+    static const int qs_sub = getenv("PBWTAMD_QS_SUB") ? atoi(getenv("PBWTAMD_QS_SUB")) : 16;
+    e->sub_rounds = qs_sub;
     CHK(pbwtamd_pass_begin(e, pStart, 0, N));
     CHK(pbwtamd_pass_begin(eq, qStart, 0, N));
     std::vector<int> nTotS((size_t)nS, 0);
@@ -1717,6 +1781,17 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     std::vector<int *> a0S((size_t)nS, nullptr);
     for (int kk = 0; kk < nS; ++kk) CHK(bufs.alloc(&a0S[kk], (size_t)e->strideA));
     CHK(bufs.alloc(&rankdir, (size_t)e->B * (wpc64 + 1)));
+    // block summaries {max d, alleles present} per 256 positions of every state of a batch: what lets the walks of reportAndUpdate skip
+    // 65 536 positions per trip to memory (qs_blocksum_kernel); PBWTAMD_QS_BLOCKS=0: the walks test every position (A/B runs)
+    static const bool qs_blocks = !(getenv("PBWTAMD_QS_BLOCKS") && !atoi(getenv("PBWTAMD_QS_BLOCKS")));
+    const int nblk = (Mp + 255) / 256;
+    int2 *bsumP[2] = {nullptr, nullptr};
+    if (qs_blocks) for (int i = 0; i < 2; ++i) CHK(bufs.alloc(&bsumP[i], (size_t)e->B * nblk));
+    struct BsGuard { pbwtamd_engine *p; ~BsGuard() { p->qs_bsum[0] = p->qs_bsum[1] = nullptr; p->qs_nblk = 0; } } bsGuard{e};
+    // the panel's summaries are written by its own consumers (stream s2, after each sub-batch's fill) — off the sweep's critical path
+    e->qs_bsum[0] = bsumP[0]; e->qs_bsum[1] = bsumP[1]; e->qs_nblk = nblk;
+    std::vector<int2 *> bsumS((size_t)nS, nullptr);
+    if (qs_blocks) for (int kk = 0; kk < nS; ++kk) CHK(bufs.alloc(&bsumS[kk], (size_t)(Bs + 2) * nblk));
     for (int i = 0; i < 2; ++i) {
         CHK(bufs.alloc(&fst[i], (size_t)Mq)); CHK(bufs.alloc(&dst[i], (size_t)Mq));
         CHK(bufs.alloc(&fss[i], (size_t)2 * std::max(nS, 1) * Mq)); CHK(bufs.alloc(&dss[i], (size_t)2 * std::max(nS, 1) * Mq));
@@ -1726,13 +1801,24 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     int4 *nm_ev; unsigned *nm_n;
     CHK(bufs.alloc(&nm_ev, (size_t)NM_CAP)); CHK(bufs.alloc(&nm_n, (size_t)1));
     e->nomatch_events.clear();
+    unsigned long long *qs_dbg = nullptr;                   // PBWTAMD_QS_DBG=<file>: per-query wave time and event count of the sweep kernel, dumped at the end
+    if (getenv("PBWTAMD_QS_DBG")) { CHK(bufs.alloc(&qs_dbg, (size_t)2 * Mq + 128)); HIPCHK(hipMemset(qs_dbg, 0, sizeof(unsigned long long) * (2 * (size_t)Mq + 128))); }
     unsigned long long *bsum; CHK(bufs.alloc(&bsum, 2 * std::max(BQ, (size_t)Mq) / SCAN_CHUNK + 2));
     std::vector<unsigned long long *> ycS((size_t)nS, nullptr); std::vector<int *> rdS((size_t)nS, nullptr);
     for (int kk = 0; kk < nS; ++kk) { CHK(bufs.alloc(&ycS[kk], (size_t)(Bs + 2) * wpc64)); CHK(bufs.alloc(&rdS[kk], (size_t)(Bs + 2) * (wpc64 + 1))); }
     QsView *dviews = nullptr; CHK(bufs.alloc(&dviews, (size_t)std::max(nS, 1)));
     std::vector<QsView> hviews_buf[2] = {std::vector<QsView>((size_t)std::max(nS, 1)), std::vector<QsView>((size_t)std::max(nS, 1))};   // per batch parity: the async upload of one batch's views may still be reading while the next batch's are filled in
     int hv_par = 0;
-    hipStream_t st = e->s2;
+    // the query sweep has a stream of its own: one wave per query walks the batch's sites one dependent round trip after the
+    // other (4.4 ms per 512 sites at M = 1 M, Q = 10 k: latency, the chip's bandwidth idles), so the NEXT batch's fill — queued on
+    // the consumer stream s2 — runs beside it instead of behind it
+    hipStream_t st = nullptr;
+    {
+        int prLow = 0, prHigh = 0; (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
+        static const int qs_prio = getenv("PBWTAMD_QS_PRIO") ? atoi(getenv("PBWTAMD_QS_PRIO")) : 0;     // 0 low, 1 normal, 2 high
+        HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, qs_prio == 2 ? prHigh : qs_prio == 1 ? 0 : prLow));
+    }
+    struct StGuard { hipStream_t s; ~StGuard() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } } stGuard{st};
     HIPCHK(hipMemsetAsync(fst[0], 0, sizeof(int) * (size_t)Mq, st));       // calloc'ed f[], d[], ff[][], dd[][] (pbwtMatch.c:512-523)
     HIPCHK(hipMemsetAsync(dst[0], 0, sizeof(int) * (size_t)Mq, st));
     HIPCHK(hipMemsetAsync(fss[0], 0, sizeof(int) * (size_t)2 * std::max(nS, 1) * Mq, st));
@@ -1770,12 +1856,45 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     // the chains of the batch starting at site `at` (panel, queries, sparse cursors): enqueued only — batch b+1's chains run
     // while batch b's query sweep does (the sweep's stream records the consumer events the chains wait for before they
     // overwrite the ring the sweep reads)
+    // The panel's decoded columns alternate between the two halves of the staging buffer, so that batch b+1's columns, rank
+    // directories and skeleton keys (skel_keys_sorted_kernel: 0.9 ms per batch at M = 1 M, a function of the columns alone) are
+    // derived on a stream of their own WHILE batch b's chain runs, instead of in front of batch b+1's chain.
+    hipStream_t pre = nullptr; hipEvent_t evPre[2] = {nullptr, nullptr};
+    {
+        int prLow = 0, prHigh = 0; (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
+        HIPCHK(hipStreamCreateWithPriority(&pre, hipStreamNonBlocking, prLow));
+        for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&evPre[i], hipEventDisableTiming));
+    }
+    struct PreGuard { hipStream_t s; hipEvent_t *ev; pbwtamd_engine *p; ~PreGuard() { p->evPreKeys = nullptr; if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } for (int i = 0; i < 2; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]); } } preGuard{pre, evPre, e};
+    int *rdPre = nullptr; CHK(bufs.alloc(&rdPre, (size_t)(e->B + 2) * (wpc64 + 1)));
+    static const bool qs_prefetch = !(getenv("PBWTAMD_QS_PREFETCH") && !atoi(getenv("PBWTAMD_QS_PREFETCH")));
+    auto stage_half = [&](int at) -> uint32_t * { return e->cols_stage + (size_t)((at / Bd) & 1) * ((size_t)e->B + 8) * wpc; };
+    int pre_at = -1;                                       // the batch whose columns + keys are prepared (or being prepared) on `pre`
+    // prepare the batch starting at `at`, which will run in ring `ring`: decode + rank directories + keys of every round
+    auto prefetch = [&](int at, int ring) -> int {
+        const int nb = std::min(Bd, N - at);
+        if (!qs_prefetch || nb % 8 || !e->skel) return 0;  // only the skeleton path consumes prepared keys
+        const int navail = std::min(nb + 1, N - at);
+        unsigned long long *yc = (unsigned long long *)stage_half(at);
+        HIPCHK(hipStreamWaitEvent(pre, evCols, 0));         // the sweep's copy out of this half (two batches ago) has been enqueued before this call
+        CHK(packed_expand(e, pre, pk, Mp, at, navail, yc, wpc64));
+        hipLaunchKernelGGL(qs_rankdir_kernel, dim3(nb), dim3(BLOCK), 0, pre, (const unsigned long long *)yc, wpc64, Mp, rdPre);
+        hipLaunchKernelGGL(skel_keys_sorted_kernel, dim3((Mp + BLOCK - 1) / BLOCK, nb / 8), dim3(BLOCK), 0, pre, (const unsigned long long *)yc, wpc64,
+                           (const int *)rdPre, Mp, e->keysR[ring], (size_t)e->Mpad);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(evPre[(at / Bd) & 1], pre));
+        pre_at = at;
+        return 0;
+    };
     auto enqueue_chains = [&](int at) -> int {
         const int nb = std::min(Bd, N - at);
         const int navail = std::min(nb + 1, N - at);
-        CHK(packed_expand(e, e->stream, pk, Mp, at, navail, (unsigned long long *)e->cols_stage, wpc64));
+        uint32_t *stage = stage_half(at);
+        if (pre_at == at) { HIPCHK(hipStreamWaitEvent(e->stream, evPre[(at / Bd) & 1], 0)); e->evPreKeys = evPre[(at / Bd) & 1]; }   // skel_prepare skips the keys
+        else CHK(packed_expand(e, e->stream, pk, Mp, at, navail, (unsigned long long *)stage, wpc64));
         CHK(packed_expand(eq, eq->stream, qk, Mq, at, navail, (unsigned long long *)eq->cols_stage, eq->wpc64));
-        CHK(pbwtamd_pass_advance(e, e->cols_stage, wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES));
+        CHK(pbwtamd_pass_advance(e, stage, wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES));
+        e->evPreKeys = nullptr;
         CHK(pbwtamd_pass_advance(eq, eq->cols_stage, eq->wpc, nb, navail, PBWTAMD_OPT_SORTED | OPT_INTERNAL_KEEP_STATES));
         for (int kk = 0; kk < nS; ++kk) {                  // the sparse cursors' steps that fall into this batch
             const int ns = nb > kk ? (nb - kk + nS - 1) / nS : 0;
@@ -1790,10 +1909,11 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         return 0;
     };
     if (N > 0) CHK(enqueue_chains(0));
+    if (N > Bd) CHK(prefetch(Bd, 1));
     for (int done = 0; done < N;) {
         const int nb = std::min(Bd, N - done);
         std::vector<QsView> &hviews = hviews_buf[hv_par]; hv_par ^= 1;
-        for (int kk = 0; kk < nS; ++kk) hviews[kk] = QsView{nullptr, nullptr, 0, 0, nullptr, nullptr, done / nS, nullptr};
+        for (int kk = 0; kk < nS; ++kk) hviews[kk] = QsView{nullptr, nullptr, 0, 0, nullptr, nullptr, done / nS, nullptr, nullptr, 0};
         lap(0);
         CHK(pbwtamd_sync(e));
         CHK(pbwtamd_sync(eq));
@@ -1801,9 +1921,14 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         const int *A = ringA(e, e->ring ^ 1), *D = ringD(e, e->ring ^ 1), *AQ = ringA(eq, eq->ring ^ 1);
         // the panel's sorted bit columns of this batch are the decoded input columns themselves (read side): a copy out of the
         // staging buffer (the next batch's decode overwrites it) instead of a pass over the tags of A
-        HIPCHK(hipMemcpyAsync(e->ycols, e->cols_stage, (size_t)nb * wpc64 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(e->ycols, stage_half(done), (size_t)nb * wpc64 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
         HIPCHK(hipEventRecord(evCols, st));                  // the next batch's decode (chain stream) must not overwrite the staging buffer before this copy has read it
         hipLaunchKernelGGL(qs_rankdir_kernel, dim3(nb), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, wpc64, Mp, rankdir);
+        if (bsumP[0]) {                                     // states the batch's consumers did not summarise (batches outside the skeleton path run no consumers for this option set)
+            const int rr = e->ring ^ 1, have = std::min(e->qs_bsum_sites[rr], nb);
+            if (have < nb) hipLaunchKernelGGL(qs_blocksum_kernel, dim3((nblk + 4 * WAVES - 1) / (4 * WAVES), nb - have), dim3(BLOCK), 0, st, D + (size_t)have * e->strideD, e->strideD,
+                                              (const unsigned long long *)e->ycols + (size_t)have * wpc64, wpc64, Mp, nblk, bsumP[rr] + (size_t)have * nblk);
+        }
         hipLaunchKernelGGL(qs_unsort_kernel, dim3(std::min(qblocks, 64), nb), dim3(BLOCK), 0, st, AQ, eq->strideA, Mq, xq, invq);
         for (int kk = 0; kk < nS; ++kk) {
             const int ns = nb > kk ? (nb - kk + nS - 1) / nS : 0;
@@ -1814,21 +1939,22 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
             dim3 gs(std::min(64, (wpc64 + WAVES - 1) / WAVES), ns);
             hipLaunchKernelGGL(tags_to_bits_kernel, gs, dim3(BLOCK), 0, st, As, s->strideA, Mp, ycS[kk], wpc64);
             hipLaunchKernelGGL(qs_rankdir_kernel, dim3(ns), dim3(BLOCK), 0, st, (const unsigned long long *)ycS[kk], wpc64, Mp, rdS[kk]);
+            if (bsumS[kk]) hipLaunchKernelGGL(qs_blocksum_kernel, dim3((nblk + 4 * WAVES - 1) / (4 * WAVES), ns), dim3(BLOCK), 0, st, Ds, s->strideD, (const unsigned long long *)ycS[kk], wpc64, Mp, nblk, bsumS[kk]);
             HIPCHK(hipMemcpyAsync(a0S[kk], As, sizeof(int) * (size_t)Mp, hipMemcpyDeviceToDevice, st));
-            hviews[kk] = QsView{As, Ds, s->strideA, s->strideD, ycS[kk], rdS[kk], done / nS, a0S[kk]};
+            hviews[kk] = QsView{As, Ds, s->strideA, s->strideD, ycS[kk], rdS[kk], done / nS, a0S[kk], bsumS[kk], nblk};
         }
         if (nS) HIPCHK(hipMemcpyAsync(dviews, hviews.data(), sizeof(QsView) * (size_t)nS, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * 2 * (size_t)nb * Mq, st));
         QssArgs g;
         HIPCHK(hipMemcpyAsync(a0P, A, sizeof(int) * (size_t)Mp, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(a0Q, AQ, sizeof(int) * (size_t)Mq, hipMemcpyDeviceToDevice, st));
-        g.dense = QsView{A, D, e->strideA, e->strideD, e->ycols, rankdir, 0, a0P}; g.sparse = dviews; g.wpc64 = wpc64; g.nS = nS;
+        g.dense = QsView{A, D, e->strideA, e->strideD, e->ycols, rankdir, 0, a0P, bsumP[e->ring ^ 1], nblk}; g.sparse = dviews; g.wpc64 = wpc64; g.nS = nS;
         g.xq = xq; g.invq = invq; g.Mp = Mp; g.Mq = Mq; g.kbase = done; g.nsites = nb;
         g.f_in = fst[cur]; g.dq_in = dst[cur]; g.f_out = fst[cur ^ 1]; g.dq_out = dst[cur ^ 1];
         g.fs_in = fss[cur]; g.ds_in = dss[cur]; g.fs_out = fss[cur ^ 1]; g.ds_out = dss[cur ^ 1];
         g.cnt = cnt; g.recs = nullptr; g.tot = tot;
         g.nm_ev = nm_ev; g.nm_n = nm_n; g.nm_cap = NM_CAP; g.evt = evt;
-        g.q_lo = e->q_lo; g.q_hi = e->q_hi;
+        g.q_lo = e->q_lo; g.q_hi = e->q_hi; g.dbg = qs_dbg;
         // a wave lives for the whole batch here (one query, site after site): at full occupancy the next batch's chain kernels,
         // enqueued below to run beside it, would find no wave slot until it ends.  26 KB of (unused) dynamic LDS per workgroup
         // holds the sweep to 6 of the 8 wave slots per SIMD.
@@ -1843,9 +1969,15 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
             CHK(mark(e)); CHK(mark(eq));
             for (int kk = 0; kk < nS; ++kk) if (hviews[kk].A) CHK(mark(es[kk]));
         }
+        static const bool qs_serial = getenv("PBWTAMD_QS_SERIAL") != nullptr;                             // measurement: the sweep alone on the device, the next batch's chains after it
+        if (qs_serial) HIPCHK(hipEventSynchronize(evTotal));
         if (done + nb < N) {                                 // runs beside the sweep; ring pointers of THIS batch were taken above
             HIPCHK(hipStreamWaitEvent(e->stream, evCols, 0));
             CHK(enqueue_chains(done + nb));
+            {   // ... and the batch after it is prepared meanwhile
+                const int at2 = done + nb + std::min(Bd, N - (done + nb));
+                if (at2 < N) CHK(prefetch(at2, (at2 / Bd) & 1));
+            }
             CHK(flush_pending(e)); CHK(flush_pending(eq));      // their fills queue behind the sweep on the consumer stream instead of waiting for the next sync
             for (int kk = 0; kk < nS; ++kk) CHK(flush_pending(es[kk]));
         }
@@ -1887,6 +2019,15 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         hipLaunchKernelGGL((qss_tail_kernel<1>), dim3(qwaves), dim3(BLOCK), 0, st, A, D, AQ, Mp, Mq, N, nS, std::max(c, 0), c >= 0 ? 1 : 0, fp, dp, cnt, recs, tot, e->q_lo, e->q_hi, e->q_part ? 1 : 0);
         HIPCHK(hipGetLastError());
         CHK(deliver((size_t)total));
+    }
+    if (qs_dbg) {
+        std::vector<unsigned long long> h((size_t)2 * Mq + 128);
+        HIPCHK(hipMemcpy(h.data(), qs_dbg, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(getenv("PBWTAMD_QS_DBG"), "w")) {
+            for (int q = 0; q < Mq; ++q) fprintf(f, "%d %llu %llu\n", q, h[2 * (size_t)q], h[2 * (size_t)q + 1]);
+            for (int b = 0; b < 64; ++b) fprintf(f, "%d %llu %llu\n", -1 - b, h[2 * (size_t)Mq + b], h[2 * (size_t)Mq + 64 + b]);     // per batch: slowest wave (ticks), most events of one query
+            fclose(f);
+        }
     }
     unsigned long long htot[4];
     HIPCHK(hipMemcpy(htot, tot, sizeof htot, hipMemcpyDeviceToHost));

@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(64) void shard_xbar_kernel(ShardPeers P, int which,
 // All <= 64 workgroups of the launch are co-resident (they wait for the last of them).  Rows are indexed by global tile; this
 // launch covers tiles w0 .. w0+Wl-1.
 struct Sk2SArgs { const int2 *tbl; int2 *scan; int *total; int w0, Wl; unsigned long long *agg; unsigned *counter; unsigned target; unsigned epoch; int *err; };
-template <int TPW, int CH = 16>
+template <int TPW, int CH = 8>
 __global__ __launch_bounds__(SKK) void skel_k2s_kernel(Sk2SArgs g, ShardPeers P) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
@@ -1075,12 +1075,12 @@ __global__ __launch_bounds__(SKK) void skel_k2s_kernel(Sk2SArgs g, ShardPeers P)
     if (s_last) {                                           // every workgroup's aggregate is out (agent scope): fold them into the rank's row
         int rc = 0, rt = 0;
 #pragma unroll 1
-        for (int i0 = 0; i0 < nwg; i0 += 32) {
-            unsigned long long pv[32];
+        for (int i0 = 0; i0 < nwg; i0 += 16) {
+            unsigned long long pv[16];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) pv[i] = (i0 + i < nwg) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+            for (int i = 0; i < 16; ++i) pv[i] = (i0 + i < nwg) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) { const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32); rt = vc ? vt : max(rt, vt); rc += vc; }
+            for (int i = 0; i < 16; ++i) { const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32); rt = vc ? vt : max(rt, vt); rc += vc; }
         }
         const unsigned long long row = ((unsigned long long)(unsigned)rt << 32) | (unsigned)rc;
         for (int p = 0; p < P.n; ++p) __hip_atomic_store(&P.x[p]->ragg[P.me][t], row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1105,12 +1105,12 @@ __global__ __launch_bounds__(SKK) void skel_k2s_kernel(Sk2SArgs g, ShardPeers P)
         }
     }
 #pragma unroll 1
-    for (int i0 = 0; i0 < j; i0 += 32) {
-        unsigned long long pv[32];
+    for (int i0 = 0; i0 < j; i0 += 16) {
+        unsigned long long pv[16];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) pv[i] = (i0 + i < j) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+        for (int i = 0; i < 16; ++i) pv[i] = (i0 + i < j) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) { const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32); et = vc ? vt : max(et, vt); ec += vc; }
+        for (int i = 0; i < 16; ++i) { const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32); et = vc ? vt : max(et, vt); ec += vc; }
     }
 #pragma unroll 1
     for (int x0 = 0; x0 < TPW; x0 += CH) {
@@ -2872,7 +2872,39 @@ struct QsView {                                              // one cursor's sta
     int sbase;                                               // sparse cursors: index of the cursor's first step in this batch
     const int *A0;                                           // a copy of the batch's FIRST a[] row for the emission pass: the next batch's chain, which runs
                                                              // beside it, ends by writing its own first state into that ring slot
+    const int2 *bsum; int nblk;                              // per slot and block of 256 positions: {max d (INT_MAX when the block reaches position M), bit 0: holds a 0, bit 1: holds a 1}; null = none
 };
+
+// block summaries for the walks of reportAndUpdate (pbwtMatch.c:452-499).  The reference walks position by position (1 ns each
+// on a CPU); here a wave tests 256 positions per trip to memory (~1.5 us), and a query whose allele is rare around its match walks
+// 10^5..10^6 of them: measured at M = 1 M, Q = 10 k, the slowest of the 10 000 waves of a 512-site batch took 3.4-4.6 ms where the
+// mean took 0.43.  With {max d, alleles present} per 256 positions a walk skips 64 blocks per lane-step: 65 536 positions per trip.
+// grid (ceil(nblk / 16), sites): a wave takes four consecutive blocks (one 16-byte load per lane and block, all four in flight).
+__global__ __launch_bounds__(BLOCK) void qs_blocksum_kernel(const int *D, size_t strideD, const unsigned long long *ycols, int wpc64, int M, int nblk, int2 *bsum) {
+    const int s = blockIdx.y, b0 = (blockIdx.x * WAVES + wave_id()) * 4, lane = lane_id();
+    if (b0 >= nblk) return;
+    const int *d = D + (size_t)s * strideD;                  // slots are 16-byte aligned (strides are multiples of 64 ints)
+    const unsigned long long *yc = ycols + (size_t)s * wpc64;
+    int4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = (b0 + q) * 256 + 4 * lane;            // reads stay inside the slot's padding (Mpad is a multiple of 4096)
+        v[q] = (b0 + q < nblk) ? *reinterpret_cast<const int4 *>(d + i) : make_int4(0, 0, 0, 0);
+    }
+    unsigned long long word = 0ULL; int valid = 0;
+    if (lane < 16) { const int w = b0 * 4 + lane; valid = min(64, M - w * 64); if (valid > 0) word = yc[w]; }
+    int fl = 0;
+    if (valid > 0) { const unsigned long long mask = (valid == 64) ? ~0ULL : ((1ULL << valid) - 1ULL); fl = ((~word & mask) ? 1 : 0) | ((word & mask) ? 2 : 0); }
+    fl |= __shfl_xor(fl, 1); fl |= __shfl_xor(fl, 2);      // lanes 4q .. 4q+3: block b0 + q
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = (b0 + q) * 256 + 4 * lane;
+        int mx = max(max(i < M ? v[q].x : 0x7fffffff, i + 1 < M ? v[q].y : 0x7fffffff), max(i + 2 < M ? v[q].z : 0x7fffffff, i + 3 < M ? v[q].w : 0x7fffffff));
+        mx = wave_max(mx);
+        const int f = __builtin_amdgcn_readlane(fl, 4 * q);
+        if (lane == 0 && b0 + q < nblk) bsum[(size_t)s * nblk + b0 + q] = make_int2(mx, f);
+    }
+}
 struct QssArgs {
     QsView dense; const QsView *sparse;                      // sparse[nS] in device memory
     int wpc64, nS;
@@ -2886,6 +2918,7 @@ struct QssArgs {
     int4 *nm_ev; unsigned *nm_n; unsigned nm_cap;            // the no-match events themselves: {site k, query rank, query jj, x | isSparse << 1}
     int2 *evt;                                               // per slot with reports: {first panel position f, reported start} — what qss_emit_kernel expands
     int q_lo, q_hi;                                          // only the queries q_lo <= jj < q_hi are swept (query sharding across GPUs: pbwtamd_set_query_range)
+    unsigned long long *dbg;                                 // measurement (PBWTAMD_QS_DBG): per query {wall-clock ticks (100 MHz) of its wave, events} accumulated over the batches
 };
 
 // reportAndUpdate (pbwtMatch.c:452-499) for one query at one site against one cursor state, executed by a whole
@@ -2897,15 +2930,29 @@ template <int MODE>
 __device__ __forceinline__ void qss_update(const int *a, const int *d, const unsigned long long *yc, int M, unsigned x, int jj, int k,
                                            int kend, int nS, int isSparse, int &f, int &dq, unsigned long long *cntslot, Rec5 *recs,
                                            unsigned long long &nTot, unsigned long long &totLen, unsigned long long &nomatch,
-                                           int rank, int4 *nm_ev, unsigned *nm_n, unsigned nm_cap, int2 *evt) {
+                                           int rank, int4 *nm_ev, unsigned *nm_n, unsigned nm_cap, int2 *evt, const int2 *bs = nullptr, int nblk = 0) {
     const int lane = lane_id();
 #define PY(i) ((unsigned)((yc[(i) >> 6] >> ((i) & 63)) & 1ULL))
     if (PY(f) == x) return;
+    const int xbit = x ? 2 : 1;
+    // first block >= b0 that may end a downward scan with threshold thr: max d above it, the allele present, or past the panel
+    auto coarse_down = [&](int b0, int thr) -> int {
+        for (int base = b0;; base += 256) {
+            int2 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int b = base + 64 * q + lane; v[q] = (b < nblk) ? bs[b] : make_int2(0x7fffffff, 3); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned long long m = __ballot(v[q].x > thr || (v[q].y & xbit));
+                if (m) return base + 64 * q + __ffsll((long long)m) - 1;
+            }
+        }
+    };
     // downward scan from `from` while d <= thr: the first position that either fails the test (or is M) or carries x
     // (256 positions per trip to memory: the four 64-position sub-steps' loads are issued together, then tested in order — a query
     // whose allele is rare around its match walks thousands of positions here, one dependent round trip per step)
     auto scan_down = [&](int from, int thr, bool &found) -> int {
-        for (int base = from;; base += 256) {
+        for (int base = from;;) {
             int dv[4]; unsigned long long yw[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { const int i = base + 64 * q + lane; dv[q] = (i < M) ? d[i] : 0x7fffffff; yw[q] = (i < M) ? yc[i >> 6] : 0ULL; }
@@ -2917,6 +2964,10 @@ __device__ __forceinline__ void qss_update(const int *a, const int *d, const uns
                 const unsigned long long mb = __ballot(bound), ms = __ballot(same), any = mb | ms;
                 if (any) { const int first = __ffsll((long long)any) - 1; found = (ms >> first) & 1ULL; return base + 64 * q + first; }
             }
+            base += 256;
+            // 256 positions without an end: skip the blocks that cannot hold one (a block flagged for what lies in its part already
+            // scanned costs one more fine trip, never a wrong answer)
+            if (bs) base = max(base, coarse_down(base >> 8, thr) << 8);
         }
     };
     bool found = false;
@@ -2936,7 +2987,8 @@ __device__ __forceinline__ void qss_update(const int *a, const int *d, const uns
         if (dMinus <= dPlus) {
             // while (d[iMinus] <= dMinus) if (y[--iMinus] == x) hit = iMinus;   d[0] = kend+1 stops it; the LOWEST hit counts
             int hit = -1;
-            for (int base4 = iMinus, go = 1; go; base4 -= 256) {
+            int skipLo = 0, skipHi = 0;                      // positions [skipLo, skipHi) were passed in whole blocks, their candidates not looked at yet
+            for (int base4 = iMinus, go = 1; go;) {
                 int dv[4]; unsigned long long yw[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { const int j = base4 - 64 * q - lane; dv[q] = (j >= 0) ? d[j] : 0x7fffffff; yw[q] = (j - 1 >= 0) ? yc[(j - 1) >> 6] : 0ULL; }
@@ -2948,8 +3000,71 @@ __device__ __forceinline__ void qss_update(const int *a, const int *d, const uns
                     const int nlive = mstop ? __ffsll((long long)mstop) - 1 : 64;     // lanes 0..nlive-1 passed the test: candidates j-1
                     const bool cand = (lane < nlive) && (j - 1 >= 0) && (unsigned)((yw[q] >> ((j - 1) & 63)) & 1ULL) == x;
                     const unsigned long long mc = __ballot(cand);
-                    if (mc) hit = base - (63 - __clzll(mc)) - 1;                       // highest lane = lowest index
+                    if (mc) { hit = base - (63 - __clzll(mc)) - 1; skipHi = skipLo = 0; }   // highest lane = lowest index; lower than anything skipped before
                     if (mstop) { iMinus = base - nlive; go = 0; }
+                }
+                if (!go) break;
+                base4 -= 256;                                // 256 positions passed, the next one to test is base4
+                if (bs && base4 > 0) {
+                    // blocks in which every d <= dMinus are passed without a stop.  Going down from the block that holds base4 (its part above
+                    // base4 was passed or lies above the walk's start: at worst it makes the block look like a stop and nothing is skipped), the first
+                    // block with a larger d — block 0 has one, the sentinel d[0] — is where the fine walk goes on, at its last position
+                    const int bt = base4 >> 8;
+                    int bstop = -1;
+                    for (int bb = bt; bstop < 0; bb -= 256) {
+                        int mxv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { const int b = bb - 64 * q - lane; mxv[q] = (b >= 0) ? bs[b].x : 0x7fffffff; }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (bstop >= 0) continue;
+                            const unsigned long long m = __ballot(mxv[q] > dMinus);
+                            if (m) bstop = bb - 64 * q - (__ffsll((long long)m) - 1);
+                        }
+                    }
+                    if (bstop < 0) bstop = 0;
+                    const int nb4 = (bstop + 1) * 256 - 1;   // last position of the stopping block
+                    if (nb4 < base4) {
+                        // every j in nb4+1 .. base4 passes; their candidates j - 1 are the positions [nb4, base4 - 1].  A candidate lower than all of
+                        // them may still turn up further down: remember the range, look into it only if that does not happen
+                        if (skipHi == skipLo) skipHi = base4;
+                        skipLo = nb4;
+                        base4 = nb4;
+                    }
+                }
+            }
+            if (skipHi > skipLo && (hit < 0 || hit >= skipHi)) {
+                // the lowest position in [skipLo, skipHi) carrying x, if any (the skipped stretch lies below every earlier hit)
+                int p = skipLo;
+                while (p < skipHi) {
+                    unsigned long long yw[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const int i = p + 64 * q + lane; yw[q] = (i < skipHi) ? yc[i >> 6] : 0ULL; }
+                    int got = -1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (got >= 0) continue;
+                        const int i = p + 64 * q + lane;
+                        const unsigned long long m = __ballot(i < skipHi && (unsigned)((yw[q] >> (i & 63)) & 1ULL) == x);
+                        if (m) got = p + 64 * q + __ffsll((long long)m) - 1;
+                    }
+                    if (got >= 0) { hit = got; break; }
+                    p += 256;
+                    if (p < skipHi) {                        // blocks without the allele: skip them
+                        int b0 = p >> 8, bfound = -1;
+                        for (int bb = b0; bfound < 0; bb += 256) {
+                            int fl[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { const int b = bb + 64 * q + lane; fl[q] = (b < nblk && (b << 8) < skipHi) ? bs[b].y : 3; }
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if (bfound >= 0) continue;
+                                const unsigned long long m = __ballot((fl[q] & xbit) != 0);
+                                if (m) bfound = bb + 64 * q + __ffsll((long long)m) - 1;
+                            }
+                        }
+                        p = max(p, bfound << 8);
+                    }
                 }
             }
             if (hit >= 0) { f = hit; dq = dMinus; return; }
@@ -2985,6 +3100,7 @@ __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
     const int M = g.Mp, nS = g.nS;
     int f = g.f_in[jj], dq = g.dq_in[jj];
     unsigned long long nTot = 0, totLen = 0, nomatch = 0;
+    const unsigned long long t_in = g.dbg ? wall_clock64() : 0ULL; unsigned nev = 0;
     // the sparse (f, d) pairs live in global memory (nS is a run-time value): working copy in the out arrays
     if (MODE == 0 && lane == 0) for (int kk = 0; kk < nS; ++kk) { g.fs_out[(size_t)kk * g.Mq + jj] = g.fs_in[(size_t)kk * g.Mq + jj]; g.ds_out[(size_t)kk * g.Mq + jj] = g.ds_in[(size_t)kk * g.Mq + jj]; }
     int fsl = 0, dsl = 0;
@@ -3012,7 +3128,9 @@ __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
                 f = x ? c0 + f - uf : uf;
                 if (f == M) f = 0;
             } else {
-                qss_update<MODE>(a, d, yc, M, x, jj, k, k, nS, 0, f, dq, g.cnt + slot, g.recs, nTot, totLen, nomatch, qrank, g.nm_ev, g.nm_n, g.nm_cap, g.evt ? g.evt + slot : nullptr);
+                ++nev;
+                qss_update<MODE>(a, d, yc, M, x, jj, k, k, nS, 0, f, dq, g.cnt + slot, g.recs, nTot, totLen, nomatch, qrank, g.nm_ev, g.nm_n, g.nm_cap, g.evt ? g.evt + slot : nullptr,
+                                 g.dense.bsum ? g.dense.bsum + (size_t)s * g.dense.nblk : nullptr, g.dense.nblk);
                 f = qss_lfmap(yc, rd, g.wpc64, M, x, f);
             }
         }
@@ -3027,7 +3145,8 @@ __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
             if (MODE == 0) { fsl = g.fs_out[ix]; dsl = g.ds_out[ix]; }
             else if (s < nS) { fsl = g.fs_in[ix]; dsl = g.ds_in[ix]; }
             else { fsl = g.fs_out[sx]; dsl = g.ds_out[sx]; }
-            qss_update<MODE>(a, d, yc, M, x, jj, k, k / nS, nS, 1, fsl, dsl, g.cnt + slot + 1, g.recs, nTot, totLen, nomatch, qrank, g.nm_ev, g.nm_n, g.nm_cap, g.evt ? g.evt + slot + 1 : nullptr);
+            qss_update<MODE>(a, d, yc, M, x, jj, k, k / nS, nS, 1, fsl, dsl, g.cnt + slot + 1, g.recs, nTot, totLen, nomatch, qrank, g.nm_ev, g.nm_n, g.nm_cap, g.evt ? g.evt + slot + 1 : nullptr,
+                             v.bsum ? v.bsum + (size_t)t * v.nblk : nullptr, v.nblk);
             fsl = qss_lfmap(yc, v.rankdir + (size_t)t * (g.wpc64 + 1), g.wpc64, M, x, fsl);
             if (lane == 0) {
                 if (MODE == 0) { g.fs_out[ix] = fsl; g.ds_out[ix] = dsl; }
@@ -3041,6 +3160,12 @@ __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
         g.f_out[jj] = f; g.dq_out[jj] = dq;
         if (nTot) { atomicAdd(g.tot, nTot); atomicAdd(g.tot + 1, totLen); }
         if (nomatch) atomicAdd(g.tot + 2, nomatch);
+        if (g.dbg) {
+            const unsigned long long dt = wall_clock64() - t_in;
+            g.dbg[2 * (size_t)jj] += dt; g.dbg[2 * (size_t)jj + 1] += nev;
+            atomicMax(g.dbg + 2 * (size_t)g.Mq + (size_t)(g.kbase / max(g.nsites, 1)) % 64, dt);           // slowest wave of the batch
+            atomicMax(g.dbg + 2 * (size_t)g.Mq + 64 + (size_t)(g.kbase / max(g.nsites, 1)) % 64, (unsigned long long)nev);
+        }
     }
 }
 

@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 from conftest import GOLDEN, golden_panels, parse_pbwt
 
 pytestmark = pytest.mark.gpu
@@ -439,6 +441,44 @@ def test_match_sweep_sparse_vs_oracle(amd, orc, Mp, Mq, N, kind, nS, batch):
         seen = []
         eng.match_sweep_sparse(pz, N, qz, Mq, nS, callback=lambda a, b, s, e, sp: seen.append((a, b, s, e, sp)))
         assert seen == [tuple(r) for r in want.tolist()]
+
+
+@pytest.mark.parametrize("Mp,Mq,N,rare,nS,batch", [(6000, 40, 160, 0.004, 0, 64), (20000, 64, 96, 0.0007, 0, 32), (9000, 30, 120, 0.002, 3, 64),
+                                                    (70000, 48, 64, 0.0002, 0, 64), (5000, 32, 100, 0.5, 2, 32)])
+def test_match_sweep_long_walks_block_skipping(amd, orc, Mp, Mq, N, rare, nS, batch, monkeypatch):
+    """reportAndUpdate's walks (pbwtMatch.c:452-499) over thousands of positions: a panel in which one allele is rare (some sites
+    carry none of it: the no-match branch), queries that carry it often.  The walks then skip whole blocks of 256 positions
+    through the {max d, alleles present} summaries (qs_blocksum_kernel) — forwards for the scan for an equally long match,
+    backwards for the widening, forwards again for the lowest candidate of a skipped stretch; records, no-match events and
+    totals are the oracle's, and identical with the summaries switched off."""
+    rng = np.random.default_rng(Mp + N)
+    hap = np.zeros((N, Mp + Mq), np.uint8)
+    p_site = np.where(rng.random(N) < 0.15, 0.0, rare)                                  # 15 % of the sites: nobody in the panel carries a 1
+    hap[:, :Mp] = rng.random((N, Mp)) < p_site[:, None]
+    flip = rng.random(N) < 0.3
+    hap[flip, :Mp] ^= 1                                                                   # ... or the rare allele is the 0
+    hap[:, Mp:] = rng.random((N, Mq)) < 0.5
+    pz = orc.build_bitcols(orc.pack_bitcols(hap[:, :Mp]), Mp, with_d=False)["yz"]
+    qz = orc.build_bitcols(orc.pack_bitcols(hap[:, Mp:]), Mq, with_d=False)["yz"]
+    want, nomatch, tot = orc.match_sweep_sparse(pz, Mp, qz, Mq, N, nS)
+    eng = amd.Engine(Mp, batch_sites=batch)
+    got, gn, gt = eng.match_sweep_sparse(pz, N, qz, Mq, nS)
+    assert gn == nomatch and tuple(gt) == tuple(tot)
+    assert len(got) == len(want)
+    for f in ("ai", "bi", "start", "end", "sparse"):
+        assert np.array_equal(got[f], want[f]), f
+    if rare < 0.5:
+        assert nomatch > 0
+    ev = eng.nomatch_events()
+    import subprocess, sys, tempfile                                                      # the switch is read once per process: a fresh interpreter for the A/B run
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), pz=pz, qz=qz)
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); import pbwt_amd as amd; z = np.load(%r); e = amd.Engine(%d, batch_sites=%d); "
+                "r, n, t = e.match_sweep_sparse(z['pz'], %d, z['qz'], %d, %d); np.savez(%r, r=r, n=n, t=np.array(t), ev=e.nomatch_events())"
+                % (ROOT_DIR, os.path.join(td, "in.npz"), Mp, batch, N, Mq, nS, os.path.join(td, "out.npz")))
+        subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, PBWTAMD_QS_BLOCKS="0"), timeout=600)
+        o = np.load(os.path.join(td, "out.npz"))
+        assert np.array_equal(o["r"], got) and int(o["n"]) == gn and np.array_equal(o["ev"], ev)
 
 
 def test_match_sweep_sparse_golden_and_no_match_branch(amd, orc):
