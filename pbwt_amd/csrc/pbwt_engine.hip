@@ -69,14 +69,36 @@ static hipError_t dev_alloc(void **out, size_t n) {
     std::lock_guard<std::mutex> lk(g_guard_mu); g_guard[*out] = g;
     return hipSuccess;
 }
+// stream-ordered host-to-device copy.  hipMemcpy from pageable host memory INTO memory mapped through the virtual-memory API (guard
+// mode) loses data on this image (tools/vmm_h2d_repro.hip: no pbwt code; every other 3 MB copy never arrives, whether or not the host waits
+// for it; kernels and device-to-host copies on the same memory are fine) — so in guard mode the bytes travel through a hipMalloc bounce
+// buffer and a copy kernel.  A debugging mode: the extra allocation and synchronisation do not matter there.
+__global__ void guard_copy_kernel(unsigned char *dst, const unsigned char *src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+static hipError_t h2d_async(void *dst, const void *src, size_t n, hipStream_t st) {
+    if (!guard_mode() || !n) return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st);
+    void *bounce = nullptr;
+    hipError_t r = hipMalloc(&bounce, n); if (r != hipSuccess) return r;
+    r = hipMemcpyAsync(bounce, src, n, hipMemcpyHostToDevice, st);
+    if (r == hipSuccess) { hipLaunchKernelGGL(guard_copy_kernel, dim3(256), dim3(256), 0, st, (unsigned char *)dst, (const unsigned char *)bounce, n); r = hipGetLastError(); }
+    const hipError_t r2 = hipStreamSynchronize(st);
+    (void)hipFree(bounce);
+    return r != hipSuccess ? r : r2;
+}
 static hipError_t dev_free(void *p) {
     if (!p) return hipSuccess;
     if (!guard_mode()) return hipFree(p);
     GuardRec g;
     { std::lock_guard<std::mutex> lk(g_guard_mu); auto it = g_guard.find(p); if (it == g_guard.end()) return hipFree(p); g = it->second; g_guard.erase(it); }
     (void)hipDeviceSynchronize();
+    // The physical memory goes back; the ADDRESS RANGE stays reserved for the life of the process.  Measured on this image: with
+    // hipMemAddressFree here, a later reservation can get the same addresses back and kernels then read stale data through the new
+    // mapping (tests/test_gpu_parity.py read-side cases under PBWTAMD_GUARD=1: 6-9 of 13 wrong, a different set every run; 13 of 13 right,
+    // run after run, once no guarded range is ever reused).  A debugging mode: 2^47 bytes of address space outlast any test run, and a
+    // dangling pointer into a freed buffer now faults instead of hitting a recycled one.
     (void)hipMemUnmap(g.mapAt, g.mapped); (void)hipMemRelease(g.h);
-    return hipMemAddressFree(g.va, g.reserved);
+    return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------ engine
@@ -468,7 +490,7 @@ extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k
     e->k0 = k0; e->k_cur = k0; e->n_total = n_total; e->prepared = false; e->pass_open = true;
     e->ring = 0; e->consRecorded[0] = e->consRecorded[1] = false; e->chainRecorded[0] = e->chainRecorded[1] = false; e->roundsRecorded[0] = e->roundsRecorded[1] = false;
     e->keys_ready[0] = e->keys_ready[1] = false;
-    if (aInit) HIPCHK(hipMemcpyAsync(e->A, aInit, sizeof(int) * (size_t)e->M, hipMemcpyHostToDevice, e->stream));
+    if (aInit) HIPCHK(h2d_async(e->A, aInit, sizeof(int) * (size_t)e->M, e->stream));
     const int nb = (e->Mpad + 1 + 255) / 256;
     hipLaunchKernelGGL(init_state_kernel, dim3(nb), dim3(256), 0, e->stream, e->A, e->D, e->M, e->Mpad, k0, aInit ? 0 : 1);
     HIPCHK(hipGetLastError());
@@ -1114,7 +1136,7 @@ extern "C" int pbwtamd_pass_set_d(pbwtamd_engine *e, const int32_t *d) {
     HIPCHK(hipSetDevice(e->device));
     if (!e->pass_open || e->k_cur != e->k0) return fail("pbwtamd_pass_set_d: only right after pbwtamd_pass_begin");
     if (d[0] != e->k0 + 1 || d[e->M] != e->k0 + 1) return fail("pbwtamd_pass_set_d: d[0] and d[M] must be the sentinels k0+1 = %d", e->k0 + 1);
-    HIPCHK(hipMemcpyAsync(ringD(e, e->ring), d, sizeof(int) * ((size_t)e->M + 1), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(h2d_async(ringD(e, e->ring), d, sizeof(int) * ((size_t)e->M + 1), e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return 0;
 }
@@ -1239,7 +1261,7 @@ extern "C" int pbwtamd_build(pbwtamd_engine *e, const uint32_t *bitcols, int wpc
         // this half was read by the chain two batches ago (same ring): wait for that chain, not for the one in flight
         if (e->chainRecorded[e->ring]) HIPCHK(hipEventSynchronize(e->evChain[e->ring]));
         if (wpc == e->wpc)
-            HIPCHK(hipMemcpyAsync(stage, bitcols + (size_t)done * wpc, (size_t)navail * wpc * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+            HIPCHK(h2d_async(stage, bitcols + (size_t)done * wpc, (size_t)navail * wpc * sizeof(uint32_t), e->stream));
         else {
             HIPCHK(hipMemsetAsync(stage, 0, (size_t)navail * e->wpc * sizeof(uint32_t), e->stream));
             HIPCHK(hipMemcpy2DAsync(stage, (size_t)e->wpc * 4, bitcols + (size_t)done * wpc, (size_t)wpc * 4,
@@ -1264,7 +1286,7 @@ struct Packed {
 static int packed_upload(pbwtamd_engine *e, hipStream_t st, int M, const uint8_t *yz, int64_t nz, int N, Packed &pk) {
     if (nz <= 0 && N > 0) return fail("pbwtamd: empty packed panel for N=%d", N);
     HIPCHK(dev_alloc((void **)&pk.z, (size_t)std::max<int64_t>(nz, 1)));
-    HIPCHK(hipMemcpyAsync(pk.z, yz, (size_t)nz, hipMemcpyHostToDevice, st));
+    HIPCHK(h2d_async(pk.z, yz, (size_t)nz, st));
     const size_t nblk = ((size_t)nz + DEC_CHUNK - 1) / DEC_CHUNK;
     HIPCHK(dev_alloc((void **)&pk.blockSum, (nblk + 1) * sizeof(unsigned long long)));
     HIPCHK(dev_alloc((void **)&pk.colStart, ((size_t)N + 2) * sizeof(long long)));
@@ -1278,7 +1300,7 @@ static int packed_upload(pbwtamd_engine *e, hipStream_t st, int M, const uint8_t
     unsigned long long total = 0;
     if (nblk) HIPCHK(hipMemcpyAsync(&total, pk.blockSum + nblk, sizeof total, hipMemcpyDeviceToHost, st));
     const long long end = nz;
-    HIPCHK(hipMemcpyAsync(pk.colStart + N, &end, sizeof end, hipMemcpyHostToDevice, st));
+    HIPCHK(h2d_async(pk.colStart + N, &end, sizeof end, st));
     HIPCHK(hipStreamSynchronize(st));
     if (total != (unsigned long long)M * (unsigned long long)N)
         return fail("pbwtamd: packed panel decodes to %llu alleles, expected M*N = %llu", total, (unsigned long long)M * (unsigned long long)N);
@@ -1520,8 +1542,8 @@ extern "C" int pbwtamd_regather(pbwtamd_engine *e, const uint8_t *yz, int64_t nz
     CHK(bufs.alloc(&cols_out, (size_t)std::max(n_out, 1) * wpc64_out + 2 * (size_t)wpc64_out));
     CHK(bufs.alloc(&d_inv, (size_t)N + 1));
     CHK(bufs.alloc(&dout, (size_t)e->B * M));
-    HIPCHK(hipMemcpyAsync(d_inv, inv.data(), sizeof(int) * ((size_t)N + 1), hipMemcpyHostToDevice, e->stream));
-    if (hap_select) { CHK(bufs.alloc(&d_sel, (size_t)M_out)); HIPCHK(hipMemcpyAsync(d_sel, hap_select, sizeof(int) * (size_t)M_out, hipMemcpyHostToDevice, e->stream)); }
+    HIPCHK(h2d_async(d_inv, inv.data(), sizeof(int) * ((size_t)N + 1), e->stream));
+    if (hap_select) { CHK(bufs.alloc(&d_sel, (size_t)M_out)); HIPCHK(h2d_async(d_sel, hap_select, sizeof(int) * (size_t)M_out, e->stream)); }
     HIPCHK(hipMemsetAsync(cols_out, 0, ((size_t)std::max(n_out, 1) * wpc64_out + 2 * (size_t)wpc64_out) * sizeof(unsigned long long), e->stream));
     CHK(packed_upload(e, e->stream, M, yz, nz, N, pk));
     // ---- phase A: forward sweep (A only), alleles of each batch back in original order, gathered into the new columns
@@ -1611,7 +1633,7 @@ extern "C" int pbwtamd_pack3(pbwtamd_engine *e, const uint32_t *sorted_bitcols, 
     unsigned long long *off = nullptr;
     for (int done = 0; done < N; done += e->B) {
         const int nb = std::min(e->B, N - done);
-        HIPCHK(hipMemcpyAsync(e->ycols, sorted_bitcols + (size_t)done * wpc, (size_t)nb * wpc * 4, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(h2d_async(e->ycols, sorted_bitcols + (size_t)done * wpc, (size_t)nb * wpc * 4, e->stream));
         launch_p3r_sizes(e->stream, nb, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->p3regs, e->colBytes);
         hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, e->stream, e->colBytes, (size_t)nb, e->scal + 2, 0ULL);
         HIPCHK(hipGetLastError());
@@ -1943,7 +1965,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
             HIPCHK(hipMemcpyAsync(a0S[kk], As, sizeof(int) * (size_t)Mp, hipMemcpyDeviceToDevice, st));
             hviews[kk] = QsView{As, Ds, s->strideA, s->strideD, ycS[kk], rdS[kk], done / nS, a0S[kk], bsumS[kk], nblk};
         }
-        if (nS) HIPCHK(hipMemcpyAsync(dviews, hviews.data(), sizeof(QsView) * (size_t)nS, hipMemcpyHostToDevice, st));
+        if (nS) HIPCHK(h2d_async(dviews, hviews.data(), sizeof(QsView) * (size_t)nS, st));
         HIPCHK(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * 2 * (size_t)nb * Mq, st));
         QssArgs g;
         HIPCHK(hipMemcpyAsync(a0P, A, sizeof(int) * (size_t)Mp, hipMemcpyDeviceToDevice, st));

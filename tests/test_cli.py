@@ -44,6 +44,78 @@ def test_older_pbwt_versions_are_read(cli, tmp_path):
     assert open(tmp_path / "v3.pbwt", "rb").read() == open(os.path.join(GOLDEN, "merge1.pbwt"), "rb").read()
 
 
+def _headerless(tag, M, N, yz):
+    """PBWT / GBWT files: no index arrays, a 4-byte byte count (pbwtIO.c:182-208)"""
+    return tag + np.array([M, N], "<i4").tobytes() + np.array([len(yz)], "<i4").tobytes() + yz.tobytes()
+
+
+def test_earliest_pbwt_versions_lack_the_end_index(cli, tmp_path):
+    """`PBWT` and `GBWT` headers store neither aFstart nor aFend: the reader sets aFstart = identity and leaves aFend empty
+    (pbwtIO.c:198-201), so -write refuses the panel exactly like the reference's pbwtWrite (pbwtIO.c:36)"""
+    M, N, aFstart, aFend, yz = parse_pbwt(os.path.join(GOLDEN, "merge1.pbwt"))
+    for tag in (b"PBWT", b"GBWT"):
+        f = tmp_path / (tag.decode() + ".pbwt")
+        f.write_bytes(_headerless(tag, M, N, yz))
+        r = run(cli, "-read", f, "-write", tmp_path / "out.pbwt", check=False)
+        assert r.returncode != 0 and "pbwtWrite called without start and end indexes" in r.stderr
+        assert ("read pbwt %s file with %d bytes: M, N are %d, %d" % (tag.decode(), len(yz), M, N)) in r.stderr
+
+
+@pytest.mark.gpu
+def test_earliest_pbwt_versions_sweep_like_v3(cli, tmp_path):
+    """the same panels through the device: -haps and -maxWithin of a `PBWT` / `GBWT` file equal those of the PBW3 file (merge1's start
+    order is the identity the old formats imply) — the reference's own test vector test/merge.1.out among them"""
+    M, N, aFstart, aFend, yz = parse_pbwt(os.path.join(GOLDEN, "merge1.pbwt"))
+    assert np.array_equal(aFstart, np.arange(M))
+    for tag in (b"PBWT", b"GBWT"):
+        f = tmp_path / (tag.decode() + ".pbwt")
+        f.write_bytes(_headerless(tag, M, N, yz))
+        run(cli, "-read", f, "-haps", tmp_path / "h.txt")
+        assert open(tmp_path / "h.txt").read() == open(os.path.join(GOLDEN, "merge1.haps")).read()
+        r = run(cli, "-read", f, "-maxWithin")
+        assert r.stdout == open(os.path.join(GOLDEN, "merge1.maxwithin.txt")).read()
+
+
+def _macs_text(bits, M, N):
+    """a MaCS output file (pbwtIO.c:426-458 grammar) for the panel `bits` (N bit columns)"""
+    hap = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, :M]
+    rows = (hap + ord("0")).astype(np.uint8)
+    out = ["COMMAND:\tmacs %d 1e6 -t 0.001 -r 0.001" % M, "SEED:\t1"]
+    body = [b"SITE:\t%d\t%.10f\t0.1\t" % (k, (k + 0.5) / N) + rows[k].tobytes() for k in range(N)]
+    return ("\n".join(out) + "\n").encode() + b"\n".join(body) + b"\n"
+
+
+@pytest.mark.gpu
+def test_config0_full_size_readMacs_write_maxWithin(cli, orc, tmp_path):
+    """BASELINE configs[0] at its own size: a 2 000-haplotype x 20 000-site MaCS text file through `-readMacs -write -maxWithin`
+    (pbwtIO.c:460-492 + pbwtMatch.c:115-142 on the device).  The .pbwt bytes equal the oracle's (and, where its library travelled
+    with the repo, the reference's own pbwtReadMacs + pbwtWrite); the 3.9 M MATCH lines equal the oracle's report stream."""
+    import hashlib
+    M, N = 2000, 20000
+    bits = orc.synth_bitcols(M, N, seed=20, kind=0)
+    macs = tmp_path / "c0.macs"
+    macs.write_bytes(_macs_text(bits, M, N))
+    out = tmp_path / "c0.pbwt"
+    r = subprocess.run([cli, "-readMacs", str(macs), "-write", str(out), "-maxWithin"], capture_output=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    o = orc.build_bitcols(bits, M, with_d=False)
+    _M, _N, a0, a1, yz = parse_pbwt(out)
+    assert (_M, _N) == (M, N) and np.array_equal(yz, o["yz"]) and np.array_equal(a1, o["aFend"]) and np.array_equal(a0, np.arange(M))
+    if orc.ref() is not None:                                  # the reference itself on the same text
+        import ctypes as C
+        rp, rs = tmp_path / "ref.pbwt", tmp_path / "ref.sites"
+        assert orc.ref().ref_macs_to_pbwt(str(macs).encode(), str(rp).encode(), str(rs).encode()) == 0
+        assert open(rp, "rb").read() == open(out, "rb").read()
+    recs = orc.max_within(o["yz"], M, N)
+    keep = recs[recs["start"] != recs["end"]]                   # reportMatch drops zero-length matches (pbwtMatch.c:48)
+    want = hashlib.sha256()
+    for lo in range(0, len(keep), 200000):
+        part = keep[lo: lo + 200000]
+        want.update("".join("MATCH\t%d\t%d\t%d\t%d\t%d\n" % (m[0], m[1], m[2], m[3], m[3] - m[2]) for m in part.tolist()).encode())
+    assert r.stdout.count(b"\n") == len(keep) and len(keep) > 1000000
+    assert hashlib.sha256(r.stdout).hexdigest() == want.hexdigest()
+
+
 def test_errors_die_like_the_reference(cli, tmp_path):
     r = run(cli, "-write", tmp_path / "x", check=False)
     assert r.returncode != 0 and r.stderr.startswith("FATAL ERROR: ")
