@@ -277,7 +277,9 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     if (const char *s = getenv("PBWTAMD_PAIR1024")) e->pair1024 = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_SKEL")) e->skel = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_SKN")) e->skn = atoi(s) != 0;
-    if (M > (1 << 21)) e->skel = false;                    // skeleton: <= 2048 tiles of 1024 positions (one lane / one workgroup slot per 32 tiles in the tile scans)
+    // skeleton at every width the engine takes: up to 4096 tiles of 1024 positions (above 2048 tiles the two-level tile scan gives each of its
+    // <= 64 co-resident workgroups 64 tiles instead of 32); PBWTAMD_SKEL_MAXM=<M> (A/B runs): the two-site chain above that width, as before round 3
+    if (const char *sm = getenv("PBWTAMD_SKEL_MAXM")) { if (M > atoi(sm)) e->skel = false; }
     int prLow = 0, prHigh = 0;
     (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);  // numerically: low >= high
     if (const char *s = getenv("PBWTAMD_NO_PRIO")) { if (atoi(s)) prLow = prHigh = 0; }
@@ -851,11 +853,12 @@ static bool launch_skel_hist_scan(pbwtamd_engine *e, hipStream_t st, const SkArg
     }
     hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, st, g);
     static const bool k2_wide = !(getenv("PBWTAMD_K2_WIDE") && !atoi(getenv("PBWTAMD_K2_WIDE")));
-    if (W > 512 && W <= 64 * 32 && k2_wide) {              // two-level scan in one launch: <= 64 co-resident workgroups of 32 tiles
+    if ((W > 512 && k2_wide) || W > 2048) {                // two-level scan in one launch: <= 64 co-resident workgroups of 32 (64) tiles
         Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = W; kw.agg = agg; kw.counter = cnt; kw.err = e->ctl + 2;
-        const int nwg = (W + 31) / 32;
+        const int tpw = W > 2048 ? 64 : 32, nwg = (W + tpw - 1) / tpw;
         *epoch += (unsigned)nwg; kw.target = *epoch;
-        hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, st, kw);
+        if (tpw == 64) hipLaunchKernelGGL((skel_k2_wide_kernel<64>), dim3(nwg), dim3(SKK), 0, st, kw);
+        else hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, st, kw);
         return true;
     }
     Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = W;
@@ -880,7 +883,7 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch, int
         return;
     }
     static const bool k2_wide_on = !(getenv("PBWTAMD_K2_WIDE") && !atoi(getenv("PBWTAMD_K2_WIDE")));
-    bool wide = e->prow || (W > 512 && W <= 64 * 32 && k2_wide_on);
+    bool wide = e->prow || (W > 512 && k2_wide_on) || W > 2048;
     if (part != 2) wide = launch_skel_hist_scan<EPT>(e, e->stream, g, e->k2agg, e->k2cnt, &e->k2epoch);
     if (part == 1) return;
     static const bool rank_r4 = !(getenv("PBWTAMD_RANK_R4") && !atoi(getenv("PBWTAMD_RANK_R4")));
