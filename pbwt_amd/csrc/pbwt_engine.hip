@@ -35,6 +35,17 @@ static int fail(const char *fmt, ...) {
 #define CHK(expr) do { int _r = (expr); if (_r) return _r; } while (0)
 
 
+// Environment switches.  The shipped library reads only those that select between bit-exact code paths the test-suite compares
+// (PBWTAMD_SKEL, _SKEL_READ, _SKN, _SKN_MAXW, _PAIR1024, _NO_PACKED_FILL, _QS_BLOCKS, _THR_ROUNDS), the debugging aids (_GUARD, _POISON,
+// _PROFILE, _TRACE_QS, _SHARD_TRACE) and PBWTAMD_LIB (Python binding).  Every tuning / probe switch (tile sizes, CU masks, stream
+// priorities, occupancy pads, alternative kernels, the query sweep's pipeline knobs ...) goes through tune_env() and exists only in a
+// measurement build (PBWTAMD_MEASURE_BUILD=1 -> -DPBWTAMD_MEASURE): DESIGN.md section 10 lists them.
+#ifdef PBWTAMD_MEASURE
+static inline const char *tune_env(const char *name) { return getenv(name); }
+#else
+static inline const char *tune_env(const char *) { return nullptr; }
+#endif
+
 // ------------------------------------------------------------------------------------ device memory
 // PBWTAMD_GUARD=1 (debugging): every device buffer is mapped through the virtual-memory API so that it ENDS (to within its 256-byte
 // alignment) at the end of its mapping with an unmapped granule behind it (=2: STARTS at the mapping's first byte, an unmapped
@@ -122,7 +133,7 @@ struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned o
 // skeleton batches whose consumers need (d, y) of every site but not the haplotype ids (histogram sweep, pack3 through the
 // sweep's bit columns): the fill writes d | y << 31 and no a — half the consumer stream's bytes (they are what slows the chain)
 static inline bool packed_fill(const Pending &p) {
-    static const bool off = getenv("PBWTAMD_NO_PACKED_FILL") != nullptr, no_fuse = getenv("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
+    static const bool off = getenv("PBWTAMD_NO_PACKED_FILL") != nullptr, no_fuse = tune_env("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
     const unsigned ids = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_LONG_RECS | 0x100u /* OPT_INTERNAL_KEEP_STATES */;
     return !off && !no_fuse && p.skel && (p.opts & PBWTAMD_OPT_WITHIN_HIST) && !(p.opts & ids);
 }
@@ -260,8 +271,8 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     e->E = 1;
     if (M > 262144) e->E = 4;                              // T = 1024 (two-site launches use 1024-thread workgroups)
     while (e->E < 16 && (M + BLOCK * e->E - 1) / (BLOCK * e->E) > 1024) e->E *= 2;
-    if (const char *s = getenv("PBWTAMD_E")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->E = v; }
-    if (const char *s = getenv("PBWTAMD_T")) { int v = atoi(s); if (v == 256 || v == 1024 || v == 2048 || v == 4096) e->E = v / BLOCK; }
+    if (const char *s = tune_env("PBWTAMD_E")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) e->E = v; }
+    if (const char *s = tune_env("PBWTAMD_T")) { int v = atoi(s); if (v == 256 || v == 1024 || v == 2048 || v == 4096) e->E = v / BLOCK; }
     e->T = BLOCK * e->E;
     e->W = (M + e->T - 1) / e->T;
     if (e->W > 1024) { delete e; return fail("pbwtamd: M=%d too large for this build (max %d)", M, 1024 * 4096); }   // nothing allocated yet
@@ -271,18 +282,18 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     e->wpc64 = e->wpc / 2;
     e->B = batch_sites > 0 ? batch_sites : 512;
     if (e->B & 1) ++e->B;                                  // two-site launches: even batches
-    if (const char *s = getenv("PBWTAMD_NO_GRAPH")) e->use_graph = !(atoi(s) != 0);
-    if (const char *s = getenv("PBWTAMD_LEAN")) e->lean = atoi(s) != 0;
-    if (const char *s = getenv("PBWTAMD_PAIR")) e->pair = atoi(s) != 0;
+    if (const char *s = tune_env("PBWTAMD_NO_GRAPH")) e->use_graph = !(atoi(s) != 0);
+    if (const char *s = tune_env("PBWTAMD_LEAN")) e->lean = atoi(s) != 0;
+    if (const char *s = tune_env("PBWTAMD_PAIR")) e->pair = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_PAIR1024")) e->pair1024 = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_SKEL")) e->skel = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_SKN")) e->skn = atoi(s) != 0;
     // skeleton at every width the engine takes: up to 4096 tiles of 1024 positions (above 2048 tiles the two-level tile scan gives each of its
     // <= 64 co-resident workgroups 64 tiles instead of 32); PBWTAMD_SKEL_MAXM=<M> (A/B runs): the two-site chain above that width, as before round 3
-    if (const char *sm = getenv("PBWTAMD_SKEL_MAXM")) { if (M > atoi(sm)) e->skel = false; }
+    if (const char *sm = tune_env("PBWTAMD_SKEL_MAXM")) { if (M > atoi(sm)) e->skel = false; }
     int prLow = 0, prHigh = 0;
     (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);  // numerically: low >= high
-    if (const char *s = getenv("PBWTAMD_NO_PRIO")) { if (atoi(s)) prLow = prHigh = 0; }
+    if (const char *s = tune_env("PBWTAMD_NO_PRIO")) { if (atoi(s)) prLow = prHigh = 0; }
     if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
     else { if (hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prHigh) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); } e->own_stream = true; }
     e->strideA = (size_t)e->Mpad;
@@ -308,7 +319,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         // consumer workgroup leaves on a CU (LDS is allocated contiguously: a 41 KB rank workgroup of 1024 positions starves beside
         // 26 KB fill workgroups).  1 M, T = 512 vs 1024: 6.25 vs 6.84 us/site; 500 k: 3.99 vs 4.32
         e->skEPT = (M <= 56000) ? 1 : 2;                       // 256- against 512-position tiles, end to end: 50 k 1.33 vs 1.37 us/site, 70 k 1.52 vs 1.45
-        if (const char *sv = getenv("PBWTAMD_SKT")) e->skEPT = (atoi(sv) == 256) ? 1 : (atoi(sv) == 512) ? 2 : 4;
+        if (const char *sv = tune_env("PBWTAMD_SKT")) e->skEPT = (atoi(sv) == 256) ? 1 : (atoi(sv) == 512) ? 2 : 4;
 
         if (M > 256 * e->skEPT * 2048) e->skEPT = 4;           // skel_k2_kernel scans at most 2048 tiles per key
         if (const char *sv = getenv("PBWTAMD_SKN_MAXW")) e->skn_maxw = std::min(atoi(sv), SKN_MAXW);
@@ -317,13 +328,13 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         ALLOC(e->xTr[0], (size_t)e->xTblocks * e->strideX * sizeof(uint32_t));
         ALLOC(e->xTr[1], (size_t)e->xTblocks * e->strideX * sizeof(uint32_t));
         if (const char *sv = getenv("PBWTAMD_THR_ROUNDS")) e->thr_rounds = atoi(sv);
-        if (const char *sv = getenv("PBWTAMD_THR_DEPTH")) e->thr_depth = std::max(1, std::min(atoi(sv), 15));
+        if (const char *sv = tune_env("PBWTAMD_THR_DEPTH")) e->thr_depth = std::max(1, std::min(atoi(sv), 15));
         for (int i = 0; i < 16; ++i) ECHK(hipEventCreateWithFlags(&e->tev[i], hipEventDisableTiming));
         {
             const int rounds = e->B / 8 + 1;
             // pair rows (wide panels at 512-position tiles): the scan over the tiles runs on 1024-position pairs — half the rows —
             // and the rank / fill workgroup of an odd tile folds the first tile's row in.  Rows 512 < W2 <= 1024: the wide scan, <= 32 workgroups
-            static const bool pair_rows = !(getenv("PBWTAMD_PAIR_ROWS") && !atoi(getenv("PBWTAMD_PAIR_ROWS")));
+            static const bool pair_rows = !(tune_env("PBWTAMD_PAIR_ROWS") && !atoi(tune_env("PBWTAMD_PAIR_ROWS")));
             e->W2 = (e->Wt + 1) / 2;
             e->prow = pair_rows && e->skEPT == 2 && e->W2 > 512 && e->W2 <= 1024;
             e->strideS = e->prow ? (size_t)SKK * e->W2 * 2 + SKK / 2 : (size_t)SKK * e->Wt + SKK / 2;
@@ -348,7 +359,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         // re-measured with the register-light tile scan (us/site, none / 160 / 192 CUs): 150 k 2.13 / 1.88 / 1.91, 200 k 2.40 / 2.11 / 2.15,
         // 250 k 2.69 / 2.35 / 2.40, 300 k 2.99 / 2.97 / 2.97, 400 k 3.43 / 3.39 / 3.35, 500 k 3.83 / . / 3.78, 700 k 4.66 / . / 4.66, 1 M 5.84 / . / 6.56
         int ncus = (ncu_dev < 64 || ncu_dev > 256) ? 0 : (M <= 270000) ? ncu_dev * 5 / 8 : (M <= 600000) ? ncu_dev * 3 / 4 : 0;
-        if (const char *s = getenv("PBWTAMD_S2_CUS")) ncus = atoi(s);
+        if (const char *s = tune_env("PBWTAMD_S2_CUS")) ncus = atoi(s);
         if (ncus > 0) {
             uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int i = 0; i < std::min(ncus, 256); ++i) mask[i / 32] |= 1u << (i % 32);
@@ -533,17 +544,17 @@ static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int
     g.A = A; g.D = D; g.strideA = e->strideA; g.strideD = e->strideD;
     g.M = e->M; g.kbase = kbase; g.final_site = final_site;
     g.blockCount = nullptr; g.recs = nullptr; g.hist = e->hist; g.histlen = e->histlen; g.err = e->ctl + 2;
-    static const bool no_fuse = getenv("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
+    static const bool no_fuse = tune_env("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
     g.ycols = (!no_fuse && final_site < 0 && (opts & PBWTAMD_OPT_PACK3) && (opts & PBWTAMD_OPT_WITHIN_HIST)) ? e->ycols : nullptr; g.wpc64 = e->wpc64;
 #ifdef PBWTAMD_MEASURE
     static const int sweep_dbg = getenv("PBWTAMD_DEBUG_SWEEP") ? atoi(getenv("PBWTAMD_DEBUG_SWEEP")) : 0; g.dbg = sweep_dbg;
 #endif
     const int tiles = (e->M + BLOCK - 1) / BLOCK;
     dim3 grid(tiles, nsites);
-    static const int sweep_it = getenv("PBWTAMD_SWEEP_ITERS") ? atoi(getenv("PBWTAMD_SWEEP_ITERS")) : 0;
+    static const int sweep_it = tune_env("PBWTAMD_SWEEP_ITERS") ? atoi(tune_env("PBWTAMD_SWEEP_ITERS")) : 0;
     g.nvb = tiles;
     const int iters = sweep_it > 0 ? sweep_it : (tiles >= 64 ? 4 : 1);
-    static const bool old_sweep = getenv("PBWTAMD_OLD_SWEEP") != nullptr;   // the walking form of the histogram sweep (A/B runs)
+    static const bool old_sweep = tune_env("PBWTAMD_OLD_SWEEP") != nullptr;   // the walking form of the histogram sweep (A/B runs)
     if ((opts & PBWTAMD_OPT_WITHIN_HIST) && !old_sweep) {  // streaming form: a wave per 256 positions
         const int ngroups = (e->M / 256 + 1 + WAVES - 1) / WAVES;    // 1024-position groups (a wave per 256 positions)
         g.hist_rep = e->hist_rep; g.iters = ngroups >= 64 ? 8 : (ngroups >= 8 ? 2 : 1);
@@ -684,8 +695,8 @@ static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites
     dim3 g1(std::min(64, (e->wpc64 + WAVES - 1) / WAVES), nsites);
     if (!have_ycols) hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, st, A, e->strideA, e->M, e->ycols, e->wpc64);   // else: emitted by the maxWithin sweep
     const bool wide = e->wpc64 > 2048;                      // > 131072 haplotypes: 1024 threads per column
-    static const bool old_pack3 = getenv("PBWTAMD_OLD_PACK3") != nullptr;   // the chunk-loop encoder (A/B runs)
-    static const int p3_form = getenv("PBWTAMD_PACK3_FORM") ? atoi(getenv("PBWTAMD_PACK3_FORM")) : 3;   // 3 = region-parallel, 2 = one workgroup per column
+    static const bool old_pack3 = tune_env("PBWTAMD_OLD_PACK3") != nullptr;   // the chunk-loop encoder (A/B runs)
+    static const int p3_form = tune_env("PBWTAMD_PACK3_FORM") ? atoi(tune_env("PBWTAMD_PACK3_FORM")) : 3;   // 3 = region-parallel, 2 = one workgroup per column
     if (!old_pack3 && p3_form == 3) launch_p3r_sizes(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->p3regs, e->colBytes);
     else if (!old_pack3) launch_pack3v2<0>(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
     else if (wide) hipLaunchKernelGGL((pack3_kernel<0, 1024>), dim3(nsites), dim3(1024), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
@@ -757,7 +768,7 @@ static int ensure_prepared(pbwtamd_engine *e, const uint32_t *col, bool sorted, 
 }
 
 // XCD-contiguous tile placement (xcd_tile): bit 0 fill, bit 1 rank, bit 2 hist.  Measured at M = 100 k: 1.600 -> 1.539 us/site.
-static int xcd_flags() { static const int v = getenv("PBWTAMD_XCD") ? atoi(getenv("PBWTAMD_XCD")) : 7; return v; }
+static int xcd_flags() { static const int v = tune_env("PBWTAMD_XCD") ? atoi(tune_env("PBWTAMD_XCD")) : 7; return v; }
 
 // batch consumers (checksums, maxWithin sweep, pack3) of the pending batch, on the second stream so
 // they overlap the next batch's launch chain (which occupies only ~W of the 256 CUs)
@@ -785,7 +796,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns) {
         f.xcd = xcd_flags() & 1;
         f.pair = e->prow ? 1 : 0; f.W2 = e->W2;
         dim3 grid(e->Wt, ns / 8);
-        static const size_t dyn = getenv("PBWTAMD_FILL_PAD_KB") ? (size_t)atoi(getenv("PBWTAMD_FILL_PAD_KB")) * 1024 : 0;   // occupancy probe (results unchanged)
+        static const size_t dyn = tune_env("PBWTAMD_FILL_PAD_KB") ? (size_t)atoi(tune_env("PBWTAMD_FILL_PAD_KB")) * 1024 : 0;   // occupancy probe (results unchanged)
 #define FILL(EP) do { if (packed) hipLaunchKernelGGL((skel_fill_kernel<EP, true>), grid, dim3(BLOCK), dyn, e->s2, f); \
                       else hipLaunchKernelGGL((skel_fill_kernel<EP, false>), grid, dim3(BLOCK), dyn, e->s2, f); } while (0)
         if (e->skEPT == 1) FILL(1); else if (e->skEPT == 2) FILL(2); else FILL(4);
@@ -811,7 +822,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns) {
         if (!e->ystale) HIPCHK(dev_alloc((void **)&e->ystale, sizeof(int) * e->strideA));
         HIPCHK(hipMemcpyAsync(e->ystale, A + (size_t)(ns - 1) * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->s2));
     }
-    static const bool no_fuse = getenv("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
+    static const bool no_fuse = tune_env("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
     if (p.opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, e->s2, A, ns, !no_fuse && (p.opts & PBWTAMD_OPT_WITHIN_HIST) != 0));
     return 0;
 }
@@ -852,7 +863,7 @@ static bool launch_skel_hist_scan(pbwtamd_engine *e, hipStream_t st, const SkArg
         return true;
     }
     hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, st, g);
-    static const bool k2_wide = !(getenv("PBWTAMD_K2_WIDE") && !atoi(getenv("PBWTAMD_K2_WIDE")));
+    static const bool k2_wide = !(tune_env("PBWTAMD_K2_WIDE") && !atoi(tune_env("PBWTAMD_K2_WIDE")));
     if ((W > 512 && k2_wide) || W > 2048) {                // two-level scan in one launch: <= 64 co-resident workgroups of 32 (64) tiles
         Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = W; kw.agg = agg; kw.counter = cnt; kw.err = e->ctl + 2;
         const int tpw = W > 2048 ? 64 : 32, nwg = (W + tpw - 1) / tpw;
@@ -882,11 +893,11 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch, int
         else hipLaunchKernelGGL((skel_rank_kernel<EPT, SKN_MAXW>), dim3(W), dim3(BLOCK), 0, e->stream, g);
         return;
     }
-    static const bool k2_wide_on = !(getenv("PBWTAMD_K2_WIDE") && !atoi(getenv("PBWTAMD_K2_WIDE")));
+    static const bool k2_wide_on = !(tune_env("PBWTAMD_K2_WIDE") && !atoi(tune_env("PBWTAMD_K2_WIDE")));
     bool wide = e->prow || (W > 512 && k2_wide_on) || W > 2048;
     if (part != 2) wide = launch_skel_hist_scan<EPT>(e, e->stream, g, e->k2agg, e->k2cnt, &e->k2epoch);
     if (part == 1) return;
-    static const bool rank_r4 = !(getenv("PBWTAMD_RANK_R4") && !atoi(getenv("PBWTAMD_RANK_R4")));
+    static const bool rank_r4 = !(tune_env("PBWTAMD_RANK_R4") && !atoi(tune_env("PBWTAMD_RANK_R4")));
     if (wide && (e->prow || rank_r4)) hipLaunchKernelGGL((skel_rank_kernel<EPT, 0, true>), dim3(W), dim3(BLOCK), 0, e->stream, g);    // more tiles than one round of the chip: occupancy counts
     else hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
 }
@@ -1020,7 +1031,7 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
             e->xT = e->xTr[r];
             CHK(skel_prepare(e, r, bc, nb, left, sorted));
             // the other stream's work is enqueued once all but the last round of this batch are (measured: better than right away)
-            static const int flush_at = getenv("PBWTAMD_FLUSH_AT") ? atoi(getenv("PBWTAMD_FLUSH_AT")) : -1;   // rounds enqueued before the consumers (-1: all but the last)
+            static const int flush_at = tune_env("PBWTAMD_FLUSH_AT") ? atoi(tune_env("PBWTAMD_FLUSH_AT")) : -1;   // rounds enqueued before the consumers (-1: all but the last)
             const int nr = nb / 8;
             int s_done = 0;
             const unsigned cons_mask = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_PACK3 | OPT_INTERNAL_KEEP_STATES;
@@ -1045,7 +1056,7 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
             // consumers of the PREVIOUS batch (other ring) are enqueued now, beside this batch's chain
             CHK(flush_pending(e));
             // the last round scatters straight into slot 0 of the other ring, once its readers are done
-            static const bool no_direct = getenv("PBWTAMD_NO_DIRECT") != nullptr;
+            static const bool no_direct = tune_env("PBWTAMD_NO_DIRECT") != nullptr;
             CHK(skel_rounds(e, r, bc, sorted, nb, left, head, nr - 1, !no_direct));
             // the last round's hist + tile scan read this ring only: with them everything this batch's consumers need is done
             // (evRounds) — only its rank launch, which scatters into the OTHER ring, has to wait for that ring's consumers
@@ -1250,7 +1261,7 @@ extern "C" int pbwtamd_build(pbwtamd_engine *e, const uint32_t *bitcols, int wpc
     const unsigned opts = (with_d ? PBWTAMD_OPT_WITH_D : 0u) | (yz_out ? PBWTAMD_OPT_PACK3 : 0u);
     // pin the caller's columns for the duration of the build: the per-batch copies then run as DMA at link speed beside the
     // chain instead of through the runtime's bounce buffers (falls back to pageable copies if registration is refused)
-    static const bool no_pin = getenv("PBWTAMD_NO_PIN") != nullptr;
+    static const bool no_pin = tune_env("PBWTAMD_NO_PIN") != nullptr;
     const size_t in_bytes = (size_t)N * wpc * sizeof(uint32_t);
     const bool pinned = !no_pin && in_bytes >= (1u << 20) && hipHostRegister((void *)bitcols, in_bytes, hipHostRegisterDefault) == hipSuccess;
     if (!pinned) (void)hipGetLastError();
@@ -1754,7 +1765,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     // the queries' dependent launches take turns (measured: 320 launches per batch one after the other); on a queue of its own the
     // query chain runs beside the panel's
     hipStream_t qchain = nullptr;
-    static const bool qs_own_queue = !(getenv("PBWTAMD_QS_QCHAIN") && !atoi(getenv("PBWTAMD_QS_QCHAIN")));
+    static const bool qs_own_queue = !(tune_env("PBWTAMD_QS_QCHAIN") && !atoi(tune_env("PBWTAMD_QS_QCHAIN")));
     if (qs_own_queue) HIPCHK(hipStreamCreateWithPriority(&qchain, hipStreamNonBlocking, 0));
     struct QcGuard { hipStream_t s; ~QcGuard() { if (s) (void)hipStreamDestroy(s); } } qcGuard{qchain};        // destroyed after the engine that runs on it
     CHK(pbwtamd_engine_create(&eq, e->device, Mq, e->B, (void *)qchain));
@@ -1792,7 +1803,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     // the panel's fill (1.3 ms per 512 sites at M = 1 M) in sub-batches of 16 rounds: it runs beside the batch's own chain and the previous
     // batch's query sweep instead of between the two
     struct SubGuard { pbwtamd_engine *p; int old; ~SubGuard() { p->sub_rounds = old; } } subGuard{e, e->sub_rounds};
-    static const int qs_sub = getenv("PBWTAMD_QS_SUB") ? atoi(getenv("PBWTAMD_QS_SUB")) : 16;
+    static const int qs_sub = tune_env("PBWTAMD_QS_SUB") ? atoi(tune_env("PBWTAMD_QS_SUB")) : 16;
     e->sub_rounds = qs_sub;
     CHK(pbwtamd_pass_begin(e, pStart, 0, N));
     CHK(pbwtamd_pass_begin(eq, qStart, 0, N));
@@ -1827,7 +1838,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     CHK(bufs.alloc(&nm_ev, (size_t)NM_CAP)); CHK(bufs.alloc(&nm_n, (size_t)1));
     e->nomatch_events.clear();
     unsigned long long *qs_dbg = nullptr;                   // PBWTAMD_QS_DBG=<file>: per-query wave time and event count of the sweep kernel, dumped at the end
-    if (getenv("PBWTAMD_QS_DBG")) { CHK(bufs.alloc(&qs_dbg, (size_t)2 * Mq + 128)); HIPCHK(hipMemset(qs_dbg, 0, sizeof(unsigned long long) * (2 * (size_t)Mq + 128))); }
+    if (tune_env("PBWTAMD_QS_DBG")) { CHK(bufs.alloc(&qs_dbg, (size_t)2 * Mq + 128)); HIPCHK(hipMemset(qs_dbg, 0, sizeof(unsigned long long) * (2 * (size_t)Mq + 128))); }
     unsigned long long *bsum; CHK(bufs.alloc(&bsum, 2 * std::max(BQ, (size_t)Mq) / SCAN_CHUNK + 2));
     std::vector<unsigned long long *> ycS((size_t)nS, nullptr); std::vector<int *> rdS((size_t)nS, nullptr);
     for (int kk = 0; kk < nS; ++kk) { CHK(bufs.alloc(&ycS[kk], (size_t)(Bs + 2) * wpc64)); CHK(bufs.alloc(&rdS[kk], (size_t)(Bs + 2) * (wpc64 + 1))); }
@@ -1840,7 +1851,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     hipStream_t st = nullptr;
     {
         int prLow = 0, prHigh = 0; (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
-        static const int qs_prio = getenv("PBWTAMD_QS_PRIO") ? atoi(getenv("PBWTAMD_QS_PRIO")) : 0;     // 0 low, 1 normal, 2 high
+        static const int qs_prio = tune_env("PBWTAMD_QS_PRIO") ? atoi(tune_env("PBWTAMD_QS_PRIO")) : 0;     // 0 low, 1 normal, 2 high
         HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, qs_prio == 2 ? prHigh : qs_prio == 1 ? 0 : prLow));
     }
     struct StGuard { hipStream_t s; ~StGuard() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } } stGuard{st};
@@ -1892,7 +1903,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     }
     struct PreGuard { hipStream_t s; hipEvent_t *ev; pbwtamd_engine *p; ~PreGuard() { p->evPreKeys = nullptr; if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } for (int i = 0; i < 2; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]); } } preGuard{pre, evPre, e};
     int *rdPre = nullptr; CHK(bufs.alloc(&rdPre, (size_t)(e->B + 2) * (wpc64 + 1)));
-    static const bool qs_prefetch = !(getenv("PBWTAMD_QS_PREFETCH") && !atoi(getenv("PBWTAMD_QS_PREFETCH")));
+    static const bool qs_prefetch = !(tune_env("PBWTAMD_QS_PREFETCH") && !atoi(tune_env("PBWTAMD_QS_PREFETCH")));
     auto stage_half = [&](int at) -> uint32_t * { return e->cols_stage + (size_t)((at / Bd) & 1) * ((size_t)e->B + 8) * wpc; };
     int pre_at = -1;                                       // the batch whose columns + keys are prepared (or being prepared) on `pre`
     // prepare the batch starting at `at`, which will run in ring `ring`: decode + rank directories + keys of every round
@@ -1983,7 +1994,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         // a wave lives for the whole batch here (one query, site after site): at full occupancy the next batch's chain kernels,
         // enqueued below to run beside it, would find no wave slot until it ends.  26 KB of (unused) dynamic LDS per workgroup
         // holds the sweep to 6 of the 8 wave slots per SIMD.
-        static const int qs_lds_kb = getenv("PBWTAMD_QS_LDS") ? atoi(getenv("PBWTAMD_QS_LDS")) : 26;
+        static const int qs_lds_kb = tune_env("PBWTAMD_QS_LDS") ? atoi(tune_env("PBWTAMD_QS_LDS")) : 26;
         hipLaunchKernelGGL((qss_sweep_kernel<0>), dim3(qwaves), dim3(BLOCK), (size_t)qs_lds_kb * 1024, st, g);
         scan_u64(st, cnt, 2 * (size_t)nb * Mq, tot + 3, bsum);
         HIPCHK(hipGetLastError());
@@ -1994,7 +2005,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
             CHK(mark(e)); CHK(mark(eq));
             for (int kk = 0; kk < nS; ++kk) if (hviews[kk].A) CHK(mark(es[kk]));
         }
-        static const bool qs_serial = getenv("PBWTAMD_QS_SERIAL") != nullptr;                             // measurement: the sweep alone on the device, the next batch's chains after it
+        static const bool qs_serial = tune_env("PBWTAMD_QS_SERIAL") != nullptr;                             // measurement: the sweep alone on the device, the next batch's chains after it
         if (qs_serial) HIPCHK(hipEventSynchronize(evTotal));
         if (done + nb < N) {                                 // runs beside the sweep; ring pointers of THIS batch were taken above
             HIPCHK(hipStreamWaitEvent(e->stream, evCols, 0));
@@ -2048,7 +2059,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     if (qs_dbg) {
         std::vector<unsigned long long> h((size_t)2 * Mq + 128);
         HIPCHK(hipMemcpy(h.data(), qs_dbg, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
-        if (FILE *f = fopen(getenv("PBWTAMD_QS_DBG"), "w")) {
+        if (FILE *f = fopen(tune_env("PBWTAMD_QS_DBG"), "w")) {
             for (int q = 0; q < Mq; ++q) fprintf(f, "%d %llu %llu\n", q, h[2 * (size_t)q], h[2 * (size_t)q + 1]);
             for (int b = 0; b < 64; ++b) fprintf(f, "%d %llu %llu\n", -1 - b, h[2 * (size_t)Mq + b], h[2 * (size_t)Mq + 64 + b]);     // per batch: slowest wave (ticks), most events of one query
             fclose(f);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/profile_round.sh <tag> — rocprofv3 evidence for one round, written under gpurun_out/<tag>/
 # (kernel-trace stats and the PMC passes are separate runs, as the pool requires)
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -20,6 +20,8 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/wide_write -o
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $out/wide_sq -o wide -- $WIDE > $out/wide_sq.log 2>&1
 # -matchDynamic, 10 000 queries against 1 M haplotypes
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/qs_trace -o qs -- python tools/qsweep_bench.py 1000000 10000 4096 > $out/qs_trace.log 2>&1
+# the position-sharded chain, one rank (the launch structure a rank of a multi-GPU job runs; the exchange degenerates)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/shard_trace -o shard -- python bench.py --mode posshard --backend gloo --haps 1000000 --steps 1 --warmup 1 > $out/shard_trace.log 2>&1
 # what the chain's launches cost beside each consumer kernel (north-star width): durations by the kernel running on the other stream
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out/wide_tl -o wide -- python tools/wide_bench.py 1000000 4096 hp > $out/wide_tl.log 2>&1
 { grep "us/site" $out/wide_tl.log; python tools/trace_overlap.py $out/wide_tl/wide_kernel_trace.csv; echo; python tools/trace_timeline.py $out/wide_tl/wide_kernel_trace.csv | tail -24; } > $out/overlap.txt 2>&1

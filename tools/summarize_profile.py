@@ -6,7 +6,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 
@@ -23,6 +23,7 @@ copy_stats("trace", "bench", tag + "_kernel_stats.csv")                 # bench.
 copy_stats("wide_trace", "wide", tag + "_wide_kernel_stats.csv")        # tools/wide_bench.py 1000000 2048 hp (north-star width)
 copy_stats("qs_trace", "qs", tag + "_matchdynamic_kernel_stats.csv")    # tools/qsweep_bench.py 1000000 10000 4096
 copy_stats("wide_alone", "wide", tag + "_wide_chain_alone_kernel_stats.csv")   # tools/wide_bench.py 1000000 4096 none
+copy_stats("shard_trace", "shard", tag + "_posshard_1rank_kernel_stats.csv")   # bench.py --mode posshard --haps 1000000 --steps 1 (one rank)
 if os.path.exists(os.path.join(src, "overlap.txt")):
     shutil.copy(os.path.join(src, "overlap.txt"), os.path.join("profiles", tag + "_overlap.txt"))
 
@@ -65,12 +66,27 @@ def counters(passname, counter, names):
     return out
 
 
+def avg_ns(stats_csv):
+    """kernel name fragment -> average duration (ns) from a rocprofv3 --stats summary (the kernel-trace pass of the same command)"""
+    out = {}
+    if os.path.exists(stats_csv):
+        for r in csv.DictReader(open(stats_csv)):
+            for nm in CHAIN + CONS:
+                if ("::" + nm) in r["Name"]:
+                    calls, tot = int(r["Calls"]), float(r["TotalDurationNs"])
+                    c0, t0 = out.get(nm, (0, 0.0))
+                    out[nm] = (c0 + calls, t0 + tot)
+    return {k: v[1] / max(v[0], 1) for k, v in out.items()}
+
+
 with open(os.path.join("profiles", tag + "_traffic.txt"), "w") as f:
     f.write("rocprofv3 PMC, separate passes (FETCH_SIZE, WRITE_SIZE), units KiB; calibration on tools/pmc_calib.hip\n")
     f.write("(1 GiB copy with 4 B/lane coalesced accesses): true/reported = %s  (FETCH_SIZE x2 on gfx950 as MI355X_MICROARCH.md says)\n\n" % cal)
     result = {}
-    for label, fp, wp, M, sites in (("configs[2] width, bench.py --steps 2 --warmup 1 (M = 100000, 3 x 8192 sites)", "pmc_fetch", "pmc_write", 100000, 3 * 8192),
-                                    ("north-star width, tools/wide_bench.py (M = 1000000, 512 + 2048 sites)", "wide_fetch", "wide_write", 1000000, 2560)):
+    f.write("us / GB/s: the kernel's average duration in the kernel-trace pass of the same command and its HBM-side bytes per dispatch over it\n\n")
+    for label, fp, wp, M, sites, stats in (("configs[2] width, bench.py --steps 2 --warmup 1 (M = 100000, 3 x 8192 sites)", "pmc_fetch", "pmc_write", 100000, 3 * 8192, tag + "_kernel_stats.csv"),
+                                           ("north-star width, tools/wide_bench.py (M = 1000000, 512 + 2048 sites)", "wide_fetch", "wide_write", 1000000, 2560, tag + "_wide_kernel_stats.csv")):
+        dur = avg_ns(os.path.join("profiles", stats))
         fe, wr = counters(fp, "FETCH_SIZE", CHAIN + CONS), counters(wp, "WRITE_SIZE", CHAIN + CONS)
         if not fe:
             continue
@@ -84,8 +100,10 @@ with open(os.path.join("profiles", tag + "_traffic.txt"), "w") as f:
             tot += b
             if nm in CHAIN:
                 chain_bytes += b; chain_launches += fe[nm + "#n"]
-            f.write("  %-22s %6d dispatches  fetch %12.0f KiB x %.2f  write %12.0f KiB x %.2f  = %8.1f MB\n"
-                    % (nm, fe[nm + "#n"], fe[nm], cf, wr.get(nm, 0.0), cw, b / 1e6))
+            per = b / max(fe[nm + "#n"], 1)
+            rate = ("  %9.1f us  %7.0f GB/s" % (dur[nm] / 1e3, per / dur[nm])) if nm in dur else ""
+            f.write("  %-22s %6d dispatches  fetch %12.0f KiB x %.2f  write %12.0f KiB x %.2f  = %8.1f MB%s\n"
+                    % (nm, fe[nm + "#n"], fe[nm], cf, wr.get(nm, 0.0), cw, b / 1e6, rate))
         alg = 16.125 * M * sites
         f.write("  => %.1f MB HBM-side traffic for %d sites = %.2f MB/site; algorithmic 16.125 B x M = %.2f MB/site: ratio %.2f\n"
                 % (tot / 1e6, sites, tot / 1e6 / sites, 16.125 * M / 1e6, tot / alg))
