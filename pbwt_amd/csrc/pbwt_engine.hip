@@ -163,6 +163,8 @@ struct pbwtamd_engine {
     hipEvent_t evChain[2] = {nullptr, nullptr}, evCons[2] = {nullptr, nullptr}; bool consRecorded[2] = {false, false}, chainRecorded[2] = {false, false};
     int2 *qs_bsum[2] = {nullptr, nullptr}; int qs_nblk = 0;   // query sweep: per ring, block summaries of every state of the batch (qs_blocksum_kernel), written by the batch's consumers
     int qs_bsum_sites[2] = {0, 0};          // ... and how many leading sites of the ring's batch they have summarised so far
+    bool persist = false;                   // small panels (two-launch regime): all rounds of a batch in ONE launch (skel_persist_kernel) — set for the query cursor of the query sweep
+    SkArgs *pargs = nullptr, *pargs_host = nullptr; unsigned *pbar = nullptr; unsigned pbar_epoch = 0; int pargs_half = 0; hipEvent_t evPargs[2] = {nullptr, nullptr};
     hipEvent_t evPreKeys = nullptr;         // read side: the next skeleton batch's rank directories and keys were derived ahead of time on another stream (query sweep); wait for this event instead
     int sub_rounds = 0; hipEvent_t evSub[8] = {}; long long evSub_n = 0;   // > 0: the consumers of a skeleton batch are enqueued every sub_rounds rounds, beside the rest of the batch's chain (query sweep)
     hipEvent_t evRounds[2] = {nullptr, nullptr}; bool roundsRecorded[2] = {false, false};   // everything the batch's consumers read is done (the last round's scatter into the OTHER ring may still wait for that ring's consumers)
@@ -245,6 +247,10 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     for (int i = 0; i < 16; ++i) if (e->tev[i]) (void)hipEventDestroy(e->tev[i]);
     for (int i = 0; i < 8; ++i) if (e->evUsed[i]) (void)hipEventDestroy(e->evUsed[i]);
     for (int i = 0; i < 8; ++i) if (e->evSub[i]) (void)hipEventDestroy(e->evSub[i]);
+    for (int i = 0; i < 2; ++i) if (e->evPargs[i]) (void)hipEventDestroy(e->evPargs[i]);
+    if (e->pargs_host) (void)hipHostFree(e->pargs_host);
+    if (e->pargs) (void)dev_free(e->pargs);
+    if (e->pbar) (void)dev_free(e->pbar);
     if (e->h_used) (void)hipHostFree(e->h_used);
     for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); if (e->evRounds[i]) (void)hipEventDestroy(e->evRounds[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
@@ -499,6 +505,7 @@ extern "C" int pbwtamd_pass_begin(pbwtamd_engine *e, const int32_t *aInit, int k
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipStreamSynchronize(e->s2));
     if (e->k2cnt) { HIPCHK(hipMemsetAsync(e->k2cnt, 0, 64, e->stream)); e->k2epoch = 0; }   // arrival counter and host epoch restart together
+    if (e->pbar) { HIPCHK(hipMemsetAsync(e->pbar, 0, 64, e->stream)); e->pbar_epoch = 0; }
     if (e->sh) { e->sh->full_state = true; e->sh->blkSite0.clear(); e->sh->blkSites.clear(); }
     e->k0 = k0; e->k_cur = k0; e->n_total = n_total; e->prepared = false; e->pass_open = true;
     e->ring = 0; e->consRecorded[0] = e->consRecorded[1] = false; e->chainRecorded[0] = e->chainRecorded[1] = false; e->roundsRecorded[0] = e->roundsRecorded[1] = false;
@@ -936,30 +943,65 @@ static int skel_prepare(pbwtamd_engine *e, int r, const uint32_t *cols, int nb, 
 
 // rounds [s_from, s_to) of the batch; `direct`: the batch's last round scatters straight into slot 0
 // (and the slot-0 keys) of the other ring, where the next batch starts
-static int skel_rounds(pbwtamd_engine *e, int r, const uint32_t *cols, bool sorted, int nb, int navail, int s_from, int s_to, bool direct, int part = 0) {
+// the arguments of round s8 of a skeleton batch on ring r
+static SkArgs skel_round_args(pbwtamd_engine *e, int r, const uint32_t *cols, bool sorted, int nb, int navail, int s8, bool direct) {
     int *A = ringA(e, r), *D = ringD(e, r);
     const int nvalid = std::min(navail, e->n_total - e->k_cur);
     unsigned char *kb = e->keysR[r];
     const uint32_t *xT = e->xTr[r];
     const int W = e->Wt;
-    const bool two = skel_two_launch(e);
     SkArgs g;
     g.tbl = (int2 *)e->skT;
     g.M = e->M; g.W = W; g.xcd = xcd_flags(); g.w0 = 0; g.Wtot = W;
+    const int site = 8 * s8;                               // relative to the batch
+    const bool last = direct && s8 == nb / 8 - 1;
+    g.a = A + (size_t)site * e->strideA; g.d = D + (size_t)site * e->strideD; g.keys = kb + (size_t)s8 * e->Mpad;
+    g.a_out = last ? ringA(e, r ^ 1) : A + (size_t)(site + 8) * e->strideA;
+    g.d_out = last ? ringD(e, r ^ 1) : D + (size_t)(site + 8) * e->strideD;
+    g.keys_out = last ? e->keysR[r ^ 1] : kb + (size_t)(s8 + 1) * e->Mpad;
+    int2 *sv = e->saveR[r] + (size_t)s8 * e->strideS;      // this round's per-key scan over the tiles, kept for the fill
+    const size_t nrow = e->prow ? (size_t)e->W2 : (size_t)W;
+    g.scan = sv; g.total = reinterpret_cast<int *>(sv + nrow * SKK); g.tbl0 = sv + nrow * SKK + SKK / 2; g.pair = e->prow ? 1 : 0;
+    g.has_next = (e->k_cur + site + 8 < e->n_total) && (site + 8 < nvalid);
+    g.kbnext = reinterpret_cast<const unsigned char *>(xT) + (size_t)((site + 8) / 8) * e->strideX;   // byte plane of sites site+8 .. site+15
+    g.ycnext = sorted ? (const unsigned long long *)cols + (size_t)(site + 8) * e->wpc64 : nullptr;
+    g.k = e->k_cur + site;
+    return g;
+}
+
+// all rounds of the batch in one launch (e->persist; two-launch regime): the last round writes slot nb of the SAME ring — the caller
+// carries it into the other ring once that ring's readers are done
+static int skel_rounds_persistent(pbwtamd_engine *e, int r, const uint32_t *cols, bool sorted, int nb, int navail) {
+    const int nr = nb / 8, maxr = e->B / 8 + 1;
+    if (!e->pargs) {
+        HIPCHK(dev_alloc((void **)&e->pargs, 2 * (size_t)maxr * sizeof(SkArgs)));
+        HIPCHK(hipHostMalloc((void **)&e->pargs_host, 2 * (size_t)maxr * sizeof(SkArgs), hipHostMallocDefault));
+        HIPCHK(dev_alloc((void **)&e->pbar, 64)); HIPCHK(hipMemsetAsync(e->pbar, 0, 64, e->stream)); e->pbar_epoch = 0;
+        for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&e->evPargs[i], hipEventDisableTiming));
+    }
+    const int h = e->pargs_half; e->pargs_half ^= 1;
+    HIPCHK(hipEventSynchronize(e->evPargs[h]));            // the copy out of this half of the pinned staging (two batches ago) is done
+    SkArgs *host = e->pargs_host + (size_t)h * maxr, *dev = e->pargs + (size_t)h * maxr;
+    for (int s8 = 0; s8 < nr; ++s8) host[s8] = skel_round_args(e, r, cols, sorted, nb, navail, s8, false);
+    HIPCHK(hipMemcpyAsync(dev, host, (size_t)nr * sizeof(SkArgs), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipEventRecord(e->evPargs[h], e->stream));
+    const int W = e->Wt;
+    const unsigned base = e->pbar_epoch;
+    e->pbar_epoch += 2u * (unsigned)nr * (unsigned)W;
+#define PERSIST(EP, TRR) hipLaunchKernelGGL((skel_persist_kernel<EP, TRR>), dim3(W), dim3(BLOCK), 0, e->stream, (const SkArgs *)dev, nr, e->pbar, base, e->ctl + 2)
+#define PERSIST_TR(EP) do { if (W <= 16) PERSIST(EP, 16); else if (W <= 32) PERSIST(EP, 32); else if (W <= 64) PERSIST(EP, 64); else PERSIST(EP, SKN_MAXW); } while (0)
+    if (e->skEPT == 1) PERSIST_TR(1); else if (e->skEPT == 2) PERSIST_TR(2); else PERSIST_TR(4);
+#undef PERSIST_TR
+#undef PERSIST
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int skel_rounds(pbwtamd_engine *e, int r, const uint32_t *cols, bool sorted, int nb, int navail, int s_from, int s_to, bool direct, int part = 0) {
+    const bool two = skel_two_launch(e);
     for (int s8 = s_from; s8 < s_to; ++s8) {
-        const int site = 8 * s8;                           // relative to the batch
         const bool last = direct && s8 == nb / 8 - 1;
-        g.a = A + (size_t)site * e->strideA; g.d = D + (size_t)site * e->strideD; g.keys = kb + (size_t)s8 * e->Mpad;
-        g.a_out = last ? ringA(e, r ^ 1) : A + (size_t)(site + 8) * e->strideA;
-        g.d_out = last ? ringD(e, r ^ 1) : D + (size_t)(site + 8) * e->strideD;
-        g.keys_out = last ? e->keysR[r ^ 1] : kb + (size_t)(s8 + 1) * e->Mpad;
-        int2 *sv = e->saveR[r] + (size_t)s8 * e->strideS;  // this round's per-key scan over the tiles, kept for the fill
-        const size_t nrow = e->prow ? (size_t)e->W2 : (size_t)W;
-        g.scan = sv; g.total = reinterpret_cast<int *>(sv + nrow * SKK); g.tbl0 = sv + nrow * SKK + SKK / 2; g.pair = e->prow ? 1 : 0;
-        g.has_next = (e->k_cur + site + 8 < e->n_total) && (site + 8 < nvalid);
-        g.kbnext = reinterpret_cast<const unsigned char *>(xT) + (size_t)((site + 8) / 8) * e->strideX;   // byte plane of sites site+8 .. site+15
-        g.ycnext = sorted ? (const unsigned long long *)cols + (size_t)(site + 8) * e->wpc64 : nullptr;
-        g.k = e->k_cur + site;
+        SkArgs g = skel_round_args(e, r, cols, sorted, nb, navail, s8, direct);
         if (e->skEPT == 1) launch_skel_round<1>(e, g, two, part); else if (e->skEPT == 2) launch_skel_round<2>(e, g, two, part); else launch_skel_round<4>(e, g, two, part);
         if (part == 1) continue;
         if (last) e->keys_ready[r ^ 1] = g.has_next != 0;
@@ -1016,7 +1058,7 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
                                e->summ, pair ? 3 * e->wpad : e->wpad, e->summ_cur);
             e->keys_ready[r] = false;
         }
-        const int nlaunch = skel ? (skel_two_launch(e) ? 2 : 3) * (nb / 8) : (pair ? L : nb);
+        const int nlaunch = skel ? ((e->persist && skel_two_launch(e) && !e->prow) ? 1 : (skel_two_launch(e) ? 2 : 3) * (nb / 8)) : (pair ? L : nb);
         if (!skel) e->summ_cur = nlaunch % 3;
         HIPCHK(hipGetLastError());
         // ---- the chain: slot j -> slot j+1 (-> slot j+2) of ring r ----
@@ -1033,6 +1075,15 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
             // the other stream's work is enqueued once all but the last round of this batch are (measured: better than right away)
             static const int flush_at = tune_env("PBWTAMD_FLUSH_AT") ? atoi(tune_env("PBWTAMD_FLUSH_AT")) : -1;   // rounds enqueued before the consumers (-1: all but the last)
             const int nr = nb / 8;
+            if (e->persist && skel_two_launch(e) && !e->prow) {    // a small panel beside a wide one: the whole batch's chain in one launch
+                CHK(skel_rounds_persistent(e, r, bc, sorted, nb, left));
+                CHK(flush_pending(e));
+                if (e->consRecorded[r ^ 1]) HIPCHK(hipStreamWaitEvent(e->stream, e->evCons[r ^ 1], 0));
+                HIPCHK(hipMemcpyAsync(ringA(e, r ^ 1), A + (size_t)nb * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->stream));
+                HIPCHK(hipMemcpyAsync(ringD(e, r ^ 1), D + (size_t)nb * e->strideD, sizeof(int) * e->strideD, hipMemcpyDeviceToDevice, e->stream));
+                e->keys_ready[r ^ 1] = false;
+                launched = true; e->prepared = false;
+            } else {
             int s_done = 0;
             const unsigned cons_mask = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_PACK3 | OPT_INTERNAL_KEEP_STATES;
             if (e->sub_rounds > 0 && nr > e->sub_rounds && (opts & cons_mask) && !(opts & (PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_LONG_RECS))) {
@@ -1070,6 +1121,7 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
                 HIPCHK(hipMemcpyAsync(ringD(e, r ^ 1), D + (size_t)nb * e->strideD, sizeof(int) * e->strideD, hipMemcpyDeviceToDevice, e->stream));
             }
             launched = true; e->prepared = false;
+            }
         }
         else if (e->use_graph && nb == e->B) {
             hipGraphExec_t exec;
@@ -1771,6 +1823,9 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     CHK(pbwtamd_engine_create(&eq, e->device, Mq, e->B, (void *)qchain));
     struct EngGuard { std::vector<pbwtamd_engine *> v; ~EngGuard() { for (auto *p : v) if (p) pbwtamd_engine_destroy(p); } } guard;
     guard.v.push_back(eq);
+    // the query cursor's chain: one launch per batch instead of two per round (skel_persist_kernel) — it leaves the launch stream to the panel
+    static const bool qs_persist = !(tune_env("PBWTAMD_QS_PERSIST") && !atoi(tune_env("PBWTAMD_QS_PERSIST")));
+    eq->persist = qs_persist;
     std::vector<pbwtamd_engine *> es((size_t)nS, nullptr);
     for (int kk = 0; kk < nS; ++kk) { CHK(pbwtamd_engine_create(&es[kk], e->device, Mp, Bs + 1, nullptr)); guard.v.push_back(es[kk]); }
     DevBufs bufs;

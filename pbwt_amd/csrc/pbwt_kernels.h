@@ -797,8 +797,8 @@ struct SkShardOut {
 // first half; the scan over the tiles then runs on half as many rows (the scan launch is what a wide panel pays most for beside
 // the consumers: 22.7 us per round at 1954 rows, 14 at 977), and the rank / fill workgroup of an odd tile folds the first half's
 // row into its pair's prefix (skel_k2_kernel's combine).  Waves 2, 3 hold the first half.
-template <int EPT, bool HALF = false>
-__global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
+template <int EPT, bool HALF>
+__device__ __forceinline__ void skel_hist_body(const SkArgs &g) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
 #endif
@@ -870,6 +870,8 @@ __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) {
         g.tbl0[(size_t)w * SKK + t] = make_int2(c0, tl0);
     }
 }
+template <int EPT, bool HALF = false>
+__global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) { skel_hist_body<EPT, HALF>(g); }
 
 // SCAN (K2): exclusive scan over the W tiles, per key, of the pair (count, max d since the key's last
 // occurrence) with combine(L,R) = (L.c+R.c, R.c ? R.t : max(L.t,R.t)) (for a tile without the key, t
@@ -1324,6 +1326,37 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) { skel_rank_
 // position-sharded form: tiles w0 .. w0+W-1, scatter through the owners' table
 template <int EPT, bool R4>
 __global__ __launch_bounds__(BLOCK) void skel_rank_shard_kernel(SkArgs g, SkShardOut so) { skel_rank_body<EPT, 0, R4, true>(g, &so); }
+
+// PERSISTENT chain of a small panel (<= TR tiles: the two-launch regime): ALL rounds of a batch in ONE launch, hist and rank of every
+// round separated by barriers over the launch's <= 128 co-resident workgroups instead of by kernel boundaries.  Such a barrier costs MORE
+// than a boundary (>= 4 us against 1.5-2.5), so this is not how a lone small panel runs fastest — it is how a small
+// panel's chain stays OFF the launch stream of a wide one: the query cursor of matchSequencesSweep (10 000 haplotypes beside a panel of
+// 10^6) costs 128 dependent launches per 512-site batch, a third of what bounds that job; here it costs one.
+// rounds[s] = the arguments of round s (device memory).  The counter only grows: barrier i of this launch waits for base + (i+1) * gridDim.x.
+__device__ __forceinline__ void skel_grid_barrier(unsigned *counter, unsigned target, int *err) {
+    __syncthreads();                                        // every wave's stores are out (vmcnt(0)) before thread 0 releases them
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 25)) { atomicExch(err, 8); break; }
+        }
+    }
+    __syncthreads();
+}
+template <int EPT, int TR>
+__global__ __launch_bounds__(BLOCK) void skel_persist_kernel(const SkArgs *rounds, int nr, unsigned *counter, unsigned base, int *err) {
+    const unsigned nwg = gridDim.x;
+    unsigned target = base;
+    for (int s = 0; s < nr; ++s) {
+        const SkArgs g = rounds[s];
+        skel_hist_body<EPT, false>(g);
+        target += nwg; skel_grid_barrier(counter, target, err);          // every tile's row is in the table
+        skel_rank_body<EPT, TR, false, false>(g, nullptr);
+        target += nwg; skel_grid_barrier(counter, target, err);          // the new state (a, d, keys) is complete
+    }
+}
 
 // READ SIDE: the columns arrive in PBWT order (y_k by position), so the 8-bit key of position i of the
 // state before site k follows the LF-mapping through the 8 columns: bit j = y_{k+j}[p_j], p_0 = i,
