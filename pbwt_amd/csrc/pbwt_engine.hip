@@ -124,6 +124,7 @@ struct DevBufs {
     }
 };
 
+constexpr int QS_SWEEP_CUS = 0;           // CUs the query sweep's stream is confined to (0: all) — see pbwtamd_match_sweep_sparse
 // internal option: the caller reads the ring slots of the batch itself (forces the fill on the skeleton path)
 constexpr unsigned OPT_INTERNAL_KEEP_STATES = 0x100u;
 
@@ -294,6 +295,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     if (const char *s = getenv("PBWTAMD_PAIR1024")) e->pair1024 = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_SKEL")) e->skel = atoi(s) != 0;
     if (const char *s = getenv("PBWTAMD_SKN")) e->skn = atoi(s) != 0;
+    if (const char *s = tune_env("PBWTAMD_PERSIST")) e->persist = atoi(s) != 0;
     // skeleton at every width the engine takes: up to 4096 tiles of 1024 positions (above 2048 tiles the two-level tile scan gives each of its
     // <= 64 co-resident workgroups 64 tiles instead of 32); PBWTAMD_SKEL_MAXM=<M> (A/B runs): the two-site chain above that width, as before round 3
     if (const char *sm = tune_env("PBWTAMD_SKEL_MAXM")) { if (M > atoi(sm)) e->skel = false; }
@@ -1907,7 +1909,16 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     {
         int prLow = 0, prHigh = 0; (void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
         static const int qs_prio = tune_env("PBWTAMD_QS_PRIO") ? atoi(tune_env("PBWTAMD_QS_PRIO")) : 0;     // 0 low, 1 normal, 2 high
-        HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, qs_prio == 2 ? prHigh : qs_prio == 1 ? 0 : prLow));
+        // the sweep's ~10 000 waves live for the whole batch and slow every dependent launch of the panel's chain that has to find room beside
+        // them; it has time to spare (2 ms of a 4.5 ms batch), so it may be confined to the LAST qs_cus CUs of the device (0 = no mask)
+        static const int qs_cus = tune_env("PBWTAMD_QS_CUS") ? atoi(tune_env("PBWTAMD_QS_CUS")) : QS_SWEEP_CUS;
+        int ncu_dev = 0; (void)hipDeviceGetAttribute(&ncu_dev, hipDeviceAttributeMultiprocessorCount, e->device);
+        if (qs_cus > 0 && qs_cus < ncu_dev && ncu_dev <= 256) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = ncu_dev - qs_cus; i < ncu_dev; ++i) mask[i / 32] |= 1u << (i % 32);
+            if (hipExtStreamCreateWithCUMask(&st, 8, mask) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
+        }
+        if (!st) HIPCHK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, qs_prio == 2 ? prHigh : qs_prio == 1 ? 0 : prLow));
     }
     struct StGuard { hipStream_t s; ~StGuard() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } } stGuard{st};
     HIPCHK(hipMemsetAsync(fst[0], 0, sizeof(int) * (size_t)Mq, st));       // calloc'ed f[], d[], ff[][], dd[][] (pbwtMatch.c:512-523)
@@ -1983,10 +1994,12 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         uint32_t *stage = stage_half(at);
         if (pre_at == at) { HIPCHK(hipStreamWaitEvent(e->stream, evPre[(at / Bd) & 1], 0)); e->evPreKeys = evPre[(at / Bd) & 1]; }   // skel_prepare skips the keys
         else CHK(packed_expand(e, e->stream, pk, Mp, at, navail, (unsigned long long *)stage, wpc64));
+        // the query cursor first: its chain is one launch (skel_persist_kernel) — enqueued behind the panel's 192 throttled launches it would
+        // only start when the host gets there, near the END of the panel's chain (measured: 3.3 ms into a 5 ms batch)
         CHK(packed_expand(eq, eq->stream, qk, Mq, at, navail, (unsigned long long *)eq->cols_stage, eq->wpc64));
+        CHK(pbwtamd_pass_advance(eq, eq->cols_stage, eq->wpc, nb, navail, PBWTAMD_OPT_SORTED | OPT_INTERNAL_KEEP_STATES));
         CHK(pbwtamd_pass_advance(e, stage, wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES));
         e->evPreKeys = nullptr;
-        CHK(pbwtamd_pass_advance(eq, eq->cols_stage, eq->wpc, nb, navail, PBWTAMD_OPT_SORTED | OPT_INTERNAL_KEEP_STATES));
         for (int kk = 0; kk < nS; ++kk) {                  // the sparse cursors' steps that fall into this batch
             const int ns = nb > kk ? (nb - kk + nS - 1) / nS : 0;
             if (!ns) continue;
