@@ -124,6 +124,7 @@ struct DevBufs {
     }
 };
 
+constexpr int QS_QUERIES_PER_WAVE = 1;     // queries a wave of the query sweep takes one after the other
 constexpr int QS_SWEEP_CUS = 0;           // CUs the query sweep's stream is confined to (0: all) — see pbwtamd_match_sweep_sparse
 // internal option: the caller reads the ring slots of the batch itself (forces the fill on the skeleton path)
 constexpr unsigned OPT_INTERNAL_KEEP_STATES = 0x100u;
@@ -2063,7 +2064,8 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         // enqueued below to run beside it, would find no wave slot until it ends.  26 KB of (unused) dynamic LDS per workgroup
         // holds the sweep to 6 of the 8 wave slots per SIMD.
         static const int qs_lds_kb = tune_env("PBWTAMD_QS_LDS") ? atoi(tune_env("PBWTAMD_QS_LDS")) : 26;
-        hipLaunchKernelGGL((qss_sweep_kernel<0>), dim3(qwaves), dim3(BLOCK), (size_t)qs_lds_kb * 1024, st, g);
+        static const int qs_qpw = tune_env("PBWTAMD_QS_QPW") ? std::max(1, atoi(tune_env("PBWTAMD_QS_QPW"))) : QS_QUERIES_PER_WAVE;
+        hipLaunchKernelGGL((qss_sweep_kernel<0>), dim3((qwaves + qs_qpw - 1) / qs_qpw), dim3(BLOCK), (size_t)qs_lds_kb * 1024, st, g);
         scan_u64(st, cnt, 2 * (size_t)nb * Mq, tot + 3, bsum);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_total, tot + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));   // read back before the next batch's fill queues on this stream

@@ -3126,11 +3126,14 @@ __device__ __forceinline__ int qss_lfmap(const unsigned long long *yc, const int
 }
 
 // one WAVE per query
+// qpw > 1: a wave takes qpw queries one after the other (query = wave + i * waves of the launch): a quarter of the waves resident for the
+// whole batch leaves the chain's dependent launches room on every CU, and the sweep has the time
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
-    const int jj = blockIdx.x * WAVES + wave_id(), lane = lane_id();
-    if (jj >= g.Mq || jj < g.q_lo || jj >= g.q_hi) return;   // another rank's query: its count slots stay zero
-    const int M = g.Mp, nS = g.nS;
+    const int lane = lane_id(), M = g.Mp, nS = g.nS;
+    const int wave0 = blockIdx.x * WAVES + wave_id(), nwaves = gridDim.x * WAVES;
+    for (int jj = wave0; jj < g.Mq; jj += nwaves) {
+    if (jj < g.q_lo || jj >= g.q_hi) continue;               // another rank's query: its count slots stay zero
     int f = g.f_in[jj], dq = g.dq_in[jj];
     unsigned long long nTot = 0, totLen = 0, nomatch = 0;
     const unsigned long long t_in = g.dbg ? wall_clock64() : 0ULL; unsigned nev = 0;
@@ -3199,6 +3202,7 @@ __global__ __launch_bounds__(BLOCK) void qss_sweep_kernel(QssArgs g) {
             atomicMax(g.dbg + 2 * (size_t)g.Mq + (size_t)(g.kbase / max(g.nsites, 1)) % 64, dt);           // slowest wave of the batch
             atomicMax(g.dbg + 2 * (size_t)g.Mq + 64 + (size_t)(g.kbase / max(g.nsites, 1)) % 64, (unsigned long long)nev);
         }
+    }
     }
 }
 
