@@ -120,9 +120,21 @@ def test_wider_than_2_20_haplotypes(gpu_lib, orc, M, N, skel, monkeypatch):
     assert np.array_equal(b["yz"], o["yz"]) and np.array_equal(b["aFend"], o["aFend"]) and np.array_equal(b["dFend"], o["d_final"])
     hist, yz, a, d = bench_pass(amd, eng, buf, N, step=16)
     assert np.array_equal(yz, o["yz"]) and np.array_equal(a, o["aFend"]) and np.array_equal(d, o["d_final"])
-    assert np.array_equal(hist, orc.max_within_hist(o["yz"], M, N)[: N + 1])
+    if M <= 1200000:
+        assert np.array_equal(hist, orc.max_within_hist(o["yz"], M, N)[: N + 1])
+    else:
+        # the oracle's matchMaximalWithin walks are quadratic in M on a panel's first sites (every haplotype still in one block): 3 minutes
+        # at 2.2 M, hours at 4 M.  The histogram is compared with the OTHER chain's instead — skeleton against the two-site fallback:
+        # independent (a, d) for every site through the same sweep, both pinned to the oracle's final state and bytes above
+        monkeypatch.setenv("PBWTAMD_SKEL", "0" if skel == "1" else "1")
+        other = amd.Engine(M, batch_sites=16)
+        hist2, yz2, a2, d2 = bench_pass(amd, other, buf, N, step=16)
+        other.close()
+        monkeypatch.setenv("PBWTAMD_SKEL", skel)
+        assert np.array_equal(yz2, o["yz"]) and np.array_equal(a2, o["aFend"]) and np.array_equal(d2, o["d_final"])
+        assert np.array_equal(hist, hist2) and int(hist.sum()) > 0
     if M > 3000000:
-        return                                     # (the read side at this width costs the CPU oracle minutes; it is covered at 2.2 M)
+        return                                     # (the read side is covered at 2.2 M)
     sw = eng.sweep_AD(o["yz"], N)
     s = orc.sweep_AD(o["yz"], M, N)
     assert np.array_equal(sw["csum_a"], s["csum_a"]) and np.array_equal(sw["csum_d"], s["csum_d"])
