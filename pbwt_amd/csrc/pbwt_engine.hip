@@ -783,7 +783,10 @@ static int xcd_flags() { static const int v = tune_env("PBWTAMD_XCD") ? atoi(tun
 // batch consumers (checksums, maxWithin sweep, pack3) of the pending batch, on the second stream so
 // they overlap the next batch's launch chain (which occupies only ~W of the 256 CUs)
 // consumers over the sites kbase+j0 .. kbase+j0+ns-1 of batch p (slots j0 .. j0+ns-1 of its ring; j0, ns multiples of 8 on the skeleton path)
-static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns) {
+// what: bit 0 = the fill (and the query sweep's block summaries), on the consumer stream s2; bit 1 = everything that reads the filled states
+// (checksums, maxWithin / longWithin sweeps, pack3), on stream sr
+static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, int what = 3, hipStream_t sr = nullptr) {
+    if (!sr) sr = e->s2;
     const int *A = ringA(e, p.ring) + (size_t)j0 * e->strideA, *D = ringD(e, p.ring) + (size_t)j0 * e->strideD;
     const int kb = p.kbase + j0;
     const bool with_d = p.opts & PBWTAMD_OPT_WITH_D;
@@ -794,7 +797,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns) {
 #endif
     const unsigned consumers = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS | OPT_INTERNAL_KEEP_STATES;
     const bool packed = packed_fill(p);
-    if (p.skel && !nofill && (p.opts & consumers)) {   // the 7 states between consecutive skeleton states: all blocks and tiles in one launch
+    if ((what & 1) && p.skel && !nofill && (p.opts & consumers)) {   // the 7 states between consecutive skeleton states: all blocks and tiles in one launch
         SkFillArgs f;
         f.A = ringA(e, p.ring) + (size_t)j0 * e->strideA; f.D = ringD(e, p.ring) + (size_t)j0 * e->strideD; f.strideA = e->strideA; f.strideD = e->strideD;
         f.keys = e->keysR[p.ring] + (size_t)(j0 / 8) * e->Mpad; f.strideK = e->Mpad; f.scan = e->saveR[p.ring] + (size_t)(j0 / 8) * e->strideS; f.strideS = e->strideS;
@@ -813,27 +816,28 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns) {
 #undef FILL
         HIPCHK(hipGetLastError());
     }
-    if (e->qs_bsum[p.ring] && (p.opts & PBWTAMD_OPT_SORTED) && p.cols) {     // read side, for the query sweep: {max d, alleles present} per 256 positions of these states
+    if ((what & 1) && e->qs_bsum[p.ring] && (p.opts & PBWTAMD_OPT_SORTED) && p.cols) {     // read side, for the query sweep: {max d, alleles present} per 256 positions of these states
         hipLaunchKernelGGL(qs_blocksum_kernel, dim3((e->qs_nblk + 4 * WAVES - 1) / (4 * WAVES), ns), dim3(BLOCK), 0, e->s2, D, e->strideD,
                            (const unsigned long long *)p.cols + (size_t)j0 * e->wpc64, e->wpc64, e->M, e->qs_nblk, e->qs_bsum[p.ring] + (size_t)j0 * e->qs_nblk);
         HIPCHK(hipGetLastError());
         if (j0 == e->qs_bsum_sites[p.ring]) e->qs_bsum_sites[p.ring] = j0 + ns;
     }
+    if (!(what & 2)) return 0;
     if (p.opts & PBWTAMD_OPT_CHECKSUM) {
         unsigned long long *ca = e->csum + (kb - e->k0), *cd = ca + e->csum_sites, *cy = cd + e->csum_sites;
         dim3 grid(std::min(64, (e->M + BLOCK) / BLOCK), ns);
-        hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, e->s2, A, D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, ns);
+        hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, sr, A, D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, ns);
         HIPCHK(hipGetLastError());
     }
-    if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, e->s2, A, D, kb, ns, -1, p.opts, packed));
+    if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, sr, A, D, kb, ns, -1, p.opts, packed));
     if (p.opts & PBWTAMD_OPT_LONG_RECS) {
-        CHK(run_long(e, e->s2, A, D, nullptr, kb, ns, -1));
+        CHK(run_long(e, sr, A, D, nullptr, kb, ns, -1));
         // keep the batch's last state (before site kbase+nb-1): it is the stale allele column if the panel ends here
         if (!e->ystale) HIPCHK(dev_alloc((void **)&e->ystale, sizeof(int) * e->strideA));
-        HIPCHK(hipMemcpyAsync(e->ystale, A + (size_t)(ns - 1) * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, e->s2));
+        HIPCHK(hipMemcpyAsync(e->ystale, A + (size_t)(ns - 1) * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, sr));
     }
     static const bool no_fuse = tune_env("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
-    if (p.opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, e->s2, A, ns, !no_fuse && (p.opts & PBWTAMD_OPT_WITHIN_HIST) != 0));
+    if (p.opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, sr, A, ns, !no_fuse && (p.opts & PBWTAMD_OPT_WITHIN_HIST) != 0));
     return 0;
 }
 
@@ -847,6 +851,8 @@ static int flush_pending(pbwtamd_engine *e) {
     // evRounds: everything the consumers READ is there while the batch's last rank launch may still be waiting for the other
     // ring — not for the packed fill, which rewrites the skeleton slots' d in place (d | y << 31), the last round's input among them
     HIPCHK(hipStreamWaitEvent(e->s2, (p.early && !packed_fill(p)) ? e->evRounds[p.ring] : e->evChain[p.ring], 0));
+    // (measured, not kept: fill on s2 and sweep + pack3 on a third stream in sub-batches of 64-256 sites, so that the two run beside each other —
+    // 5.81 -> 5.97 us/site at 1 M, 1.68 -> 1.83 at 100 k: end to end is the CHAIN's time beside the consumers, not the consumers' own)
     if (p.nb > p.flushed) CHK(run_consumers(e, p, p.flushed, p.nb - p.flushed));
     HIPCHK(hipEventRecord(e->evCons[p.ring], e->s2));
     e->consRecorded[p.ring] = true;
