@@ -40,6 +40,6 @@ def test_product_does_not_import_oracle():
     for base in ("pbwt_amd", "include"):
         for dp, _, fs in os.walk(os.path.join(ROOT, base)):
             for f in fs:
-                if f.endswith((".py", ".h", ".hip", ".c", ".cpp")):
+                if f.endswith((".py", ".h", ".hip", ".inc", ".c", ".cpp")):
                     txt = open(os.path.join(dp, f)).read()
                     assert "import oracle" not in txt and "liboracle" not in txt and "orc_" not in txt, f
