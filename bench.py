@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--own-stream", action="store_true", help="let the engine create its own (high-priority) chain stream instead of torch's current stream")
     ap.add_argument("--mode", default=os.environ.get("PBWT_BENCH_MODE", "replicas"), choices=["replicas", "siteblock", "posshard"],
                     help="multi-GPU mode: independent panels per rank (weak) or one panel sharded by site blocks (strong)")
-    ap.add_argument("--panels", type=int, default=1, help="independent panels run concurrently on this GPU (throughput mode; default 1 = the named config)")
+    ap.add_argument("--panels", type=int, default=1, help="independent panels (chromosomes) advanced by the same chain launches on this GPU (pbwtamd_pass_advance_many); default 1 = the named config")
     args = ap.parse_args()
     if args.haps is None:
         args.haps = 1000000 if args.mode == "posshard" else 100000
@@ -146,6 +146,45 @@ def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=1000000,
         out["panel"] = panel
     eng.close()
     return out
+
+
+def many_panels(torch, pbwt_amd, dev, opts, kind, M, P=2, sites=32768, batch=512, step=8192):
+    """whole-genome throughput: P independent panels (chromosomes) of M haplotypes advanced by the SAME chain launches
+    (pbwtamd_pass_advance_many: grid.y = panel).  Below ~250 k haplotypes a chain launch costs its 3-4 us whatever runs inside it, so the
+    panels share that cost — until chain plus consumers fill the GPU: at 100 k haplotypes P=2 is the best point measured (1.4x one panel; P=4, 8 give
+    1.2x, chain-only 2.2x), at 10 k-25 k P=16 gives 2.5-3x.  A labelled secondary object, never `value`; every panel's output is pinned to the oracle by
+    tests/test_gpu_parity.py::test_many_panels_per_launch."""
+    shared = torch.cuda.Stream(device=dev)                  # a null stream handle would give every engine a stream of its own
+    st = shared.cuda_stream
+    engs = [pbwt_amd.Engine(M, batch_sites=batch, device=dev.index, stream=st) for _ in range(P)]
+    n_total = sites + batch
+    bufs = [torch.empty((n_total, engs[0].wpc), dtype=torch.int32, device=dev) for _ in range(P)]
+    for p in range(P):
+        engs[p].synth_device(bufs[p].data_ptr(), 0, n_total, seed=0x77AA00 + p, kind=kind)
+        engs[p].sync()
+        engs[p].pass_begin(n_total)
+    rb = engs[0].wpc * 4
+    adv = lambda k, n: pbwt_amd.pass_advance_many(engs, [b.data_ptr() + k * rb for b in bufs], n, min(n + 8, n_total - k), opts)
+    adv(0, batch)                                            # warm-up batch
+    for e in engs:
+        e.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k = batch
+    while k < n_total:
+        n = min(step, n_total - k)
+        adv(k, n)
+        k += n
+    for e in engs:
+        e.pass_end(opts)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tot = int(sum(int(e.get_hist(n_total + 1).sum()) for e in engs))
+    for e in engs:
+        e.close()
+    return {"panels": P, "haplotypes_per_panel": M, "sites_timed": sites, "value": P * M * sites / dt, "unit": "site*haps/s over all panels",
+            "us_per_site_per_panel": 1e6 * dt / sites / P, "us_per_site_all_panels": 1e6 * dt / sites, "within_reports_hist_total": tot,
+            "note": "pbwtamd_pass_advance_many: every launch of the chain covers all panels (grid.y = panel); consumers per panel"}
 
 
 def match_dynamic(torch, pbwt_amd, dev, kind, M=1000000, Q=10000, sites=65536, batch=512):
@@ -329,6 +368,9 @@ def main():
     M, S, K, Wm = args.haps, args.sites_per_step, args.steps, args.warmup
     n_total = (K + Wm) * S
     stream = torch.cuda.current_stream().cuda_stream
+    if args.panels > 1:                                     # the fused launches need every panel's engine on ONE (non-null) stream
+        shared = torch.cuda.Stream(device=dev)
+        stream = shared.cuda_stream
     eng = pbwt_amd.Engine(M, batch_sites=args.batch, device=dev.index, stream=None if args.own_stream else stream)
     wpc = eng.wpc
     # the panel, resident in HBM before the timed region (bit-packed, original haplotype order)
@@ -336,32 +378,31 @@ def main():
     unit = pdist.units_for_rank(world, rank, world)[0]      # one independent panel per rank (weak scaling)
     eng.synth_device(panel.data_ptr(), 0, n_total, seed=pdist.panel_seed(0x5EED0001, unit), kind=args.kind)
     eng.sync()
-    extra = []                                              # --panels P: P-1 more independent panels on this GPU
+    extra = []                                              # --panels P: P-1 more independent panels (chromosomes) on this GPU, same stream
     for pi in range(1, args.panels):
-        e2 = pbwt_amd.Engine(M, batch_sites=args.batch, device=dev.index)
+        e2 = pbwt_amd.Engine(M, batch_sites=args.batch, device=dev.index, stream=None if args.own_stream else stream)
         p2 = torch.empty((n_total, wpc), dtype=torch.int32, device=dev)
         e2.synth_device(p2.data_ptr(), 0, n_total, seed=pdist.panel_seed(0x5EED0001, world * pi + unit), kind=args.kind)
         e2.sync()
         extra.append((e2, p2))
+    if extra and args.own_stream:
+        raise SystemExit("--panels needs the engines on one stream (drop --own-stream)")
     opts = pbwt_amd.OPT_WITH_D
     if not args.no_within:
         opts |= pbwt_amd.OPT_WITHIN_HIST
     if not args.no_pack3:
         opts |= pbwt_amd.OPT_PACK3
     row_bytes = wpc * 4
-
-    pool = None
-    if extra:                              # one host thread per panel: launches are enqueued concurrently (ctypes drops the GIL)
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=len(extra))
+    engines = [eng] + [e2 for e2, _ in extra]
+    panels = [panel] + [p2 for _, p2 in extra]
 
     def step(i):
         k = i * S
         avail = min(S + 8, n_total - k)    # look-ahead columns: the chain's radix step spans 8 sites (2 for the two-site path)
-        futs = [pool.submit(e2.pass_advance, p2.data_ptr() + k * row_bytes, S, avail, opts) for e2, p2 in extra]
-        eng.pass_advance(panel.data_ptr() + k * row_bytes, S, avail, opts)
-        for f in futs:
-            f.result()
+        if extra:                          # ONE launch of the chain covers every panel (pbwtamd_pass_advance_many)
+            pbwt_amd.pass_advance_many(engines, [p.data_ptr() + k * row_bytes for p in panels], S, avail, opts)
+        else:
+            eng.pass_advance(panel.data_ptr() + k * row_bytes, S, avail, opts)
 
     eng.pass_begin(n_total)
     for e2, _ in extra:
@@ -428,6 +469,9 @@ def main():
     }
     if hep:
         out["host_entry_points"] = hep
+    if rank == 0 and world == 1 and not args.no_1m and args.panels == 1:
+        out["many_panels"] = many_panels(torch, pbwt_amd, dev, opts, args.kind, M)
+        out["many_panels"]["speedup_vs_one_panel"] = out["many_panels"]["value"] / out["value"]
     if rank == 0 and world == 1 and not args.no_1m:
         del panel
         torch.cuda.empty_cache()

@@ -6,6 +6,6 @@ thin ctypes binding used by the tests, bench.py and Python callers.  There is no
 importing works anywhere, but creating an Engine without a HIP device (or without the built
 library) raises.
 """
-from .api import Engine, PbwtAmdError, lib_path, load_library, wpc_for, MATCH_DTYPE  # noqa: F401
+from .api import Engine, PbwtAmdError, lib_path, load_library, wpc_for, pass_advance_many, MATCH_DTYPE  # noqa: F401
 from .api import OPT_WITH_D, OPT_SORTED, OPT_WITHIN_HIST, OPT_CHECKSUM, OPT_PACK3, OPT_WITHIN_RECS  # noqa: F401
 from .build import build_library, build_cli  # noqa: F401

@@ -60,6 +60,18 @@ def load_library():
     return _lib
 
 
+def pass_advance_many(engines, dptrs, ncols, ncols_avail, opts):
+    """advance several engines of the same width, created on the SAME stream, with fused chain launches (pbwtamd_pass_advance_many):
+    dptrs[p] = device address of panel p's bit columns"""
+    L = load_library()
+    P = len(engines)
+    hs = (C.c_void_p * P)(*[e._h for e in engines])
+    ps = (C.c_void_p * P)(*[C.c_void_p(int(d)) for d in dptrs])
+    rc = L.pbwtamd_pass_advance_many(hs, C.c_int(P), ps, C.c_int(engines[0].wpc), C.c_int(ncols), C.c_int(ncols_avail), C.c_uint(opts))
+    if rc:
+        raise PbwtAmdError(L.pbwtamd_last_error().decode())
+
+
 def wpc_for(M):
     return ((M + 31) // 32 + 3) // 4 * 4
 

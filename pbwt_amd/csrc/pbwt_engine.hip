@@ -165,6 +165,7 @@ struct pbwtamd_engine {
     hipEvent_t evChain[2] = {nullptr, nullptr}, evCons[2] = {nullptr, nullptr}; bool consRecorded[2] = {false, false}, chainRecorded[2] = {false, false};
     int2 *qs_bsum[2] = {nullptr, nullptr}; int qs_nblk = 0;   // query sweep: per ring, block summaries of every state of the batch (qs_blocksum_kernel), written by the batch's consumers
     int qs_bsum_sites[2] = {0, 0};          // ... and how many leading sites of the ring's batch they have summarised so far
+    SkArgs *margs = nullptr, *margs_host = nullptr; size_t margs_cap = 0; int margs_half = 0; hipEvent_t evMargs[2] = {nullptr, nullptr};   // pbwtamd_pass_advance_many (panel 0 owns them)
     bool persist = false;                   // small panels (two-launch regime): all rounds of a batch in ONE launch (skel_persist_kernel) — set for the query cursor of the query sweep
     SkArgs *pargs = nullptr, *pargs_host = nullptr; unsigned *pbar = nullptr; unsigned pbar_epoch = 0; int pargs_half = 0; hipEvent_t evPargs[2] = {nullptr, nullptr};
     hipEvent_t evPreKeys = nullptr;         // read side: the next skeleton batch's rank directories and keys were derived ahead of time on another stream (query sweep); wait for this event instead
@@ -250,6 +251,9 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     for (int i = 0; i < 8; ++i) if (e->evUsed[i]) (void)hipEventDestroy(e->evUsed[i]);
     for (int i = 0; i < 8; ++i) if (e->evSub[i]) (void)hipEventDestroy(e->evSub[i]);
     for (int i = 0; i < 2; ++i) if (e->evPargs[i]) (void)hipEventDestroy(e->evPargs[i]);
+    for (int i = 0; i < 2; ++i) if (e->evMargs[i]) (void)hipEventDestroy(e->evMargs[i]);
+    if (e->margs_host) (void)hipHostFree(e->margs_host);
+    if (e->margs) (void)dev_free(e->margs);
     if (e->pargs_host) (void)hipHostFree(e->pargs_host);
     if (e->pargs) (void)dev_free(e->pargs);
     if (e->pbar) (void)dev_free(e->pbar);
@@ -1164,6 +1168,112 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         }
         e->ring = r ^ 1;
         e->k_cur += nb;
+        done += nb;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- many panels per launch
+// P engines of the same width and batch, created on the SAME stream, advanced in lockstep: every chain launch covers all P panels
+// (grid.y = panel, skel_*_many_kernel).  A chain launch below ~250 k haplotypes costs its 3-4 us whatever it does, so
+// P panels — the chromosomes of one cohort — share that cost.  Consumers (fill, sweeps, pack3) stay per engine, on each engine's own
+// consumer stream.  Batches the skeleton cannot take, wide (pair-row / two-level-scan) panels and special modes fall back to one
+// pbwtamd_pass_advance per engine.
+template <int EPT>
+static void launch_round_many(pbwtamd_engine *e0, const SkArgs *dargs, int P, int W, bool two) {
+    hipStream_t st = e0->stream;
+    hipLaunchKernelGGL((skel_hist_many_kernel<EPT>), dim3(W, P), dim3(BLOCK), 0, st, dargs);
+    if (two) {
+        if (W <= 16) hipLaunchKernelGGL((skel_rank_many_kernel<EPT, 16>), dim3(W, P), dim3(BLOCK), 0, st, dargs);
+        else if (W <= 32) hipLaunchKernelGGL((skel_rank_many_kernel<EPT, 32>), dim3(W, P), dim3(BLOCK), 0, st, dargs);
+        else if (W <= 64) hipLaunchKernelGGL((skel_rank_many_kernel<EPT, 64>), dim3(W, P), dim3(BLOCK), 0, st, dargs);
+        else hipLaunchKernelGGL((skel_rank_many_kernel<EPT, SKN_MAXW>), dim3(W, P), dim3(BLOCK), 0, st, dargs);
+        return;
+    }
+    if (W <= 256) hipLaunchKernelGGL((skel_k2_many_kernel<4, 4>), dim3(SKK / 4, P), dim3(BLOCK), 0, st, dargs);
+    else hipLaunchKernelGGL((skel_k2_many_kernel<4, 16>), dim3(SKK / 4, P), dim3(BLOCK), 0, st, dargs);
+    hipLaunchKernelGGL((skel_rank_many_kernel<EPT, 0>), dim3(W, P), dim3(BLOCK), 0, st, dargs);
+}
+
+extern "C" int pbwtamd_pass_advance_many(pbwtamd_engine **es, int P, const void *const *d_bitcols, int wpc, int ncols, int ncols_avail, unsigned opts) {
+    if (P < 1 || !es || !d_bitcols) return fail("pbwtamd_pass_advance_many: no panels");
+    pbwtamd_engine *e0 = es[0];
+    HIPCHK(hipSetDevice(e0->device));
+    bool fused = P > 1 && e0->skel && !e0->prow && e0->Wt <= 1024 && !(opts & PBWTAMD_OPT_SORTED) && !e0->sh && !e0->persist && !e0->sub_rounds;
+    for (int p = 0; p < P; ++p) {
+        pbwtamd_engine *e = es[p];
+        if (!e->pass_open) return fail("pbwtamd_pass_advance_many: panel %d without pass_begin", p);
+        if (e->M != e0->M || e->B != e0->B || e->stream != e0->stream || e->device != e0->device || e->k_cur != e0->k_cur || e->n_total != e0->n_total || e->ring != e0->ring)
+            return fail("pbwtamd_pass_advance_many: panel %d differs from panel 0 in %s (same width, batch, stream, device and progress required)", p,
+                        e->M != e0->M ? "width" : e->B != e0->B ? "batch" : e->stream != e0->stream ? "stream" : e->device != e0->device ? "device" : "progress");
+        if (e->sh || e->persist || e->sub_rounds) fused = false;
+    }
+    if (wpc != e0->wpc) return fail("pbwtamd_pass_advance_many: wpc %d != engine wpc %d", wpc, e0->wpc);
+    if (e0->k_cur + ncols > e0->n_total) return fail("pbwtamd_pass_advance_many: beyond n_total");
+    if ((opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_LONG_RECS)) && !(opts & PBWTAMD_OPT_WITH_D)) return fail("pbwtamd: the maxWithin sweep needs OPT_WITH_D");
+    int done = 0;
+    while (done < ncols) {
+        const int nb = std::min(e0->B, ncols - done), left = ncols_avail - done, remaining = e0->n_total - e0->k_cur;
+        if (!fused || nb % 8 || left < std::min(nb + 8, remaining)) {           // one panel after the other for this batch
+            for (int p = 0; p < P; ++p) CHK(pbwtamd_pass_advance(es[p], (const uint32_t *)d_bitcols[p] + (size_t)done * wpc, wpc, nb, left, opts));
+            done += nb;
+            continue;
+        }
+        const int r = e0->ring, nr = nb / 8, W = e0->Wt;
+        const bool two = skel_two_launch(e0);
+        // per panel: what pbwtamd_pass_advance does in front of a skeleton batch
+        for (int p = 0; p < P; ++p) {
+            pbwtamd_engine *e = es[p];
+            e->qs_bsum_sites[r] = 0;
+            if (e->ev_used == e->ev.size()) { hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); e->ev.push_back({a, b}); }
+            HIPCHK(hipEventRecord(e->ev[e->ev_used].first, e->stream));
+            e->xT = e->xTr[r];
+            CHK(skel_prepare(e, r, (const uint32_t *)d_bitcols[p] + (size_t)done * wpc, nb, left, false));
+        }
+        // the arguments of every round and panel, uploaded once (panel 0 owns the staging: two halves, reused two batches later)
+        const size_t need = (size_t)(e0->B / 8 + 1) * (size_t)P;
+        if (e0->margs_cap < need) {
+            if (e0->margs) { HIPCHK(hipStreamSynchronize(e0->stream)); HIPCHK(dev_free(e0->margs)); HIPCHK(hipHostFree(e0->margs_host)); }
+            HIPCHK(dev_alloc((void **)&e0->margs, 2 * need * sizeof(SkArgs)));
+            HIPCHK(hipHostMalloc((void **)&e0->margs_host, 2 * need * sizeof(SkArgs), hipHostMallocDefault));
+            e0->margs_cap = need;
+            for (int i = 0; i < 2; ++i) if (!e0->evMargs[i]) HIPCHK(hipEventCreateWithFlags(&e0->evMargs[i], hipEventDisableTiming));
+        }
+        const int h = e0->margs_half; e0->margs_half ^= 1;
+        HIPCHK(hipEventSynchronize(e0->evMargs[h]));
+        SkArgs *host = e0->margs_host + (size_t)h * e0->margs_cap, *dev = e0->margs + (size_t)h * e0->margs_cap;
+        for (int s8 = 0; s8 < nr; ++s8)
+            for (int p = 0; p < P; ++p) host[(size_t)s8 * P + p] = skel_round_args(es[p], r, (const uint32_t *)d_bitcols[p] + (size_t)done * wpc, false, nb, left, s8, true);
+        HIPCHK(hipMemcpyAsync(dev, host, (size_t)nr * P * sizeof(SkArgs), hipMemcpyHostToDevice, e0->stream));
+        HIPCHK(hipEventRecord(e0->evMargs[h], e0->stream));
+        auto rounds = [&](int s_from, int s_to) -> int {
+            for (int s8 = s_from; s8 < s_to; ++s8) {
+                const SkArgs *da = dev + (size_t)s8 * P;
+                if (e0->skEPT == 1) launch_round_many<1>(e0, da, P, W, two); else if (e0->skEPT == 2) launch_round_many<2>(e0, da, P, W, two); else launch_round_many<4>(e0, da, P, W, two);
+                if (e0->thr_rounds > 0 && (s8 + 1) % e0->thr_rounds == 0) {
+                    HIPCHK(hipEventRecord(e0->tev[e0->tev_n % 16], e0->stream));
+                    if (e0->tev_n >= e0->thr_depth) HIPCHK(hipEventSynchronize(e0->tev[(e0->tev_n - e0->thr_depth) % 16]));
+                    ++e0->tev_n;
+                }
+            }
+            HIPCHK(hipGetLastError());
+            return 0;
+        };
+        CHK(rounds(0, nr - 1));
+        for (int p = 0; p < P; ++p) CHK(flush_pending(es[p]));                    // the previous batch's consumers, beside this batch's chain
+        for (int p = 0; p < P; ++p) if (es[p]->consRecorded[r ^ 1]) HIPCHK(hipStreamWaitEvent(e0->stream, es[p]->evCons[r ^ 1], 0));
+        CHK(rounds(nr - 1, nr));                                                   // scatters into slot 0 (and the key row) of every panel's other ring
+        for (int p = 0; p < P; ++p) {
+            pbwtamd_engine *e = es[p];
+            e->keys_ready[r ^ 1] = host[(size_t)(nr - 1) * P + p].has_next != 0;
+            e->prepared = false;
+            HIPCHK(hipEventRecord(e->ev[e->ev_used].second, e->stream));
+            HIPCHK(hipEventRecord(e->evChain[r], e->stream)); e->chainRecorded[r] = true;
+            ++e->ev_used; e->launches += (p == 0) ? (long long)(two ? 2 : 3) * nr : 0; e->sites_done += nb;
+            e->pend.valid = true; e->pend.ring = r; e->pend.kbase = e->k_cur; e->pend.nb = nb; e->pend.opts = opts; e->pend.skel = true; e->pend.sharded = false;
+            e->pend.early = false; e->pend.flushed = 0; e->pend.cols = (const uint32_t *)d_bitcols[p] + (size_t)done * wpc;
+            e->ring = r ^ 1; e->k_cur += nb;
+        }
         done += nb;
     }
     return 0;

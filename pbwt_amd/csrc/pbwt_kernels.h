@@ -882,7 +882,7 @@ __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) { skel_hist_
 // total[key].  grid = 256 / KPW workgroups of KPW waves.
 struct Sk2Args { const int2 *tbl; int2 *scan; int *total; int W; };
 template <int KPW, int TPL>
-__global__ __launch_bounds__(KPW * 64) void skel_k2_kernel(Sk2Args g) {
+__device__ __forceinline__ void skel_k2_body(const Sk2Args &g) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
@@ -932,6 +932,8 @@ __global__ __launch_bounds__(KPW * 64) void skel_k2_kernel(Sk2Args g) {
         g.scan[(size_t)r * SKK + key0 + kq] = s_v[kq][r + r / TPL];
     }
 }
+template <int KPW, int TPL>
+__global__ __launch_bounds__(KPW * 64) void skel_k2_kernel(Sk2Args g) { skel_k2_body<KPW, TPL>(g); }
 
 // SCAN for wide panels (more than 512 tiles): the per-key scan over the tiles in two levels inside ONE launch.
 // skel_k2_kernel reads the row-major table in 16-byte pieces of 2 KB rows (a quarter of every 64-byte sector is used) and
@@ -1357,6 +1359,21 @@ __global__ __launch_bounds__(BLOCK) void skel_persist_kernel(const SkArgs *round
         target += nwg; skel_grid_barrier(counter, target, err);          // the new state (a, d, keys) is complete
     }
 }
+
+// MANY PANELS PER LAUNCH (pbwtamd_pass_advance_many): P independent panels of the same width — chromosomes side by side — advance through the
+// same round in the same three (two) launches: blockIdx.y = panel, args[panel] = that panel's arguments for the round (device memory, the
+// whole batch uploaded at once).  Below ~250 k haplotypes a chain launch costs its 3-4 us whatever runs inside it, so P panels per launch
+// cost little more than one.
+template <int EPT>
+__global__ __launch_bounds__(BLOCK) void skel_hist_many_kernel(const SkArgs *args) { const SkArgs g = args[blockIdx.y]; skel_hist_body<EPT, false>(g); }
+template <int KPW, int TPL>
+__global__ __launch_bounds__(KPW * 64) void skel_k2_many_kernel(const SkArgs *args) {
+    const SkArgs g = args[blockIdx.y];
+    Sk2Args k; k.tbl = g.tbl; k.scan = g.scan; k.total = g.total; k.W = g.W;
+    skel_k2_body<KPW, TPL>(k);
+}
+template <int EPT, int TR>
+__global__ __launch_bounds__(BLOCK) void skel_rank_many_kernel(const SkArgs *args) { const SkArgs g = args[blockIdx.y]; skel_rank_body<EPT, TR, false, false>(g, nullptr); }
 
 // READ SIDE: the columns arrive in PBWT order (y_k by position), so the 8-bit key of position i of the
 // state before site k follows the LF-mapping through the 8 columns: bit j = y_{k+j}[p_j], p_0 = i,

@@ -481,6 +481,39 @@ def test_match_sweep_long_walks_block_skipping(amd, orc, Mp, Mq, N, rare, nS, ba
         assert np.array_equal(o["r"], got) and int(o["n"]) == gn and np.array_equal(o["ev"], ev)
 
 
+@pytest.mark.parametrize("P,M,N,B", [(3, 5000, 602, 256), (4, 30000, 520, 256), (2, 100000, 264, 128), (2, 600100, 24, 8)])
+def test_many_panels_per_launch(amd, orc, P, M, N, B):
+    """pbwtamd_pass_advance_many: P independent panels (chromosomes) of one width advance through fused chain launches (grid.y = panel;
+    two launches per round at 5 000 haplotypes, three at 30 000 / 100 000; the 600 100-wide case and the ragged tails take the per-engine
+    fallback).  Every panel's .pbwt bytes, final a / d and -stats histogram equal the oracle's for that panel alone."""
+    import torch
+    st = torch.cuda.Stream()
+    engs = [amd.Engine(M, batch_sites=B, stream=st.cuda_stream) for _ in range(P)]
+    bufs = [torch.zeros((N, engs[0].wpc), dtype=torch.int32, device="cuda") for _ in range(P)]
+    torch.cuda.synchronize()
+    for p in range(P):
+        engs[p].synth_device(bufs[p].data_ptr(), 0, N, seed=900 + 17 * p + M, kind=p % 2)
+        engs[p].sync()
+    opts = amd.OPT_WITH_D | amd.OPT_WITHIN_HIST | amd.OPT_PACK3
+    for e in engs:
+        e.pass_begin(N)
+    step = 8 * ((B + 40) // 8)                              # not a multiple of the batch: full and partial batches in one call
+    k = 0
+    while k < N:
+        n = min(step, N - k)
+        amd.pass_advance_many(engs, [b.data_ptr() + k * engs[0].wpc * 4 for b in bufs], n, min(n + 8, N - k), opts)
+        k += n
+    for p in range(P):
+        engs[p].pass_end(opts)
+        bits = bufs[p].cpu().numpy().view(np.uint32)
+        o = orc.build_bitcols(bits, M, with_d=True)
+        a, d = engs[p].get_state()
+        assert np.array_equal(a, o["aFend"]) and np.array_equal(d, o["d_final"]), p
+        assert np.array_equal(engs[p].get_packed(), o["yz"]), p
+        if M <= 100000:
+            assert np.array_equal(engs[p].get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1]), p
+
+
 def test_match_sweep_sparse_golden_and_no_match_branch(amd, orc):
     """records captured from the reference itself (tests/golden/sparse_sweep.npz), incl. sites where no panel
     haplotype carries the query's allele; and nSparse larger than the batch is refused"""
