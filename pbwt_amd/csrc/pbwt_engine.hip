@@ -128,6 +128,9 @@ constexpr int QS_QUERIES_PER_WAVE = 1;     // queries a wave of the query sweep 
 constexpr int QS_SWEEP_CUS = 0;           // CUs the query sweep's stream is confined to (0: all) — see pbwtamd_match_sweep_sparse
 // internal option: the caller reads the ring slots of the batch itself (forces the fill on the skeleton path)
 constexpr unsigned OPT_INTERNAL_KEEP_STATES = 0x100u;
+// internal option, with KEEP_STATES on a skeleton batch: the caller reads d of every slot but a[] only at the skeleton slots (0, 8, ...) — the fill
+// neither reads nor writes a (half its bytes); the query sweep recovers the few ids it reports from the next skeleton state
+constexpr unsigned OPT_INTERNAL_D_ONLY = 0x200u;
 
 struct GraphKey { int with_d, sorted, ring, pair; hipGraphExec_t exec; };
 struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; bool skel = false; bool sharded = false; bool early = false; int flushed = 0; /* leading sites whose consumers are enqueued already */ const uint32_t *cols = nullptr; /* the batch's bit columns */ };
@@ -198,6 +201,7 @@ struct pbwtamd_engine {
     std::vector<GraphKey> graphs; bool use_graph = true; bool lean = true; bool pair = true;
     bool pair1024 = false;
     bool skn = true;                        // skeleton rounds of two launches (hist, rank) when the panel has <= 128 tiles of 1024; PBWTAMD_SKN=0: K1/K2/K3
+    bool ring_skel[2] = {false, false};     // the batch last advanced in each ring went through the skeleton path (its slots 1..7 mod 8 come from the fill)
     bool skel = true;                       // skeleton + fill (8 sites per round of K1/K2/K3 on the chain, the 7 states between filled beside it); PBWTAMD_SKEL=0: two-site chain
     uint32_t *xT = nullptr; size_t strideX = 0; int xTblocks = 0;   // transposed panel of the batch in flight (= xTr[ring])
     uint32_t *xTr[2] = {nullptr, nullptr}; // one per ring: the fill of batch n reads it while the chain transposes batch n+1
@@ -814,8 +818,10 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
         f.pair = e->prow ? 1 : 0; f.W2 = e->W2;
         dim3 grid(e->Wt, ns / 8);
         static const size_t dyn = tune_env("PBWTAMD_FILL_PAD_KB") ? (size_t)atoi(tune_env("PBWTAMD_FILL_PAD_KB")) * 1024 : 0;   // occupancy probe (results unchanged)
-#define FILL(EP) do { if (packed) hipLaunchKernelGGL((skel_fill_kernel<EP, true>), grid, dim3(BLOCK), dyn, e->s2, f); \
-                      else hipLaunchKernelGGL((skel_fill_kernel<EP, false>), grid, dim3(BLOCK), dyn, e->s2, f); } while (0)
+        const bool d_only = !packed && (p.opts & OPT_INTERNAL_D_ONLY);
+#define FILL(EP) do { if (packed) hipLaunchKernelGGL((skel_fill_kernel<EP, 1>), grid, dim3(BLOCK), dyn, e->s2, f); \
+                      else if (d_only) hipLaunchKernelGGL((skel_fill_kernel<EP, 2>), grid, dim3(BLOCK), dyn, e->s2, f); \
+                      else hipLaunchKernelGGL((skel_fill_kernel<EP, 0>), grid, dim3(BLOCK), dyn, e->s2, f); } while (0)
         if (e->skEPT == 1) FILL(1); else if (e->skEPT == 2) FILL(2); else FILL(4);
 #undef FILL
         HIPCHK(hipGetLastError());
@@ -1166,6 +1172,7 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         if (skel || (opts & (PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS))) {
             e->pend.valid = true; e->pend.ring = r; e->pend.kbase = e->k_cur; e->pend.nb = nb; e->pend.opts = opts; e->pend.skel = skel; e->pend.sharded = false; e->pend.early = early; e->pend.flushed = flushed_sites; e->pend.cols = bc;
         }
+        e->ring_skel[r] = skel;
         e->ring = r ^ 1;
         e->k_cur += nb;
         done += nb;
@@ -1889,11 +1896,11 @@ extern "C" int pbwtamd_match_sweep(pbwtamd_engine *e, const uint8_t *pz, int64_t
     }
     pbwtamd_match5 *r5 = nullptr; int64_t n5 = 0;
     CHK(pbwtamd_match_sweep_sparse(e, pz, pnz, N, pStart, Mq, qz, qnz, qStart, 0, nullptr, &r5, &n5, n_nomatch, tot_out));
-    pbwtamd_match *buf = (pbwtamd_match *)malloc(std::max<size_t>(1, (size_t)n5) * sizeof(pbwtamd_match));
-    if (!buf) { free(r5); return fail("pbwtamd_match_sweep: out of host memory"); }
-    for (int64_t i = 0; i < n5; ++i) { buf[i].ai = r5[i].ai; buf[i].bi = r5[i].bi; buf[i].start = r5[i].start; buf[i].end = r5[i].end; }
-    free(r5);
-    *recs_out = buf; *nrecs_out = n5;
+    // five fields to four in place: record i ends at byte 16 i + 16 <= 20 (i + 1), where record i + 1 of the source starts
+    unsigned char *raw = (unsigned char *)r5;
+    for (int64_t i = 0; i < n5; ++i) { pbwtamd_match5 v; memcpy(&v, raw + 20 * i, sizeof v); const pbwtamd_match m = {v.ai, v.bi, v.start, v.end}; memcpy(raw + 16 * i, &m, sizeof m); }
+    static_assert(sizeof(pbwtamd_match5) == 20 && sizeof(pbwtamd_match) == 16, "record layouts");
+    *recs_out = (pbwtamd_match *)raw; *nrecs_out = n5;
     return 0;
 }
 
@@ -1926,6 +1933,8 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
                                           int64_t *n_nomatch, int64_t *tot_out) {
     HIPCHK(hipSetDevice(e->device));
     if ((report ? 1 : 0) + (recs_out ? 1 : 0) != 1) return fail("pbwtamd_match_sweep_sparse: exactly one of report / recs_out must be given");
+    auto wall = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+    const double tw0 = wall(); double tw1 = tw0, tw2 = tw0, tw3 = tw0, tw4 = tw0;
     const int nS = nSparse > 1 ? nSparse : 0;
     const int Mp = e->M, wpc = e->wpc, wpc64 = e->wpc64;
     if (nS > e->B) return fail("pbwtamd_match_sweep_sparse: nSparse %d exceeds the engine's batch of %d sites", nSparse, e->B);
@@ -1949,8 +1958,10 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     for (int kk = 0; kk < nS; ++kk) { CHK(pbwtamd_engine_create(&es[kk], e->device, Mp, Bs + 1, nullptr)); guard.v.push_back(es[kk]); }
     DevBufs bufs;
     Packed pk, qk;
+    tw1 = wall();
     CHK(packed_upload(e, e->stream, Mp, pz, pnz, N, pk));
     CHK(packed_upload(eq, eq->stream, Mq, qz, qnz, N, qk));
+    tw2 = wall();
     // ---- phase A: original-order bit columns of the whole panel ----
     uint32_t *orig = nullptr;
     if (nS) {
@@ -2044,7 +2055,9 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     HIPCHK(hipMemsetAsync(dss[0], 0, sizeof(int) * (size_t)2 * std::max(nS, 1) * Mq, st));
     HIPCHK(hipMemsetAsync(tot, 0, 4 * sizeof(unsigned long long), st));
     HIPCHK(hipMemsetAsync(nm_n, 0, sizeof(unsigned), st));
-    std::vector<pbwtamd_match5> all;
+    // the records on the host: ONE malloc'ed buffer that grows geometrically and is handed to the caller as it is (recs_out; pbwtamd_free) —
+    // at 10^7 records a std::vector cost a zero-fill per growth and a copy out at the end
+    struct HostRecs { pbwtamd_match5 *p = nullptr; size_t n = 0, cap = 0; ~HostRecs() { free(p); } } all;
     auto ensure_recs = [&](size_t total) -> int {
         if (total <= recsCap) return 0;
         recsCap = total + total / 4 + 1024;
@@ -2052,11 +2065,17 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     };
     auto deliver = [&](size_t total) -> int {
         if (!total) return 0;
-        const size_t old = all.size();
-        all.resize(old + total);
-        HIPCHK(hipMemcpyAsync(all.data() + old, recs, total * sizeof(Rec5), hipMemcpyDeviceToHost, st));
+        const size_t old = all.n;
+        if (old + total > all.cap) {
+            const size_t cap = std::max(old + total, all.cap + all.cap / 2 + 4096);
+            pbwtamd_match5 *q = (pbwtamd_match5 *)realloc(all.p, cap * sizeof(pbwtamd_match5));
+            if (!q) return fail("pbwtamd_match_sweep_sparse: out of host memory");
+            all.p = q; all.cap = cap;
+        }
+        HIPCHK(hipMemcpyAsync(all.p + old, recs, total * sizeof(Rec5), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (report) { for (size_t r = old; r < old + total; ++r) report(all[r].ai, all[r].bi, all[r].start, all[r].end, all[r].sparse); all.resize(old); }
+        all.n = old + total;
+        if (report) { for (size_t r = old; r < old + total; ++r) report(all.p[r].ai, all.p[r].bi, all.p[r].start, all.p[r].end, all.p[r].sparse); all.n = old; }
         return 0;
     };
     unsigned long long *h_total = nullptr; hipEvent_t evTotal = nullptr;      // the batch's record count comes back through pinned memory + an event
@@ -2087,7 +2106,12 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     struct PreGuard { hipStream_t s; hipEvent_t *ev; pbwtamd_engine *p; ~PreGuard() { p->evPreKeys = nullptr; if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } for (int i = 0; i < 2; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]); } } preGuard{pre, evPre, e};
     int *rdPre = nullptr; CHK(bufs.alloc(&rdPre, (size_t)(e->B + 2) * (wpc64 + 1)));
     static const bool qs_prefetch = !(tune_env("PBWTAMD_QS_PREFETCH") && !atoi(tune_env("PBWTAMD_QS_PREFETCH")));
-    auto stage_half = [&](int at) -> uint32_t * { return e->cols_stage + (size_t)((at / Bd) & 1) * ((size_t)e->B + 8) * wpc; };
+    // three staging slots in rotation: batch b's columns are read by the sweep and the emission pass of batch b (this loop's iteration b, which
+    // ends with the host waiting for both), by the chain + fill of batch b (enqueued in iteration b-1), and written by the prefetch enqueued in
+    // iteration b-2 — the slot's previous tenant, batch b-3, was finished with in iteration b-3.  (Two halves needed a 64 MB copy per batch at
+    // M = 1 M to keep the sweep's columns alive: 0.1-0.6 ms of a 6.6 ms batch beside the other kernels.)
+    uint32_t *stage_extra = nullptr; CHK(bufs.alloc(&stage_extra, ((size_t)e->B + 8) * wpc));
+    auto stage_half = [&](int at) -> uint32_t * { const int sl = (at / Bd) % 3; return sl == 2 ? stage_extra : e->cols_stage + (size_t)sl * ((size_t)e->B + 8) * wpc; };
     int pre_at = -1;                                       // the batch whose columns + keys are prepared (or being prepared) on `pre`
     // prepare the batch starting at `at`, which will run in ring `ring`: decode + rank directories + keys of every round
     auto prefetch = [&](int at, int ring) -> int {
@@ -2105,6 +2129,8 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         pre_at = at;
         return 0;
     };
+    // the panel's fill writes d only; the ids of reported positions come from the next skeleton state (qss_emit_kernel)
+    static const bool qs_lazy_ids = !(tune_env("PBWTAMD_QS_LAZY_IDS") && !atoi(tune_env("PBWTAMD_QS_LAZY_IDS")));
     auto enqueue_chains = [&](int at) -> int {
         const int nb = std::min(Bd, N - at);
         const int navail = std::min(nb + 1, N - at);
@@ -2115,7 +2141,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         // only start when the host gets there, near the END of the panel's chain (measured: 3.3 ms into a 5 ms batch)
         CHK(packed_expand(eq, eq->stream, qk, Mq, at, navail, (unsigned long long *)eq->cols_stage, eq->wpc64));
         CHK(pbwtamd_pass_advance(eq, eq->cols_stage, eq->wpc, nb, navail, PBWTAMD_OPT_SORTED | OPT_INTERNAL_KEEP_STATES));
-        CHK(pbwtamd_pass_advance(e, stage, wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES));
+        CHK(pbwtamd_pass_advance(e, stage, wpc, nb, navail, PBWTAMD_OPT_SORTED | PBWTAMD_OPT_WITH_D | OPT_INTERNAL_KEEP_STATES | (qs_lazy_ids ? OPT_INTERNAL_D_ONLY : 0u)));
         e->evPreKeys = nullptr;
         for (int kk = 0; kk < nS; ++kk) {                  // the sparse cursors' steps that fall into this batch
             const int ns = nb > kk ? (nb - kk + nS - 1) / nS : 0;
@@ -2129,6 +2155,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         }
         return 0;
     };
+    tw3 = wall();
     if (N > 0) CHK(enqueue_chains(0));
     if (N > Bd) CHK(prefetch(Bd, 1));
     for (int done = 0; done < N;) {
@@ -2140,15 +2167,16 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         CHK(pbwtamd_sync(eq));
         lap(1);
         const int *A = ringA(e, e->ring ^ 1), *D = ringD(e, e->ring ^ 1), *AQ = ringA(eq, eq->ring ^ 1);
-        // the panel's sorted bit columns of this batch are the decoded input columns themselves (read side): a copy out of the
-        // staging buffer (the next batch's decode overwrites it) instead of a pass over the tags of A
-        HIPCHK(hipMemcpyAsync(e->ycols, stage_half(done), (size_t)nb * wpc64 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipEventRecord(evCols, st));                  // the next batch's decode (chain stream) must not overwrite the staging buffer before this copy has read it
-        hipLaunchKernelGGL(qs_rankdir_kernel, dim3(nb), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, wpc64, Mp, rankdir);
+        const bool lazy = qs_lazy_ids && e->ring_skel[e->ring ^ 1];   // this batch's slots 1..7 mod 8 hold no ids
+        const int *Anext = ringA(e, e->ring);                // the state after the batch's last site (written by the batch's last launch; the next writer is the chain two batches on, which waits for this stream)
+        // the panel's sorted bit columns of this batch are the decoded input columns themselves (read side), read where the decode left them
+        const unsigned long long *ycB = (const unsigned long long *)stage_half(done);
+        HIPCHK(hipEventRecord(evCols, st));
+        hipLaunchKernelGGL(qs_rankdir_kernel, dim3(nb), dim3(BLOCK), 0, st, ycB, wpc64, Mp, rankdir);
         if (bsumP[0]) {                                     // states the batch's consumers did not summarise (batches outside the skeleton path run no consumers for this option set)
             const int rr = e->ring ^ 1, have = std::min(e->qs_bsum_sites[rr], nb);
             if (have < nb) hipLaunchKernelGGL(qs_blocksum_kernel, dim3((nblk + 4 * WAVES - 1) / (4 * WAVES), nb - have), dim3(BLOCK), 0, st, D + (size_t)have * e->strideD, e->strideD,
-                                              (const unsigned long long *)e->ycols + (size_t)have * wpc64, wpc64, Mp, nblk, bsumP[rr] + (size_t)have * nblk);
+                                              ycB + (size_t)have * wpc64, wpc64, Mp, nblk, bsumP[rr] + (size_t)have * nblk);
         }
         hipLaunchKernelGGL(qs_unsort_kernel, dim3(std::min(qblocks, 64), nb), dim3(BLOCK), 0, st, AQ, eq->strideA, Mq, xq, invq);
         for (int kk = 0; kk < nS; ++kk) {
@@ -2169,7 +2197,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         QssArgs g;
         HIPCHK(hipMemcpyAsync(a0P, A, sizeof(int) * (size_t)Mp, hipMemcpyDeviceToDevice, st));
         HIPCHK(hipMemcpyAsync(a0Q, AQ, sizeof(int) * (size_t)Mq, hipMemcpyDeviceToDevice, st));
-        g.dense = QsView{A, D, e->strideA, e->strideD, e->ycols, rankdir, 0, a0P, bsumP[e->ring ^ 1], nblk}; g.sparse = dviews; g.wpc64 = wpc64; g.nS = nS;
+        g.dense = QsView{A, D, e->strideA, e->strideD, ycB, rankdir, 0, a0P, bsumP[e->ring ^ 1], nblk}; g.sparse = dviews; g.wpc64 = wpc64; g.nS = nS;
         g.xq = xq; g.invq = invq; g.Mp = Mp; g.Mq = Mq; g.kbase = done; g.nsites = nb;
         g.f_in = fst[cur]; g.dq_in = dst[cur]; g.f_out = fst[cur ^ 1]; g.dq_out = dst[cur ^ 1];
         g.fs_in = fss[cur]; g.ds_in = dss[cur]; g.fs_out = fss[cur ^ 1]; g.ds_out = dss[cur ^ 1];
@@ -2213,6 +2241,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
             em.off = cnt; em.total = tot + 3; em.evt = evt; em.nslots = 2 * (size_t)nb * Mq;
             em.dense = g.dense; em.sparse = dviews; em.nS = std::max(nS, 1);
             em.AQ = AQ; em.strideAQ = eq->strideA; em.AQ0 = a0Q; em.Mq = Mq; em.kbase = done; em.recs = recs; em.emit_rank = e->q_part ? 1 : 0;
+            em.lazy = lazy ? 1 : 0; em.nsites = nb; em.wpc64 = wpc64; em.Anext = Anext;
             const size_t ewaves = (em.nslots + 63) / 64;
             hipLaunchKernelGGL(qss_emit_kernel, dim3((unsigned)((ewaves + WAVES - 1) / WAVES)), dim3(BLOCK), 0, st, em);
             HIPCHK(hipGetLastError());
@@ -2222,6 +2251,8 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         cur ^= 1;
         done += nb;
     }
+    tw4 = wall();
+    if (trace_qs) fprintf(stderr, "pbwt_amd query sweep outside the loop (s): engines %.4f  upload of the packed panels %.4f  buffers + phase A %.4f  loop %.4f\n", tw1 - tw0, tw2 - tw1, tw3 - tw2, tw4 - tw3);
     if (trace_qs) fprintf(stderr, "pbwt_amd query sweep host phases (s): enqueue chains %.4f  wait chains+fill %.4f  enqueue sweep %.4f  wait count %.4f  emit+deliver %.4f\n", tph[0], tph[1], tph[2], tph[3], tph[4]);
     // ---- matches still open at N: the panel cursor for every query, then each sparse cursor in turn (pbwtMatch.c:577-594) ----
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -2268,10 +2299,10 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     CHK(pbwtamd_pass_end(eq, 0));
     for (int kk = 0; kk < nS; ++kk) CHK(pbwtamd_pass_end(es[kk], 0));
     if (recs_out) {
-        pbwtamd_match5 *buf = (pbwtamd_match5 *)malloc(std::max<size_t>(1, all.size()) * sizeof(pbwtamd_match5));
-        if (!buf) return fail("pbwtamd_match_sweep_sparse: out of host memory");
-        if (!all.empty()) memcpy(buf, all.data(), all.size() * sizeof(pbwtamd_match5));
-        *recs_out = buf; *nrecs_out = (int64_t)all.size();
+        if (!all.p && !(all.p = (pbwtamd_match5 *)malloc(sizeof(pbwtamd_match5)))) return fail("pbwtamd_match_sweep_sparse: out of host memory");
+        *recs_out = all.p; *nrecs_out = (int64_t)all.n;
+        all.p = nullptr;                                    // the caller's now
     }
+    if (trace_qs) fprintf(stderr, "pbwt_amd query sweep after the loop (s): tails + pass_end + copy out %.4f; whole call %.4f\n", wall() - tw4, wall() - tw0);
     return 0;
 }

@@ -1430,8 +1430,10 @@ struct SkFillArgs {
     int pair, W2;                                           // pair rows: scan[W2][256], total, then the first halves' rows tbl0[W2][256] per round
 };
 
-// PACKY: the consumers need (d, y) of every site but not the haplotype ids — a[] is neither read nor written
-template <int EPT, bool PACKY>
+// PACKY 1: the consumers need (d, y) of every site but not the haplotype ids — a[] is neither read nor written, slots hold d | y << 31
+// PACKY 2: d only, plain (the query sweep: y comes from the decoded columns, the ids of the few reported positions are recovered from the
+//          next skeleton state by qss_emit_kernel) — a[] neither read nor written, the skeleton slots left as they are
+template <int EPT, int PACKY>
 __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     constexpr int T = BLOCK * EPT, NC = EPT * WAVES;
     // Range maxima of d_k through a RADIX-4 sparse table: level e holds max d over (i - 4^e, i], windows 1, 4, 16, 64 (, 256): a
@@ -1467,7 +1469,7 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
         av[r] = PACKY ? 0 : (a_in[i] & AMASK); key[r] = valid ? (int)keys[i] : -1;
         const int dv = valid ? d_in[i] : 0;
         s_tbl01[0][l] = dv;
-        if (PACKY && valid) d_in[i] = dv | (int)(((unsigned)key[r] & 1u) << 31);   // the skeleton slot itself, in the packed form of the other seven
+        if (PACKY == 1 && valid) d_in[i] = dv | (int)(((unsigned)key[r] & 1u) << 31);   // the skeleton slot itself, in the packed form of the other seven
     }
     {
         const int nrow = g.pair ? g.W2 : g.W;
@@ -1595,7 +1597,8 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
 #endif
             const int yb = (int)(((unsigned)(key[r] >> j) & 1u) << 31);
             // streamed once by the consumers: non-temporal, so the chain's working set stays in L2 (measured +1 %)
-            if (PACKY) __builtin_nontemporal_store(dd | yb, d_out + pos);
+            if (PACKY == 1) __builtin_nontemporal_store(dd | yb, d_out + pos);
+            else if (PACKY == 2) __builtin_nontemporal_store(dd, d_out + pos);
             else { __builtin_nontemporal_store(av[r] | yb, a_out + pos); __builtin_nontemporal_store(dd, d_out + pos); }
         }
         if (w == g.W - 1 && t == 0) d_out[g.M] = k + j + 1;
@@ -3233,6 +3236,10 @@ struct QssEmitArgs {
     const int *AQ; size_t strideAQ; const int *AQ0;              // query cursor: position r of site s holds the query index (AQ0: copy of row 0, see QsView::A0)
     int Mq, kbase;
     Rec5 *recs;
+    // lazy ids (dense cursor): the batch's fill wrote d only (skel_fill_kernel<., 2>); a[] exists at the skeleton slots 0, 8, 16, ... and at
+    // slot 0 of the other ring (Anext = the state after the batch's last site).  The id at position p of slot s = 8b + j is the id at
+    // LF^(8-j)(p) of slot 8(b+1): <= 7 steps of pbwtCursorMap (pbwt.h:130-131) through the batch's own columns and rank directories
+    int lazy, nsites, wpc64; const int *Anext;
     int emit_rank;                                           // query sharding: the query's rank r in the query panel's order at the site goes into sparse >> 1 (the merge key)
 };
 __global__ __launch_bounds__(BLOCK) void qss_emit_kernel(QssEmitArgs g) {
@@ -3255,7 +3262,18 @@ __global__ __launch_bounds__(BLOCK) void qss_emit_kernel(QssEmitArgs g) {
         const int *a;
         if (sparse) { const QsView v = g.sparse[k % g.nS]; const int t = k / g.nS - v.sbase; a = t ? v.A + (size_t)t * v.strideA : v.A0; }
         else a = s ? g.dense.A + (size_t)s * g.dense.strideA : g.dense.A0;
-        for (int i = lane; i < cntN; i += 64) { Rec5 rr; rr.ai = jj; rr.bi = a[ev.x + i] & AMASK; rr.start = ev.y; rr.end = k; rr.sparse = sparse | (g.emit_rank ? (r << 1) : 0); g.recs[o0 + i] = rr; }
+        int s8 = s;                                          // the slot the ids are read from
+        if (!sparse && g.lazy && (s & 7)) { s8 = (s | 7) + 1; a = (s8 < g.nsites) ? g.dense.A + (size_t)s8 * g.dense.strideA : g.Anext; }
+        for (int i = lane; i < cntN; i += 64) {
+            int p = ev.x + i;
+            for (int t = s; t < s8; ++t) {
+                const unsigned long long wdv = g.dense.ycols[(size_t)t * g.wpc64 + (p >> 6)];
+                const int *rd = g.dense.rankdir + (size_t)t * (g.wpc64 + 1);
+                const int up = rd[p >> 6] + ((p & 63) - __popcll(wdv & ((1ULL << (p & 63)) - 1ULL)));
+                p = ((wdv >> (p & 63)) & 1ULL) ? rd[g.wpc64] + p - up : up;
+            }
+            Rec5 rr; rr.ai = jj; rr.bi = a[p] & AMASK; rr.start = ev.y; rr.end = k; rr.sparse = sparse | (g.emit_rank ? (r << 1) : 0); g.recs[o0 + i] = rr;
+        }
     }
 }
 
