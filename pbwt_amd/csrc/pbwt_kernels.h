@@ -2246,6 +2246,9 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
         }
         mPendUp |= __ballot(pendUp[c]); mPendDn |= __ballot(pendDn[c]);
     }
+#ifdef PBWTAMD_MEASURE
+    if (g.dbg >= 2) mPendUp = mPendDn = 0;                   // measurement (results WRONG): no scans beyond the first step
+#endif
     if (mPendUp) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
