@@ -26,6 +26,14 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/shard_t
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out/wide_tl -o wide -- python tools/wide_bench.py 1000000 4096 hp > $out/wide_tl.log 2>&1
 { grep "us/site" $out/wide_tl.log; python tools/trace_overlap.py $out/wide_tl/wide_kernel_trace.csv; echo; python tools/trace_timeline.py $out/wide_tl/wide_kernel_trace.csv | tail -24; } > $out/overlap.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/wide_alone -o wide -- python tools/wide_bench.py 1000000 4096 none > $out/wide_alone.log 2>&1
-rm -f $out/*/*_kernel_trace.csv
+# -matchDynamic: what runs beside what in the steady loop (10 batches before the last sweep launch)
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out/qs_tl -o qs -- python tools/qsweep_bench.py 1000000 10000 8192 > $out/qs_tl.log 2>&1 < /dev/null
+{ grep matchDynamic $out/qs_tl.log; python tools/trace_busy.py $(find $out/qs_tl -name "*kernel_trace.csv" | head -1) @qss_sweep 10; } > $out/matchdynamic_busy.txt 2>&1
+# what the consumers cost at the north-star width: the measurement build (wrong results) with the fill, its stores, the sweep's walks switched off
+if [ -f pbwt_amd/libpbwtgpu_measure.so ]; then
+  { for env in "X=1" "PBWTAMD_NOFILL=1" "PBWTAMD_DEBUG_FILL_NOWRITE=1" "PBWTAMD_DEBUG_SWEEP=2"; do echo "$env"; env PBWTAMD_LIB=$PWD/pbwt_amd/libpbwtgpu_measure.so $env timeout 200 python tools/wide_bench.py 1000000 8192 hp 2>&1 | tail -1; done
+    echo "chain alone"; timeout 200 python tools/wide_bench.py 1000000 8192 none 2>&1 | tail -1; } > $out/consumer_pricing.txt 2>&1
+fi
+rm -f $out/*/*_kernel_trace.csv $out/*/*/*_kernel_trace.csv
 find $out -name "*.csv" | head -40
 du -sh $out

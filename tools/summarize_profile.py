@@ -24,8 +24,9 @@ copy_stats("wide_trace", "wide", tag + "_wide_kernel_stats.csv")        # tools/
 copy_stats("qs_trace", "qs", tag + "_matchdynamic_kernel_stats.csv")    # tools/qsweep_bench.py 1000000 10000 4096
 copy_stats("wide_alone", "wide", tag + "_wide_chain_alone_kernel_stats.csv")   # tools/wide_bench.py 1000000 4096 none
 copy_stats("shard_trace", "shard", tag + "_posshard_1rank_kernel_stats.csv")   # bench.py --mode posshard --haps 1000000 --steps 1 (one rank)
-if os.path.exists(os.path.join(src, "overlap.txt")):
-    shutil.copy(os.path.join(src, "overlap.txt"), os.path.join("profiles", tag + "_overlap.txt"))
+for extra in ("overlap.txt", "matchdynamic_busy.txt", "consumer_pricing.txt"):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join("profiles", tag + "_" + extra))
 
 
 def agg(path):
