@@ -811,7 +811,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
         f.keys = e->keysR[p.ring] + (size_t)(j0 / 8) * e->Mpad; f.strideK = e->Mpad; f.scan = e->saveR[p.ring] + (size_t)(j0 / 8) * e->strideS; f.strideS = e->strideS;
         f.M = e->M; f.W = e->Wt; f.kbase = kb;
 #ifdef PBWTAMD_MEASURE
-        static const int dbg_nowrite = getenv("PBWTAMD_DEBUG_FILL_NOWRITE") ? 1 : 0; f.dbg_nowrite = dbg_nowrite;
+        static const int dbg_nowrite = getenv("PBWTAMD_DEBUG_FILL_NOWRITE") ? std::max(1, atoi(getenv("PBWTAMD_DEBUG_FILL_NOWRITE"))) : 0; f.dbg_nowrite = dbg_nowrite;
 #endif
         f.pack_y = packed ? 1 : 0;
         f.xcd = xcd_flags() & 1;

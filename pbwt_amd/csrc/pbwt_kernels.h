@@ -1593,7 +1593,8 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
             const int pos = s_GH[h] + s_bH[h] + rank;
             if (pos == 0) dd = k + j + 1;
 #ifdef PBWTAMD_MEASURE
-            if (g.dbg_nowrite && pos >= 0) continue;
+            if (g.dbg_nowrite == 1 && pos >= 0) continue;
+            if (g.dbg_nowrite == 2) { __builtin_nontemporal_store(dd, d_out + S + l); continue; }   // same bytes, coalesced, WRONG place: what the scatter itself costs
 #endif
             const int yb = (int)(((unsigned)(key[r] >> j) & 1u) << 31);
             // streamed once by the consumers: non-temporal, so the chain's working set stays in L2 (measured +1 %)
