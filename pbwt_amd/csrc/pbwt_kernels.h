@@ -1445,12 +1445,14 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     // heap layout: level j (keys of j bits) lives at [2^j, 2^(j+1)); levels 1..7 in s_rawH / s_lastH, the rank kernel's level 8 in s_raw8 / s_last8
     __shared__ short s_rawH[NC][SKK], s_lastH[NC][SKK];      // per chunk: count / last local position (-1) -> base / previous position (exclusive over the chunks)
     constexpr int UBYTES = (2 * NC * SKK * 2 > (NL4 - 2) * T * 4) ? 2 * NC * SKK * 2 : (NL4 - 2) * T * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char s_u[UBYTES];
+    // ONE array: sparse levels 0, 1, then the shared storage — level lv starts at lv * T words whatever lv is (no select per query)
+    __shared__ __attribute__((aligned(16))) unsigned char s_tb[2 * T * 4 + UBYTES];
+    unsigned char *const s_u = s_tb + 2 * T * 4;
     short (*const s_raw8)[SKK] = reinterpret_cast<short (*)[SKK]>(s_u);                      // until fold step 1
     short (*const s_last8)[SKK] = reinterpret_cast<short (*)[SKK]>(s_u + NC * SKK * 2);
-    int (*const s_tblU)[T] = reinterpret_cast<int (*)[T]>(s_u);                              // sparse levels 2 .. NL4-1, from step 2 on
-    __shared__ int s_tbl01[2][T];                                                            // sparse levels 0, 1
-    auto TBL = [&](int lv) -> int * { return lv < 2 ? s_tbl01[lv] : s_tblU[lv - 2]; };
+    int (*const s_tbl01)[T] = reinterpret_cast<int (*)[T]>(s_tb);                            // sparse levels 0, 1; levels 2 .. NL4-1 (from step 2 on) follow in s_u
+    auto TBL = [&](int lv) -> int * { return reinterpret_cast<int *>(s_tb) + lv * T; };
+    constexpr int EFLAG = 0x40000000;                        // s_cH[h] after level_scan: carry | EFLAG (max with the range maximum) or the final value
     __shared__ int s_bH[2 * SKK], s_cH[2 * SKK], s_tH[2 * SKK];
     int *const s_GH = &s_bH[SKK], *const s_lowH = &s_cH[SKK];   // the level-8 halves are dead once level 7 is folded
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
@@ -1560,7 +1562,13 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
                 const int v = (kj < K) ? s_tH[K + kj] : 0;
                 const int ginc = wave_iscan_sum(v), linc = wave_iscan_max(v ? kj + 1 : 0);
                 const int lexc = lane_shr1(linc, 0);
-                if (kj < K) { s_GH[K + kj] = carryG + ginc - v; s_lowH[K + kj] = max(carryL, lexc) - 1; }
+                if (kj < K) {
+                    const int low = max(carryL, lexc) - 1, c1 = s_cH[K + kj];
+                    s_GH[K + kj] = carryG + ginc - v; s_lowH[K + kj] = low;
+                    // what an element without a predecessor in the tile gets, per heap entry instead of per output: the carry (to be
+                    // maxed with the range maximum), or the divergence against the nearest lower non-empty key, or 0
+                    s_cH[K + kj] = (c1 >= 0) ? (c1 | EFLAG) : (low >= 0) ? k + 1 + (31 - __clz(kj ^ low)) : 0;
+                }
                 carryG += __builtin_amdgcn_readlane(ginc, 63); carryL = max(carryL, __builtin_amdgcn_readlane(linc, 63));
             }
         };
@@ -1584,12 +1592,10 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
             // max d over (p, l]: windows of 4^lv ending at l and at p + 4^lv, and two more in between when the range is longer than 2 / 3 windows
             const int len = l - p, lv = min((31 - __clz(len)) >> 1, NL4 - 1), wq = 1 << (2 * lv);
             const int *tb = TBL(lv);
-            const int rm = max(max(tb[l], tb[p + wq]), max(tb[len > 2 * wq ? l - wq : l], tb[len > 3 * wq ? l - 2 * wq : l]));
-            int dd;
-            if (p >= 0) dd = rm;
-            else if (s_cH[h] >= 0) dd = max(s_cH[h], rm);
-            else if (s_lowH[h] >= 0) dd = k + 1 + (31 - __clz(kj ^ s_lowH[h]));
-            else dd = 0;
+            const int q3 = p + wq, q1 = max(l - wq, q3), q2 = max(l - 2 * wq, q3);   // windows ending at l, l - wq, l - 2 wq, never starting before p
+            const int rm = max(max(tb[l], tb[q3]), max(tb[q1], tb[q2]));
+            int dd = rm;
+            if (p < 0) { const int e = s_cH[h]; dd = (e & EFLAG) ? max(e & ~EFLAG, rm) : e; }
             const int pos = s_GH[h] + s_bH[h] + rank;
             if (pos == 0) dd = k + j + 1;
 #ifdef PBWTAMD_MEASURE
