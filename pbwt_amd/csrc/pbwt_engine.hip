@@ -1279,6 +1279,7 @@ extern "C" int pbwtamd_pass_advance_many(pbwtamd_engine **es, int P, const void 
             ++e->ev_used; e->launches += (p == 0) ? (long long)(two ? 2 : 3) * nr : 0; e->sites_done += nb;
             e->pend.valid = true; e->pend.ring = r; e->pend.kbase = e->k_cur; e->pend.nb = nb; e->pend.opts = opts; e->pend.skel = true; e->pend.sharded = false;
             e->pend.early = false; e->pend.flushed = 0; e->pend.cols = (const uint32_t *)d_bitcols[p] + (size_t)done * wpc;
+            e->ring_skel[r] = true;
             e->ring = r ^ 1; e->k_cur += nb;
         }
         done += nb;
