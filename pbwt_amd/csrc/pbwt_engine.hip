@@ -883,9 +883,11 @@ static bool launch_skel_hist_scan(pbwtamd_engine *e, hipStream_t st, const SkArg
         SkArgs h = g; h.W = e->W2; h.Wtot = e->W2;
         hipLaunchKernelGGL((skel_hist_kernel<4, true>), dim3(e->W2), dim3(BLOCK), 0, st, h);
         Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = e->W2; kw.agg = agg; kw.counter = cnt; kw.err = e->ctl + 2;
-        const int nwg = (e->W2 + 31) / 32;
+        static const int tpw = tune_env("PBWTAMD_K2_TPW") ? atoi(tune_env("PBWTAMD_K2_TPW")) : 32;     // rows per workgroup (measurement builds: 16 / 32; <= 64 workgroups)
+        const int nwg = (e->W2 + tpw - 1) / tpw;
         *epoch += (unsigned)nwg; kw.target = *epoch;
-        hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, st, kw);
+        if (tpw == 16 && nwg <= 64) hipLaunchKernelGGL((skel_k2_wide_kernel<16, 16, 32>), dim3(nwg), dim3(SKK), 0, st, kw);
+        else hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, st, kw);
         return true;
     }
     hipLaunchKernelGGL((skel_hist_kernel<EPT>), dim3(W), dim3(BLOCK), 0, st, g);
