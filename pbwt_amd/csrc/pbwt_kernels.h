@@ -1454,7 +1454,14 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     auto TBL = [&](int lv) -> int * { return reinterpret_cast<int *>(s_tb) + lv * T; };
     constexpr int EFLAG = 0x40000000;                        // s_cH[h] after level_scan: carry | EFLAG (max with the range maximum) or the final value
     __shared__ int s_bH[2 * SKK], s_cH[2 * SKK], s_tH[2 * SKK];
-    int *const s_GH = &s_bH[SKK], *const s_lowH = &s_cH[SKK];   // the level-8 halves are dead once level 7 is folded
+    int *const s_GH = &s_bH[SKK];                            // the level-8 halves are dead once level 7 is folded
+    // STAGE (no ids to move, T <= 512): every sub-step's outputs pass through LDS in DESTINATION order, so that a wave's store covers a few
+    // runs of consecutive addresses instead of 64 scattered words (at the seventh sub-step a tile feeds 128 runs of ~4 positions).  No
+    // LDS is added: values in s_tH (dead after the level scans), key bytes and the tile's own bucket totals in the dead half of s_cH.
+    constexpr bool STAGE = (PACKY >= 1) && (EPT <= 2);
+    short *const s_loc = reinterpret_cast<short *>(&s_cH[SKK]);                              // [256] this tile's total per heap entry
+    unsigned char *const s_kb = reinterpret_cast<unsigned char *>(&s_cH[SKK]) + 2 * SKK;     // [T] key bytes, destination order
+    int *const s_stage = s_tH;                                                               // [T] values, destination order
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
     int w = blockIdx.x, b = blockIdx.y;
     if (g.xcd) { const int lg = xcd_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y); b = lg / g.W; w = lg - b * g.W; }
@@ -1551,6 +1558,7 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
             s_rawH[c][t] = (short)base; s_lastH[c][t] = (short)last;
             base += cn; if (cn) last = lp;
         }
+        if (STAGE) s_loc[t] = (short)base;
     }
     // (ii) per level: bucket bases G (exclusive prefix of the key totals) and the nearest lower non-empty key; one wave per level
     {
@@ -1564,7 +1572,7 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
                 const int lexc = lane_shr1(linc, 0);
                 if (kj < K) {
                     const int low = max(carryL, lexc) - 1, c1 = s_cH[K + kj];
-                    s_GH[K + kj] = carryG + ginc - v; s_lowH[K + kj] = low;
+                    s_GH[K + kj] = carryG + ginc - v;
                     // what an element without a predecessor in the tile gets, per heap entry instead of per output: the carry (to be
                     // maxed with the range maximum), or the divergence against the nearest lower non-empty key, or 0
                     s_cH[K + kj] = (c1 >= 0) ? (c1 | EFLAG) : (low >= 0) ? k + 1 + (31 - __clz(kj ^ low)) : 0;
@@ -1578,6 +1586,63 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
         else { level_scan(3); level_scan(7); }
     }
     lds_barrier();
+    if constexpr (STAGE) {
+        // (iii) where a bucket starts in the tile's own destination order (Ls, exclusive prefix of the tile's totals per level): s_GH := Ls,
+        // s_bH := G + before - Ls, so that local index = Ls + rank in the bucket and destination = local index + s_bH
+        auto loc_scan = [&](int j) {
+            const int K = 1 << j;
+            int carry = 0;
+            for (int base = 0; base < K; base += 64) {
+                const int kj = base + lane;
+                const int v = (kj < K) ? (int)s_loc[K + kj] : 0;
+                const int inc = wave_iscan_sum(v);
+                if (kj < K) { const int Ls = carry + inc - v, Gb = s_GH[K + kj] + s_bH[K + kj]; s_GH[K + kj] = Ls; s_bH[K + kj] = Gb - Ls; }
+                carry += __builtin_amdgcn_readlane(inc, 63);
+            }
+        };
+        if (wv == 0) loc_scan(6);
+        else if (wv == 1) { loc_scan(5); loc_scan(1); }
+        else if (wv == 2) { loc_scan(4); loc_scan(2); }
+        else { loc_scan(3); loc_scan(7); }
+        lds_barrier();
+        const int nv = min(T, g.M - S);
+#pragma unroll
+        for (int j = SKB - 1; j >= 1; --j) {
+            const int K = 1 << j;
+            int *d_out = g.D + (size_t)(8 * b + j) * g.strideD;
+#pragma unroll
+            for (int r = 0; r < EPT; ++r) {
+                if (key[r] < 0) continue;
+                const int l = r * BLOCK + t, c = r * 4 + wv, kj = key[r] & (K - 1), h = K + kj;
+                const int p = (pl[r][j] >= 0) ? pl[r][j] : s_lastH[c][h];
+                const int len = l - p, lv = min((31 - __clz(len)) >> 1, NL4 - 1), wq = 1 << (2 * lv);
+                const int *tb = TBL(lv);
+                const int q3 = p + wq, q1 = max(l - wq, q3), q2 = max(l - 2 * wq, q3);
+                const int rm = max(max(tb[l], tb[q3]), max(tb[q1], tb[q2]));
+                int dd = rm;
+                if (p < 0) { const int e = s_cH[h]; dd = (e & EFLAG) ? max(e & ~EFLAG, rm) : e; }
+                const int lp = s_GH[h] + s_rawH[c][h] + rk[r][j];
+                s_stage[lp] = dd; s_kb[lp] = (unsigned char)key[r];
+            }
+            lds_barrier();
+#pragma unroll
+            for (int r = 0; r < EPT; ++r) {
+                const int i = r * BLOCK + t;
+                if (i >= nv) continue;
+                const int kb = s_kb[i], pos = i + s_bH[K + (kb & (K - 1))];
+                int v = s_stage[i];
+                if (pos == 0) v = k + j + 1;
+#ifdef PBWTAMD_MEASURE
+                if (g.dbg_nowrite) continue;
+#endif
+                if (PACKY == 1) v |= (int)(((unsigned)(kb >> j) & 1u) << 31);
+                __builtin_nontemporal_store(v, d_out + pos);
+            }
+            if (w == g.W - 1 && t == 0) d_out[g.M] = k + j + 1;
+            if (j > 1) lds_barrier();
+        }
+        return;
+    }
     // all seven levels, no barrier in between: positions, divergences, scatter
 #pragma unroll
     for (int j = SKB - 1; j >= 1; --j) {
