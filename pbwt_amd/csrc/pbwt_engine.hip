@@ -349,11 +349,14 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         for (int i = 0; i < 16; ++i) ECHK(hipEventCreateWithFlags(&e->tev[i], hipEventDisableTiming));
         {
             const int rounds = e->B / 8 + 1;
-            // pair rows (wide panels at 512-position tiles): the scan over the tiles runs on 1024-position pairs — half the rows —
-            // and the rank / fill workgroup of an odd tile folds the first tile's row in.  Rows 512 < W2 <= 1024: the wide scan, <= 32 workgroups
+            // pair rows (512-position tiles): the scan over the tiles runs on 1024-position pairs — half the rows — and the rank / fill
+            // workgroup of an odd tile folds the first tile's row in.  Rows 512 < W2 <= 1024: the wide scan, <= 32 workgroups; 136 < W2 <= 512
+            // (139 k < M <= 524 k): the one-level scan on half the rows — measured -2 % at 140 k, -3 % at 160-250 k, -12 % at 300 k, -8 % at
+            // 400 k, -6 % at 500 k end to end; +4..6 % at 100-120 k, where the hist workgroup of two tiles costs more than the shorter scan saves
             static const bool pair_rows = !(tune_env("PBWTAMD_PAIR_ROWS") && !atoi(tune_env("PBWTAMD_PAIR_ROWS")));
             e->W2 = (e->Wt + 1) / 2;
-            e->prow = pair_rows && e->skEPT == 2 && e->W2 > 512 && e->W2 <= 1024;
+            static const int prow_min = tune_env("PBWTAMD_PROW_MIN") ? atoi(tune_env("PBWTAMD_PROW_MIN")) : 136;
+            e->prow = pair_rows && e->skEPT == 2 && e->W2 > prow_min && e->W2 <= 1024;
             e->strideS = e->prow ? (size_t)SKK * e->W2 * 2 + SKK / 2 : (size_t)SKK * e->Wt + SKK / 2;
             for (int i = 0; i < 2; ++i) {
                 ALLOC(e->keysR[i], (size_t)(rounds + 1) * e->Mpad);
@@ -882,6 +885,12 @@ static bool launch_skel_hist_scan(pbwtamd_engine *e, hipStream_t st, const SkArg
     if (e->prow) {                                         // wide panels: hist and scan on PAIRS of tiles (half the rows), rank on tiles
         SkArgs h = g; h.W = e->W2; h.Wtot = e->W2;
         hipLaunchKernelGGL((skel_hist_kernel<4, true>), dim3(e->W2), dim3(BLOCK), 0, st, h);
+        if (e->W2 <= 512) {                                // few enough rows for the one-level scan
+            Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = e->W2;
+            if (e->W2 <= 256) hipLaunchKernelGGL((skel_k2_kernel<4, 4>), dim3(SKK / 4), dim3(BLOCK), 0, st, k2);
+            else hipLaunchKernelGGL((skel_k2_kernel<4, 16>), dim3(SKK / 4), dim3(BLOCK), 0, st, k2);
+            return false;
+        }
         Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = e->W2; kw.agg = agg; kw.counter = cnt; kw.err = e->ctl + 2;
         static const int tpw = tune_env("PBWTAMD_K2_TPW") ? atoi(tune_env("PBWTAMD_K2_TPW")) : 32;     // rows per workgroup (measurement builds: 16 / 32; <= 64 workgroups)
         const int nwg = (e->W2 + tpw - 1) / tpw;
@@ -922,7 +931,7 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch, int
         return;
     }
     static const bool k2_wide_on = !(tune_env("PBWTAMD_K2_WIDE") && !atoi(tune_env("PBWTAMD_K2_WIDE")));
-    bool wide = e->prow || (W > 512 && k2_wide_on) || W > 2048;
+    bool wide = (e->prow && e->W2 > 512) || (!e->prow && W > 512 && k2_wide_on) || W > 2048;
     if (part != 2) wide = launch_skel_hist_scan<EPT>(e, e->stream, g, e->k2agg, e->k2cnt, &e->k2epoch);
     if (part == 1) return;
     static const bool rank_r4 = !(tune_env("PBWTAMD_RANK_R4") && !atoi(tune_env("PBWTAMD_RANK_R4")));

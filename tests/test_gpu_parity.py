@@ -357,7 +357,8 @@ def test_malformed_packed_panel_is_rejected(amd, orc):
 
 @pytest.mark.parametrize("skel", ["1", "0"])
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1024, 130, 32, 1), (1025, 96, 24, 0), (70001, 80, 40, 0),
-                                            (300000, 40, 16, 0), (600100, 24, 8, 0), (1500, 41, 8, 1), (5, 64, 16, 1), (1, 16, 8, 0)])
+                                            (300000, 40, 16, 0), (600100, 24, 8, 0), (1500, 41, 8, 1), (5, 64, 16, 1), (1, 16, 8, 0),
+                                            (150600, 40, 16, 0), (524288, 24, 8, 1)])   # pair rows with the one-level scan: 148 rows (odd tile count), 512 rows
 def test_both_chains_every_site(amd, orc, skel, M, N, batch, kind, monkeypatch):
     """the two chain implementations — skeleton (8-bit radix step every 8 sites, K1/K2/K3, with the
     seven states between filled by batched single-site kernels) and the two-site chain — against the
@@ -397,7 +398,7 @@ def test_both_chains_every_site(amd, orc, skel, M, N, batch, kind, monkeypatch):
 
 @pytest.mark.parametrize("packed", ["1", "0"])
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1025, 96, 24, 0), (70001, 80, 40, 1), (2, 40, 8, 1), (300000, 24, 8, 0),
-                                            (600100, 24, 8, 1)])     # 600 100: pair rows with an odd number of tiles (1173)
+                                            (600100, 24, 8, 1), (150600, 32, 16, 1), (139300, 24, 8, 0)])     # 600 100: pair rows with an odd number of tiles (1173); 150 600 / 139 300: pair rows, one-level scan (the narrowest: 137 rows)
 def test_histogram_and_pack3_consumers_without_ids(amd, orc, packed, M, N, batch, kind, monkeypatch):
     """the bench configuration (divergence + maxWithin histogram + pack3, no per-site checksums): on the
     skeleton path the fill then writes d | y << 31 and no haplotype ids, the sweep reads that and emits
