@@ -338,7 +338,11 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         e->skEPT = (M <= 56000) ? 1 : 2;                       // 256- against 512-position tiles, end to end: 50 k 1.33 vs 1.37 us/site, 70 k 1.52 vs 1.45
         if (const char *sv = tune_env("PBWTAMD_SKT")) e->skEPT = (atoi(sv) == 256) ? 1 : (atoi(sv) == 512) ? 2 : 4;
 
-        if (M > 256 * e->skEPT * 2048) e->skEPT = 4;           // skel_k2_kernel scans at most 2048 tiles per key
+        // pair rows carry 512-position tiles up to 2048 rows of pairs = 2^21 haplotypes (the wide scan takes <= 64 workgroups of 32 rows): against
+        // 1024-position tiles above 2^20, end to end 7.42 -> 6.61 us/site at 1.1 M, 9.77 -> 8.90 at 1.5 M, 12.68 -> 11.60 at 2.0 M
+        static const int prow_max = tune_env("PBWTAMD_PROW_MAX") ? std::min(2048, atoi(tune_env("PBWTAMD_PROW_MAX"))) : 2048;
+        const bool pairs_reach = e->skEPT == 2 && (M + 1023) / 1024 <= prow_max;
+        if (M > 256 * e->skEPT * 2048 && !pairs_reach) e->skEPT = 4;   // skel_k2_kernel scans at most 2048 tiles per key
         if (const char *sv = getenv("PBWTAMD_SKN_MAXW")) e->skn_maxw = std::min(atoi(sv), SKN_MAXW);
         e->Wt = (M + 256 * e->skEPT - 1) / (256 * e->skEPT);
         e->strideX = (size_t)e->Mpad; e->xTblocks = (e->B + 8 + 31) / 32 + 1;
@@ -356,7 +360,8 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             static const bool pair_rows = !(tune_env("PBWTAMD_PAIR_ROWS") && !atoi(tune_env("PBWTAMD_PAIR_ROWS")));
             e->W2 = (e->Wt + 1) / 2;
             static const int prow_min = tune_env("PBWTAMD_PROW_MIN") ? atoi(tune_env("PBWTAMD_PROW_MIN")) : 136;
-            e->prow = pair_rows && e->skEPT == 2 && e->W2 > prow_min && e->W2 <= 1024;
+            e->prow = pair_rows && e->skEPT == 2 && e->W2 > prow_min && e->W2 <= prow_max;
+            if (e->skEPT == 2 && e->Wt > 2048 && !e->prow) { const int r = fail("pbwtamd_engine_create: %d tiles of 512 positions need pair rows", e->Wt); pbwtamd_engine_destroy(e); return r; }
             e->strideS = e->prow ? (size_t)SKK * e->W2 * 2 + SKK / 2 : (size_t)SKK * e->Wt + SKK / 2;
             for (int i = 0; i < 2; ++i) {
                 ALLOC(e->keysR[i], (size_t)(rounds + 1) * e->Mpad);
