@@ -338,9 +338,11 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         e->skEPT = (M <= 56000) ? 1 : 2;                       // 256- against 512-position tiles, end to end: 50 k 1.33 vs 1.37 us/site, 70 k 1.52 vs 1.45
         if (const char *sv = tune_env("PBWTAMD_SKT")) e->skEPT = (atoi(sv) == 256) ? 1 : (atoi(sv) == 512) ? 2 : 4;
 
-        // pair rows carry 512-position tiles up to 2048 rows of pairs = 2^21 haplotypes (the wide scan takes <= 64 workgroups of 32 rows): against
-        // 1024-position tiles above 2^20, end to end 7.42 -> 6.61 us/site at 1.1 M, 9.77 -> 8.90 at 1.5 M, 12.68 -> 11.60 at 2.0 M
-        static const int prow_max = tune_env("PBWTAMD_PROW_MAX") ? std::min(2048, atoi(tune_env("PBWTAMD_PROW_MAX"))) : 2048;
+        // pair rows carry 512-position tiles up to 4096 rows of pairs = 2^22 haplotypes, every width the skeleton takes (the wide scan: <= 64
+        // workgroups of 32 rows up to 2048 rows, of 64 above): against 1024-position tiles, end to end 7.42 -> 6.61 us/site at 1.1 M, 9.77 -> 8.90
+        // at 1.5 M, 12.68 -> 11.60 at 2.0 M, 13.90 -> 12.57 at 2.2 M, 18.74 -> 17.00 at 3 M, 24.68 -> 22.40 at 4 M.  1024-position tiles are left
+        // to measurement builds (PBWTAMD_SKT=1024 / PBWTAMD_PROW_MAX)
+        static const int prow_max = tune_env("PBWTAMD_PROW_MAX") ? std::min(4096, atoi(tune_env("PBWTAMD_PROW_MAX"))) : 4096;
         const bool pairs_reach = e->skEPT == 2 && (M + 1023) / 1024 <= prow_max;
         if (M > 256 * e->skEPT * 2048 && !pairs_reach) e->skEPT = 4;   // skel_k2_kernel scans at most 2048 tiles per key
         if (const char *sv = getenv("PBWTAMD_SKN_MAXW")) e->skn_maxw = std::min(atoi(sv), SKN_MAXW);
@@ -897,10 +899,12 @@ static bool launch_skel_hist_scan(pbwtamd_engine *e, hipStream_t st, const SkArg
             return false;
         }
         Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = e->W2; kw.agg = agg; kw.counter = cnt; kw.err = e->ctl + 2;
-        static const int tpw = tune_env("PBWTAMD_K2_TPW") ? atoi(tune_env("PBWTAMD_K2_TPW")) : 32;     // rows per workgroup (measurement builds: 16 / 32; <= 64 workgroups)
+        static const int tpw_env = tune_env("PBWTAMD_K2_TPW") ? atoi(tune_env("PBWTAMD_K2_TPW")) : 32;     // rows per workgroup (measurement builds: 16 / 32; <= 64 workgroups)
+        const int tpw = e->W2 > 2048 ? 64 : tpw_env;
         const int nwg = (e->W2 + tpw - 1) / tpw;
         *epoch += (unsigned)nwg; kw.target = *epoch;
-        if (tpw == 16 && nwg <= 64) hipLaunchKernelGGL((skel_k2_wide_kernel<16, 16, 32>), dim3(nwg), dim3(SKK), 0, st, kw);
+        if (tpw == 64) hipLaunchKernelGGL((skel_k2_wide_kernel<64>), dim3(nwg), dim3(SKK), 0, st, kw);
+        else if (tpw == 16 && nwg <= 64) hipLaunchKernelGGL((skel_k2_wide_kernel<16, 16, 32>), dim3(nwg), dim3(SKK), 0, st, kw);
         else hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, st, kw);
         return true;
     }

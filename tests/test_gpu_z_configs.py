@@ -107,10 +107,10 @@ def test_config4_shape_million_haplotypes(gpu_lib, orc, kind, Q):
 
 @pytest.mark.parametrize("M,N,skel", [(1100000, 40, "1"), (2097152, 16, "1"), (2200000, 24, "1"), (4194000, 8, "1"), (2200000, 16, "0")])
 def test_wider_than_2_20_haplotypes(gpu_lib, orc, M, N, skel, monkeypatch):
-    """M > 2^20: up to 2^21 haplotypes the skeleton keeps its 512-position tiles with pair rows (the two-level scan on up to 2048 rows of
-    pairs: 1.1 M, and 2 097 152 = the last width of that form); above, 1024-position tiles — 64 rows per scan workgroup up to the 4096 tiles
-    the engine takes (2^22) — and, with PBWTAMD_SKEL=0, the wide fallback chain (2048-position tiles, two sites per launch), which was all
-    there was above 2^21 until round 3"""
+    """M > 2^20: the skeleton keeps its 512-position tiles with pair rows — the two-level scan on up to 2048 rows of pairs with 32 rows per
+    scan workgroup (1.1 M; 2 097 152 = the last width of that form), 64 rows per workgroup up to the 4096 rows the engine takes (2.2 M,
+    4 194 000 ~ 2^22) — and, with PBWTAMD_SKEL=0, the wide fallback chain (2048-position tiles, two sites per launch), which was all there
+    was above 2^21 until round 3"""
     monkeypatch.setenv("PBWTAMD_SKEL", skel)
     amd = gpu_lib
     eng = amd.Engine(M, batch_sites=16)
