@@ -892,7 +892,8 @@ static bool launch_skel_hist_scan(pbwtamd_engine *e, hipStream_t st, const SkArg
     if (e->prow) {                                         // wide panels: hist and scan on PAIRS of tiles (half the rows), rank on tiles
         SkArgs h = g; h.W = e->W2; h.Wtot = e->W2;
         hipLaunchKernelGGL((skel_hist_kernel<4, true>), dim3(e->W2), dim3(BLOCK), 0, st, h);
-        if (e->W2 <= 512) {                                // few enough rows for the one-level scan
+        static const int one_max = tune_env("PBWTAMD_PROW_ONE_MAX") ? std::min(1024, atoi(tune_env("PBWTAMD_PROW_ONE_MAX"))) : 512;
+        if (e->W2 <= one_max) {                            // few enough rows for the one-level scan
             Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = e->W2;
             if (e->W2 <= 256) hipLaunchKernelGGL((skel_k2_kernel<4, 4>), dim3(SKK / 4), dim3(BLOCK), 0, st, k2);
             else hipLaunchKernelGGL((skel_k2_kernel<4, 16>), dim3(SKK / 4), dim3(BLOCK), 0, st, k2);
@@ -940,11 +941,15 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch, int
         return;
     }
     static const bool k2_wide_on = !(tune_env("PBWTAMD_K2_WIDE") && !atoi(tune_env("PBWTAMD_K2_WIDE")));
-    bool wide = (e->prow && e->W2 > 512) || (!e->prow && W > 512 && k2_wide_on) || W > 2048;
+    static const int one_max_r = tune_env("PBWTAMD_PROW_ONE_MAX") ? std::min(1024, atoi(tune_env("PBWTAMD_PROW_ONE_MAX"))) : 512;
+    bool wide = (e->prow && e->W2 > one_max_r) || (!e->prow && W > 512 && k2_wide_on) || W > 2048;
     if (part != 2) wide = launch_skel_hist_scan<EPT>(e, e->stream, g, e->k2agg, e->k2cnt, &e->k2epoch);
     if (part == 1) return;
     static const bool rank_r4 = !(tune_env("PBWTAMD_RANK_R4") && !atoi(tune_env("PBWTAMD_RANK_R4")));
-    if (wide && (e->prow || rank_r4)) hipLaunchKernelGGL((skel_rank_kernel<EPT, 0, true>), dim3(W), dim3(BLOCK), 0, e->stream, g);    // more tiles than one round of the chip: occupancy counts
+    // the 22 KB rank workgroup (radix-4 range maxima) from two workgroups per CU on, whatever the scan: end to end 2.68 -> 2.56 us/site at
+    // 300 k haplotypes (586 tiles), 3.13 -> 2.94 at 400 k; nothing up to 250 k (489 tiles)
+    static const int r4_from = tune_env("PBWTAMD_RANK_R4_FROM") ? atoi(tune_env("PBWTAMD_RANK_R4_FROM")) : 512;
+    if ((wide && (e->prow || rank_r4)) || W >= r4_from) hipLaunchKernelGGL((skel_rank_kernel<EPT, 0, true>), dim3(W), dim3(BLOCK), 0, e->stream, g);    // more tiles than one round of the chip: occupancy counts
     else hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
 }
 
