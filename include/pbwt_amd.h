@@ -210,7 +210,7 @@ int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, int wpc, int 
  * (d_bitcols[p] = panel p's columns, same layout as pbwtamd_pass_advance) with every launch of the chain covering all P panels: below
  * ~250 000 haplotypes the per-site loop of pbwtReadMacs (pbwtIO.c:477-483) is bound by the cost of a dependent launch, which the panels
  * then share.  pass_begin / pass_end / the result getters stay per engine.  Falls back to one pbwtamd_pass_advance per engine where
- * the fused form does not apply (wide panels, batches that are not a multiple of 8 sites, sorted columns). */
+ * the fused form does not apply (panels of more than 139 264 haplotypes, batches that are not a multiple of 8 sites, sorted columns). */
 int pbwtamd_pass_advance_many(pbwtamd_engine **engines, int P, const void *const *d_bitcols, int wpc, int ncols, int ncols_avail, unsigned opts);
 
 /* finish: runs the k==N sweep if a WITHIN sink is active; synchronises */
