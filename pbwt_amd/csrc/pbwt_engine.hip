@@ -895,6 +895,10 @@ static bool launch_skel_hist_scan(pbwtamd_engine *e, hipStream_t st, const SkArg
         static const int one_max = tune_env("PBWTAMD_PROW_ONE_MAX") ? std::min(1024, atoi(tune_env("PBWTAMD_PROW_ONE_MAX"))) : 512;
         if (e->W2 <= one_max) {                            // few enough rows for the one-level scan
             Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = e->W2;
+            static const int lean = tune_env("PBWTAMD_K2_LEAN") ? atoi(tune_env("PBWTAMD_K2_LEAN")) : 0;   // measurement builds: two keys per workgroup (17 KB of LDS)
+            if (lean && e->W2 > 512) hipLaunchKernelGGL((skel_k2_kernel<2, 16>), dim3(SKK / 2), dim3(128), 0, st, k2);
+            else if (lean && e->W2 > 256) hipLaunchKernelGGL((skel_k2_kernel<2, 8>), dim3(SKK / 2), dim3(128), 0, st, k2);
+            else
             if (e->W2 <= 256) hipLaunchKernelGGL((skel_k2_kernel<4, 4>), dim3(SKK / 4), dim3(BLOCK), 0, st, k2);
             else hipLaunchKernelGGL((skel_k2_kernel<4, 16>), dim3(SKK / 4), dim3(BLOCK), 0, st, k2);
             return false;
