@@ -908,6 +908,11 @@ static bool launch_skel_hist_scan(pbwtamd_engine *e, hipStream_t st, const SkArg
         const int tpw = e->W2 > 2048 ? 64 : tpw_env;
         const int nwg = (e->W2 + tpw - 1) / tpw;
         *epoch += (unsigned)nwg; kw.target = *epoch;
+        static const int pch = tune_env("PBWTAMD_K2_PCH") ? atoi(tune_env("PBWTAMD_K2_PCH")) : 32;        // measurement builds: aggregates in flight per lane (16: 48 VGPRs instead of 74)
+        if (pch == 16 && tpw == 32) hipLaunchKernelGGL((skel_k2_wide_kernel<32, 16, 16>), dim3(nwg), dim3(SKK), 0, st, kw);
+        else if (pch == 16 && tpw == 64) hipLaunchKernelGGL((skel_k2_wide_kernel<64, 16, 16>), dim3(nwg), dim3(SKK), 0, st, kw);
+        else if (pch == 8 && tpw == 32) hipLaunchKernelGGL((skel_k2_wide_kernel<32, 8, 8>), dim3(nwg), dim3(SKK), 0, st, kw);
+        else
         if (tpw == 64) hipLaunchKernelGGL((skel_k2_wide_kernel<64>), dim3(nwg), dim3(SKK), 0, st, kw);
         else if (tpw == 16 && nwg <= 64) hipLaunchKernelGGL((skel_k2_wide_kernel<16, 16, 32>), dim3(nwg), dim3(SKK), 0, st, kw);
         else hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, st, kw);
@@ -919,6 +924,11 @@ static bool launch_skel_hist_scan(pbwtamd_engine *e, hipStream_t st, const SkArg
         Sk2WArgs kw; kw.tbl = g.tbl; kw.scan = g.scan; kw.total = g.total; kw.W = W; kw.agg = agg; kw.counter = cnt; kw.err = e->ctl + 2;
         const int tpw = W > 2048 ? 64 : 32, nwg = (W + tpw - 1) / tpw;
         *epoch += (unsigned)nwg; kw.target = *epoch;
+        static const int pch = tune_env("PBWTAMD_K2_PCH") ? atoi(tune_env("PBWTAMD_K2_PCH")) : 32;        // measurement builds: aggregates in flight per lane (16: 48 VGPRs instead of 74)
+        if (pch == 16 && tpw == 32) hipLaunchKernelGGL((skel_k2_wide_kernel<32, 16, 16>), dim3(nwg), dim3(SKK), 0, st, kw);
+        else if (pch == 16 && tpw == 64) hipLaunchKernelGGL((skel_k2_wide_kernel<64, 16, 16>), dim3(nwg), dim3(SKK), 0, st, kw);
+        else if (pch == 8 && tpw == 32) hipLaunchKernelGGL((skel_k2_wide_kernel<32, 8, 8>), dim3(nwg), dim3(SKK), 0, st, kw);
+        else
         if (tpw == 64) hipLaunchKernelGGL((skel_k2_wide_kernel<64>), dim3(nwg), dim3(SKK), 0, st, kw);
         else hipLaunchKernelGGL((skel_k2_wide_kernel<32>), dim3(nwg), dim3(SKK), 0, st, kw);
         return true;

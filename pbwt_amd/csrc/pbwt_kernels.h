@@ -948,9 +948,10 @@ struct Sk2WArgs { const int2 *tbl; int2 *scan; int *total; int W; unsigned long 
 // form of this kernel held all 32 rows + 64 aggregates in 200 VGPRs (one round trip each, 8.0 us alone).  A 200-VGPR wave fits
 // on no SIMD while a consumer kernel is at full occupancy (sweep: 8 waves x 56 VGPRs, fill: 6 x 56), and the 56 registers a
 // retiring consumer workgroup frees go to the next consumer workgroup: measured (rocprofv3 trace), that launch waited for the
-// END of the fill, 1.1-1.4 ms, and the chain stood still beside fill + sweep.  This form (44 VGPRs, no LDS) fits into the slot
-// any retiring consumer workgroup leaves: 9.3 us alone, 14 us beside the fill instead of 185; end to end at 1 M 7.25 -> 6.25
-// us/site.  Around the shipped (rows, aggregates) = (16, 32): (8, 32) 6.21, (32, 32) 6.25, (16, 64) 6.93, (32, 64) 7.12 against 6.12.
+// END of the fill, 1.1-1.4 ms, and the chain stood still beside fill + sweep.  This form (no LDS; 74 VGPRs with this compiler, 44 with 16
+// aggregates in flight — measured equal at the end of round 3: 5.94 against 5.91 us/site at 1 M) runs beside the consumers: 9.3 us alone, 14 us
+// beside the fill instead of 185; end to end at 1 M 7.25 -> 6.25 us/site.  Around the shipped (rows, aggregates) = (16, 32): (8, 32) 6.21,
+// (32, 32) 6.25, (16, 64) 6.93, (32, 64) 7.12 against 6.12.
 template <int TPW, int CH = 16, int PCH = 32>                // rows / aggregates in flight per lane
 __global__ __launch_bounds__(SKK) void skel_k2_wide_kernel(Sk2WArgs g) {
 #ifndef PBWT_NO_SETPRIO
