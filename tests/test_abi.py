@@ -43,3 +43,31 @@ def test_product_does_not_import_oracle():
                 if f.endswith((".py", ".h", ".hip", ".inc", ".c", ".cpp")):
                     txt = open(os.path.join(dp, f)).read()
                     assert "import oracle" not in txt and "liboracle" not in txt and "orc_" not in txt, f
+
+
+def test_records_are_wrapped_not_copied():
+    """record blocks the library malloc's are handed to numpy as they are (pbwt_amd.api._take): the array aliases the block, views keep
+    it alive, and an empty result still frees it"""
+    import ctypes as C
+    import gc
+    import numpy as np
+    import pbwt_amd
+    from pbwt_amd import api
+    L = pbwt_amd.load_library()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    n = 5
+    p = libc.malloc(n * api.MATCH_DTYPE.itemsize)
+    raw = (C.c_int32 * (4 * n)).from_address(p)
+    for i in range(4 * n):
+        raw[i] = 100 + i
+    arr = api._take(L, C.c_void_p(p), n, api.MATCH_DTYPE)
+    assert arr.shape == (n,) and arr.ctypes.data == p                  # the same memory
+    assert [int(x) for x in arr[2]] == [108, 109, 110, 111]
+    tail = arr[3:]
+    del arr
+    gc.collect()
+    assert [int(x) for x in tail[0]] == [112, 113, 114, 115]           # a view keeps the block alive
+    empty = api._take(L, C.c_void_p(libc.malloc(16)), 0, api.MATCH_DTYPE)
+    assert empty.shape == (0,)
