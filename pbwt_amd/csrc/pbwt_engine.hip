@@ -362,7 +362,8 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             static const bool pair_rows = !(tune_env("PBWTAMD_PAIR_ROWS") && !atoi(tune_env("PBWTAMD_PAIR_ROWS")));
             e->W2 = (e->Wt + 1) / 2;
             static const int prow_min = tune_env("PBWTAMD_PROW_MIN") ? atoi(tune_env("PBWTAMD_PROW_MIN")) : 136;
-            e->prow = pair_rows && e->skEPT == 2 && e->W2 > prow_min && e->W2 <= prow_max;
+            static const bool prow_ept1 = tune_env("PBWTAMD_PROW_EPT1") && atoi(tune_env("PBWTAMD_PROW_EPT1"));   // measurement builds: pairs of 256-position tiles
+            e->prow = pair_rows && (e->skEPT == 2 || (e->skEPT == 1 && prow_ept1)) && e->W2 > prow_min && e->W2 <= prow_max;
             if (e->skEPT == 2 && e->Wt > 2048 && !e->prow) { const int r = fail("pbwtamd_engine_create: %d tiles of 512 positions need pair rows", e->Wt); pbwtamd_engine_destroy(e); return r; }
             e->strideS = e->prow ? (size_t)SKK * e->W2 * 2 + SKK / 2 : (size_t)SKK * e->Wt + SKK / 2;
             for (int i = 0; i < 2; ++i) {
@@ -891,7 +892,8 @@ static bool launch_skel_hist_scan(pbwtamd_engine *e, hipStream_t st, const SkArg
     const int W = g.W;
     if (e->prow) {                                         // wide panels: hist and scan on PAIRS of tiles (half the rows), rank on tiles
         SkArgs h = g; h.W = e->W2; h.Wtot = e->W2;
-        hipLaunchKernelGGL((skel_hist_kernel<4, true>), dim3(e->W2), dim3(BLOCK), 0, st, h);
+        if (EPT == 1) hipLaunchKernelGGL((skel_hist_kernel<2, true>), dim3(e->W2), dim3(BLOCK), 0, st, h);
+        else hipLaunchKernelGGL((skel_hist_kernel<4, true>), dim3(e->W2), dim3(BLOCK), 0, st, h);
         static const int one_max = tune_env("PBWTAMD_PROW_ONE_MAX") ? std::min(1024, atoi(tune_env("PBWTAMD_PROW_ONE_MAX"))) : 512;
         if (e->W2 <= one_max) {                            // few enough rows for the one-level scan
             Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = e->W2;
