@@ -833,6 +833,9 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
 #define FILL(EP) do { if (packed) hipLaunchKernelGGL((skel_fill_kernel<EP, 1>), grid, dim3(BLOCK), dyn, e->s2, f); \
                       else if (d_only) hipLaunchKernelGGL((skel_fill_kernel<EP, 2>), grid, dim3(BLOCK), dyn, e->s2, f); \
                       else hipLaunchKernelGGL((skel_fill_kernel<EP, 0>), grid, dim3(BLOCK), dyn, e->s2, f); } while (0)
+        static const bool fill_pair4 = tune_env("PBWTAMD_FILL_PAIR4") && atoi(tune_env("PBWTAMD_FILL_PAIR4"));   // measurement builds: with pair rows, one fill workgroup per PAIR (1024 positions, the pair's own scan row)
+        if (fill_pair4 && e->prow && e->skEPT == 2) { f.W = e->W2; f.pair = 0; grid = dim3(e->W2, ns / 8); FILL(4); }
+        else
         if (e->skEPT == 1) FILL(1); else if (e->skEPT == 2) FILL(2); else FILL(4);
 #undef FILL
         HIPCHK(hipGetLastError());
