@@ -336,6 +336,10 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         // consumer workgroup leaves on a CU (LDS is allocated contiguously: a 41 KB rank workgroup of 1024 positions starves beside
         // 26 KB fill workgroups).  1 M, T = 512 vs 1024: 6.25 vs 6.84 us/site; 500 k: 3.99 vs 4.32
         e->skEPT = (M <= 56000) ? 1 : 2;                       // 256- against 512-position tiles, end to end: 50 k 1.33 vs 1.37 us/site, 70 k 1.52 vs 1.45
+        // 8 193 .. 12 288 haplotypes: the two-launch round (the rank launch scans the tile table itself) on 17-24 tiles of 512 positions instead of
+        // 33-48 of 256 — half the rows in front of every rank workgroup: 1.30 -> 1.21 us/site at 10 k, 1.31 -> 1.22 at 12 k; equal at 5-8 k,
+        // worse at 2 k (0.98 -> 1.05) and from 13 k on, where three launches on 256-position tiles take over (1.20)
+        if (M > 8192 && M <= 12288) e->skEPT = 2;
         if (const char *sv = tune_env("PBWTAMD_SKT")) e->skEPT = (atoi(sv) == 256) ? 1 : (atoi(sv) == 512) ? 2 : 4;
 
         // pair rows carry 512-position tiles up to 4096 rows of pairs = 2^22 haplotypes, every width the skeleton takes (the wide scan: <= 64

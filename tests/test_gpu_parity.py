@@ -358,7 +358,8 @@ def test_malformed_packed_panel_is_rejected(amd, orc):
 @pytest.mark.parametrize("skel", ["1", "0"])
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1024, 130, 32, 1), (1025, 96, 24, 0), (70001, 80, 40, 0),
                                             (300000, 40, 16, 0), (600100, 24, 8, 0), (1500, 41, 8, 1), (5, 64, 16, 1), (1, 16, 8, 0),
-                                            (150600, 40, 16, 0), (524288, 24, 8, 1)])   # pair rows with the one-level scan: 148 rows (odd tile count), 512 rows
+                                            (150600, 40, 16, 0), (524288, 24, 8, 1),    # pair rows with the one-level scan: 148 rows (odd tile count), 512 rows
+                                            (9000, 136, 64, 0), (12288, 96, 32, 1), (8193, 72, 24, 0)])   # two launches per round on 512-position tiles (17-24 tiles)
 def test_both_chains_every_site(amd, orc, skel, M, N, batch, kind, monkeypatch):
     """the two chain implementations — skeleton (8-bit radix step every 8 sites, K1/K2/K3, with the
     seven states between filled by batched single-site kernels) and the two-site chain — against the
