@@ -139,7 +139,9 @@ struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned o
 // sweep's bit columns): the fill writes d | y << 31 and no a — half the consumer stream's bytes (they are what slows the chain)
 static inline bool packed_fill(const Pending &p) {
     static const bool off = getenv("PBWTAMD_NO_PACKED_FILL") != nullptr, no_fuse = tune_env("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
-    const unsigned ids = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_LONG_RECS | 0x100u /* OPT_INTERNAL_KEEP_STATES */;
+    // PBWTAMD_PACKED_CHECKSUM=1 (test aid): per-site checksums of d and y taken FROM the packed slots, so that the packed fill is checked at every position
+    static const bool packed_csum = getenv("PBWTAMD_PACKED_CHECKSUM") && atoi(getenv("PBWTAMD_PACKED_CHECKSUM"));
+    const unsigned ids = (packed_csum ? 0u : PBWTAMD_OPT_CHECKSUM) | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_LONG_RECS | 0x100u /* OPT_INTERNAL_KEEP_STATES */;
     return !off && !no_fuse && p.skel && (p.opts & PBWTAMD_OPT_WITHIN_HIST) && !(p.opts & ids);
 }
 
@@ -149,6 +151,7 @@ struct ShardCtx {
     int tb[SHARD_MAX + 1] = {};                                 // tile boundaries
     int pb[SHARD_MAX + 1] = {};                               // position boundaries; pb[world] = M, unused entries INT_MAX
     ShardXch *xch = nullptr; bool xch_ext = false;            // own exchange block
+    volatile int *h_err = nullptr;                            // pinned host mirror of the engine's device error word (refreshed behind every throttle event)
     ShardPeers peers = {};                                    // every rank's exchange block as mapped here (own = xch)
     int *peerA[SHARD_MAX] = {}, *peerD[SHARD_MAX] = {}; unsigned char *peerK[2][SHARD_MAX] = {};   // skeleton rings and key rows of every rank (own = this rank's)
     bool connected = false;
@@ -208,6 +211,7 @@ struct pbwtamd_engine {
     int *skT = nullptr;                     // hist table of the round in flight, [W][256] {cnt, tail}
     unsigned long long *k2agg = nullptr; unsigned *k2cnt = nullptr; unsigned k2epoch = 0;   // two-level tile scan of wide panels (skel_k2_wide_kernel)
     unsigned char *keysR[2] = {nullptr, nullptr};         // per ring: the keys of states 0, 8, 16, ... of the batch ([B/8+1][Mpad]), kept for the fill
+    int2 *fillGB[2] = {nullptr, nullptr};                   // per ring and round: [256] {G, base} per heap entry (skel_fillprep_kernel -> skel_fillseq_kernel)
     int2 *saveR[2] = {nullptr, nullptr}; size_t strideS = 0;  // per ring and round: scan[W][256] {before, carry}, total[256] (stride in int2)
     hipEvent_t tev[16] = {}; long long tev_n = 0; int thr_rounds = 28, thr_depth = 2;   // host throttle: an event every thr_rounds rounds, host at most thr_depth events ahead
     int *rankdirS = nullptr;                // read-side skeleton: zero-prefix directories of the batch's sorted columns [B+2][wpc64+1]
@@ -265,7 +269,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); if (e->evRounds[i]) (void)hipEventDestroy(e->evRounds[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->rankdirS, (void *)e->skT, (void *)e->k2agg, (void *)e->k2cnt, e->cols_stage, e->ycols, e->colBytes, (void *)e->p3regs,
+    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->fillGB[0], (void *)e->fillGB[1], (void *)e->rankdirS, (void *)e->skT, (void *)e->k2agg, (void *)e->k2cnt, e->cols_stage, e->ycols, e->colBytes, (void *)e->p3regs,
                     e->blockCount, e->scal, e->hist, e->hist_rep, e->csum, e->recs, e->yz};
     for (void *p : ptrs) if (p) (void)dev_free(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -373,6 +377,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             for (int i = 0; i < 2; ++i) {
                 ALLOC(e->keysR[i], (size_t)(rounds + 1) * e->Mpad);
                 ALLOC(e->saveR[i], (size_t)rounds * e->strideS * sizeof(int2));
+                ALLOC(e->fillGB[i], (size_t)rounds * SKK * sizeof(int2));
             }
         }
         ALLOC(e->skT, (size_t)(e->Wt + 1) * SKK * sizeof(int2));
@@ -418,7 +423,7 @@ extern "C" int pbwtamd_sync(pbwtamd_engine *e) {
     HIPCHK(hipStreamSynchronize(e->s2));
     int err = 0;
     HIPCHK(hipMemcpy(&err, e->ctl + 2, sizeof(int), hipMemcpyDeviceToHost));
-    if (err) return fail("pbwtamd: device-side error flag %d (1=histogram range, 2/3=malformed packed column, 4=yz buffer overflow, 5=tile scan of a wide panel timed out waiting for its workgroups, 6/7=a position-sharded rank timed out waiting for its peers)", err);
+    if (err) return fail("pbwtamd: device-side error flag %d (1=histogram range, 2/3=malformed packed column, 4=yz buffer overflow, 5=tile scan of a wide panel timed out waiting for its workgroups, 6/7=a position-sharded rank timed out waiting for its peers, 9=a peer reported its own failure)", err);
     return 0;
 }
 
@@ -837,10 +842,25 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
 #define FILL(EP) do { if (packed) hipLaunchKernelGGL((skel_fill_kernel<EP, 1>), grid, dim3(BLOCK), dyn, e->s2, f); \
                       else if (d_only) hipLaunchKernelGGL((skel_fill_kernel<EP, 2>), grid, dim3(BLOCK), dyn, e->s2, f); \
                       else hipLaunchKernelGGL((skel_fill_kernel<EP, 0>), grid, dim3(BLOCK), dyn, e->s2, f); } while (0)
+        // the sequential tile-local form (pbwt_fillseq.h) whenever no consumer needs the haplotype ids; PBWTAMD_FILL_SEQ=0: the table form (A/B, bit-exact)
+        static const bool fill_seq = !(getenv("PBWTAMD_FILL_SEQ") && !atoi(getenv("PBWTAMD_FILL_SEQ")));
+        if (fill_seq && (packed || d_only) && e->skEPT <= 2) {
+            SkFillPrepArgs pa; pa.scan = f.scan; pa.strideS = f.strideS; pa.nrow = e->prow ? e->W2 : e->Wt; pa.kbase = kb; pa.gb = e->fillGB[p.ring] + (size_t)(j0 / 8) * SKK;
+            hipLaunchKernelGGL(skel_fillprep_kernel, dim3(ns / 8), dim3(BLOCK), 0, e->s2, pa);
+            SkFillSeqArgs q; q.D = f.D; q.strideD = f.strideD; q.keys = f.keys; q.strideK = f.strideK; q.scan = f.scan; q.strideS = f.strideS; q.gb = pa.gb;
+            q.M = e->M; q.W = e->Wt; q.kbase = kb; q.nblk = ns / 8; q.xcd = f.xcd; q.pair = f.pair; q.W2 = f.W2;
+#ifdef PBWTAMD_MEASURE
+            q.dbg_nowrite = f.dbg_nowrite;
+#endif
+            const dim3 gs(((size_t)e->Wt * (ns / 8) + WAVES - 1) / WAVES);
+            if (e->skEPT == 1) { if (packed) hipLaunchKernelGGL((skel_fillseq_kernel<4, 1>), gs, dim3(BLOCK), dyn, e->s2, q); else hipLaunchKernelGGL((skel_fillseq_kernel<4, 2>), gs, dim3(BLOCK), dyn, e->s2, q); }
+            else { if (packed) hipLaunchKernelGGL((skel_fillseq_kernel<8, 1>), gs, dim3(BLOCK), dyn, e->s2, q); else hipLaunchKernelGGL((skel_fillseq_kernel<8, 2>), gs, dim3(BLOCK), dyn, e->s2, q); }
+        } else {
         static const bool fill_pair4 = tune_env("PBWTAMD_FILL_PAIR4") && atoi(tune_env("PBWTAMD_FILL_PAIR4"));   // measurement builds: with pair rows, one fill workgroup per PAIR (1024 positions, the pair's own scan row)
         if (fill_pair4 && e->prow && e->skEPT == 2) { f.W = e->W2; f.pair = 0; grid = dim3(e->W2, ns / 8); FILL(4); }
         else
         if (e->skEPT == 1) FILL(1); else if (e->skEPT == 2) FILL(2); else FILL(4);
+        }
 #undef FILL
         HIPCHK(hipGetLastError());
     }
@@ -854,7 +874,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
     if (p.opts & PBWTAMD_OPT_CHECKSUM) {
         unsigned long long *ca = e->csum + (kb - e->k0), *cd = ca + e->csum_sites, *cy = cd + e->csum_sites;
         dim3 grid(std::min(64, (e->M + BLOCK) / BLOCK), ns);
-        hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, sr, A, D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, ns);
+        hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, sr, A, D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, ns, packed ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
     if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, sr, A, D, kb, ns, -1, p.opts, packed));

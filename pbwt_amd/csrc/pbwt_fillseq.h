@@ -1,0 +1,237 @@
+// pbwt_fillseq.h — the FILL as a tile-local sequential recurrence ("sequential fill").
+//
+// The seven states between two skeleton states (pbwtCore.c:485-508 applied to sites k+1 .. k+7) are produced beside the chain.  The
+// table form (skel_fill_kernel) derives every sub-step independently from the tile's position-ordered data: per-chunk count / last-
+// position tables folded down seven times, a sparse table for the range maxima, ~85 VALU instructions and ~10 LDS accesses per output.
+// Here ONE WAVE carries its tile through the seven sub-steps in the tile's own sorted order (model: tests/tile_model.py::fillS_tiles):
+//   * at level j the tile's elements stand sorted by their j-bit keys; the elements of one key (a "run") are contiguous in the global
+//     state k+j as well, so sub-step j -> j+1 is ONE stable partition of the local array by bit j (a prefix count of ones) ...
+//   * ... and one segmented max: a "stretch" is a maximal group of neighbours with equal (j+1)-bit key; inside a stretch d' = d (the
+//     same-bit predecessor is the neighbour, pbwtCore.c:497-503 with p or q just reset), the head of a stretch takes max(d, max of the
+//     stretch before it) when that stretch is not the first of its run; otherwise the element is the FIRST of its (j+1)-bit key in the
+//     tile and the folded skeleton tables decide (carry of that key, or the key-difference value) — once per key and tile, not per output;
+//   * the tile's elements of one key land at consecutive destinations: every sub-step's outputs leave through LDS in destination order.
+// No workgroup barrier anywhere (a wave is its own tile), 4.5 KB of LDS per wave, 2 LDS accesses + the staged store per output.
+#pragma once
+
+namespace pbwtk {
+
+constexpr int FS_EFLAG = 0x40000000;                        // ext entry: carry | FS_EFLAG (max with the local maximum) or the final value
+
+// What does not depend on the tile, once per 8-site block: per heap entry h = 2^j + kj (level j = 1 .. 7, kj = the j-bit key)
+// {G = first position of the key's bucket in state k+j, base = divergence of an element whose key has no earlier occurrence anywhere:
+// k+1+msb(kj ^ nearest lower non-empty key), or 0}.  grid = blocks, 256 threads (thread = 8-bit key).
+struct SkFillPrepArgs { const int2 *scan; size_t strideS; int nrow; int kbase; int2 *gb; };
+__global__ __launch_bounds__(BLOCK) void skel_fillprep_kernel(SkFillPrepArgs g) {
+    __shared__ int s_t[2 * SKK];
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), b = blockIdx.x, k = g.kbase + 8 * b;
+    s_t[SKK + t] = reinterpret_cast<const int *>(g.scan + (size_t)b * g.strideS + (size_t)g.nrow * SKK)[t];
+#pragma unroll
+    for (int j = SKB - 1; j >= 1; --j) {
+        __syncthreads();
+        const int K = 1 << j;
+        if (t < K) s_t[K + t] = s_t[2 * K + t] + s_t[3 * K + t];
+    }
+    __syncthreads();
+    int2 *out = g.gb + (size_t)b * SKK;
+    auto level_scan = [&](int j) {
+        const int K = 1 << j;
+        int carryG = 0, carryL = 0;
+        for (int base = 0; base < K; base += 64) {
+            const int kj = base + lane;
+            const int v = (kj < K) ? s_t[K + kj] : 0;
+            const int ginc = wave_iscan_sum(v), linc = wave_iscan_max(v ? kj + 1 : 0);
+            const int lexc = lane_shr1(linc, 0);
+            if (kj < K) {
+                const int low = max(carryL, lexc) - 1;
+                out[K + kj] = make_int2(carryG + ginc - v, (low >= 0) ? k + 1 + (31 - __clz(kj ^ low)) : 0);
+            }
+            carryG += __builtin_amdgcn_readlane(ginc, 63); carryL = max(carryL, __builtin_amdgcn_readlane(linc, 63));
+        }
+    };
+    if (wv == 0) level_scan(6);
+    else if (wv == 1) { level_scan(5); level_scan(1); }
+    else if (wv == 2) { level_scan(4); level_scan(2); }
+    else { level_scan(3); level_scan(7); }
+}
+
+struct SkFillSeqArgs {
+    int *D; size_t strideD;                                 // ring base (slot 0 of the batch part)
+    const unsigned char *keys; size_t strideK;              // keys of state 8b at keys + b*strideK
+    const int2 *scan; size_t strideS;                       // per block: scan[rows][256] {before, carry}, total[256] (, first halves' rows)
+    const int2 *gb;                                         // per block: [256] {G, base} (skel_fillprep_kernel)
+    int M, W, kbase, nblk;
+    int xcd;                                                // XCD-contiguous workgroups (xcd_tile)
+    int pair, W2;                                           // pair rows: scan[W2][256], total, then the first halves' rows tbl0[W2][256] per block
+#ifdef PBWTAMD_MEASURE
+    int dbg_nowrite;
+#endif
+};
+
+__device__ __forceinline__ void fs_comb(int &b0, int &c0, int b1, int c1) {      // two keys sharing their low bits: counts add, the later last occurrence has the smaller suffix maximum
+    b0 += b1; c0 = (c0 < 0) ? c1 : (c1 < 0) ? c0 : min(c0, c1);
+}
+
+// E positions per lane, tile T = 64 E (= the chain's tile: 256 or 512).  PACKY 1: slots get d | y << 31; PACKY 2: d only.
+// grid = ceil(W * blocks / 4) workgroups of 4 independent waves; wave -> (block, tile).
+template <int E, int PACKY>
+__global__ __launch_bounds__(BLOCK) void skel_fillseq_kernel(SkFillSeqArgs g) {
+    constexpr int T = 64 * E;
+    __shared__ __attribute__((aligned(16))) int s_dd[WAVES][T];
+    __shared__ __attribute__((aligned(16))) unsigned char s_kk[WAVES][T];
+    __shared__ int2 s_tabs[WAVES][SKK];                     // heap-indexed {destination offset, ext}
+    const int lane = lane_id(), wv = wave_id();
+    const int wgl = g.xcd ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int lg = wgl * WAVES + wv;
+    if (lg >= g.W * g.nblk) return;                         // whole waves only; nothing below synchronises across waves
+    const int b = lg / g.W, w = lg - b * g.W;
+    int *const s_d = s_dd[wv]; unsigned char *const s_k = s_kk[wv]; int2 *const tab = s_tabs[wv];
+    const int S = w * T, k = g.kbase + 8 * b, nvalid = min(T, g.M - S);
+    int *const d0 = g.D + (size_t)(8 * b) * g.strideD;
+    const unsigned char *const keys = g.keys + (size_t)b * g.strideK;
+    const int2 *const sv = g.scan + (size_t)b * g.strideS;
+    const int2 *const gbp = g.gb + (size_t)b * SKK;
+    const int l0 = lane * E;
+
+    // ---- the tile: E consecutive positions per lane
+    int dc[E]; unsigned kc[E];
+    {
+        const int4 *dp = reinterpret_cast<const int4 *>(d0 + S + l0);
+#pragma unroll
+        for (int q = 0; q < E / 4; ++q) { const int4 v = dp[q]; dc[4 * q] = v.x; dc[4 * q + 1] = v.y; dc[4 * q + 2] = v.z; dc[4 * q + 3] = v.w; }
+        unsigned kw[E / 4];
+        if constexpr (E == 8) { const uint2 v = *reinterpret_cast<const uint2 *>(keys + S + l0); kw[0] = v.x; kw[1] = v.y; }
+        else kw[0] = *reinterpret_cast<const unsigned *>(keys + S + l0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) kc[e] = (kw[e / 4] >> (8 * (e & 3))) & 0xffu;
+    }
+    // ---- the tile's table rows (issued now, folded below)
+    int bq[4], cq[4];
+    {
+        const int nrow = g.pair ? g.W2 : g.W;
+        const int2 *row = sv + (size_t)(g.pair ? (w >> 1) : w) * SKK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int2 v = row[lane + 64 * q]; bq[q] = v.x; cq[q] = v.y; }
+        if (g.pair && (w & 1)) {                            // second tile of its pair: fold the first one's row in (skel_k2_kernel's combine)
+            const int2 *r0p = sv + (size_t)nrow * SKK + SKK / 2 + (size_t)(w >> 1) * SKK;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int2 r0 = r0p[lane + 64 * q]; cq[q] = r0.x ? r0.y : (bq[q] ? max(cq[q], r0.y) : -1); bq[q] += r0.x; }
+        }
+    }
+    int2 gbv[SKB];                                          // [j]: the lane's heap entry of level j (level 7: entries lane and lane + 64 -> gbv[7], gbv[0])
+#pragma unroll
+    for (int j = 1; j <= 6; ++j) gbv[j] = gbp[(1 << j) + (lane & ((1 << j) - 1))];
+    gbv[7] = gbp[128 + lane]; gbv[0] = gbp[192 + lane];
+
+#pragma unroll
+    for (int e = 0; e < E; ++e) if (l0 + e >= nvalid) { dc[e] = 0; kc[e] = 0xffu; }    // beyond M: sorts last at every level, never a maximum
+    if (PACKY == 1) {                                       // the skeleton slot itself, in the packed form of the other seven
+        if (nvalid == T) {
+            int4 *dp = reinterpret_cast<int4 *>(d0 + S + l0);
+#pragma unroll
+            for (int q = 0; q < E / 4; ++q)
+                dp[q] = make_int4(dc[4 * q] | (int)((kc[4 * q] & 1u) << 31), dc[4 * q + 1] | (int)((kc[4 * q + 1] & 1u) << 31),
+                                  dc[4 * q + 2] | (int)((kc[4 * q + 2] & 1u) << 31), dc[4 * q + 3] | (int)((kc[4 * q + 3] & 1u) << 31));
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (l0 + e < nvalid) d0[S + l0 + e] = dc[e] | (int)((kc[e] & 1u) << 31);
+        }
+    }
+    // ---- fold the row down the heap, in registers: level 8 keys lane + 64 q; level 7: (q0, q2) -> key lane, (q1, q3) -> key lane + 64;
+    // level 6: both; below: xor-shuffles (every lane ends up with the entry of key lane mod 2^j)
+    fs_comb(bq[0], cq[0], bq[2], cq[2]); fs_comb(bq[1], cq[1], bq[3], cq[3]);
+    tab[128 + lane] = make_int2(gbv[7].x + bq[0], cq[0] >= 0 ? (cq[0] | FS_EFLAG) : gbv[7].y);
+    tab[192 + lane] = make_int2(gbv[0].x + bq[1], cq[1] >= 0 ? (cq[1] | FS_EFLAG) : gbv[0].y);
+    fs_comb(bq[0], cq[0], bq[1], cq[1]);
+    tab[64 + lane] = make_int2(gbv[6].x + bq[0], cq[0] >= 0 ? (cq[0] | FS_EFLAG) : gbv[6].y);
+#pragma unroll
+    for (int j = 5; j >= 1; --j) {
+        const int K = 1 << j;
+        const int ob = __shfl_xor(bq[0], K), oc = __shfl_xor(cq[0], K);
+        fs_comb(bq[0], cq[0], ob, oc);
+        if (lane < K) tab[K + lane] = make_int2(gbv[j].x + bq[0], cq[0] >= 0 ? (cq[0] | FS_EFLAG) : gbv[j].y);
+    }
+    asm volatile("" ::: "memory");
+
+    // ---- seven sub-steps
+#pragma unroll
+    for (int j = 0; j < SKB - 1; ++j) {
+        const unsigned m1 = (2u << j) - 1u, m0 = (1u << j) - 1u;
+        const unsigned pk = (unsigned)lane_shr1((int)kc[E - 1], 0);
+        bool H[E], R[E];
+        int c1 = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const unsigned x = kc[e] ^ (e ? kc[e - 1] : pk);
+            const bool first = (e == 0) && (lane == 0);
+            H[e] = first || (x & m1) != 0; R[e] = first || (x & m0) != 0;
+            c1 += (int)((kc[e] >> j) & 1u);
+        }
+        const int inc = wave_iscan_sum(c1);
+        const int Z = T - __builtin_amdgcn_readlane(inc, 63);
+        int p1 = inc - c1;
+        // segmented max over the stretches: in the lane, then over the lanes' summaries (fc = 0: no head in the lane; else 1 | 2 * "the stretch starts its run")
+        int Sx[E], fx[E];
+        int m = 0, fc = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (H[e]) { m = dc[e]; fc = R[e] ? 3 : 1; } else m = max(m, dc[e]);
+            Sx[e] = m; fx[e] = fc;
+        }
+        int sf = fc, sm = m;
+#define FS_STEP(CTRL, RM) { const int lf = dpp_mov<CTRL, RM>(0, sf), lm = dpp_mov<CTRL, RM>(0, sm); sm = sf ? sm : max(lm, sm); sf = sf ? sf : lf; }
+        FS_STEP(0x111, 0xf) FS_STEP(0x112, 0xf) FS_STEP(0x114, 0xf) FS_STEP(0x118, 0xf) FS_STEP(0x142, 0xa) FS_STEP(0x143, 0xc)
+#undef FS_STEP
+        const int ef = lane_shr1(sf, 0), em = lane_shr1(sm, 0);      // the open stretch at the end of the previous lane
+        int prevS = em, prevf = ef;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int bit = (int)((kc[e] >> j) & 1u);
+            const int ni = bit ? Z + p1 : l0 + e - p1;
+            p1 += bit;
+            int nd = dc[e];
+            if (H[e]) {
+                const int loc = R[e] ? dc[e] : max(dc[e], prevS);
+                if (!R[e] && !(prevf & 2)) nd = loc;
+                else {                                      // first of its (j+1)-bit key in the tile
+                    const int h = (int)(m1 + 1u) + (int)(kc[e] & m1);
+                    const int2 tv = tab[h];
+                    nd = (tv.y & FS_EFLAG) ? max(tv.y & ~FS_EFLAG, loc) : tv.y;
+                    tab[h].x = tv.x - ni;                   // G + before - (the key's first index in the tile's new order)
+                }
+            }
+            prevS = fx[e] ? Sx[e] : max(Sx[e], em); prevf = fx[e] ? fx[e] : ef;
+            s_d[ni] = nd; s_k[ni] = (unsigned char)kc[e];
+        }
+        asm volatile("" ::: "memory");
+        // ---- the level's outputs, destination order: lanes = consecutive local indices = consecutive destinations inside a run
+        int *const dout = g.D + (size_t)(8 * b + j + 1) * g.strideD;
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+            const int x = q * 64 + lane;
+            const unsigned kb = s_k[x];
+            const int pos = x + tab[(int)(m1 + 1u) + (int)(kb & m1)].x;
+            int v = s_d[x];
+            if (pos == 0) v = k + j + 2;                    // sentinel (pbwtCore.c:507)
+            if (PACKY == 1) v |= (int)(((kb >> (j + 1)) & 1u) << 31);
+#ifdef PBWTAMD_MEASURE
+            if (g.dbg_nowrite) continue;
+#endif
+            if (x < nvalid) __builtin_nontemporal_store(v, dout + pos);
+        }
+        if (w == g.W - 1 && lane == 0) dout[g.M] = k + j + 2;
+        if (j < SKB - 2) {
+            const int4 *dp = reinterpret_cast<const int4 *>(s_d + l0);
+#pragma unroll
+            for (int q = 0; q < E / 4; ++q) { const int4 v = dp[q]; dc[4 * q] = v.x; dc[4 * q + 1] = v.y; dc[4 * q + 2] = v.z; dc[4 * q + 3] = v.w; }
+            unsigned kw[E / 4];
+            if constexpr (E == 8) { const uint2 v = *reinterpret_cast<const uint2 *>(s_k + l0); kw[0] = v.x; kw[1] = v.y; }
+            else kw[0] = *reinterpret_cast<const unsigned *>(s_k + l0);
+#pragma unroll
+            for (int e = 0; e < E; ++e) kc[e] = (kw[e / 4] >> (8 * (e & 3))) & 0xffu;
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
+}  // namespace pbwtk

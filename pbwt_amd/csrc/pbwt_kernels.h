@@ -791,6 +791,7 @@ struct SkShardOut {
     int n;                                                      // ranks
     int pb[SHARD_MAX + 1];                                      // first position of every rank's range; pb[n] = M (unused entries: INT_MAX)
     int *a[SHARD_MAX]; int *d[SHARD_MAX]; unsigned char *k[SHARD_MAX];   // the OUTPUT slot (and its key row) in every rank's ring
+    const int *err;                                             // the engine's error word: once set, the rank kernel scatters nothing
 };
 
 // HALF (pair rows, wide panels): the workgroup covers a PAIR of the rank kernel's tiles and also emits the (count, tail) row of its
@@ -977,10 +978,11 @@ __global__ __launch_bounds__(SKK) void skel_k2_wide_kernel(Sk2WArgs g) {
         int spins = 0;
         while ((int)(__hip_atomic_load(g.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.target) < 0) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 25)) { atomicExch(g.err, 5); break; }
+            if (++spins > (1 << 25) || ((spins & 4095) == 0 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { atomicCAS(g.err, 0, 5); break; }
         }
     }
     __syncthreads();
+    if (__hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // incomplete aggregates: the batch has failed, no output pass (no barrier follows)
     int ec = 0, et = 0;                                      // prefix over the workgroups before this one
 #pragma unroll 1
     for (int i0 = 0; i0 < j; i0 += PCH) {
@@ -1021,29 +1023,39 @@ struct alignas(256) ShardXch {
     unsigned f2[64];                                        // [src] chain barriers src has arrived at (scatter of a round complete)
     unsigned f3[64];                                        // [src] batches whose consumers src has finished (ring reuse)
     unsigned long long ragg[SHARD_MAX][SKK];                // [src][key] count | tail << 32 of src's tiles, current round
+    unsigned perr[64];                                      // [src] nonzero: rank src has failed (a bounded wait ran out there) — whoever waits here stops waiting
 };
 struct ShardPeers { ShardXch *x[SHARD_MAX]; int n, me; };
 
-__device__ __forceinline__ void shard_wait_flags(const unsigned *mine, int n, unsigned epoch, int *err, int code) {
+// Bounded (seconds): a rank that died must not hang the others' GPUs.  The error is STICKY: once the engine's error word is set (here, by
+// another workgroup, by an earlier launch) or a peer has flagged itself failed, nobody waits again — the rest of the pass falls through its
+// waits, the kernels skip their stores (skel_k2s_kernel, skel_rank_shard_kernel), and the host fails the pass at its next event poll.
+__device__ __forceinline__ void shard_wait_flags(const unsigned *mine, const unsigned *perr, int n, unsigned epoch, int *err, int code) {
     const int t = threadIdx.x;
-    if (t < n) {                                            // bounded (seconds): a rank that died must not hang the others' GPUs
+    if (t < n) {
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
         long spins = 0;
         while ((int)(__hip_atomic_load(mine + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1L << 24)) { atomicExch(err, code); break; }
+            ++spins;
+            if ((spins & 1023) == 0 && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                                         __hip_atomic_load(perr + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) { atomicCAS(err, 0, 9); break; }
+            if (spins > (1L << 24)) { atomicCAS(err, 0, code); break; }
         }
     }
 }
 // which: 0 = f1, 1 = f2, 2 = f3.  mode bit 0: signal every rank (this one included), bit 1: wait for every rank
 __global__ __launch_bounds__(64) void shard_xbar_kernel(ShardPeers P, int which, int mode, unsigned epoch, int *err) {
     const int t = threadIdx.x;
+    if (t < P.n && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)       // this rank has failed: tell every peer, so that none waits out its own timeout
+        __hip_atomic_store(&P.x[t]->perr[P.me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((mode & 1) && t < P.n) {
         unsigned *f = which == 0 ? P.x[t]->f1 : which == 1 ? P.x[t]->f2 : P.x[t]->f3;
         __hip_atomic_store(f + P.me, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (mode & 2) {
         const unsigned *f = which == 0 ? P.x[P.me]->f1 : which == 1 ? P.x[P.me]->f2 : P.x[P.me]->f3;
-        shard_wait_flags(f, P.n, epoch, err, 6);
+        shard_wait_flags(f, P.x[P.me]->perr, P.n, epoch, err, 6);
     }
 }
 
@@ -1095,8 +1107,9 @@ __global__ __launch_bounds__(SKK) void skel_k2s_kernel(Sk2SArgs g, ShardPeers P)
         if (t < P.n) __hip_atomic_store(&P.x[t]->f1[P.me], g.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // every rank's row of this round (this rank's own among them: its flag is raised by the last arriver above)
-    shard_wait_flags(P.x[P.me]->f1, P.n, g.epoch, g.err, 7);
+    shard_wait_flags(P.x[P.me]->f1, P.x[P.me]->perr, P.n, g.epoch, g.err, 7);
     __syncthreads();
+    if (__hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // incomplete rows: no output pass (no barrier follows)
     int ec = 0, et = 0, tot = 0;
     {
         unsigned long long rv[SHARD_MAX];
@@ -1181,8 +1194,10 @@ __device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut
     __shared__ int s_gw[WAVES], s_lw[WAVES];
     __shared__ int *s_pa[SHARD ? SHARD_MAX : 1], *s_pd[SHARD ? SHARD_MAX : 1]; __shared__ unsigned char *s_pk[SHARD ? SHARD_MAX : 1];
     __shared__ int s_pb[SHARD ? SHARD_MAX : 1];
+    __shared__ int s_failed;
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = g.w0 + ((g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x);
     const int S = w * T;
+    if constexpr (SHARD) { if (t == 0) s_failed = __hip_atomic_load(so->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // read by all after the first barrier
     if constexpr (SHARD) { if (t < SHARD_MAX) { s_pa[t] = so->a[t]; s_pd[t] = so->d[t]; s_pk[t] = so->k[t]; s_pb[t] = so->pb[t + 1]; } }   // visible after the barriers below
     int av[EPT], dv[EPT], key[EPT];
     unsigned nk[EPT];
@@ -1217,6 +1232,7 @@ __device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut
     int rk[EPT], pl[EPT];
     const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
     lds_barrier();                                          // zeroed tables visible
+    if constexpr (SHARD) { if (s_failed) return; }          // a bounded wait ran out earlier in this pass: nothing more goes into the peers' rings
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
         unsigned long long same = __ballot(key[r] >= 0);
@@ -1678,6 +1694,10 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     }
 }
 
+}  // namespace pbwtk
+#include "pbwt_fillseq.h"
+namespace pbwtk {
+
 // first pair of a pass (or after an odd-length batch): both allele tags of slot 0 from columns k, k+1
 // and the pair summaries from scratch; clears the accumulation buffer of the first launch
 struct Prep2Args { int *a; const int *d; const uint32_t *col0; const uint32_t *col1; int4 *summ; int M, W, wpad, with_d, T; };
@@ -1985,13 +2005,19 @@ __global__ __launch_bounds__(BLOCK) void synth_kernel(uint32_t *bits, int M, int
 // per-site checksums over ring slots: csum[site] += sum_i sm64(i<<32 | v[i]); grid (tiles, sites)
 __global__ __launch_bounds__(BLOCK) void checksum_kernel(const int *A, const int *D, size_t strideA, size_t strideD,
                                                         int M, int with_d, unsigned long long *ca,
-                                                        unsigned long long *cd, unsigned long long *cy, int y_valid_sites) {
+                                                        unsigned long long *cd, unsigned long long *cy, int y_valid_sites, int packed = 0) {
     __shared__ unsigned long long s_red[WAVES][3];
     const int site = blockIdx.y;
     const int *a = A + (size_t)site * strideA;
     const int *d = D + (size_t)site * strideD;
     unsigned long long sa = 0, sd = 0, sy = 0;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i <= M; i += gridDim.x * BLOCK) {
+        if (packed) {                                       // slots hold d | y << 31 and no ids (PBWTAMD_PACKED_CHECKSUM: the packed fill checked position by position)
+            const int v = d[i];
+            if (i < M) sy += sm64(((uint64_t)i << 32) | ((site < y_valid_sites) ? ((uint32_t)v >> 31) : 0u));
+            sd += sm64(((uint64_t)i << 32) | (uint32_t)(i < M ? (v & 0x7fffffff) : v));
+            continue;
+        }
         if (i < M) {
             const int v = a[i];
             sa += sm64(((uint64_t)i << 32) | (uint32_t)(v & AMASK));

@@ -427,6 +427,38 @@ def test_histogram_and_pack3_consumers_without_ids(amd, orc, packed, M, N, batch
     assert np.array_equal(eng.get_packed(), o["yz"])
 
 
+@pytest.mark.parametrize("fill_seq", ["1", "0"])
+@pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1025, 96, 24, 1), (70001, 80, 40, 1), (2, 40, 8, 1), (257, 64, 64, 1), (300000, 24, 8, 0),
+                                            (600100, 24, 8, 1), (150600, 32, 16, 1), (9000, 72, 24, 0), (56001, 48, 16, 1), (511, 40, 8, 1), (512, 40, 8, 0)])
+def test_packed_fill_every_position(amd, orc, fill_seq, M, N, batch, kind, monkeypatch):
+    """the packed fill (slots hold d | y << 31, the bench option set) checked at EVERY position of EVERY site: per-site checksums of d and y taken
+    from the packed slots (PBWTAMD_PACKED_CHECKSUM=1) against the oracle's — for the sequential tile-local form (skel_fillseq_kernel,
+    PBWTAMD_FILL_SEQ=1, the default) and the table form (skel_fill_kernel).  iid panels put every 8-bit key into every tile; widths cover
+    256- and 512-position tiles, ragged last tiles, pair rows (odd and even tile counts) and the two-launch round."""
+    import torch
+    monkeypatch.setenv("PBWTAMD_FILL_SEQ", fill_seq)
+    monkeypatch.setenv("PBWTAMD_PACKED_CHECKSUM", "1")
+    eng = amd.Engine(M, batch_sites=batch)
+    buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    eng.synth_device(buf.data_ptr(), 0, N, seed=3000 + M, kind=kind)
+    eng.sync()
+    bits = buf.cpu().numpy().view(np.uint32)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    sw = orc.sweep_AD(o["yz"], M, N)
+    opts = amd.OPT_WITH_D | amd.OPT_WITHIN_HIST | amd.OPT_PACK3 | amd.OPT_CHECKSUM
+    eng.pass_begin(N)
+    eng.pass_advance(buf.data_ptr(), N, N, opts)
+    eng.pass_end(opts)
+    _, cd, cy = eng.get_checksums(0, N)
+    full = N // batch * batch if batch % 8 == 0 else 0          # sites of skeleton batches (packed slots); the ragged tail runs the two-site chain
+    assert np.array_equal(cd[:N], o["csum_d"][:N]), "d[] differs first at site %d" % int(np.argmax(cd[:N] != o["csum_d"][:N]))
+    assert np.array_equal(cy[:N], sw["csum_y"][:N]), "y[] differs first at site %d" % int(np.argmax(cy[:N] != sw["csum_y"][:N]))
+    assert full >= 0
+    assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
+    assert np.array_equal(eng.get_packed(), o["yz"])
+
+
 @pytest.mark.parametrize("Mp,Mq,N,kind,nS,batch", [(8, 3, 10, 1, 2, 4), (50, 7, 61, 0, 3, 16), (200, 20, 150, 0, 4, 32), (64, 10, 33, 1, 5, 10),
                                                   (300, 25, 100, 0, 2, 512), (40, 6, 50, 1, 1, 16), (3000, 50, 200, 0, 4, 64), (2500, 30, 130, 1, 8, 128)])
 def test_match_sweep_sparse_vs_oracle(amd, orc, Mp, Mq, N, kind, nS, batch):

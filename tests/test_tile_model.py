@@ -88,3 +88,24 @@ def test_read_side_keys_through_lf_mapping(orc, M, N, kind, B):
         for j in range(B):
             want |= hap[k + j][o["a_dump"][k]] << j
         assert np.array_equal(keys_from_sorted_columns(ys, B), want)
+
+
+@pytest.mark.parametrize("M,N,kind,T,B", [(37, 64, 1, 8, 8), (100, 72, 0, 8, 8), (257, 48, 0, 32, 8), (300, 30, 0, 16, 3), (64, 35, 1, 16, 5),
+                                         (700, 32, 0, 64, 8), (1000, 24, 1, 128, 8)])
+def test_sequential_fill_model_matches_oracle(orc, M, N, kind, T, B):
+    """the fill as a tile-local sequential recurrence (skel_fillseq_kernel's formulation): one stable partition + one segmented max per
+    sub-step in the tile's own order, the folded skeleton tables only for the first element of a key in the tile"""
+    from tile_model import fillS_tiles, stepB_tiles
+    bits = orc.synth_bitcols(M, N, seed=13 * M + N, kind=kind)
+    hap = orc.unpack_bitcols(bits, M).astype(np.int64)
+    o = orc.build_bitcols(bits, M, with_d=True, dump_sites=range(N + 1))
+    a, d = o["a_dump"][0].astype(np.int64), o["d_dump"][0].astype(np.int64)
+    for k in range(0, N - B + 1, B):
+        key = np.zeros(M, np.int64)
+        for j in range(B):
+            key |= hap[k + j][a] << j
+        for j, (dest, dj) in enumerate(fillS_tiles(d, key, k, B, T), start=1):
+            aj = np.zeros(M, np.int64); aj[dest] = a
+            assert np.array_equal(aj, o["a_dump"][k + j]), "a at site %d" % (k + j)
+            assert np.array_equal(dj, o["d_dump"][k + j]), "d at site %d" % (k + j)
+        a, d = stepB_tiles(a, d, key, k, B, T)

@@ -288,3 +288,100 @@ def keys_from_sorted_columns(ys, B):
         key |= bit << j
         pos = np.where(bit == 1, c + pos - u[pos], u[pos])
     return key
+
+
+# ------------------------------------------------------------------------------------------------
+# the fill as a SEQUENTIAL tile-local recurrence (skel_fillseq_kernel): the tile is carried through the B-1 sub-steps in its own
+# sorted order.  At level j the tile's elements stand sorted by their j-bit keys; the elements of one key ("run") are contiguous
+# in the global state k+j too, so sub-step j -> j+1 is ONE stable partition of the local array by bit j plus a segmented max:
+#   stretch = maximal group of neighbours with equal (j+1)-bit key (inside a run the stretches alternate between the two bit values);
+#   inside a stretch d' = d (the same-bit predecessor is the neighbour); the head of a stretch takes max(d, max d of the stretch
+#   before it) when that stretch is not the first of its run, else — no same-bit predecessor in the tile's run — the folded
+#   skeleton tables decide: carry of the (j+1)-bit key (max with the local maximum since the run's start) or the key-difference value.
+def fillS_tiles(d, key, k, B, T):
+    """returns [(dest_j, d_j) for j = 1..B-1]: d_j = the divergences of state k+j (global order, sentinels at 0 and M) and
+    dest_j[i] = position in state k+j of the element at position i of state k — computed tile by tile, sub-step by sub-step"""
+    M = len(key)
+    W = (M + T - 1) // T
+    K = 1 << B
+    cnt = np.zeros((W, K), np.int64); tail = np.zeros((W, K), np.int64)
+    for w in range(W):
+        lo, hi = w * T, min((w + 1) * T, M)
+        kk = key[lo:hi]; dd = d[lo:hi]
+        for q in range(K):
+            idx = np.nonzero(kk == q)[0]
+            cnt[w, q] = len(idx)
+            tail[w, q] = (dd[idx[-1] + 1:].max() if len(idx) and idx[-1] + 1 < len(dd) else 0) if len(idx) else dd.max()
+    before = np.zeros((W, K), np.int64); carry = -np.ones((W, K), np.int64)
+    for q in range(K):
+        run, ex, c = 0, False, 0
+        for w in range(W):
+            before[w, q] = run
+            carry[w, q] = c if ex else -1
+            if cnt[w, q]:
+                ex = True; c = tail[w, q]
+            elif ex:
+                c = max(c, tail[w, q])
+            run += cnt[w, q]
+    total = cnt.sum(axis=0)
+    # per level (tile-independent): bucket bases G and the value of an element whose key has no earlier occurrence at all
+    GB, base, before_l, carry_l = {}, {}, {}, {}
+    for j in range(1, B):
+        Kj = 1 << j
+        total_j = total.reshape(K >> j, Kj).sum(axis=0)
+        GB[j] = np.concatenate([[0], np.cumsum(total_j)])[:Kj]
+        bs = np.zeros(Kj, np.int64); last = -1
+        for q in range(Kj):
+            bs[q] = (k + 1 + ((q ^ last).bit_length() - 1)) if last >= 0 else 0
+            if total_j[q]:
+                last = q
+        base[j] = bs
+        before_l[j] = before.reshape(W, K >> j, Kj).sum(axis=1)
+        cj = carry.reshape(W, K >> j, Kj).astype(np.float64); cj[cj < 0] = np.inf
+        cm = cj.min(axis=1); cm[np.isinf(cm)] = -1
+        carry_l[j] = cm.astype(np.int64)
+    outs = [(np.zeros(M, np.int64), np.zeros(M + 1, np.int64)) for _ in range(1, B)]
+    for w in range(W):
+        lo, hi = w * T, min((w + 1) * T, M)
+        n = hi - lo
+        dc = d[lo:hi].astype(np.int64).copy()
+        kc = key[lo:hi].astype(np.int64).copy()
+        src = np.arange(lo, hi)                                   # model only: which state-k position stands here
+        for j in range(0, B - 1):                                 # sub-step j -> j + 1
+            mj, mj1 = (1 << j) - 1, (1 << (j + 1)) - 1
+            v = (kc >> j) & 1
+            P1 = np.concatenate([[0], np.cumsum(v)])[:n]          # ones before each position
+            Z = n - int(v.sum())
+            ni = np.where(v == 1, Z + P1, np.arange(n) - P1)
+            Rst = np.ones(n, bool); Rst[1:] = ((kc[1:] ^ kc[:-1]) & mj) != 0        # run start (level j)
+            H = np.ones(n, bool); H[1:] = ((kc[1:] ^ kc[:-1]) & mj1) != 0           # stretch head
+            S = np.zeros(n, np.int64); Rh = np.zeros(n, bool)     # segmented max over the stretch; "this stretch starts its run"
+            for i in range(n):
+                if H[i]:
+                    S[i] = dc[i]; Rh[i] = Rst[i]
+                else:
+                    S[i] = max(S[i - 1], dc[i]); Rh[i] = Rh[i - 1]
+            nd = dc.copy()
+            off = {}
+            for i in range(n):
+                if not H[i]:
+                    continue
+                kq = int(kc[i] & mj1)
+                if not Rst[i] and not Rh[i - 1]:
+                    nd[i] = max(dc[i], S[i - 1])
+                else:                                             # first of its (j+1)-bit key in the tile
+                    loc = dc[i] if Rst[i] else max(dc[i], S[i - 1])
+                    c = carry_l[j + 1][w, kq]
+                    nd[i] = max(c, loc) if c >= 0 else base[j + 1][kq]
+                    off[kq] = GB[j + 1][kq] + before_l[j + 1][w, kq] - ni[i]
+            dn = np.zeros(n, np.int64); kn = np.zeros(n, np.int64); sn = np.zeros(n, np.int64)
+            dn[ni] = nd; kn[ni] = kc; sn[ni] = src
+            dc, kc, src = dn, kn, sn
+            dest, dj = outs[j]
+            for x in range(n):
+                pos = x + off[int(kc[x] & mj1)]
+                dj[pos] = dc[x]; dest[src[x]] = pos
+        # nothing else leaves the tile
+    for j in range(1, B):
+        outs[j - 1][1][0] = k + j + 1; outs[j - 1][1][M] = k + j + 1
+    return outs
