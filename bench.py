@@ -30,6 +30,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # hipIpc (the position-sharded rings) needs the dmabuf IPC mode on this driver stack; read when HSA initialises
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -66,6 +68,11 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-1m", action="store_true", help="skip the measurements at the north-star width (1M haplotypes)")
     ap.add_argument("--ns-sites", type=int, default=1000000, help="sites of the north-star job (1M haplotypes x this many sites; the bit panel, 125 KB per site, is resident)")
+    ap.add_argument("--ps-sites", type=int, default=None, help="sites of the position-sharded job attached at N > 1 (default: --ns-sites, i.e. the north-star job itself)")
+    ap.add_argument("--ps-timeout", type=float, default=900.0, help="seconds after which the attached position-sharded job is given up (the line is printed without it)")
+    ap.add_argument("--no-posshard", action="store_true", help="N > 1: do not attach the position-sharded job")
+    ap.add_argument("--stream-panel", action="store_true", help="run ONLY the north-star job with the panel generated per step into a column ring (configs[4] at its own length: --ns-sites 10000000); prints that object")
+    ap.add_argument("--ns-no-pack3", action="store_true", help="--stream-panel: build + maxWithin without the pack3 consumer (10 M sites of .pbwt bytes do not fit beside the job)")
     ap.add_argument("--own-stream", action="store_true", help="let the engine create its own (high-priority) chain stream instead of torch's current stream")
     ap.add_argument("--mode", default=os.environ.get("PBWT_BENCH_MODE", "replicas"), choices=["replicas", "siteblock", "posshard"],
                     help="multi-GPU mode: independent panels per rank (weak) or one panel sharded by site blocks (strong)")
@@ -98,6 +105,66 @@ def cpu_baseline(args, first_cols):
     return {"value": M * n / (tb + tw), "unit": "site*haps/s", "cores": 1, "kind": kind,
             "sample": "first %d sites of the same %d-haplotype panel, %s: build(WriteForwardsAD + pack3) %.2fs + -stats maxWithin %.2fs"
                       % (n, M, what, tb, tw)}
+
+
+def north_star_streamed(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=10000000, batch=512, step=8192, snapshot_at=1000000):
+    """BASELINE configs[4] at its own length (1 M haplotypes x 10 M sites): the bit panel would be 1.25 TB, so it is GENERATED per step of 8 192 sites
+    (pbwtamd_synth_device on a second engine's stream — the same counter-based generator, column by column) into a two-slot column ring, one step
+    ahead of the chain; events order the generator behind the chain's last read of a slot and the chain behind the generator.  Same seed and pass
+    structure as north_star_width(), so the histogram total after the first `snapshot_at` sites (read once, mid-pass) is comparable with that run's."""
+    sites = (sites // step) * step
+    s_chain, s_gen = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    eng = pbwt_amd.Engine(M, batch_sites=batch, device=dev.index, stream=s_chain.cuda_stream)
+    gen = pbwt_amd.Engine(M, batch_sites=8, device=dev.index, stream=s_gen.cuda_stream)        # only its generator and its stream are used
+    n_total = sites + batch
+    look = 8
+    ring = [torch.empty((step + look, eng.wpc), dtype=torch.int32, device=dev) for _ in range(2)]
+    ev_gen = [torch.cuda.Event() for _ in range(2)]; ev_read = [torch.cuda.Event() for _ in range(2)]
+    torch.cuda.synchronize()
+
+    def generate(slot, k0):                                 # columns k0 .. k0 + step + look - 1 (clipped to the panel) into ring[slot]
+        n = min(step + look, n_total - k0)
+        s_gen.wait_event(ev_read[slot])
+        gen.synth_device(ring[slot].data_ptr(), k0, n, seed=0x1A2B3C, kind=kind)
+        ev_gen[slot].record(s_gen)
+
+    for sl in range(2):
+        ev_read[sl].record(s_chain)
+    eng.pass_begin(n_total)
+    generate(0, 0)
+    s_chain.wait_event(ev_gen[0])
+    eng.pass_advance(ring[0].data_ptr(), batch, batch + look, opts)          # warm-up batch (untimed), as in north_star_width()
+    eng.sync()
+    # the timed region: steps of `step` sites starting at site `batch`; slot i % 2 holds the columns of step i
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k, i = batch, 0
+    generate(1, k)
+    snap = None
+    while k < n_total:
+        n = min(step, n_total - k)
+        slot = (i + 1) % 2
+        s_chain.wait_event(ev_gen[slot])
+        eng.pass_advance(ring[slot].data_ptr(), n, min(n + look, n_total - k), opts)
+        ev_read[slot].record(s_chain)                        # the chain's last read of this slot (transpose + key gathers) is enqueued
+        k += n; i += 1
+        if k < n_total:
+            generate((i + 1) % 2, k)
+        if snap is None and k >= snapshot_at + batch:
+            t_s = time.perf_counter()
+            snap = {"sites": k, "within_reports_hist_total": int(eng.get_hist(n_total + 1).sum()), "seconds_so_far": time.perf_counter() - t0}
+            snap["snapshot_cost_s"] = time.perf_counter() - t_s
+    eng.pass_end(opts)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    hist = eng.get_hist(n_total + 1)
+    eng.close(); gen.close()
+    return {"haplotypes": M, "sites_timed": sites, "seconds": dt, "value": M * sites / dt, "unit": "site*haps/s", "us_per_site": 1e6 * dt / sites,
+            "within_reports_hist_total": int(hist.sum()), "snapshot": snap,
+            "whole_job_frac_of_hbm_peak": ALG_BYTES_PER_SITEHAP * M * sites / dt / 1e9 / HBM_PEAK_GBPS,
+            "panel": "generated per %d-site step into a two-slot column ring (%.1f GB instead of %.0f GB resident), one step ahead of the chain"
+                     % (step, 2 * (step + look) * ((M + 31) // 32) * 4 / 1e9, n_total * ((M + 31) // 32) * 4 / 1e9),
+            "pack3": bool(opts & pbwt_amd.OPT_PACK3)}
 
 
 def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=1000000, batch=512, step=8192, want_hist=False):
@@ -238,6 +305,90 @@ def match_dynamic(torch, pbwt_amd, dev, kind, M=1000000, Q=10000, sites=65536, b
             "note": "host-buffer entry point (packed panels in host memory in, records out), one call over all the sites (set-up and the closing tails included)"}
 
 
+def position_sharded_selfcheck(torch, pdist, pbwt_amd, dev, rank, world, backend, kind, M=70000, N=264, batch=128):
+    """before the big job, on whatever hardware this is: a small panel through the position-sharded engine against the SAME panel through the
+    plain engine on rank 0 (histogram, .pbwt bytes, final a/d).  On a multi-GPU node this is the first thing that exercises the peer stores and
+    flag barriers over xGMI; a mismatch is reported and the big job is skipped."""
+    from pbwt_amd import posshard as ps
+    opts = pbwt_amd.OPT_WITH_D | pbwt_amd.OPT_WITHIN_HIST | pbwt_amd.OPT_PACK3
+    eng = pbwt_amd.Engine(M, batch_sites=batch, device=dev.index)
+    ps.setup(eng, rank, world)
+    panel = torch.empty((N, eng.wpc), dtype=torch.int32, device=dev)
+    eng.synth_device(panel.data_ptr(), 0, N, seed=0x9051, kind=kind)
+    eng.sync()
+    ps.run(eng, lambda k: panel.data_ptr() + k * eng.wpc * 4, N, opts)
+    hist = ps.reduce_hist(eng.get_hist(N + 1), device=dev if backend == "nccl" else None)
+    yz = ps.gather_packed(eng)
+    a, d = eng.get_state()
+    eng.close()
+    ok = True
+    if rank == 0:
+        ref = pbwt_amd.Engine(M, batch_sites=batch, device=dev.index)
+        ref.pass_begin(N); ref.pass_advance(panel.data_ptr(), N, N, opts); ref.pass_end(opts)
+        a0, d0 = ref.get_state()
+        ok = bool(np.array_equal(hist, ref.get_hist(N + 1)) and np.array_equal(yz, ref.get_packed()) and np.array_equal(a, a0) and np.array_equal(d, d0))
+        ref.close()
+    return bool(pdist.max_over_ranks(0.0 if ok else 1.0, device=dev if backend == "nccl" else None) == 0.0)
+
+
+def position_sharded_job(torch, pdist, pbwt_amd, dev, rank, world, backend, opts, kind, M=1000000, sites=1000000, batch=512, step=8192):
+    """BASELINE configs[3] / the north star's multi-GPU form: ONE panel of M haplotypes x `sites` sites, the RECURRENCE position-sharded over the
+    ranks (pbwt_amd/posshard.py, csrc/pbwt_shard.inc).  Same panel (seed, kind), same pass structure (one untimed warm-up batch, then the rest)
+    and same option set as north_star_width(), so `within_reports_hist_total` must equal that object's from the N = 1 run when `sites` is the same."""
+    from pbwt_amd import posshard as ps
+    red = dev if backend == "nccl" else None
+    sites = (sites // batch) * batch
+    eng = pbwt_amd.Engine(M, batch_sites=batch, device=dev.index)
+    ps.setup(eng, rank, world)
+    n_total = sites + batch
+    panel = torch.empty((n_total, eng.wpc), dtype=torch.int32, device=dev)      # replicated: every rank holds the panel's columns
+    eng.synth_device(panel.data_ptr(), 0, n_total, seed=0x1A2B3C, kind=kind)
+    eng.sync()
+    col = lambda k: panel.data_ptr() + k * eng.wpc * 4
+    eng.pass_begin(n_total)
+    eng.pass_advance(col(0), batch, batch + 8, opts)
+    eng.sync()
+    ms0, n0 = eng.chain_timing(); s0 = eng.chain_sites()
+    pdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k = batch
+    while k < n_total:
+        n = min(step, n_total - k)
+        eng.pass_advance(col(k), n, min(n + 8, n_total - k), opts)
+        k += n
+    eng.pass_end(opts)
+    hist = ps.reduce_hist(eng.get_hist(n_total + 1), device=red)              # the one collective of the mode, inside the timed region
+    pdist.barrier(); torch.cuda.synchronize()
+    dt = pdist.max_over_ranks(time.perf_counter() - t0, device=red)
+    ms1, n1 = eng.chain_timing(); s1 = eng.chain_sites()
+    us = 1e3 * (ms1 - ms0) / max(n1 - n0, 1); spl = (s1 - s0) / max(n1 - n0, 1)
+    lo, hi = eng.shard_range(rank)
+    ach = ALG_BYTES_PER_SITEHAP * (hi - lo) * spl / (us * 1e-6) / 1e9
+    ndev = len({int(x) for x in _gather_ints(pdist, torch, dev.index if dev.index is not None else 0, red)})
+    eng.close()
+    del panel
+    return {"haplotypes": M, "sites_timed": sites, "n_ranks": world, "devices": ndev, "backend": backend, "seconds": dt, "value": M * sites / dt, "unit": "site*haps/s",
+            "us_per_site": 1e6 * dt / sites, "scaling": "strong", "within_reports_hist_total": int(hist.sum()),
+            "whole_job_achieved_GBps": ALG_BYTES_PER_SITEHAP * M * sites / dt / 1e9,
+            "whole_job_frac_of_hbm_peak": ALG_BYTES_PER_SITEHAP * M * sites / dt / 1e9 / (HBM_PEAK_GBPS * max(ndev, 1)),
+            "validated_on": ("%d devices" % ndev) if ndev > 1 else "ranks sharing ONE device (peer stores never left the GPU): correctness only, not a scaling result",
+            "roofline": {"bound": "hbm", "kernel": "sharded skeleton chain: skel_hist_kernel + skel_k2s_kernel + skel_rank_shard_kernel + shard_xbar_kernel, 4 launches per 8 sites",
+                         "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None, "us_per_launch": us, "sites_per_launch": spl,
+                         "positions_of_rank0": [lo, hi], "note": "rank 0's chain over its own range of positions (launch gaps and peer waits included)"},
+            "exchange": "per round of 8 sites: one row of 256 (count, carry) per rank + the scatter as peer stores (hipIpc / xGMI), 2 flag barriers; consumers sharded "
+                        "by site inside every batch (bulk pulls); one all-reduce of the histogram at the end"}
+
+
+def _gather_ints(pdist, torch, value, device):
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [value]
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device if device is not None else "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [int(x.item()) for x in out]
+
+
 def host_entry_points(torch, pbwt_amd, panel, M, sites=16384, batch=512):
     """PCIe-inclusive rates of the host-buffer entry points on the first `sites` columns of the same panel (reported
     next to the headline, never part of `value`): pbwtamd_build (columns in host memory -> .pbwt bytes) and the read side
@@ -360,6 +511,11 @@ def main():
         torch.cuda.set_device(dev)
         pdist.init(args.backend)
     import pbwt_amd
+    if args.stream_panel:
+        o = pbwt_amd.OPT_WITH_D | pbwt_amd.OPT_WITHIN_HIST | (0 if args.ns_no_pack3 else pbwt_amd.OPT_PACK3)
+        out = north_star_streamed(torch, pbwt_amd, dev, o, args.kind, sites=args.ns_sites)
+        print(json.dumps(out), flush=True)
+        return pdist.finish()
     if args.mode == "siteblock":
         return run_siteblock(args, torch, pdist, pbwt_amd, dev, rank, world)
     if args.mode == "posshard":
@@ -482,8 +638,43 @@ def main():
         out["match_dynamic"] = match_dynamic(torch, pbwt_amd, dev, args.kind)
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args, first)
+    if world > 1 and not args.no_posshard and args.panels == 1:
+        # N > 1: after the replicas measurement (independent panels, `value`), the SAME process group runs the north star's multi-GPU form — ONE
+        # 1 M-haplotype panel with the recurrence position-sharded over the ranks (BASELINE configs[3]) — and attaches it as `position_sharded`.
+        # Never `value`.  It has only ever run with the ranks sharing one GPU, so it is fenced: a small self-check against the plain engine first,
+        # exceptions caught, and a watchdog that prints the line without it if it does not come back.
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(args.ps_timeout):
+                if rank == 0:
+                    out["position_sharded"] = {"error": "gave up after %.0f s (--ps-timeout)" % args.ps_timeout}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            del panel
+            torch.cuda.empty_cache()
+            rpd = max(1, world // max(1, min(world, torch.cuda.device_count())))       # ranks per device (gloo on the one-GPU box: all of them)
+            free_b = torch.cuda.mem_get_info(dev)[0] / rpd
+            ps_sites = args.ps_sites if args.ps_sites else args.ns_sites
+            ps_sites = min(ps_sites, int((free_b - 24e9 / rpd) // 125000) // 512 * 512)
+            red = dev if args.backend == "nccl" else None
+            ps_sites = int(-pdist.max_over_ranks(-float(ps_sites), device=red))         # the same job on every rank: the smallest
+            check = position_sharded_selfcheck(torch, pdist, pbwt_amd, dev, rank, world, args.backend, args.kind)
+            if not check:
+                out["position_sharded"] = {"error": "self-check failed: the sharded engine's histogram / bytes / final state differ from the plain engine's on a 70 000 x 264 panel", "selfcheck": False}
+            elif ps_sites < 512:
+                out["position_sharded"] = {"error": "not enough free device memory for the replicated panel", "selfcheck": True}
+            else:
+                out["position_sharded"] = position_sharded_job(torch, pdist, pbwt_amd, dev, rank, world, args.backend, opts, args.kind, sites=ps_sites)
+                out["position_sharded"]["selfcheck"] = True
+        except Exception as ex:                              # the secondary object must not cost the line
+            out["position_sharded"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:500])}
+        done.set()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     pdist.finish()
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PBWTAMD_ABI_VERSION 1
+#define PBWTAMD_ABI_VERSION 2   /* 2: pbwtamd_shard_* , pbwtamd_pass_advance_many, pbwtamd_get_nomatch_events (round 3-4) */
 
 typedef struct pbwtamd_engine pbwtamd_engine;
 

@@ -211,6 +211,9 @@ struct pbwtamd_engine {
     int *skT = nullptr;                     // hist table of the round in flight, [W][256] {cnt, tail}
     unsigned long long *k2agg = nullptr; unsigned *k2cnt = nullptr; unsigned k2epoch = 0;   // two-level tile scan of wide panels (skel_k2_wide_kernel)
     unsigned char *keysR[2] = {nullptr, nullptr};         // per ring: the keys of states 0, 8, 16, ... of the batch ([B/8+1][Mpad]), kept for the fill
+    unsigned *wflags = nullptr; size_t strideF = 0;           // fused fill + maxWithin: one bit per position and slot of a batch = "not decided in the fill" (sweep_resid_kernel clears what it reads)
+    unsigned long long *nflag = nullptr, *h_nflag = nullptr; hipEvent_t evFlag = nullptr; bool flagPending = false;   // positions flagged (device total, pinned mirror)
+    unsigned long long nflag_prev = 0; double flag_sites = 0; bool fuse_ok = true;      // ... a panel that leaves too many undecided goes back to the streaming sweep
     int2 *fillGB[2] = {nullptr, nullptr};                   // per ring and round: [256] {G, base} per heap entry (skel_fillprep_kernel -> skel_fillseq_kernel)
     int2 *saveR[2] = {nullptr, nullptr}; size_t strideS = 0;  // per ring and round: scan[W][256] {before, carry}, total[256] (stride in int2)
     hipEvent_t tev[16] = {}; long long tev_n = 0; int thr_rounds = 28, thr_depth = 2;   // host throttle: an event every thr_rounds rounds, host at most thr_depth events ahead
@@ -266,10 +269,12 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (e->pargs) (void)dev_free(e->pargs);
     if (e->pbar) (void)dev_free(e->pbar);
     if (e->h_used) (void)hipHostFree(e->h_used);
+    if (e->h_nflag) (void)hipHostFree(e->h_nflag);
+    if (e->evFlag) (void)hipEventDestroy(e->evFlag);
     for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); if (e->evRounds[i]) (void)hipEventDestroy(e->evRounds[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->fillGB[0], (void *)e->fillGB[1], (void *)e->rankdirS, (void *)e->skT, (void *)e->k2agg, (void *)e->k2cnt, e->cols_stage, e->ycols, e->colBytes, (void *)e->p3regs,
+    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->fillGB[0], (void *)e->fillGB[1], (void *)e->wflags, (void *)e->nflag, (void *)e->rankdirS, (void *)e->skT, (void *)e->k2agg, (void *)e->k2cnt, e->cols_stage, e->ycols, e->colBytes, (void *)e->p3regs,
                     e->blockCount, e->scal, e->hist, e->hist_rep, e->csum, e->recs, e->yz};
     for (void *p : ptrs) if (p) (void)dev_free(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -600,7 +605,9 @@ static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int
         if (packed) hipLaunchKernelGGL((sweep_hist_kernel<true>), gs, dim3(BLOCK), 0, st, g);
         else hipLaunchKernelGGL((sweep_hist_kernel<false>), gs, dim3(BLOCK), 0, st, g);
         HIPCHK(hipGetLastError());
-    } else if (opts & PBWTAMD_OPT_WITHIN_HIST) {
+    }
+#ifdef PBWTAMD_MEASURE
+    else if (opts & PBWTAMD_OPT_WITHIN_HIST) {
         dim3 gh((tiles + iters - 1) / iters, nsites);
 #define SWEEP_HIST(P, I) hipLaunchKernelGGL((sweep_within_kernel<2, P, I>), gh, dim3(BLOCK), 0, st, g)
         if (packed) { if (iters == 8) SWEEP_HIST(true, 8); else if (iters == 4) SWEEP_HIST(true, 4); else if (iters == 2) SWEEP_HIST(true, 2); else { gh.x = tiles; SWEEP_HIST(true, 1); } }
@@ -608,6 +615,9 @@ static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int
 #undef SWEEP_HIST
         HIPCHK(hipGetLastError());
     }
+#else
+    (void)iters; (void)old_sweep;
+#endif
     if (opts & PBWTAMD_OPT_WITHIN_RECS) {
         const size_t nblk = (size_t)tiles * nsites;
         CHK(ensure_blockcount(e, nblk));
@@ -718,6 +728,7 @@ static void launch_p3r_emit(hipStream_t st, int nsites, const unsigned long long
     hipLaunchKernelGGL((p3r_emit_kernel<1>), dim3((R + WAVES - 1) / WAVES, nsites), dim3(BLOCK), 0, st, ycols, wpc64, M, R, regs, colOff, out);
 }
 
+#ifdef PBWTAMD_MEASURE
 template <int MODE>
 static void launch_pack3v2(hipStream_t st, int nsites, const unsigned long long *ycols, int wpc64, int M, unsigned long long *colBytes, uint8_t *out) {
     const int nw = (M + 63) / 64;
@@ -728,17 +739,25 @@ static void launch_pack3v2(hipStream_t st, int nsites, const unsigned long long 
     else if (nw <= 4096) P3(1024, 4); else if (nw <= 8192) P3(1024, 8); else if (nw <= 16384) P3(1024, 16); else P3(1024, 64);
 #undef P3
 }
+#endif
 
 static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites, bool have_ycols) {
     dim3 g1(std::min(64, (e->wpc64 + WAVES - 1) / WAVES), nsites);
     if (!have_ycols) hipLaunchKernelGGL(tags_to_bits_kernel, g1, dim3(BLOCK), 0, st, A, e->strideA, e->M, e->ycols, e->wpc64);   // else: emitted by the maxWithin sweep
     const bool wide = e->wpc64 > 2048;                      // > 131072 haplotypes: 1024 threads per column
+#ifdef PBWTAMD_MEASURE
     static const bool old_pack3 = tune_env("PBWTAMD_OLD_PACK3") != nullptr;   // the chunk-loop encoder (A/B runs)
     static const int p3_form = tune_env("PBWTAMD_PACK3_FORM") ? atoi(tune_env("PBWTAMD_PACK3_FORM")) : 3;   // 3 = region-parallel, 2 = one workgroup per column
+#endif
+#ifndef PBWTAMD_MEASURE
+    launch_p3r_sizes(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->p3regs, e->colBytes);
+    (void)wide;
+#else
     if (!old_pack3 && p3_form == 3) launch_p3r_sizes(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->p3regs, e->colBytes);
     else if (!old_pack3) launch_pack3v2<0>(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
     else if (wide) hipLaunchKernelGGL((pack3_kernel<0, 1024>), dim3(nsites), dim3(1024), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
     else hipLaunchKernelGGL((pack3_kernel<0>), dim3(nsites), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, (uint8_t *)nullptr);
+#endif
     // exclusive offsets inside the batch; batch total -> scal[2]
     hipLaunchKernelGGL(scan_u64_kernel, dim3(1), dim3(1024), 0, st, e->colBytes, (size_t)nsites, e->scal + 2, 0ULL);
     HIPCHK(hipGetLastError());
@@ -762,10 +781,14 @@ static int run_pack3(pbwtamd_engine *e, hipStream_t st, const int *A, int nsites
     }
     hipLaunchKernelGGL(pack3_offsets_kernel, dim3((nsites + 255) / 256), dim3(256), 0, st, e->colBytes, (size_t)nsites, (const unsigned long long *)(e->scal + 1),
                        e->scal + 2, e->scal + 1, (unsigned long long)e->yzCap, e->ctl + 2);
+#ifndef PBWTAMD_MEASURE
+    launch_p3r_emit(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->p3regs, e->colBytes, e->yz);
+#else
     if (!old_pack3 && p3_form == 3) launch_p3r_emit(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->p3regs, e->colBytes, e->yz);
     else if (!old_pack3) launch_pack3v2<1>(st, nsites, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
     else if (wide) hipLaunchKernelGGL((pack3_kernel<1, 1024>), dim3(nsites), dim3(1024), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
     else hipLaunchKernelGGL((pack3_kernel<1>), dim3(nsites), dim3(BLOCK), 0, st, (const unsigned long long *)e->ycols, e->wpc64, e->M, e->colBytes, e->yz);
+#endif
     hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, st, e->scal + 1, (const unsigned long long *)(e->scal + 2), (unsigned long long)e->yzCap, e->ctl + 2);
     HIPCHK(hipGetLastError());
     e->yz_upper += worst;
@@ -825,6 +848,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
 #endif
     const unsigned consumers = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS | OPT_INTERNAL_KEEP_STATES;
     const bool packed = packed_fill(p);
+    bool fused = false;                                     // this call's fill has decided most of the -stats sweep and emitted the bit columns
     if ((what & 1) && p.skel && !nofill && (p.opts & consumers)) {   // the 7 states between consecutive skeleton states: all blocks and tiles in one launch
         SkFillArgs f;
         f.A = ringA(e, p.ring) + (size_t)j0 * e->strideA; f.D = ringD(e, p.ring) + (size_t)j0 * e->strideD; f.strideA = e->strideA; f.strideD = e->strideD;
@@ -853,7 +877,38 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
             q.dbg_nowrite = f.dbg_nowrite;
 #endif
             const dim3 gs(((size_t)e->Wt * (ns / 8) + WAVES - 1) / WAVES);
+            // FUSED with the -stats sweep (PBWTAMD_FILL_FUSE=0: off): the fill decides the first step of matchMaximalWithin's scans for every position
+            // whose neighbours stand in the same run, flags the rest for sweep_resid_kernel and emits the sorted bit columns pack3 encodes
+#ifdef PBWTAMD_MEASURE
+            // measurement builds only: built, bit-exact (every-position checksums, histogram, .pbwt bytes on mosaic and iid panels), and SLOWER — the fused
+            // fill takes 1.85 ms per 512-site batch at 1 M haplotypes against 0.80 + 0.91 for fill + streaming sweep, the residual sweep 0.89 ms for the 1 %
+            // of positions left to it: both consumers are bound by instruction issue, not by the bytes the fusion saves
+            static const bool fuse_env = getenv("PBWTAMD_FILL_FUSE") && atoi(getenv("PBWTAMD_FILL_FUSE"));
+#else
+            constexpr bool fuse_env = false;
+#endif
+            fused = fuse_env && e->fuse_ok && packed && what == 3 && sr == e->s2 && (p.opts & PBWTAMD_OPT_WITHIN_HIST) && !(p.opts & PBWTAMD_OPT_WITHIN_RECS);
+            q.flags = nullptr; q.strideF = 0; q.ycols = nullptr; q.wpc64 = e->wpc64; q.nflag = nullptr;
+            if (fused) {
+                if (!e->wflags) {
+                    e->strideF = (size_t)e->Mpad / 32;
+                    HIPCHK(dev_alloc((void **)&e->wflags, (size_t)(e->B + 8) * e->strideF * sizeof(unsigned)));
+                    HIPCHK(hipMemsetAsync(e->wflags, 0, (size_t)(e->B + 8) * e->strideF * sizeof(unsigned), e->s2));
+                    HIPCHK(dev_alloc((void **)&e->nflag, sizeof(unsigned long long)));
+                    HIPCHK(hipMemsetAsync(e->nflag, 0, sizeof(unsigned long long), e->s2));
+                    HIPCHK(hipHostMalloc((void **)&e->h_nflag, sizeof(unsigned long long), hipHostMallocDefault)); *e->h_nflag = 0;
+                    HIPCHK(hipEventCreateWithFlags(&e->evFlag, hipEventDisableTiming));
+                }
+                q.flags = e->wflags; q.strideF = e->strideF; q.nflag = e->nflag;
+                if (p.opts & PBWTAMD_OPT_PACK3) { q.ycols = e->ycols; HIPCHK(hipMemsetAsync(e->ycols, 0, (size_t)ns * e->wpc64 * sizeof(unsigned long long), e->s2)); }
+            }
+#ifdef PBWTAMD_MEASURE
+            if (fused) { if (e->skEPT == 1) hipLaunchKernelGGL((skel_fillseq_kernel<4, 1, true>), gs, dim3(BLOCK), dyn, e->s2, q); else hipLaunchKernelGGL((skel_fillseq_kernel<8, 1, true>), gs, dim3(BLOCK), dyn, e->s2, q); }
+            else
+#endif
             if (e->skEPT == 1) { if (packed) hipLaunchKernelGGL((skel_fillseq_kernel<4, 1>), gs, dim3(BLOCK), dyn, e->s2, q); else hipLaunchKernelGGL((skel_fillseq_kernel<4, 2>), gs, dim3(BLOCK), dyn, e->s2, q); }
+            // (77 VGPRs, 6 waves per SIMD.  Forced to 64 VGPRs / 8 waves — 12 registers spilled — the fill itself gains 4 % and the chain's rank launch
+            // beside it goes from 13.0 to 19.9 us: 5.50 -> 5.74 us/site at 1 M.  Not kept.)
             else { if (packed) hipLaunchKernelGGL((skel_fillseq_kernel<8, 1>), gs, dim3(BLOCK), dyn, e->s2, q); else hipLaunchKernelGGL((skel_fillseq_kernel<8, 2>), gs, dim3(BLOCK), dyn, e->s2, q); }
         } else {
         static const bool fill_pair4 = tune_env("PBWTAMD_FILL_PAIR4") && atoi(tune_env("PBWTAMD_FILL_PAIR4"));   // measurement builds: with pair rows, one fill workgroup per PAIR (1024 positions, the pair's own scan row)
@@ -877,6 +932,31 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
         hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, sr, A, D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, ns, packed ? 1 : 0);
         HIPCHK(hipGetLastError());
     }
+#ifdef PBWTAMD_MEASURE
+    if (fused) {                                            // what the fill left undecided: ~1 % of the positions of a founder-mosaic panel
+        SweepResidArgs ra; ra.D = D; ra.strideD = e->strideD; ra.flags = e->wflags; ra.strideF = e->strideF; ra.M = e->M; ra.kbase = kb;
+        ra.hist = e->hist; ra.histlen = e->histlen; ra.hist_rep = e->hist_rep; ra.err = e->ctl + 2;
+        const int nwords = (e->M + 31) / 32;
+        hipLaunchKernelGGL(sweep_resid_kernel, dim3((nwords + BLOCK - 1) / BLOCK, ns), dim3(BLOCK), 0, sr, ra);
+        HIPCHK(hipGetLastError());
+        // how much was left: read back without waiting; a panel whose scans rarely end at their first step (iid: half of all positions) is
+        // cheaper through the streaming sweep, which reads every state once but tests 256 positions per wave and step
+        if (e->flagPending && hipEventQuery(e->evFlag) == hipSuccess) {
+            const unsigned long long tot = *e->h_nflag;
+            const double frac = (double)(tot - e->nflag_prev) / std::max(1.0, e->flag_sites * (double)e->M);
+            e->nflag_prev = tot; e->flag_sites = 0; e->flagPending = false;
+            static const double fuse_max = getenv("PBWTAMD_FUSE_MAX_FLAGGED") ? atof(getenv("PBWTAMD_FUSE_MAX_FLAGGED")) : 0.10;
+            if (frac > fuse_max) e->fuse_ok = false;
+        }
+        (void)hipGetLastError();
+        e->flag_sites += ns;
+        if (!e->flagPending) {
+            HIPCHK(hipMemcpyAsync(e->h_nflag, e->nflag, sizeof(unsigned long long), hipMemcpyDeviceToHost, sr));
+            HIPCHK(hipEventRecord(e->evFlag, sr));
+            e->flagPending = true;
+        }
+    } else
+#endif
     if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, sr, A, D, kb, ns, -1, p.opts, packed));
     if (p.opts & PBWTAMD_OPT_LONG_RECS) {
         CHK(run_long(e, sr, A, D, nullptr, kb, ns, -1));
@@ -885,7 +965,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
         HIPCHK(hipMemcpyAsync(e->ystale, A + (size_t)(ns - 1) * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, sr));
     }
     static const bool no_fuse = tune_env("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
-    if (p.opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, sr, A, ns, !no_fuse && (p.opts & PBWTAMD_OPT_WITHIN_HIST) != 0));
+    if (p.opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, sr, A, ns, fused || (!no_fuse && (p.opts & PBWTAMD_OPT_WITHIN_HIST) != 0)));
     return 0;
 }
 
@@ -1404,6 +1484,10 @@ extern "C" int pbwtamd_pass_set_d(pbwtamd_engine *e, const int32_t *d) {
 
 extern "C" int pbwtamd_get_state(pbwtamd_engine *e, int32_t *a, int32_t *d) {
     HIPCHK(hipSetDevice(e->device));
+    // position-sharded engine: between pass_begin and pass_end / pass_stop the cursor lives in the ranks' skeleton rings, slot 0 of the full ring is
+    // stale, and completing it is a collective step (every rank pulls from every rank behind a barrier) — refuse instead of returning a stale state
+    if (e->sh && e->sh->world > 1 && e->pass_open && !e->sh->full_state)
+        return fail("pbwtamd_get_state: on a position-sharded engine the cursor is complete only after pbwtamd_pass_end / pbwtamd_pass_stop (mid-pass it is spread over the ranks)");
     CHK(flush_pending(e));
     HIPCHK(hipStreamSynchronize(e->s2));                   // ycols scratch is shared with pack3
     // slot 0 of the current ring holds the cursor; strip the allele tags through the ycols scratch
@@ -2087,7 +2171,10 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         CHK(bufs.alloc(&fss[i], (size_t)2 * std::max(nS, 1) * Mq)); CHK(bufs.alloc(&dss[i], (size_t)2 * std::max(nS, 1) * Mq));
     }
     CHK(bufs.alloc(&tot, (size_t)4));
-    constexpr unsigned NM_CAP = 1u << 16;                   // no-match events kept for the log (the count is exact beyond that)
+    // "no match to query" events (pbwtMatch.c:405-410 / 494): the reference logs every one, in site order.  The device buffer is drained after EVERY
+    // batch (sorted by site, query rank, dense before sparse = the log order), so the first NM_KEEP events kept for the caller's log are the
+    // reference's first NM_KEEP lines; the count is exact beyond that.  (One batch alone would have to exceed NM_CAP events to lose that.)
+    constexpr unsigned NM_CAP = 1u << 20, NM_KEEP = 1u << 16;
     int4 *nm_ev; unsigned *nm_n;
     CHK(bufs.alloc(&nm_ev, (size_t)NM_CAP)); CHK(bufs.alloc(&nm_n, (size_t)1));
     e->nomatch_events.clear();
@@ -2148,7 +2235,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         return 0;
     };
     unsigned long long *h_total = nullptr; hipEvent_t evTotal = nullptr;      // the batch's record count comes back through pinned memory + an event
-    HIPCHK(hipHostMalloc((void **)&h_total, sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h_total, 2 * sizeof(unsigned long long), hipHostMallocDefault));     // [1]: the batch's no-match event count
     HIPCHK(hipEventCreateWithFlags(&evTotal, hipEventDisableTiming));
     hipEvent_t evCols = nullptr; HIPCHK(hipEventCreateWithFlags(&evCols, hipEventDisableTiming));
     struct TotGuard { unsigned long long *p; hipEvent_t ev, ev2; ~TotGuard() { if (ev) (void)hipEventDestroy(ev); if (ev2) (void)hipEventDestroy(ev2); if (p) (void)hipHostFree(p); } } totGuard{h_total, evTotal, evCols};
@@ -2282,6 +2369,7 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         scan_u64(st, cnt, 2 * (size_t)nb * Mq, tot + 3, bsum);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_total, tot + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));   // read back before the next batch's fill queues on this stream
+        HIPCHK(hipMemcpyAsync(h_total + 1, nm_n, sizeof(unsigned), hipMemcpyDeviceToHost, st));
         HIPCHK(hipEventRecord(evTotal, st));
         {   // this batch's rings are read by the kernels just enqueued on `st`: the next batch's chains wait for them
             auto mark = [&](pbwtamd_engine *x) -> int { const int r = x->ring ^ 1; HIPCHK(hipEventRecord(x->evCons[r], st)); x->consRecorded[r] = true; return 0; };
@@ -2303,6 +2391,19 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
         lap(2);
         HIPCHK(hipEventSynchronize(evTotal));
         const unsigned long long total = *h_total;
+        if (const unsigned nev_b = std::min(*reinterpret_cast<unsigned *>(h_total + 1), NM_CAP)) {       // this batch's no-match events, in log order, while fewer than NM_KEEP are kept
+            if (e->nomatch_events.size() / 4 < NM_KEEP) {
+                std::vector<int4> ev(nev_b);
+                HIPCHK(hipMemcpyAsync(ev.data(), nm_ev, sizeof(int4) * nev_b, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                std::sort(ev.begin(), ev.end(), [](const int4 &a, const int4 &b) { return a.x != b.x ? a.x < b.x : a.y != b.y ? a.y < b.y : (a.w >> 1) < (b.w >> 1); });
+                for (const int4 &v : ev) {
+                    if (e->nomatch_events.size() / 4 >= NM_KEEP) break;
+                    e->nomatch_events.push_back(v.z); e->nomatch_events.push_back(v.w & 1); e->nomatch_events.push_back(v.x); e->nomatch_events.push_back((v.w >> 1) | (e->q_part ? (v.y << 1) : 0));
+                }
+            }
+            HIPCHK(hipMemsetAsync(nm_n, 0, sizeof(unsigned), st));
+        }
         lap(3);
         if (total) {
             CHK(ensure_recs((size_t)total));
@@ -2355,15 +2456,6 @@ extern "C" int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, 
     HIPCHK(hipMemcpy(htot, tot, sizeof htot, hipMemcpyDeviceToHost));
     if (tot_out) { tot_out[0] = (int64_t)htot[0]; tot_out[1] = (int64_t)htot[1]; }
     if (n_nomatch) *n_nomatch = (int64_t)htot[2];
-    if (htot[2]) {                                          // the events, in the order the reference logs them: site, then query PBWT rank, dense before sparse
-        unsigned nev = 0;
-        HIPCHK(hipMemcpy(&nev, nm_n, sizeof nev, hipMemcpyDeviceToHost));
-        nev = std::min(nev, NM_CAP);
-        std::vector<int4> ev(nev);
-        if (nev) HIPCHK(hipMemcpy(ev.data(), nm_ev, sizeof(int4) * nev, hipMemcpyDeviceToHost));
-        std::sort(ev.begin(), ev.end(), [](const int4 &a, const int4 &b) { return a.x != b.x ? a.x < b.x : a.y != b.y ? a.y < b.y : (a.w >> 1) < (b.w >> 1); });
-        for (const int4 &v : ev) { e->nomatch_events.push_back(v.z); e->nomatch_events.push_back(v.w & 1); e->nomatch_events.push_back(v.x); e->nomatch_events.push_back((v.w >> 1) | (e->q_part ? (v.y << 1) : 0)); }
-    }
     CHK(pbwtamd_pass_end(e, 0));
     CHK(pbwtamd_pass_end(eq, 0));
     for (int kk = 0; kk < nS; ++kk) CHK(pbwtamd_pass_end(es[kk], 0));

@@ -1,0 +1,725 @@
+// pbwt_k_chain.h — the SKELETON chain: transpose32, skel_hist / skel_k2 / skel_k2_wide / skel_rank (8 sites per round), the position-sharded forms, the persistent and many-panel forms, read-side keys.
+// Part of the kernel set of pbwt_kernels.h (include that, not this file: the parts build on each other in its order).
+#pragma once
+
+namespace pbwtk {
+
+// =============================================================================================
+// SKELETON + FILL.  The critical chain advances EIGHT sites per round with three
+// launches (K1, K2, K3) and produces only every 8th state; the seven states in between are filled
+// in afterwards by batched single-site kernels that run over all blocks of a batch at once.
+//   a_{k+8} = stable sort of a_k by the 8-bit key (bit j = allele at site k+j);
+//   d_{k+8}[e] = range max of d_k since the previous element with the same key (level-0 order), or
+//                k+1+msb(key ^ key') with key' the nearest lower non-empty key when there is none
+//   (tests/tile_model.py::stepB_tiles).  Tiles of 1024 positions, 256 threads.
+// ---------------------------------------------------------------------------------------------
+constexpr int SKB = 8, SKK = 1 << SKB;
+
+// 32 sites x 32 haplotypes bit transpose: xT[blk][h] bit j = allele of haplotype h at site 32*blk + j
+// (sites at or beyond n_valid read as 0).  grid (ceil(wpc/256), nblk).
+__global__ __launch_bounds__(BLOCK) void transpose32_kernel(const uint32_t *cols, int wpc, int n_valid, uint32_t *xT, size_t strideX, int Mpad) {
+    const int wd = blockIdx.x * BLOCK + threadIdx.x, blk = blockIdx.y;
+    if (wd >= wpc) return;
+    uint32_t r[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { const int site = blk * 32 + j; r[j] = (site < n_valid) ? cols[(size_t)site * wpc + wd] : 0u; }
+    // r[j] bit i = hap 32*wd+i at site j  ->  r[i] bit j: five butterfly stages (80 swaps instead of 1024 bit moves)
+#pragma unroll
+    for (int j = 16, st = 0; st < 5; ++st, j >>= 1) {
+        const uint32_t m = (j == 16) ? 0x0000ffffu : (j == 8) ? 0x00ff00ffu : (j == 4) ? 0x0f0f0f0fu : (j == 2) ? 0x33333333u : 0x55555555u;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if (k & j) continue;                            // pairs (k, k + j) with bit j of k clear
+            const uint32_t tt = ((r[k] >> j) ^ r[k + j]) & m;
+            r[k + j] ^= tt; r[k] ^= tt << j;
+        }
+    }
+    // four BYTE planes per 32-site block: plane 4 blk + q holds, per haplotype, the alleles of sites 32 blk + 8 q .. + 7 = the 8-bit
+    // key of one radix step.  A round gathers its next keys from ONE plane: Mpad bytes (1 MB at M = 1 M, L2-resident) instead of
+    // 4-byte words of a 4 MB array — the rank kernel's gather was 42 of its 61 MB of HBM-side traffic per launch at that width.
+    if (wd * 32 >= Mpad) return;
+    unsigned char *base = reinterpret_cast<unsigned char *>(xT) + (size_t)blk * 4 * strideX + (size_t)wd * 32;   // strideX = Mpad: bytes per plane
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t pk[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            pk[j] = ((r[4 * j] >> (8 * q)) & 0xffu) | (((r[4 * j + 1] >> (8 * q)) & 0xffu) << 8) | (((r[4 * j + 2] >> (8 * q)) & 0xffu) << 16) | (((r[4 * j + 3] >> (8 * q)) & 0xffu) << 24);
+        uint4 *dst = reinterpret_cast<uint4 *>(base + (size_t)q * strideX);
+        dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+    }
+}
+
+// HIST (K1): per tile of T = 256*EPT positions — count the 8-bit keys, and the max of d_k after each
+// key's last occurrence (whole-tile max for absent keys).  The keys travel with the state (the rank
+// kernel of the previous round scattered them), so this reads 1 + 4 bytes per position.  Threads own
+// positions in REVERSE blocked order so that a forward scan over threads is a suffix scan over
+// positions.  Output: tbl[tile][key] {count, tail}.
+// Workgroups are dealt to the 8 XCDs round-robin by linear id (observed: block b runs on XCD b % 8) and every XCD has its own
+// L2.  xcd_tile gives XCD x a CONTIGUOUS range of logical tiles, so that neighbouring tiles — which write neighbouring
+// destinations of the same bucket — complete their 64-B lines in one L2 instead of eight.  Placement is for speed only.
+__device__ __forceinline__ int xcd_tile(int lin, int n) {
+    const int q = n >> 3, r = n & 7, x = lin & 7, idx = lin >> 3;
+    return x * q + min(x, r) + idx;
+}
+
+struct SkArgs {
+    const int *a; const int *d; const unsigned char *keys;     // input state and its 8-bit keys
+    int *a_out; int *d_out; unsigned char *keys_out;
+    int2 *tbl;                                                  // hist -> scan: [W][256] {count, tail}
+    int2 *tbl0;                                                 // pair rows: the same pair for the FIRST HALF of every hist tile (kept beside the scan)
+    int pair;                                                   // rank: the scan rows are per PAIR of tiles (row w / 2); odd tiles fold tbl0[w / 2] in
+    int2 *scan; int *total;                                     // scan -> rank (kept for the fill): [W][256] {keys before the tile, carry}, total[256]
+    const unsigned char *kbnext; int has_next;                  // byte plane of the NEXT round's keys by haplotype (transpose32_kernel)
+    const unsigned long long *ycnext;                           // read side: sorted bit column of the OUTPUT state's site (tag by position); keys are precomputed
+    int M, W, k;                                                // k = site of the input state; W = tiles of this launch
+    int xcd;                                                    // bit 1: rank, bit 2: hist — XCD-contiguous tiles (xcd_tile)
+    int w0, Wtot;                                               // position sharding: this launch covers tiles w0 .. w0+W-1 of Wtot (one GPU: 0, W)
+};
+
+// Position sharding: the ranks of one panel own contiguous ranges of TILES of the sorted order.  Every rank keeps
+// full-width ring slots; the chain of rank g reads and writes positions pb[g] .. pb[g+1]-1 of them only, and its rank kernel
+// stores each (a | tag, d', key) into the slot of the position's OWNER through the peers' mapped ring pointers (hipIpc).
+constexpr int SHARD_MAX = 8;
+struct SkShardOut {
+    int n;                                                      // ranks
+    int pb[SHARD_MAX + 1];                                      // first position of every rank's range; pb[n] = M (unused entries: INT_MAX)
+    int *a[SHARD_MAX]; int *d[SHARD_MAX]; unsigned char *k[SHARD_MAX];   // the OUTPUT slot (and its key row) in every rank's ring
+    const int *err;                                             // the engine's error word: once set, the rank kernel scatters nothing
+};
+
+// HALF (pair rows, wide panels): the workgroup covers a PAIR of the rank kernel's tiles and also emits the (count, tail) row of its
+// first half; the scan over the tiles then runs on half as many rows (the scan launch is what a wide panel pays most for beside
+// the consumers: 22.7 us per round at 1954 rows, 14 at 977), and the rank / fill workgroup of an odd tile folds the first half's
+// row into its pair's prefix (skel_k2_kernel's combine).  Waves 2, 3 hold the first half.
+template <int EPT, bool HALF>
+__device__ __forceinline__ void skel_hist_body(const SkArgs &g) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
+#endif
+    constexpr int T = BLOCK * EPT;
+    __shared__ int h_cnt[SKK], h_last[SKK];
+    __shared__ int s_suf[T];
+    __shared__ int s_w[WAVES];
+    __shared__ int h_cnt0[HALF ? SKK : 1], h_last0[HALF ? SKK : 1], s_suf0[HALF ? T / 2 : 1];
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = g.w0 + ((g.xcd & 4) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x);
+    const int rb = BLOCK - 1 - t;
+    const int l0 = rb * EPT, i0 = w * T + l0;
+    unsigned packed;
+    int dv[EPT];
+    if constexpr (EPT == 4) {
+        packed = *reinterpret_cast<const unsigned *>(g.keys + i0);
+        const int4 vd = *reinterpret_cast<const int4 *>(g.d + i0);
+        dv[0] = vd.x; dv[1] = vd.y; dv[2] = vd.z; dv[3] = vd.w;
+    } else if constexpr (EPT == 2) {
+        packed = *reinterpret_cast<const unsigned short *>(g.keys + i0);
+        const int2 vd = *reinterpret_cast<const int2 *>(g.d + i0);
+        dv[0] = vd.x; dv[1] = vd.y;
+    } else {
+        packed = g.keys[i0]; dv[0] = g.d[i0];
+    }
+    h_cnt[t] = 0; h_last[t] = -1;
+    if (HALF) { h_cnt0[t] = 0; h_last0[t] = -1; }
+    int key[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const bool valid = i0 + e < g.M;
+        key[e] = valid ? (int)((packed >> (8 * e)) & 0xffu) : -1;
+        if (!valid) dv[e] = 0;
+    }
+    lds_barrier();
+    // one LDS atomic pair per (wave, key) instead of per position: real panels are skewed (most positions share the all-zero
+    // key), and same-address LDS atomics serialise.  The first lane of a key group holds its highest position (reverse order).
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        unsigned long long same = __ballot(key[e] >= 0);
+#pragma unroll
+        for (int b = 0; b < SKB; ++b) { const unsigned long long bal = __ballot((key[e] >> b) & 1); same &= ((key[e] >> b) & 1) ? bal : ~bal; }
+        if (key[e] >= 0 && (same & ((lane == 0) ? 0ULL : (~0ULL >> (64 - lane)))) == 0) {
+            atomicAdd(&h_cnt[key[e]], __popcll(same)); atomicMax(&h_last[key[e]], l0 + e);
+            if (HALF && wv >= 2) { atomicAdd(&h_cnt0[key[e]], __popcll(same)); atomicMax(&h_last0[key[e]], l0 + e); }
+        }
+    }
+    int own = dv[0];
+#pragma unroll
+    for (int e = 1; e < EPT; ++e) own = max(own, dv[e]);
+    int inc = wave_iscan_max(own);                         // lanes before me = positions after mine
+    if (lane == 63) s_w[wv] = inc;
+    const int excl_lane = lane_shr1(inc, 0);
+    lds_barrier();
+    int later = excl_lane, later0 = excl_lane;
+    for (int q = 0; q < wv; ++q) later = max(later, s_w[q]);
+    if (HALF && wv == 3) later0 = max(later0, s_w[2]);
+#pragma unroll
+    for (int e = EPT - 1; e >= 0; --e) {                   // s_suf[l] = max d over positions > l (s_suf0: inside the first half)
+        s_suf[l0 + e] = later; later = max(later, dv[e]);
+        if (HALF && wv >= 2) { s_suf0[l0 + e] = later0; later0 = max(later0, dv[e]); }
+    }
+    int tilemax = 0;
+    for (int q = 0; q < WAVES; ++q) tilemax = max(tilemax, s_w[q]);
+    lds_barrier();
+    const int c = h_cnt[t], tl = c ? s_suf[h_last[t]] : tilemax;
+    g.tbl[(size_t)w * SKK + t] = make_int2(c, tl);         // row-major: one coalesced 2 KB row per tile
+    if (HALF) {
+        const int c0 = h_cnt0[t], tl0 = c0 ? s_suf0[h_last0[t]] : max(s_w[2], s_w[3]);
+        g.tbl0[(size_t)w * SKK + t] = make_int2(c0, tl0);
+    }
+}
+template <int EPT, bool HALF = false>
+__global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) { skel_hist_body<EPT, HALF>(g); }
+
+// SCAN (K2): exclusive scan over the W tiles, per key, of the pair (count, max d since the key's last
+// occurrence) with combine(L,R) = (L.c+R.c, R.c ? R.t : max(L.t,R.t)) (for a tile without the key, t
+// is the tile's max).  A workgroup owns KPW keys: it pulls the [W][KPW] slab of the row-major table
+// through LDS (8*KPW-byte row segments: 32-byte sectors at KPW = 4), each wave scans KPW/4 keys
+// with lanes = tiles (TPL consecutive tiles per lane, DPP scan across lanes), and the slab goes back
+// the same way.  Output scan[tile][key] = {keys before the tile, carry (-1: no earlier occurrence)},
+// total[key].  grid = 256 / KPW workgroups of KPW waves.
+struct Sk2Args { const int2 *tbl; int2 *scan; int *total; int W; };
+template <int KPW, int TPL>
+__device__ __forceinline__ void skel_k2_body(const Sk2Args &g) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    constexpr int NT = KPW * 64;                            // one wave per key
+    constexpr int WP = 64 * (TPL + 1);                      // a lane's TPL tiles + one pad entry: lane stride TPL+1 is odd, no LDS bank conflicts
+    __shared__ int2 s_v[KPW][WP];
+    const int t = threadIdx.x, lane = lane_id(), kk = t >> 6, key0 = blockIdx.x * KPW;
+    constexpr int NIT = 64 * TPL * KPW / NT;                // = TPL: all loads in flight at once (one round trip, not NIT)
+    int2 ld[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = t + i * NT, r = idx / KPW, kq = idx % KPW;
+        ld[i] = (r < g.W) ? g.tbl[(size_t)r * SKK + key0 + kq] : make_int2(0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int idx = t + i * NT, r = idx / KPW, kq = idx % KPW;
+        s_v[kq][r + r / TPL] = ld[i];
+    }
+    __syncthreads();
+    {
+        int c[TPL], tt[TPL];
+        int sc = 0, st = 0;                                // this lane's tiles combined
+#pragma unroll
+        for (int x = 0; x < TPL; ++x) {
+            const int w = lane * TPL + x;
+            const int2 v = (w < g.W) ? s_v[kk][lane * (TPL + 1) + x] : make_int2(0, 0);
+            c[x] = v.x; tt[x] = v.y;
+            st = c[x] ? tt[x] : max(st, tt[x]); sc += c[x];
+        }
+        int ic = sc, it = st;                              // inclusive wave scan of (sc, st)
+#define SK2_STEP(CTRL, RM) { const int lc = dpp_mov<CTRL, RM>(0, ic), lt2 = dpp_mov<CTRL, RM>(0, it); it = ic ? it : max(lt2, it); /* uses OLD ic = R.c */ ic += lc; }
+        SK2_STEP(0x111, 0xf) SK2_STEP(0x112, 0xf) SK2_STEP(0x114, 0xf) SK2_STEP(0x118, 0xf) SK2_STEP(0x142, 0xa) SK2_STEP(0x143, 0xc)
+#undef SK2_STEP
+        int ec = lane_shr1(ic, 0), et = lane_shr1(it, 0);  // exclusive prefix of this lane's first tile
+#pragma unroll
+        for (int x = 0; x < TPL; ++x) {
+            const int w = lane * TPL + x;
+            if (w < g.W) s_v[kk][lane * (TPL + 1) + x] = make_int2(ec, ec ? et : -1);
+            et = c[x] ? tt[x] : max(et, tt[x]); ec += c[x];
+        }
+        if (lane == 63) g.total[key0 + kk] = ic;
+    }
+    __syncthreads();
+    for (int idx = t; idx < g.W * KPW; idx += NT) {
+        const int r = idx / KPW, kq = idx % KPW;
+        g.scan[(size_t)r * SKK + key0 + kq] = s_v[kq][r + r / TPL];
+    }
+}
+template <int KPW, int TPL>
+__global__ __launch_bounds__(KPW * 64) void skel_k2_kernel(Sk2Args g) { skel_k2_body<KPW, TPL>(g); }
+
+// SCAN for wide panels (more than 512 tiles): the per-key scan over the tiles in two levels inside ONE launch.
+// skel_k2_kernel reads the row-major table in 16-byte pieces of 2 KB rows (a quarter of every 64-byte sector is used) and
+// walks 32 tiles per lane serially: 13.9 us at M = 1 M (1954 tiles).  Here a workgroup owns TPW consecutive TILES and all
+// 256 keys (thread = key): whole rows, every load in flight at once; it publishes its (count, carry) aggregate per key,
+// arrives on a counter, and once all workgroups have arrived folds the aggregates of the workgroups before it.
+// All of them are resident at once (W / TPW <= 64 workgroups).  Cross-workgroup visibility: 8-byte agent-scope relaxed
+// atomics on both sides (write-through stores, L1-bypassing loads), `s_waitcnt vmcnt(0)` before the arrival — the
+// granule form of MI355X_MICROARCH.md "Workgroup dispatch ... inter-workgroup visibility".
+struct Sk2WArgs { const int2 *tbl; int2 *scan; int *total; int W; unsigned long long *agg; unsigned *counter; unsigned target; int *err; };
+// 16 rows / 32 aggregates in flight per lane, and the rows are read a second time (from L2) for the output pass.  The first
+// form of this kernel held all 32 rows + 64 aggregates in 200 VGPRs (one round trip each, 8.0 us alone).  A 200-VGPR wave fits
+// on no SIMD while a consumer kernel is at full occupancy (sweep: 8 waves x 56 VGPRs, fill: 6 x 56), and the 56 registers a
+// retiring consumer workgroup frees go to the next consumer workgroup: measured (rocprofv3 trace), that launch waited for the
+// END of the fill, 1.1-1.4 ms, and the chain stood still beside fill + sweep.  This form (no LDS; 74 VGPRs with this compiler, 44 with 16
+// aggregates in flight — measured equal at the end of round 3: 5.94 against 5.91 us/site at 1 M) runs beside the consumers: 9.3 us alone, 14 us
+// beside the fill instead of 185; end to end at 1 M 7.25 -> 6.25 us/site.  Around the shipped (rows, aggregates) = (16, 32): (8, 32) 6.21,
+// (32, 32) 6.25, (16, 64) 6.93, (32, 64) 7.12 against 6.12.
+template <int TPW, int CH = 16, int PCH = 32>                // rows / aggregates in flight per lane
+__global__ __launch_bounds__(SKK) void skel_k2_wide_kernel(Sk2WArgs g) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    const int t = threadIdx.x, j = blockIdx.x, w0 = j * TPW;
+    int ac = 0, at = 0;                                      // this workgroup's aggregate for key t
+#pragma unroll 1
+    for (int x0 = 0; x0 < TPW; x0 += CH) {
+        int2 v[CH];
+#pragma unroll
+        for (int x = 0; x < CH; ++x) v[x] = (w0 + x0 + x < g.W) ? g.tbl[(size_t)(w0 + x0 + x) * SKK + t] : make_int2(0, 0);
+#pragma unroll
+        for (int x = 0; x < CH; ++x) { at = v[x].x ? v[x].y : max(at, v[x].y); ac += v[x].x; }
+    }
+    __hip_atomic_store(g.agg + (size_t)j * SKK + t, ((unsigned long long)(unsigned)at << 32) | (unsigned)ac, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        __hip_atomic_fetch_add(g.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // bounded wait (~1 s): if an earlier launch of this chain never ran, the arrivals it owes never come — flag it (device
+        // error 5, reported at the next pbwtamd_sync) instead of hanging the GPU
+        int spins = 0;
+        while ((int)(__hip_atomic_load(g.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 25) || ((spins & 4095) == 0 && __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { atomicCAS(g.err, 0, 5); break; }
+        }
+    }
+    __syncthreads();
+    if (__hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // incomplete aggregates: the batch has failed, no output pass (no barrier follows)
+    int ec = 0, et = 0;                                      // prefix over the workgroups before this one
+#pragma unroll 1
+    for (int i0 = 0; i0 < j; i0 += PCH) {
+        unsigned long long pv[PCH];
+#pragma unroll
+        for (int i = 0; i < PCH; ++i) pv[i] = (i0 + i < j) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+#pragma unroll
+        for (int i = 0; i < PCH; ++i) {
+            const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32);     // beyond j: (0, 0), the identity
+            et = vc ? vt : max(et, vt); ec += vc;
+        }
+    }
+#pragma unroll 1
+    for (int x0 = 0; x0 < TPW; x0 += CH) {                   // output pass: the rows again (L2), the running prefix written in front of each
+        int2 v[CH];
+#pragma unroll
+        for (int x = 0; x < CH; ++x) v[x] = (w0 + x0 + x < g.W) ? g.tbl[(size_t)(w0 + x0 + x) * SKK + t] : make_int2(0, 0);
+#pragma unroll
+        for (int x = 0; x < CH; ++x) {
+            if (w0 + x0 + x < g.W) g.scan[(size_t)(w0 + x0 + x) * SKK + t] = make_int2(ec, ec ? et : -1);
+            et = v[x].x ? v[x].y : max(et, v[x].y); ec += v[x].x;
+        }
+    }
+    if (j == (int)gridDim.x - 1) g.total[t] = ec;
+}
+
+// ---------------------------------------------------------------------------------------------
+// POSITION SHARDING across GPUs (pbwtCore.c:485-508 is what is sharded).  With the skeleton the per-site
+// "exclusive scan of local counts + all-to-all" of the north star becomes, per ROUND of 8 sites:
+//   (1) every rank publishes ONE row of 256 {count, tail} — its tiles' rows folded with the scan's own combine — into every
+//       peer's exchange block, and the scan of a rank starts from the fold of the rows of the ranks before it;
+//   (2) the rank kernel stores (a | tag, d', key) straight into the owner's ring slot (peer stores through hipIpc mappings),
+//       and a flag barrier closes the round.
+// The exchange block lives in device memory of its owner, mapped into every peer; everything in it is accessed with
+// system-scope atomics only (no cached copies), the bulk data only across kernel boundaries (tools/ipcprobe.hip measures both).
+struct alignas(256) ShardXch {
+    unsigned f1[64];                                        // [src] round whose row aggregate src has published here
+    unsigned f2[64];                                        // [src] chain barriers src has arrived at (scatter of a round complete)
+    unsigned f3[64];                                        // [src] batches whose consumers src has finished (ring reuse)
+    unsigned long long ragg[SHARD_MAX][SKK];                // [src][key] count | tail << 32 of src's tiles, current round
+    unsigned perr[64];                                      // [src] nonzero: rank src has failed (a bounded wait ran out there) — whoever waits here stops waiting
+};
+struct ShardPeers { ShardXch *x[SHARD_MAX]; int n, me; };
+
+// Bounded (seconds): a rank that died must not hang the others' GPUs.  The error is STICKY: once the engine's error word is set (here, by
+// another workgroup, by an earlier launch) or a peer has flagged itself failed, nobody waits again — the rest of the pass falls through its
+// waits, the kernels skip their stores (skel_k2s_kernel, skel_rank_shard_kernel), and the host fails the pass at its next event poll.
+__device__ __forceinline__ void shard_wait_flags(const unsigned *mine, const unsigned *perr, int n, unsigned epoch, int *err, int code) {
+    const int t = threadIdx.x;
+    if (t < n) {
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+        long spins = 0;
+        while ((int)(__hip_atomic_load(mine + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            ++spins;
+            if ((spins & 1023) == 0 && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                                         __hip_atomic_load(perr + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) { atomicCAS(err, 0, 9); break; }
+            if (spins > (1L << 24)) { atomicCAS(err, 0, code); break; }
+        }
+    }
+}
+// which: 0 = f1, 1 = f2, 2 = f3.  mode bit 0: signal every rank (this one included), bit 1: wait for every rank
+__global__ __launch_bounds__(64) void shard_xbar_kernel(ShardPeers P, int which, int mode, unsigned epoch, int *err) {
+    const int t = threadIdx.x;
+    if (t < P.n && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)       // this rank has failed: tell every peer, so that none waits out its own timeout
+        __hip_atomic_store(&P.x[t]->perr[P.me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((mode & 1) && t < P.n) {
+        unsigned *f = which == 0 ? P.x[t]->f1 : which == 1 ? P.x[t]->f2 : P.x[t]->f3;
+        __hip_atomic_store(f + P.me, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (mode & 2) {
+        const unsigned *f = which == 0 ? P.x[P.me]->f1 : which == 1 ? P.x[P.me]->f2 : P.x[P.me]->f3;
+        shard_wait_flags(f, P.x[P.me]->perr, P.n, epoch, err, 6);
+    }
+}
+
+// SCAN of a shard, ONE launch (the two-level form of skel_k2_wide_kernel with the other ranks as a third level): workgroup j
+// folds the rows of its TPW tiles per key (thread = key) and publishes the aggregate; the last workgroup to arrive folds the
+// workgroups' aggregates into the RANK's row, stores it into every rank's exchange block and raises f1 there; every workgroup
+// then waits until all ranks' rows have arrived here — prefix = fold of the rows of the ranks before this one and of this rank's
+// workgroups before j — and writes the running prefix in front of each of its tiles, plus the totals over ALL ranks.
+// All <= 64 workgroups of the launch are co-resident (they wait for the last of them).  Rows are indexed by global tile; this
+// launch covers tiles w0 .. w0+Wl-1.
+struct Sk2SArgs { const int2 *tbl; int2 *scan; int *total; int w0, Wl; unsigned long long *agg; unsigned *counter; unsigned target; unsigned epoch; int *err; };
+template <int TPW, int CH = 8>
+__global__ __launch_bounds__(SKK) void skel_k2s_kernel(Sk2SArgs g, ShardPeers P) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    __shared__ int s_last;
+    const int t = threadIdx.x, j = blockIdx.x, r0 = j * TPW;
+    int ac = 0, at = 0;
+#pragma unroll 1
+    for (int x0 = 0; x0 < TPW; x0 += CH) {
+        int2 v[CH];
+#pragma unroll
+        for (int x = 0; x < CH; ++x) v[x] = (r0 + x0 + x < g.Wl) ? g.tbl[(size_t)(g.w0 + r0 + x0 + x) * SKK + t] : make_int2(0, 0);
+#pragma unroll
+        for (int x = 0; x < CH; ++x) { at = v[x].x ? v[x].y : max(at, v[x].y); ac += v[x].x; }
+    }
+    __hip_atomic_store(g.agg + (size_t)j * SKK + t, ((unsigned long long)(unsigned)at << 32) | (unsigned)ac, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) s_last = (__hip_atomic_fetch_add(g.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == g.target) ? 1 : 0;
+    __syncthreads();
+    const int nwg = (int)gridDim.x;
+    if (s_last) {                                           // every workgroup's aggregate is out (agent scope): fold them into the rank's row
+        int rc = 0, rt = 0;
+#pragma unroll 1
+        for (int i0 = 0; i0 < nwg; i0 += 16) {
+            unsigned long long pv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pv[i] = (i0 + i < nwg) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32); rt = vc ? vt : max(rt, vt); rc += vc; }
+        }
+        const unsigned long long row = ((unsigned long long)(unsigned)rt << 32) | (unsigned)rc;
+        for (int p = 0; p < P.n; ++p) __hip_atomic_store(&P.x[p]->ragg[P.me][t], row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __atomic_thread_fence(__ATOMIC_RELEASE);            // system scope: the row is out before the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t < P.n) __hip_atomic_store(&P.x[t]->f1[P.me], g.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // every rank's row of this round (this rank's own among them: its flag is raised by the last arriver above)
+    shard_wait_flags(P.x[P.me]->f1, P.x[P.me]->perr, P.n, g.epoch, g.err, 7);
+    __syncthreads();
+    if (__hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // incomplete rows: no output pass (no barrier follows)
+    int ec = 0, et = 0, tot = 0;
+    {
+        unsigned long long rv[SHARD_MAX];
+#pragma unroll
+        for (int r = 0; r < SHARD_MAX; ++r) rv[r] = (r < P.n) ? __hip_atomic_load(&P.x[P.me]->ragg[r][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ULL;
+#pragma unroll
+        for (int r = 0; r < SHARD_MAX; ++r) {
+            const int vc = (int)(unsigned)rv[r], vt = (int)(rv[r] >> 32);
+            tot += vc;
+            if (r < P.me) { et = vc ? vt : max(et, vt); ec += vc; }
+        }
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < j; i0 += 16) {
+        unsigned long long pv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[i] = (i0 + i < j) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32); et = vc ? vt : max(et, vt); ec += vc; }
+    }
+#pragma unroll 1
+    for (int x0 = 0; x0 < TPW; x0 += CH) {
+        int2 v[CH];
+#pragma unroll
+        for (int x = 0; x < CH; ++x) v[x] = (r0 + x0 + x < g.Wl) ? g.tbl[(size_t)(g.w0 + r0 + x0 + x) * SKK + t] : make_int2(0, 0);
+#pragma unroll
+        for (int x = 0; x < CH; ++x) {
+            if (r0 + x0 + x < g.Wl) g.scan[(size_t)(g.w0 + r0 + x0 + x) * SKK + t] = make_int2(ec, ec ? et : -1);
+            et = v[x].x ? v[x].y : max(et, v[x].y); ec += v[x].x;
+        }
+    }
+    if (j == 0) g.total[t] = tot;
+}
+
+// PULL: the consumer of rounds s0 .. s0+ns-1 of a batch copies those skeleton states (a, d, keys) out of every rank's skeleton
+// ring — the range each rank owns — into slots slot_step * s of its own full ring.  grid (chunks, ns, ranks); 16 bytes per
+// thread and array.  slot_step == 0 (with ns == 1): skeleton slot s0 into slot 0.
+struct ShardPullArgs {
+    const int *A[SHARD_MAX]; const int *D[SHARD_MAX]; const unsigned char *K[SHARD_MAX];   // slot 0 of the batch's SKELETON ring / key row 0 in every rank
+    int *a; int *d; unsigned char *k;                                                      // slot 0 of the FULL ring / key row 0 in this rank
+    size_t strideA, strideD, strideK;                                                      // per slot (ints) / per key row (bytes)
+    int pb[SHARD_MAX + 1]; int n, me, M, s0, slot_step;
+};
+__global__ __launch_bounds__(BLOCK) void shard_pull_kernel(ShardPullArgs g) {
+    const int o = blockIdx.z, s = g.s0 + blockIdx.y;
+    const int lo = g.pb[o], hi = g.pb[o + 1];               // multiples of 256 except the last rank's end (= M)
+    const size_t dst = (size_t)s * g.slot_step;
+    const int4 *sa = reinterpret_cast<const int4 *>(g.A[o] + (size_t)s * g.strideA), *sd = reinterpret_cast<const int4 *>(g.D[o] + (size_t)s * g.strideD);
+    int4 *da = reinterpret_cast<int4 *>(g.a + dst * g.strideA), *dd = reinterpret_cast<int4 *>(g.d + dst * g.strideD);
+    const int hiD = (o == g.n - 1) ? hi + 1 : hi;           // d[M], the closing sentinel, lives with the last rank
+    for (int i = lo / 4 + blockIdx.x * BLOCK + threadIdx.x; i < (hiD + 3) / 4; i += gridDim.x * BLOCK) {
+        if (i < (hi + 3) / 4) da[i] = sa[i];
+        dd[i] = sd[i];
+    }
+    if (g.slot_step == 0 && o != g.me) return;              // the keys of a pulled slot 0 are re-derived (pass start / replicated batch)
+    const uint4 *sk = reinterpret_cast<const uint4 *>(g.K[o] + (size_t)s * g.strideK);
+    uint4 *dk = reinterpret_cast<uint4 *>(g.k + (size_t)s * g.strideK);
+    if (o != g.me) for (int i = lo / 16 + blockIdx.x * BLOCK + threadIdx.x; i < (hi + 15) / 16; i += gridDim.x * BLOCK) dk[i] = sk[i];
+}
+
+// RANK (K3): per tile — stable rank of every position among its key (ballot refinement inside
+// 64-position chunks + a per-key scan over the chunks), previous same-key position, range max of d_k
+// through a sparse table in LDS, scatter of (a | next allele tag, d', next key).
+// TR > 0 (two-launch round, W <= TR tiles): the per-key scan over the tiles is done here, from the
+// table: W coalesced 8-byte loads per thread, issued first and consumed last, behind the
+// ballot refinement and the sparse table.  TR == 0: before/carry/total come from skel_k2_kernel.
+constexpr int SKN_MAXW = 128;
+// R4 (wide panels: more tiles than fit the chip at once): the range maxima come from a radix-4 sparse table (windows 1, 4, 16, 64,
+// 256; <= 4 reads per query instead of 2) — 10 KB instead of 18 at T = 512, 22 KB per workgroup instead of 30: 7 workgroups per
+// CU instead of 5, so the 1954 tiles of M = 1 M almost fit in one round (1792 resident) instead of needing two (1280).
+template <int EPT, int TR, bool R4, bool SHARD>
+__device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut *so) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
+#endif
+    constexpr int T = BLOCK * EPT, NC = EPT * WAVES;        // positions per tile, 64-position chunks per tile
+    constexpr int NL = R4 ? ((EPT == 1) ? 4 : 5) : ((EPT == 4) ? 10 : (EPT == 2) ? 9 : 8);   // sparse table levels: windows 1 .. T/2 (radix 2) or 1 .. 4^(NL-1) (radix 4)
+    __shared__ short s_cnt[NC][SKK];                        // per chunk: count -> base (exclusive over chunks)
+    __shared__ short s_lastp[NC][SKK];                      // per chunk: last local position of the key -> previous one before the chunk
+    __shared__ int s_tbl[NL][T];                            // s_tbl[l][i] = max d over (i-2^l, i]
+    __shared__ int s_before[SKK], s_carry[SKK], s_G[SKK], s_lower[SKK];
+    __shared__ int s_gw[WAVES], s_lw[WAVES];
+    __shared__ int *s_pa[SHARD ? SHARD_MAX : 1], *s_pd[SHARD ? SHARD_MAX : 1]; __shared__ unsigned char *s_pk[SHARD ? SHARD_MAX : 1];
+    __shared__ int s_pb[SHARD ? SHARD_MAX : 1];
+    __shared__ int s_failed;
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = g.w0 + ((g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x);
+    const int S = w * T;
+    if constexpr (SHARD) { if (t == 0) s_failed = __hip_atomic_load(so->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // read by all after the first barrier
+    if constexpr (SHARD) { if (t < SHARD_MAX) { s_pa[t] = so->a[t]; s_pd[t] = so->d[t]; s_pk[t] = so->k[t]; s_pb[t] = so->pb[t + 1]; } }   // visible after the barriers below
+    int av[EPT], dv[EPT], key[EPT];
+    unsigned nk[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {                         // striped: chunk r*4+wv = 64 consecutive positions
+        const int i = S + r * BLOCK + t;
+        av[r] = g.a[i]; dv[r] = g.d[i]; key[r] = (int)g.keys[i];
+    }
+    int2 row[TR > 0 ? TR : 1];
+    int bq = 0, cq = -1, tq = 0;
+    if constexpr (TR > 0) {
+#pragma unroll
+        for (int r = 0; r < TR; ++r) row[r] = (r < g.W) ? g.tbl[(size_t)r * SKK + t] : make_int2(0, 0);
+    } else {
+        int2 sv = g.scan[(size_t)(g.pair ? (w >> 1) : w) * SKK + t];
+        if (g.pair && (w & 1)) {                            // second tile of its pair: fold the first one's row in
+            const int2 r0 = g.tbl0[(size_t)(w >> 1) * SKK + t];
+            sv.y = r0.x ? r0.y : (sv.x ? max(sv.y, r0.y) : -1);
+            sv.x += r0.x;
+        }
+        bq = sv.x; cq = sv.y; tq = g.total[t];
+    }
+    for (int x = t; x < NC * SKK / 2; x += BLOCK) { reinterpret_cast<int *>(&s_cnt[0][0])[x] = 0; reinterpret_cast<int *>(&s_lastp[0][0])[x] = -1; }
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        const int l = r * BLOCK + t;
+        const bool valid = S + l < g.M;
+        av[r] &= AMASK; if (!valid) { dv[r] = 0; key[r] = -1; }
+        s_tbl[0][l] = dv[r];
+        nk[r] = (g.has_next && valid && !g.ycnext) ? (unsigned)g.kbnext[av[r]] : 0u;   // next round's key (bit 0 = the output state's tag)
+    }
+    int rk[EPT], pl[EPT];
+    const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+    lds_barrier();                                          // zeroed tables visible
+    if constexpr (SHARD) { if (s_failed) return; }          // a bounded wait ran out earlier in this pass: nothing more goes into the peers' rings
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        unsigned long long same = __ballot(key[r] >= 0);
+#pragma unroll
+        for (int b = 0; b < SKB; ++b) { const unsigned long long bal = __ballot((key[r] >> b) & 1); same &= ((key[r] >> b) & 1) ? bal : ~bal; }
+        const unsigned long long before = same & lt;
+        rk[r] = __popcll(before);
+        pl[r] = before ? (r * 4 + wv) * 64 + (63 - __clzll(before)) : -1;
+        if (key[r] >= 0 && !before) {                       // leader of its key in this chunk
+            s_cnt[r * 4 + wv][key[r]] = (short)__popcll(same);
+            s_lastp[r * 4 + wv][key[r]] = (short)((r * 4 + wv) * 64 + (63 - __clzll(same)));
+        }
+    }
+    lds_barrier();
+    {   // thread q = key: exclusive scan over the chunks
+        int base = 0, last = -1;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int cn = s_cnt[c][t], lp = s_lastp[c][t];
+            s_cnt[c][t] = (short)base; s_lastp[c][t] = (short)last;
+            base += cn; if (cn) last = lp;
+        }
+    }
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const int i = r * BLOCK + t;
+            if (R4) {
+                const int wq = 1 << (2 * (l - 1));
+                int m = s_tbl[l - 1][i];
+                if (i - wq >= 0) m = max(m, s_tbl[l - 1][i - wq]);
+                if (i - 2 * wq >= 0) m = max(m, s_tbl[l - 1][i - 2 * wq]);
+                if (i - 3 * wq >= 0) m = max(m, s_tbl[l - 1][i - 3 * wq]);
+                s_tbl[l][i] = m;
+            } else {
+                const int j = i - (1 << (l - 1));
+                s_tbl[l][i] = (j >= 0) ? max(s_tbl[l - 1][i], s_tbl[l - 1][j]) : s_tbl[l - 1][i];
+            }
+        }
+    }
+    if constexpr (TR > 0) {   // thread q = key: scan of the tiles (keys before this tile, carry = max d since the key's last earlier occurrence, total)
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            const int c = row[r].x, tl = row[r].y;
+            if (r < w) { cq = c ? tl : (cq >= 0 ? max(cq, tl) : -1); bq += c; }
+            tq += c;
+        }
+        g.scan[(size_t)w * SKK + t] = make_int2(bq, cq);   // kept for the fill kernel
+        if (w == 0) g.total[t] = tq;
+    }
+    // bucket bases G (exclusive prefix of the key totals) and the nearest lower non-empty key
+    const int ginc = wave_iscan_sum(tq), linc = wave_iscan_max(tq ? t + 1 : 0);
+    if (lane == 63) { s_gw[wv] = ginc; s_lw[wv] = linc; }
+    const int lexc = lane_shr1(linc, 0);
+    lds_barrier();
+    int Gq = ginc - tq, lq = lexc;
+    for (int x = 0; x < wv; ++x) { Gq += s_gw[x]; lq = max(lq, s_lw[x]); }
+    lq -= 1;
+    s_before[t] = bq; s_carry[t] = cq; s_G[t] = Gq; s_lower[t] = lq;
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        if (key[r] < 0) continue;
+        const int l = r * BLOCK + t, c = r * 4 + wv, ky = key[r];
+        const int rank = s_cnt[c][ky] + rk[r];
+        const int p = (pl[r] >= 0) ? pl[r] : s_lastp[c][ky];        // previous same-key position in the tile, or -1
+        // range max of d over (p, l]  (p = -1: the whole prefix): two windows of 2^lv >= len/2
+        const int len = l - p;
+        int rm;
+        if (R4) {
+            const int lv = min((31 - __clz(len)) >> 1, NL - 1), wq = 1 << (2 * lv);
+            rm = max(max(s_tbl[lv][l], s_tbl[lv][p + wq]), max(s_tbl[lv][len > 2 * wq ? l - wq : l], s_tbl[lv][len > 3 * wq ? l - 2 * wq : l]));
+        } else {
+            const int lv = min(31 - __clz(len), NL - 1);
+            rm = max(s_tbl[lv][l], s_tbl[lv][p + (1 << lv)]);
+        }
+        int dd;
+        if (p >= 0) dd = rm;
+        else if (s_carry[ky] >= 0) dd = max(s_carry[ky], rm);
+        else if (s_lower[ky] >= 0) dd = g.k + 1 + (31 - __clz(ky ^ s_lower[ky]));
+        else dd = 0;
+        const int pos = s_G[ky] + s_before[ky] + rank;
+        if (pos == 0) dd = g.k + SKB + 1;                  // sentinel (pbwtCore.c:507 after the 8th site)
+        if constexpr (SHARD) {                              // the owner of the destination: pb[o] <= pos < pb[o+1] (s_pb holds pb[1..]; unused entries INT_MAX)
+            int o = 0;
+#pragma unroll
+            for (int x = 0; x < SHARD_MAX - 1; ++x) o += (pos >= s_pb[x]) ? 1 : 0;
+            s_pa[o][pos] = av[r] | (int)((nk[r] & 1u) << 31);
+            s_pd[o][pos] = dd;
+            s_pk[o][pos] = (unsigned char)nk[r];
+        } else if (g.ycnext) {                              // read side: the tag of a position is a bit of the sorted column, the keys were derived from the columns
+            const unsigned tg = g.has_next ? (unsigned)((g.ycnext[pos >> 6] >> (pos & 63)) & 1ULL) : 0u;
+            g.a_out[pos] = av[r] | (int)(tg << 31);
+            g.d_out[pos] = dd;
+        } else {
+            g.a_out[pos] = av[r] | (int)((nk[r] & 1u) << 31);
+            g.d_out[pos] = dd;
+            g.keys_out[pos] = (unsigned char)nk[r];
+        }
+    }
+    if (w == g.Wtot - 1 && t == 0) {
+        if constexpr (SHARD) so->d[so->n - 1][g.M] = g.k + SKB + 1;      // d[M] lives with the last rank
+        else g.d_out[g.M] = g.k + SKB + 1;
+    }
+}
+template <int EPT, int TR, bool R4 = false>
+__global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) { skel_rank_body<EPT, TR, R4, false>(g, nullptr); }
+// position-sharded form: tiles w0 .. w0+W-1, scatter through the owners' table
+template <int EPT, bool R4>
+__global__ __launch_bounds__(BLOCK) void skel_rank_shard_kernel(SkArgs g, SkShardOut so) { skel_rank_body<EPT, 0, R4, true>(g, &so); }
+
+// PERSISTENT chain of a small panel (<= TR tiles: the two-launch regime): ALL rounds of a batch in ONE launch, hist and rank of every
+// round separated by barriers over the launch's <= 128 co-resident workgroups instead of by kernel boundaries.  Such a barrier costs MORE
+// than a boundary (>= 4 us against 1.5-2.5), so this is not how a lone small panel runs fastest — it is how a small
+// panel's chain stays OFF the launch stream of a wide one: the query cursor of matchSequencesSweep (10 000 haplotypes beside a panel of
+// 10^6) costs 128 dependent launches per 512-site batch, a third of what bounds that job; here it costs one.
+// rounds[s] = the arguments of round s (device memory).  The counter only grows: barrier i of this launch waits for base + (i+1) * gridDim.x.
+__device__ __forceinline__ void skel_grid_barrier(unsigned *counter, unsigned target, int *err) {
+    __syncthreads();                                        // every wave's stores are out (vmcnt(0)) before thread 0 releases them
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 25)) { atomicExch(err, 8); break; }
+        }
+    }
+    __syncthreads();
+}
+template <int EPT, int TR>
+__global__ __launch_bounds__(BLOCK) void skel_persist_kernel(const SkArgs *rounds, int nr, unsigned *counter, unsigned base, int *err) {
+    const unsigned nwg = gridDim.x;
+    unsigned target = base;
+    for (int s = 0; s < nr; ++s) {
+        const SkArgs g = rounds[s];
+        skel_hist_body<EPT, false>(g);
+        target += nwg; skel_grid_barrier(counter, target, err);          // every tile's row is in the table
+        skel_rank_body<EPT, TR, false, false>(g, nullptr);
+        target += nwg; skel_grid_barrier(counter, target, err);          // the new state (a, d, keys) is complete
+    }
+}
+
+// MANY PANELS PER LAUNCH (pbwtamd_pass_advance_many): P independent panels of the same width — chromosomes side by side — advance through the
+// same round in the same three (two) launches: blockIdx.y = panel, args[panel] = that panel's arguments for the round (device memory, the
+// whole batch uploaded at once).  Below ~250 k haplotypes a chain launch costs its 3-4 us whatever runs inside it, so P panels per launch
+// cost little more than one.
+template <int EPT>
+__global__ __launch_bounds__(BLOCK) void skel_hist_many_kernel(const SkArgs *args) { const SkArgs g = args[blockIdx.y]; skel_hist_body<EPT, false>(g); }
+template <int KPW, int TPL>
+__global__ __launch_bounds__(KPW * 64) void skel_k2_many_kernel(const SkArgs *args) {
+    const SkArgs g = args[blockIdx.y];
+    Sk2Args k; k.tbl = g.tbl; k.scan = g.scan; k.total = g.total; k.W = g.W;
+    skel_k2_body<KPW, TPL>(k);
+}
+template <int EPT, int TR>
+__global__ __launch_bounds__(BLOCK) void skel_rank_many_kernel(const SkArgs *args) { const SkArgs g = args[blockIdx.y]; skel_rank_body<EPT, TR, false, false>(g, nullptr); }
+
+// READ SIDE: the columns arrive in PBWT order (y_k by position), so the 8-bit key of position i of the
+// state before site k follows the LF-mapping through the 8 columns: bit j = y_{k+j}[p_j], p_0 = i,
+// p_{j+1} = y ? c + p_j - u(p_j) : u(p_j) with u = zeros before p_j (rank directory + popcount).  It
+// depends on the columns only, not on a[]: all rounds of a batch at once.  grid (tiles, rounds).
+__global__ __launch_bounds__(BLOCK) void skel_keys_sorted_kernel(const unsigned long long *ycols, int wpc64, const int *rankdir, int M,
+                                                                unsigned char *keys, size_t strideK) {
+    const int r = blockIdx.y, i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= M) return;
+    int pos = i;
+    unsigned key = 0;
+#pragma unroll
+    for (int j = 0; j < SKB; ++j) {
+        const int site = SKB * r + j;
+        const unsigned long long w = ycols[(size_t)site * wpc64 + (pos >> 6)];
+        const int *rd = rankdir + (size_t)site * (wpc64 + 1);
+        const unsigned bit = (unsigned)((w >> (pos & 63)) & 1ULL);
+        key |= bit << j;
+        const int u = rd[pos >> 6] + ((pos & 63) - __popcll(w & ((1ULL << (pos & 63)) - 1ULL)));
+        pos = bit ? rd[wpc64] + pos - u : u;
+    }
+    keys[(size_t)r * strideK + i] = (unsigned char)key;
+}
+
+// read side: tag slot 0 of a batch with its column (by position)
+__global__ void skel_tag_sorted_kernel(int *a, const unsigned long long *yc, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) a[i] = (a[i] & AMASK) | (int)((unsigned)((yc[i >> 6] >> (i & 63)) & 1ULL) << 31);
+}
+
+// keys (and tags) of a state from the transposed panel: start of a batch
+__global__ void skel_keys_kernel(int *a, const unsigned char *kb, int M, unsigned char *keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) { const int v = a[i] & AMASK; const unsigned kk = kb[v]; a[i] = v | (int)((kk & 1u) << 31); keys[i] = (unsigned char)kk; }
+}
+
+}  // namespace pbwtk

@@ -1,4 +1,4 @@
-// pbwt_fillseq.h — the FILL as a tile-local sequential recurrence ("sequential fill").
+// pbwt_k_fillseq.h — the FILL as a tile-local sequential recurrence ("sequential fill").
 //
 // The seven states between two skeleton states (pbwtCore.c:485-508 applied to sites k+1 .. k+7) are produced beside the chain.  The
 // table form (skel_fill_kernel) derives every sub-step independently from the tile's position-ordered data: per-chunk count / last-
@@ -66,6 +66,10 @@ struct SkFillSeqArgs {
 #ifdef PBWTAMD_MEASURE
     int dbg_nowrite;
 #endif
+    // FUSE: the first step of matchMaximalWithin's two scans (pbwtMatch.c:124-129) decided here, and the sites' sorted bit columns emitted
+    unsigned *flags; size_t strideF;                        // [site][ceil(M / 32)]: bit p set = position p is NOT decided here (sweep_resid_kernel takes it)
+    unsigned long long *ycols; int wpc64;                   // [site][wpc64], zeroed by the caller: the allele column of every state in sorted order (what pack3 encodes)
+    unsigned long long *nflag;                              // += positions flagged (the host falls back to the streaming sweep when a panel leaves too many)
 };
 
 __device__ __forceinline__ void fs_comb(int &b0, int &c0, int b1, int c1) {      // two keys sharing their low bits: counts add, the later last occurrence has the smaller suffix maximum
@@ -74,8 +78,17 @@ __device__ __forceinline__ void fs_comb(int &b0, int &c0, int b1, int c1) {     
 
 // E positions per lane, tile T = 64 E (= the chain's tile: 256 or 512).  PACKY 1: slots get d | y << 31; PACKY 2: d only.
 // grid = ceil(W * blocks / 4) workgroups of 4 independent waves; wave -> (block, tile).
-template <int E, int PACKY>
-__global__ __launch_bounds__(BLOCK) void skel_fillseq_kernel(SkFillSeqArgs g) {
+//
+// FUSE — MEASUREMENT BUILDS ONLY: built, bit-exact, slower (see run_consumers in pbwt_engine.hip for the numbers; kept as the record of the experiment).
+// (With PACKY 1, the -stats option set.)  matchMaximalWithin (pbwtMatch.c:115-131) reports position i of a state unless one of its two
+// scans meets y[i] again, and almost everywhere the FIRST step decides: with b = y[i], "d[i] <= d[i+1] and y[i-1] == b" or "d[i] >= d[i+1]
+// and y[i+1] == b" means not reported.  The tile's elements of one key are neighbours in the state too, so while a level's outputs stand
+// in LDS in destination order every position whose neighbours belong to the same run is tested here, from LDS, and only what is left —
+// the two ends of every run and the positions whose scans go on — is flagged (one bit per position) for sweep_resid_kernel, which reads
+// just those from HBM: on a founder-mosaic panel ~1 % of the positions in ~6 % of the 64-byte lines, instead of every state once more.
+// The states' allele columns in sorted order (what pack3 encodes) leave as 64-bit atomic ORs, two per run and 64 positions.
+template <int E, int PACKY, bool FUSE = false, int WPE = 4>
+__global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs g) {
     constexpr int T = 64 * E;
     __shared__ __attribute__((aligned(16))) int s_dd[WAVES][T];
     __shared__ __attribute__((aligned(16))) unsigned char s_kk[WAVES][T];
@@ -153,10 +166,16 @@ __global__ __launch_bounds__(BLOCK) void skel_fillseq_kernel(SkFillSeqArgs g) {
     }
     asm volatile("" ::: "memory");
 
-    // ---- seven sub-steps
+    int nfl = 0;                                            // FUSE: positions this wave flagged
+    // ---- seven sub-steps (FUSE: level 0, the skeleton state itself, first — tested like the others, nothing stored)
 #pragma unroll
-    for (int j = 0; j < SKB - 1; ++j) {
-        const unsigned m1 = (2u << j) - 1u, m0 = (1u << j) - 1u;
+    for (int j = FUSE ? -1 : 0; j < SKB - 1; ++j) {
+        const unsigned m1 = (1u << (j + 1)) - 1u, m0 = (j > 0) ? (1u << j) - 1u : 0u;
+      if (j < 0) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) { s_d[l0 + e] = dc[e]; s_k[l0 + e] = (unsigned char)kc[e]; }
+        if (lane == 0) tab[1] = make_int2(S, 0);
+      } else {
         const unsigned pk = (unsigned)lane_shr1((int)kc[E - 1], 0);
         bool H[E], R[E];
         int c1 = 0;
@@ -203,23 +222,79 @@ __global__ __launch_bounds__(BLOCK) void skel_fillseq_kernel(SkFillSeqArgs g) {
             prevS = fx[e] ? Sx[e] : max(Sx[e], em); prevf = fx[e] ? fx[e] : ef;
             s_d[ni] = nd; s_k[ni] = (unsigned char)kc[e];
         }
+      }
         asm volatile("" ::: "memory");
         // ---- the level's outputs, destination order: lanes = consecutive local indices = consecutive destinations inside a run
         int *const dout = g.D + (size_t)(8 * b + j + 1) * g.strideD;
+        int vq[E], pq[E]; unsigned kq[E];
 #pragma unroll
         for (int q = 0; q < E; ++q) {
             const int x = q * 64 + lane;
-            const unsigned kb = s_k[x];
-            const int pos = x + tab[(int)(m1 + 1u) + (int)(kb & m1)].x;
-            int v = s_d[x];
-            if (pos == 0) v = k + j + 2;                    // sentinel (pbwtCore.c:507)
-            if (PACKY == 1) v |= (int)(((kb >> (j + 1)) & 1u) << 31);
-#ifdef PBWTAMD_MEASURE
-            if (g.dbg_nowrite) continue;
-#endif
-            if (x < nvalid) __builtin_nontemporal_store(v, dout + pos);
+            kq[q] = s_k[x];
+            pq[q] = x + tab[(int)(m1 + 1u) + (int)(kq[q] & m1)].x;
+            vq[q] = s_d[x];
         }
-        if (w == g.W - 1 && lane == 0) dout[g.M] = k + j + 2;
+        if (j >= 0) {
+            if (pq[0] == 0) vq[0] = k + j + 2;              // sentinel (pbwtCore.c:507): position 0 of the state is the first element of its first run (level 0 holds it already)
+#ifdef PBWTAMD_MEASURE
+            if (!g.dbg_nowrite)
+#endif
+            {
+                if (nvalid == T) {                          // (wave-uniform: all tiles but the panel's last)
+#pragma unroll
+                    for (int q = 0; q < E; ++q) __builtin_nontemporal_store((PACKY == 1) ? (vq[q] | (int)(((kq[q] >> (j + 1)) & 1u) << 31)) : vq[q], dout + pq[q]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < E; ++q) if (q * 64 + lane < nvalid) __builtin_nontemporal_store((PACKY == 1) ? (vq[q] | (int)(((kq[q] >> (j + 1)) & 1u) << 31)) : vq[q], dout + pq[q]);
+                }
+            }
+            if (w == g.W - 1 && lane == 0) dout[g.M] = k + j + 2;
+        }
+        if constexpr (FUSE) {
+            const int L = j + 1;                            // the state's site is k + L, its alleles bit L of the keys
+            unsigned *const fl = g.flags + (size_t)(8 * b + L) * g.strideF;
+            unsigned long long *const yc = g.ycols + (size_t)(8 * b + L) * g.wpc64;
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                const int x = q * 64 + lane;
+                const bool valid = x < nvalid;
+                // neighbours in the tile's order; beyond the chunk: the next / previous chunk's edge lane; beyond the tile: none
+                const int fvr = (q < E - 1) ? __builtin_amdgcn_readlane(vq[q < E - 1 ? q + 1 : q], 0) : 0;
+                const int fkr = (q < E - 1) ? __builtin_amdgcn_readlane((int)kq[q < E - 1 ? q + 1 : q], 0) : 0;
+                const int fkl = (q > 0) ? __builtin_amdgcn_readlane((int)kq[q > 0 ? q - 1 : q], 63) : 0;
+                const int vr = __builtin_amdgcn_update_dpp(fvr, vq[q], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+                const unsigned kr = (unsigned)__builtin_amdgcn_update_dpp(fkr, (int)kq[q], 0x130, 0xf, 0xf, false);
+                const unsigned kl = (unsigned)lane_shr1((int)kq[q], fkl);
+                const bool sameR = ((kr ^ kq[q]) & m1) == 0 && x + 1 < nvalid;      // x + 1 in the tile and in the same run: the state's position + 1
+                const bool sameL = ((kl ^ kq[q]) & m1) == 0 && x > 0;
+                const unsigned yI = (kq[q] >> L) & 1u, yR = (kr >> L) & 1u, yL = (kl >> L) & 1u;
+                const int dI = vq[q], dN = vr;
+                const bool skip = sameR && ((dI <= dN && sameL && yL == yI) || (dI >= dN && yR == yI));
+                const bool flg = valid && !skip;
+                const unsigned long long fm = __ballot(flg);
+                if (fm) { nfl += __popcll(fm); if (flg) atomicOr(fl + (pq[q] >> 5), 1u << (pq[q] & 31)); }
+                // the allele column: per stretch of lanes with one destination offset, the bits go out as two 64-bit ORs
+                const int offq = pq[q] - x;
+                const int offl = lane_shr1(offq, 0);
+                unsigned long long hm = __ballot(lane == 0 || offl != offq);
+                const unsigned long long ym = g.ycols ? __ballot(valid && yI) : 0ULL;
+                if (ym) {
+                    while (hm) {
+                        const int s0 = __ffsll((long long)hm) - 1;
+                        hm &= hm - 1;
+                        const int s1 = hm ? __ffsll((long long)hm) - 1 : 64;
+                        const unsigned long long seg = ((s1 == 64) ? ~0ULL : ((1ULL << s1) - 1ULL)) & ~((1ULL << s0) - 1ULL);
+                        const unsigned long long bits = ym & seg;
+                        if (!bits) continue;
+                        const int base = __builtin_amdgcn_readlane(pq[q], s0) - s0;     // destination of (virtual) lane 0 of this stretch; may be negative
+                        const int sh = base & 63, w0 = base >> 6;
+                        const unsigned long long lo = bits << sh, hi = sh ? (bits >> (64 - sh)) : 0ULL;
+                        if (lane == 0 && lo) atomicOr(yc + w0, lo);
+                        if (lane == 1 && hi) atomicOr(yc + w0 + 1, hi);
+                    }
+                }
+            }
+        }
         if (j < SKB - 2) {
             const int4 *dp = reinterpret_cast<const int4 *>(s_d + l0);
 #pragma unroll
@@ -232,6 +307,7 @@ __global__ __launch_bounds__(BLOCK) void skel_fillseq_kernel(SkFillSeqArgs g) {
         }
         asm volatile("" ::: "memory");
     }
+    if constexpr (FUSE) { if (lane == 0 && nfl) atomicAdd(g.nflag, (unsigned long long)nfl); }
 }
 
 }  // namespace pbwtk

@@ -35,6 +35,11 @@ def setup(eng, rank=None, world=None):
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
     import os, sys
+    # hipIpc export / open of the rings needs the dmabuf IPC mode on this driver stack (the legacy mode fails with hipIpcGetMemHandle: invalid
+    # argument); the variable is read when the HSA runtime initialises, i.e. before the first HIP call of the process — bench.py and the test
+    # workers export it themselves, a caller embedding this module has to as well
+    if world > 1 and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+        print("[posshard %d] warning: HSA_ENABLE_IPC_MODE_LEGACY is not 0 in this process; hipIpc handles may not export (set it before HIP initialises)" % rank, file=sys.stderr, flush=True)
     tr = (lambda m: print("[posshard %d] %s" % (rank, m), file=sys.stderr, flush=True)) if os.environ.get("PBWTAMD_SHARD_TRACE") else (lambda m: None)
     blob = eng.shard_init(rank, world)
     if world > 1:

@@ -168,6 +168,9 @@ def test_position_sharded_step_on_device_tensors_over_rccl(tmp_path):
     (3, 70000, 776, 512, 0, 8192, 1),         # N not a multiple of 8: the tail runs replicated
     (2, 1000000, 1024, 512, 0, 8192, 0),      # BASELINE configs[3]'s width (1 M haplotypes), bench option set, two ranks, two batches
     (3, 1000000, 264, 128, 0, 8192, 1),       # the same width on three ranks with every site's checksum
+    (4, 70000, 264, 128, 0, 8192, 1),         # world 4: 137 tiles of 512 positions -> 34-35 tiles per rank, four ranks' rows folded in front of the last
+    (8, 70000, 136, 64, 0, 8192, 1),          # world 8 = SHARD_MAX: all eight entries of pb[] / tb[], the 7-compare owner search, 8 exchange rows, one round per rank and batch
+    (8, 300000, 72, 64, 1, 8192, 0),          # world 8, iid panel on the bench option set (packed fill), 586 tiles: 73-74 per rank
 ])
 def test_position_sharded_chain_ranks_one_gpu(world, M, N, B, kind, step, csum, tmp_path):
     """BASELINE configs[3]'s device path at small widths: `world` processes on one GPU, each owning a range of positions of the

@@ -427,16 +427,23 @@ def test_histogram_and_pack3_consumers_without_ids(amd, orc, packed, M, N, batch
     assert np.array_equal(eng.get_packed(), o["yz"])
 
 
-@pytest.mark.parametrize("fill_seq", ["1", "0"])
+@pytest.mark.parametrize("form", ["seq", "table"] + (["fused", "fused_always"] if os.environ.get("PBWTAMD_MEASURE_BUILD") else []))
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1025, 96, 24, 1), (70001, 80, 40, 1), (2, 40, 8, 1), (257, 64, 64, 1), (300000, 24, 8, 0),
-                                            (600100, 24, 8, 1), (150600, 32, 16, 1), (9000, 72, 24, 0), (56001, 48, 16, 1), (511, 40, 8, 1), (512, 40, 8, 0)])
-def test_packed_fill_every_position(amd, orc, fill_seq, M, N, batch, kind, monkeypatch):
+                                            (600100, 24, 8, 1), (150600, 32, 16, 1), (9000, 72, 24, 0), (56001, 48, 16, 1), (511, 40, 8, 1), (512, 40, 8, 0),
+                                            (100000, 136, 64, 0), (1000003, 16, 8, 0)])
+def test_packed_fill_every_position(amd, orc, form, M, N, batch, kind, monkeypatch):
     """the packed fill (slots hold d | y << 31, the bench option set) checked at EVERY position of EVERY site: per-site checksums of d and y taken
     from the packed slots (PBWTAMD_PACKED_CHECKSUM=1) against the oracle's — for the sequential tile-local form (skel_fillseq_kernel,
-    PBWTAMD_FILL_SEQ=1, the default) and the table form (skel_fill_kernel).  iid panels put every 8-bit key into every tile; widths cover
+    PBWTAMD_FILL_SEQ=1, the default; with and without the fused first step of matchMaximalWithin) and the table form (skel_fill_kernel).  iid panels put every 8-bit key into every tile; widths cover
     256- and 512-position tiles, ragged last tiles, pair rows (odd and even tile counts) and the two-launch round."""
     import torch
-    monkeypatch.setenv("PBWTAMD_FILL_SEQ", fill_seq)
+    # seq: sequential fill + streaming sweep (the shipped path); table: skel_fill_kernel.  Measurement builds (PBWTAMD_MEASURE_BUILD=1) also run the fused
+    # forms — the sequential fill deciding the first step of the -stats sweep and emitting the bit columns, the rest through sweep_resid_kernel; a panel
+    # that leaves more than 10 % undecided (iid) switches back after its first batches, fused_always never does — which passed here and measured slower
+    monkeypatch.setenv("PBWTAMD_FILL_SEQ", "0" if form == "table" else "1")
+    monkeypatch.setenv("PBWTAMD_FILL_FUSE", "1" if form.startswith("fused") else "0")
+    if form == "fused_always":
+        monkeypatch.setenv("PBWTAMD_FUSE_MAX_FLAGGED", "2")
     monkeypatch.setenv("PBWTAMD_PACKED_CHECKSUM", "1")
     eng = amd.Engine(M, batch_sites=batch)
     buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
@@ -513,6 +520,25 @@ def test_match_sweep_long_walks_block_skipping(amd, orc, Mp, Mq, N, rare, nS, ba
         subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, PBWTAMD_QS_BLOCKS="0"), timeout=600)
         o = np.load(os.path.join(td, "out.npz"))
         assert np.array_equal(o["r"], got) and int(o["n"]) == gn and np.array_equal(o["ev"], ev)
+
+
+def test_no_match_events_beyond_the_cap_keep_the_log_order(amd, orc):
+    """matchSequencesSweep logs "no match to query jj value x at site k" (pbwtMatch.c:405-410) for every event, in site order; the engine keeps
+    the first 65 536 for the caller's log and counts the rest.  They have to be the FIRST 65 536 in log order — site, then query rank — not
+    whichever arrived first: a panel without a single 1 against queries of all 1s gives an event per (site, query), 90 000 here over five batches."""
+    Mp, Mq, N = 16, 300, 300
+    pz = orc.build_bitcols(orc.pack_bitcols(np.zeros((N, Mp), np.uint8)), Mp, with_d=False)["yz"]
+    qz = orc.build_bitcols(orc.pack_bitcols(np.ones((N, Mq), np.uint8)), Mq, with_d=False)["yz"]
+    want, w_nomatch, w_tot = orc.match_sweep(pz, Mp, qz, Mq, N)
+    assert w_nomatch == N * Mq
+    eng = amd.Engine(Mp, batch_sites=64)
+    recs, nomatch, tot = eng.match_sweep(pz, N, qz, Mq)
+    assert nomatch == w_nomatch and tuple(tot) == tuple(w_tot) and len(recs) == len(want)
+    ev = eng.nomatch_events()
+    assert ev.shape == (65536, 4)
+    idx = np.arange(65536)
+    assert np.array_equal(ev[:, 2], idx // Mq), "sites of the kept events are not the first ones in log order"
+    assert np.array_equal(ev[:, 0], idx % Mq) and np.all(ev[:, 1] == 1) and np.all(ev[:, 3] == 0)   # identical queries keep their original order in the query PBWT
 
 
 @pytest.mark.parametrize("P,M,N,B", [(3, 5000, 602, 256), (4, 30000, 520, 256), (2, 100000, 264, 128), (2, 600100, 24, 8)])
