@@ -112,7 +112,7 @@ def north_star_streamed(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=10000
     (pbwtamd_synth_device on a second engine's stream — the same counter-based generator, column by column) into a two-slot column ring, one step
     ahead of the chain; events order the generator behind the chain's last read of a slot and the chain behind the generator.  Same seed and pass
     structure as north_star_width(), so the histogram total after the first `snapshot_at` sites (read once, mid-pass) is comparable with that run's."""
-    sites = (sites // step) * step
+    sites = (sites // batch) * batch                        # as north_star_width(): the same n_total for the same --ns-sites, so the totals are comparable
     s_chain, s_gen = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     eng = pbwt_amd.Engine(M, batch_sites=batch, device=dev.index, stream=s_chain.cuda_stream)
     gen = pbwt_amd.Engine(M, batch_sites=8, device=dev.index, stream=s_gen.cuda_stream)        # only its generator and its stream are used

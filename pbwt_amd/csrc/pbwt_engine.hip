@@ -582,7 +582,7 @@ static int ensure_blockcount(pbwtamd_engine *e, size_t n) {
 }
 
 // maxWithin sweep over `nsites` slots of (A, D) (sites kbase..) on stream st: histogram or records
-static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int *D, int kbase, int nsites, int final_site, unsigned opts, bool packed = false) {
+static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int *D, int kbase, int nsites, int final_site, unsigned opts, bool packed = false, bool ycin = false) {
     SweepArgs g;
     g.A = A; g.D = D; g.strideA = e->strideA; g.strideD = e->strideD;
     g.M = e->M; g.kbase = kbase; g.final_site = final_site;
@@ -602,6 +602,13 @@ static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int
         const int ngroups = (e->M / 256 + 1 + WAVES - 1) / WAVES;    // 1024-position groups (a wave per 256 positions)
         g.hist_rep = e->hist_rep; g.iters = ngroups >= 64 ? 8 : (ngroups >= 8 ? 2 : 1);
         dim3 gs((ngroups + g.iters - 1) / g.iters, nsites);
+#ifdef PBWTAMD_MEASURE
+        if (packed && ycin) {                               // the fill emitted the allele columns: the sweep reads them first and loads d | y only where it has to
+            g.ycols = e->ycols;
+            const int nw = (e->M + 63) / 64;
+            hipLaunchKernelGGL((sweep_hist_kernel<true, true>), dim3((nw + 64 * WAVES - 1) / (64 * WAVES), nsites), dim3(BLOCK), 0, st, g);
+        } else
+#endif
         if (packed) hipLaunchKernelGGL((sweep_hist_kernel<true>), gs, dim3(BLOCK), 0, st, g);
         else hipLaunchKernelGGL((sweep_hist_kernel<false>), gs, dim3(BLOCK), 0, st, g);
         HIPCHK(hipGetLastError());
@@ -849,6 +856,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
     const unsigned consumers = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS | OPT_INTERNAL_KEEP_STATES;
     const bool packed = packed_fill(p);
     bool fused = false;                                     // this call's fill has decided most of the -stats sweep and emitted the bit columns
+    bool yc = false;                                        // this call's fill has emitted the sorted allele columns (the sweep reads them, pack3 encodes them)
     if ((what & 1) && p.skel && !nofill && (p.opts & consumers)) {   // the 7 states between consecutive skeleton states: all blocks and tiles in one launch
         SkFillArgs f;
         f.A = ringA(e, p.ring) + (size_t)j0 * e->strideA; f.D = ringD(e, p.ring) + (size_t)j0 * e->strideD; f.strideA = e->strideA; f.strideD = e->strideD;
@@ -887,8 +895,27 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
 #else
             constexpr bool fuse_env = false;
 #endif
+            if (fuse_env) yc = false;
             fused = fuse_env && e->fuse_ok && packed && what == 3 && sr == e->s2 && (p.opts & PBWTAMD_OPT_WITHIN_HIST) && !(p.opts & PBWTAMD_OPT_WITHIN_RECS);
             q.flags = nullptr; q.strideF = 0; q.ycols = nullptr; q.wpc64 = e->wpc64; q.nflag = nullptr;
+            // YC (PBWTAMD_FILL_YC=0: off): with the -stats sweep behind it the fill also emits every state's sorted allele column; the sweep reads those
+            // first and pack3 encodes them
+#ifdef PBWTAMD_MEASURE
+            // measurement builds only (PBWTAMD_FILL_YC=1): bit-exact, and a wash — at 1 M haplotypes the fill goes from 0.65 to 0.79 ms per batch, the sweep from
+            // 0.79 to 0.56 (it loads a quarter of the groups but its waves are then too short to hide their round trips), 5.47 -> 5.54 us/site end to end;
+            // at 100 k 1.525 -> 1.486; on an iid panel (every chunk has ones, runs of a few positions: an atomic pair per run) 4.7 -> 6.0
+            static const bool yc_env = getenv("PBWTAMD_FILL_YC") && atoi(getenv("PBWTAMD_FILL_YC"));
+#else
+            constexpr bool yc_env = false;
+#endif
+            yc = yc_env && packed && what == 3 && sr == e->s2 && (p.opts & PBWTAMD_OPT_WITHIN_HIST) && !(p.opts & PBWTAMD_OPT_WITHIN_RECS);
+            // (Two experiments on WHERE the fill's stores go, both bit-exact, both slower, both removed — DESIGN.md section 2: (1) the packed slots in a ring
+            // of their own in UNCACHED device memory, so that the fill leaves no dirty lines in the L2s for the chain's kernel boundaries to write back:
+            // the 4-byte-per-lane stores take 2.3x as long without the L2 to merge them (fill 0.65 -> 1.48 ms per batch at 1 M, 5.4 -> 6.9 us/site; the
+            // sweep reads the uncached ring at the same 0.79 ms); (2) every n-th fill wave writing the L2 back itself when it is done (buffer_wbl2):
+            // 5.29 us/site without, 5.42 / 5.69 / 6.50 / 9.13 with n = 256 / 64 / 16 / 4.)
+            q.Dout = q.D;
+            if (yc && !fused) { q.ycols = e->ycols; HIPCHK(hipMemsetAsync(e->ycols, 0, (size_t)ns * e->wpc64 * sizeof(unsigned long long), e->s2)); }
             if (fused) {
                 if (!e->wflags) {
                     e->strideF = (size_t)e->Mpad / 32;
@@ -903,7 +930,11 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
                 if (p.opts & PBWTAMD_OPT_PACK3) { q.ycols = e->ycols; HIPCHK(hipMemsetAsync(e->ycols, 0, (size_t)ns * e->wpc64 * sizeof(unsigned long long), e->s2)); }
             }
 #ifdef PBWTAMD_MEASURE
-            if (fused) { if (e->skEPT == 1) hipLaunchKernelGGL((skel_fillseq_kernel<4, 1, true>), gs, dim3(BLOCK), dyn, e->s2, q); else hipLaunchKernelGGL((skel_fillseq_kernel<8, 1, true>), gs, dim3(BLOCK), dyn, e->s2, q); }
+            if (fused) { if (e->skEPT == 1) hipLaunchKernelGGL((skel_fillseq_kernel<4, 1, 2>), gs, dim3(BLOCK), dyn, e->s2, q); else hipLaunchKernelGGL((skel_fillseq_kernel<8, 1, 2>), gs, dim3(BLOCK), dyn, e->s2, q); }
+            else
+#endif
+#ifdef PBWTAMD_MEASURE
+            if (yc) { if (e->skEPT == 1) hipLaunchKernelGGL((skel_fillseq_kernel<4, 1, 1>), gs, dim3(BLOCK), dyn, e->s2, q); else hipLaunchKernelGGL((skel_fillseq_kernel<8, 1, 1>), gs, dim3(BLOCK), dyn, e->s2, q); }
             else
 #endif
             if (e->skEPT == 1) { if (packed) hipLaunchKernelGGL((skel_fillseq_kernel<4, 1>), gs, dim3(BLOCK), dyn, e->s2, q); else hipLaunchKernelGGL((skel_fillseq_kernel<4, 2>), gs, dim3(BLOCK), dyn, e->s2, q); }
@@ -957,7 +988,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
         }
     } else
 #endif
-    if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, sr, A, D, kb, ns, -1, p.opts, packed));
+    if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, sr, A, D, kb, ns, -1, p.opts, packed, yc));
     if (p.opts & PBWTAMD_OPT_LONG_RECS) {
         CHK(run_long(e, sr, A, D, nullptr, kb, ns, -1));
         // keep the batch's last state (before site kbase+nb-1): it is the stale allele column if the panel ends here
@@ -965,7 +996,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
         HIPCHK(hipMemcpyAsync(e->ystale, A + (size_t)(ns - 1) * e->strideA, sizeof(int) * e->strideA, hipMemcpyDeviceToDevice, sr));
     }
     static const bool no_fuse = tune_env("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
-    if (p.opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, sr, A, ns, fused || (!no_fuse && (p.opts & PBWTAMD_OPT_WITHIN_HIST) != 0)));
+    if (p.opts & PBWTAMD_OPT_PACK3) CHK(run_pack3(e, sr, A, ns, fused || yc || (!no_fuse && (p.opts & PBWTAMD_OPT_WITHIN_HIST) != 0)));
     return 0;
 }
 
@@ -1562,8 +1593,8 @@ extern "C" int pbwtamd_synth_device(pbwtamd_engine *e, void *d_bitcols, int k0, 
     HIPCHK(hipSetDevice(e->device));
     int done = 0;
     while (done < ncols) {
-        const int nb = std::min(ncols - done, 32768);
-        dim3 grid(std::max(1, std::min(16, (e->wpc + BLOCK - 1) / BLOCK)), nb);
+        const int nb = std::min(ncols - done, 32768 * SYNTH_CPB);
+        dim3 grid((e->wpc * 32 + BLOCK - 1) / BLOCK, (nb + SYNTH_CPB - 1) / SYNTH_CPB);    // every word of a column: wpc is padded beyond ceil(M / 32)
         hipLaunchKernelGGL(synth_kernel, grid, dim3(BLOCK), 0, e->stream, (uint32_t *)d_bitcols + (size_t)done * e->wpc, e->M, k0 + done, nb, e->wpc, seed, kind);
         HIPCHK(hipGetLastError());
         done += nb;

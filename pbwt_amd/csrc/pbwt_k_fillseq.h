@@ -70,6 +70,7 @@ struct SkFillSeqArgs {
     unsigned *flags; size_t strideF;                        // [site][ceil(M / 32)]: bit p set = position p is NOT decided here (sweep_resid_kernel takes it)
     unsigned long long *ycols; int wpc64;                   // [site][wpc64], zeroed by the caller: the allele column of every state in sorted order (what pack3 encodes)
     unsigned long long *nflag;                              // += positions flagged (the host falls back to the streaming sweep when a panel leaves too many)
+    int *Dout;                                              // where the seven filled states (and, PACKY 1, the packed skeleton state) go: D, or the packed-slot ring of the same geometry
 };
 
 __device__ __forceinline__ void fs_comb(int &b0, int &c0, int b1, int c1) {      // two keys sharing their low bits: counts add, the later last occurrence has the smaller suffix maximum
@@ -87,7 +88,11 @@ __device__ __forceinline__ void fs_comb(int &b0, int &c0, int b1, int c1) {     
 // the two ends of every run and the positions whose scans go on — is flagged (one bit per position) for sweep_resid_kernel, which reads
 // just those from HBM: on a founder-mosaic panel ~1 % of the positions in ~6 % of the 64-byte lines, instead of every state once more.
 // The states' allele columns in sorted order (what pack3 encodes) leave as 64-bit atomic ORs, two per run and 64 positions.
-template <int E, int PACKY, bool FUSE = false, int WPE = 4>
+// FUSE 1 = YC (measurement builds, with PACKY 1 and the -stats sweep; bit-exact, a wash: numbers in run_consumers): the fill also EMITS the sorted allele column of every state it writes (and of the skeleton
+// state) — the column pack3 encodes and, since round 4, the first thing the sweep reads (sweep_hist_kernel<true, YCIN>): per 64 destination-ordered
+// positions one ballot, nothing to do when it is 0 (most sites carry a rare allele), else two 64-bit ORs per stretch of one destination offset.
+// FUSE 2 = the measurement-only full fusion described above (decisions + flags as well).
+template <int E, int PACKY, int FUSE = 0, int WPE = 4>
 __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs g) {
     constexpr int T = 64 * E;
     __shared__ __attribute__((aligned(16))) int s_dd[WAVES][T];
@@ -101,6 +106,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
     int *const s_d = s_dd[wv]; unsigned char *const s_k = s_kk[wv]; int2 *const tab = s_tabs[wv];
     const int S = w * T, k = g.kbase + 8 * b, nvalid = min(T, g.M - S);
     int *const d0 = g.D + (size_t)(8 * b) * g.strideD;
+    int *const p0 = g.Dout + (size_t)(8 * b) * g.strideD;       // the skeleton state's slot in the output ring
     const unsigned char *const keys = g.keys + (size_t)b * g.strideK;
     const int2 *const sv = g.scan + (size_t)b * g.strideS;
     const int2 *const gbp = g.gb + (size_t)b * SKK;
@@ -140,15 +146,16 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
     for (int e = 0; e < E; ++e) if (l0 + e >= nvalid) { dc[e] = 0; kc[e] = 0xffu; }    // beyond M: sorts last at every level, never a maximum
     if (PACKY == 1) {                                       // the skeleton slot itself, in the packed form of the other seven
         if (nvalid == T) {
-            int4 *dp = reinterpret_cast<int4 *>(d0 + S + l0);
+            int4 *dp = reinterpret_cast<int4 *>(p0 + S + l0);
 #pragma unroll
             for (int q = 0; q < E / 4; ++q)
                 dp[q] = make_int4(dc[4 * q] | (int)((kc[4 * q] & 1u) << 31), dc[4 * q + 1] | (int)((kc[4 * q + 1] & 1u) << 31),
                                   dc[4 * q + 2] | (int)((kc[4 * q + 2] & 1u) << 31), dc[4 * q + 3] | (int)((kc[4 * q + 3] & 1u) << 31));
         } else {
 #pragma unroll
-            for (int e = 0; e < E; ++e) if (l0 + e < nvalid) d0[S + l0 + e] = dc[e] | (int)((kc[e] & 1u) << 31);
+            for (int e = 0; e < E; ++e) if (l0 + e < nvalid) p0[S + l0 + e] = dc[e] | (int)((kc[e] & 1u) << 31);
         }
+        if (g.Dout != g.D && w == g.W - 1 && lane == 0) p0[g.M] = d0[g.M];      // the closing sentinel travels with the state
     }
     // ---- fold the row down the heap, in registers: level 8 keys lane + 64 q; level 7: (q0, q2) -> key lane, (q1, q3) -> key lane + 64;
     // level 6: both; below: xor-shuffles (every lane ends up with the entry of key lane mod 2^j)
@@ -168,8 +175,22 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
 
     int nfl = 0;                                            // FUSE: positions this wave flagged
     // ---- seven sub-steps (FUSE: level 0, the skeleton state itself, first — tested like the others, nothing stored)
+    if constexpr (FUSE == 1) {
+        // the skeleton state's own allele column (bit 0 of the keys, positions S .. S + T - 1 = whole, tile-aligned words): a lane's E consecutive
+        // positions are E bits of one word, OR-ed together over the 64 / E lanes that share it — plain stores, nobody else writes these words
+        if (g.ycols) {
+            unsigned long long v = 0;
 #pragma unroll
-    for (int j = FUSE ? -1 : 0; j < SKB - 1; ++j) {
+            for (int e = 0; e < E; ++e) v |= (unsigned long long)((l0 + e < nvalid) ? (kc[e] & 1u) : 0u) << e;
+            v <<= (lane % (64 / E)) * E;
+#pragma unroll
+            for (int o = 1; o < 64 / E; o <<= 1) v |= __shfl_xor(v, o);
+            unsigned long long *const yc0 = g.ycols + (size_t)(8 * b) * g.wpc64 + (S >> 6);
+            if ((lane % (64 / E)) == 0 && (S >> 6) + lane / (64 / E) < g.wpc64) yc0[lane / (64 / E)] = v;
+        }
+    }
+#pragma unroll
+    for (int j = (FUSE == 2) ? -1 : 0; j < SKB - 1; ++j) {
         const unsigned m1 = (1u << (j + 1)) - 1u, m0 = (j > 0) ? (1u << j) - 1u : 0u;
       if (j < 0) {
 #pragma unroll
@@ -225,7 +246,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
       }
         asm volatile("" ::: "memory");
         // ---- the level's outputs, destination order: lanes = consecutive local indices = consecutive destinations inside a run
-        int *const dout = g.D + (size_t)(8 * b + j + 1) * g.strideD;
+        int *const dout = g.Dout + (size_t)(8 * b + j + 1) * g.strideD;
         int vq[E], pq[E]; unsigned kq[E];
 #pragma unroll
         for (int q = 0; q < E; ++q) {
@@ -250,14 +271,16 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
             }
             if (w == g.W - 1 && lane == 0) dout[g.M] = k + j + 2;
         }
-        if constexpr (FUSE) {
+        if constexpr (FUSE != 0) {
             const int L = j + 1;                            // the state's site is k + L, its alleles bit L of the keys
-            unsigned *const fl = g.flags + (size_t)(8 * b + L) * g.strideF;
+            unsigned *const fl = (FUSE == 2) ? g.flags + (size_t)(8 * b + L) * g.strideF : nullptr;
             unsigned long long *const yc = g.ycols + (size_t)(8 * b + L) * g.wpc64;
 #pragma unroll
             for (int q = 0; q < E; ++q) {
                 const int x = q * 64 + lane;
                 const bool valid = x < nvalid;
+                const unsigned yI = (kq[q] >> L) & 1u;
+                if constexpr (FUSE == 2) {
                 // neighbours in the tile's order; beyond the chunk: the next / previous chunk's edge lane; beyond the tile: none
                 const int fvr = (q < E - 1) ? __builtin_amdgcn_readlane(vq[q < E - 1 ? q + 1 : q], 0) : 0;
                 const int fkr = (q < E - 1) ? __builtin_amdgcn_readlane((int)kq[q < E - 1 ? q + 1 : q], 0) : 0;
@@ -267,18 +290,19 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
                 const unsigned kl = (unsigned)lane_shr1((int)kq[q], fkl);
                 const bool sameR = ((kr ^ kq[q]) & m1) == 0 && x + 1 < nvalid;      // x + 1 in the tile and in the same run: the state's position + 1
                 const bool sameL = ((kl ^ kq[q]) & m1) == 0 && x > 0;
-                const unsigned yI = (kq[q] >> L) & 1u, yR = (kr >> L) & 1u, yL = (kl >> L) & 1u;
+                const unsigned yR = (kr >> L) & 1u, yL = (kl >> L) & 1u;
                 const int dI = vq[q], dN = vr;
                 const bool skip = sameR && ((dI <= dN && sameL && yL == yI) || (dI >= dN && yR == yI));
                 const bool flg = valid && !skip;
                 const unsigned long long fm = __ballot(flg);
                 if (fm) { nfl += __popcll(fm); if (flg) atomicOr(fl + (pq[q] >> 5), 1u << (pq[q] & 31)); }
+                }
                 // the allele column: per stretch of lanes with one destination offset, the bits go out as two 64-bit ORs
-                const int offq = pq[q] - x;
-                const int offl = lane_shr1(offq, 0);
-                unsigned long long hm = __ballot(lane == 0 || offl != offq);
                 const unsigned long long ym = g.ycols ? __ballot(valid && yI) : 0ULL;
                 if (ym) {
+                    const int offq = pq[q] - x;
+                    const int offl = lane_shr1(offq, 0);
+                    unsigned long long hm = __ballot(lane == 0 || offl != offq);
                     while (hm) {
                         const int s0 = __ffsll((long long)hm) - 1;
                         hm &= hm - 1;
@@ -307,7 +331,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
         }
         asm volatile("" ::: "memory");
     }
-    if constexpr (FUSE) { if (lane == 0 && nfl) atomicAdd(g.nflag, (unsigned long long)nfl); }
+    if constexpr (FUSE == 2) { if (lane == 0 && nfl) atomicAdd(g.nflag, (unsigned long long)nfl); }
 }
 
 }  // namespace pbwtk

@@ -10,42 +10,52 @@ __device__ __forceinline__ uint64_t h2(uint64_t seed, uint64_t a, uint64_t b) {
     return sm64(sm64(seed ^ (a * 0xD1B54A32D192ED03ULL)) + b);
 }
 
+// A thread owns ONE haplotype and walks SYNTH_CPB consecutive columns: what depends on the haplotype alone (its offset into the 2048-site
+// segments) or changes once per segment (its founder) stays in registers, so a (haplotype, site) cell costs one hash — the mutation draw — instead
+// of three; the allele bits of 64 haplotypes leave as one ballot.  Same integer arithmetic cell by cell as the oracle's restatement
+// (oracle/pbwt_oracle.c: orc_synth_bitcols).  grid (ceil(M / 256), ceil(ncols / SYNTH_CPB)).
+constexpr int SYNTH_CPB = 32;
 __global__ __launch_bounds__(BLOCK) void synth_kernel(uint32_t *bits, int M, int k0, int ncols, int wpc,
                                                      uint64_t seed, int kind) {
-    __shared__ uint64_t s_fw;
-    const int col = blockIdx.y;
-    const uint64_t k = (uint64_t)(k0 + col);
+    __shared__ uint64_t s_fw[SYNTH_CPB];
+    const int t = threadIdx.x, lane = lane_id(), c0 = blockIdx.y * SYNTH_CPB, nc = min(SYNTH_CPB, ncols - c0);
     if (kind == 0) {
-        // founder word for this site: bit f = founder f carries the derived allele
-        if (threadIdx.x < 64) {
-            const uint64_t hk = h2(seed ^ 0xB, k, 0);
-            const uint32_t e = (uint32_t)(hk & 0xff) % 11u;
-            const uint32_t bse = 1u << (31 - e);
-            const uint32_t thr = bse / 2 + (uint32_t)((hk >> 8) % (bse / 2));
-            const bool on = (uint32_t)(h2(seed ^ 0xA, (uint64_t)threadIdx.x, k) >> 32) < thr;
-            const unsigned long long m = __ballot(on);
-            if (threadIdx.x == 0) s_fw = m;
+        // founder word of every site of the block: bit f = founder f carries the derived allele
+        if (t < 64) {
+            for (int c = 0; c < nc; ++c) {
+                const uint64_t k = (uint64_t)(k0 + c0 + c);
+                const uint64_t hk = h2(seed ^ 0xB, k, 0);
+                const uint32_t e = (uint32_t)(hk & 0xff) % 11u;
+                const uint32_t bse = 1u << (31 - e);
+                const uint32_t thr = bse / 2 + (uint32_t)((hk >> 8) % (bse / 2));
+                const bool on = (uint32_t)(h2(seed ^ 0xA, (uint64_t)t, k) >> 32) < thr;
+                const unsigned long long m = __ballot(on);
+                if (t == 0) s_fw[c] = m;
+            }
         }
         __syncthreads();
     }
-    const uint64_t fw = (kind == 0) ? s_fw : 0;
-    for (int wd = blockIdx.x * BLOCK + threadIdx.x; wd < wpc; wd += gridDim.x * BLOCK) {
-        uint32_t out = 0;
-        for (int b = 0; b < 32; ++b) {
-            const uint64_t h = (uint64_t)wd * 32 + b;
-            if (h >= (uint64_t)M) break;
-            uint32_t al;
-            if (kind == 1) al = (uint32_t)(h2(seed ^ 0xE, h, k) >> 63);
-            else {
-                const uint64_t off = h2(seed ^ 0xD, h, 0) % 2048u;
-                const uint64_t seg = (k + off) / 2048u;
-                const uint32_t F = (uint32_t)(h2(seed ^ 0xC, h, seg) & 63);
-                const uint32_t mut = ((uint32_t)(h2(seed ^ 0xE, h, k) >> 32) < 4294967u) ? 1u : 0u;
-                al = ((uint32_t)(fw >> F) & 1u) ^ mut;
-            }
-            out |= al << b;
+    const uint64_t h = (uint64_t)blockIdx.x * BLOCK + t;
+    const bool valid = h < (uint64_t)M;
+    const int wd = (int)((h - lane) >> 5);                  // first of the two 32-bit words the wave's 64 haplotypes fill
+    const uint64_t off = (kind == 0) ? h2(seed ^ 0xD, h, 0) % 2048u : 0;
+    uint64_t curseg = ~0ULL; uint32_t F = 0;
+    for (int c = 0; c < nc; ++c) {
+        const uint64_t k = (uint64_t)(k0 + c0 + c);
+        uint32_t al;
+        if (kind == 1) al = (uint32_t)(h2(seed ^ 0xE, h, k) >> 63);
+        else {
+            const uint64_t seg = (k + off) / 2048u;
+            if (seg != curseg) { F = (uint32_t)(h2(seed ^ 0xC, h, seg) & 63); curseg = seg; }
+            const uint32_t mut = ((uint32_t)(h2(seed ^ 0xE, h, k) >> 32) < 4294967u) ? 1u : 0u;
+            al = ((uint32_t)(s_fw[c] >> F) & 1u) ^ mut;
         }
-        bits[(size_t)col * wpc + wd] = out;
+        const unsigned long long m = __ballot(valid && al);
+        if (lane == 0) {
+            uint32_t *row = bits + (size_t)(c0 + c) * wpc;
+            if (wd < wpc) row[wd] = (uint32_t)m;
+            if (wd + 1 < wpc) row[wd + 1] = (uint32_t)(m >> 32);
+        }
     }
 }
 

@@ -229,7 +229,11 @@ __device__ __forceinline__ bool coop_walk4(const int *a, const int *d, int from,
 // above the threshold ends the block, or the same allele turns up).  Those few are resolved wave-cooperatively: first
 // inside the wave's own 256 words with ballots (no memory access), then 256 positions per step through memory.
 // Emits the site's sorted bit column as a by-product (one ballot per chunk) when ycols is set.
-template <bool PACKED>
+// YCIN (round 4; with PACKED): the sites' sorted allele columns are an INPUT — the fill emitted them (skel_fillseq_kernel<.., YC>) — and the sweep
+// reads THOSE first, one bit per position: a wave takes 64 column words = 16 groups of 256 positions, finds the groups that are not y-uniform
+// (all four words 0 or all ~0, and the neighbouring bit on either side the same) from ballots of the words, and loads d | y only for them — on a
+// founder-mosaic panel a quarter of the groups.  Everything a loaded group goes through is the code below, unchanged.
+template <bool PACKED, bool YCIN = false>
 __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
     constexpr int CH = 4;
     __shared__ unsigned s_hist[HIST_LBINS];
@@ -250,15 +254,14 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
     // register sets: the kernel is bound by the bytes it keeps in flight (8 waves per SIMD x 1.5 KB per wave and group), not by issue — with one
     // group in flight it read 2.5 TB/s whether or not the y-uniform fast path below removed most of its instructions
     struct Grp { int w[CH]; int hl, hr; };
-    auto request = [&](Grp &q, int it) {
-        const int wb = ((blockIdx.x * g.iters + it) * WAVES + wave_id()) * (64 * CH);
+    auto request = [&](Grp &q, int wvq) {                   // wvq = index of the 256-position group
+        const int wb = wvq * (64 * CH);
 #pragma unroll
         for (int c = 0; c < CH; ++c) q.w[c] = WD(wb + 64 * c + lane);
         q.hl = WD(wb - 1);
         q.hr = WD(wb + 64 * CH);
     };
-    auto process = [&](const Grp &q, int it) -> bool {      // false: beyond the panel, stop
-    const int wv = (blockIdx.x * g.iters + it) * WAVES + wave_id();
+    auto process = [&](const Grp &q, int wv) -> bool {      // false: beyond the panel, stop
     const int wbase = wv * (64 * CH);
     int w[CH];
 #pragma unroll
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
     // the side its scan starts from (d[i] <= d[i+1]: y[i-1]; else d[i] >= d[i+1]: y[i+1]), so nothing reports and nothing scans on
     // (pbwtMatch.c:124-129) — four sign tests instead of ~430 instructions.  On a founder-mosaic panel 3 groups in 4 are like that (most sites
     // carry a rare allele); the group holding position 0 or M and the k == N sweep take the general path.
-    if (!fin && wbase > 0 && wbase + 64 * CH < M) {
+    if (!YCIN && !fin && wbase > 0 && wbase + 64 * CH < M) {
         const unsigned long long m0 = __ballot(w[0] < 0), m1 = __ballot(w[1] < 0), m2 = __ballot(w[2] < 0), m3 = __ballot(w[3] < 0);
         const int h0 = __builtin_amdgcn_readfirstlane(hl), h1 = __builtin_amdgcn_readfirstlane(hr);
         const bool all0 = (m0 | m1 | m2 | m3) == 0ULL && h0 >= 0 && h1 >= 0, all1 = (m0 & m1 & m2 & m3) == ~0ULL && h0 < 0 && h1 < 0;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
         rep[c] = valid && !skip;
         pendUp[c] = rep[c] && !fin && up;                      // the scans that go beyond their first step
         pendDn[c] = rep[c] && !fin && down;
-        if (g.ycols) {                                      // this site's sorted bit column (what pack3 encodes)
+        if (!YCIN && g.ycols) {                             // this site's sorted bit column (what pack3 encodes)
             const unsigned long long mk = __ballot(valid && yI[c]);
             const int wd = wv * CH + c;
             if (lane == 0 && wd < g.wpc64) (g.ycols + (size_t)site * g.wpc64)[wd] = mk;
@@ -364,13 +367,46 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
     return true;
     };
     Grp ga, gb;
-    request(ga, 0); request(gb, 1);
+    if constexpr (YCIN) {
+        // 64 words of the site's allele column per wave (lane = word) -> the groups that have to be looked at
+        const int wave_lin = blockIdx.x * WAVES + wave_id(), w64 = wave_lin * 64 + lane, g0 = wave_lin * 16;
+        const unsigned long long *yc = g.ycols + (size_t)site * g.wpc64;
+        const int nw = (M + 63) / 64;
+        const unsigned long long yw = (w64 < nw) ? __builtin_nontemporal_load(yc + w64) : 0ULL;
+        const unsigned long long yl = (wave_lin > 0) ? __builtin_nontemporal_load(yc + wave_lin * 64 - 1) : 0ULL;          // wave-uniform: the word before / after the wave's 64
+        const unsigned long long yr = (wave_lin * 64 + 64 < nw) ? __builtin_nontemporal_load(yc + wave_lin * 64 + 64) : 0ULL;
+        const unsigned long long z0 = __ballot(yw == 0ULL), z1 = __ballot(yw == ~0ULL);             // words all 0 / all 1
+        const unsigned long long top = __ballot((long long)yw < 0), low = __ballot((yw & 1ULL) != 0);
+        const unsigned long long tl = (top << 1) | ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(yl >> 63)) & 1ULL);       // bit w: top bit of word w - 1
+        const unsigned long long lr = (low >> 1) | ((unsigned long long)(__builtin_amdgcn_readfirstlane((int)(yr & 1ULL))) << 63);     // bit w: low bit of word w + 1
+        unsigned nu = 0;                                    // bit gq: group g0 + gq has to be loaded
+#pragma unroll
+        for (int gq = 0; gq < 16; ++gq) {
+            const unsigned f0 = (unsigned)(z0 >> (4 * gq)) & 15u, f1 = (unsigned)(z1 >> (4 * gq)) & 15u;
+            const bool u0 = f0 == 15u && !((tl >> (4 * gq)) & 1ULL) && !((lr >> (4 * gq + 3)) & 1ULL);
+            const bool u1 = f1 == 15u && ((tl >> (4 * gq)) & 1ULL) && ((lr >> (4 * gq + 3)) & 1ULL);
+            const int wb = (g0 + gq) * (64 * CH);
+            const bool inside = wb > 0 && wb + 64 * CH < M;  // the groups holding position 0 or M always take the general path
+            if (wb <= M && !((u0 || u1) && inside)) nu |= 1u << gq;
+        }
+        // the groups to look at, two in flight (any order: the histogram is a sum)
+        auto next = [&]() -> int { if (!nu) return -1; const int b = __ffs((int)nu) - 1; nu &= nu - 1; return g0 + b; };
+        int ca = next(); if (ca >= 0) request(ga, ca);
+        int cb = next(); if (cb >= 0) request(gb, cb);
+        while (ca >= 0 || cb >= 0) {
+            if (ca >= 0) { process(ga, ca); ca = next(); if (ca >= 0) request(ga, ca); }
+            if (cb >= 0) { process(gb, cb); cb = next(); if (cb >= 0) request(gb, cb); }
+        }
+    } else {
+    const int wv0 = blockIdx.x * g.iters * WAVES + wave_id();   // group of iteration it: wv0 + it * WAVES
+    request(ga, wv0); request(gb, wv0 + WAVES);
     for (int it = 0; it < g.iters; it += 2) {
-        if (!process(ga, it)) break;
-        request(ga, it + 2);
+        if (!process(ga, wv0 + it * WAVES)) break;
+        request(ga, wv0 + (it + 2) * WAVES);
         if (it + 1 >= g.iters) break;
-        if (!process(gb, it + 1)) break;
-        request(gb, it + 3);
+        if (!process(gb, wv0 + (it + 1) * WAVES)) break;
+        request(gb, wv0 + (it + 3) * WAVES);
+    }
     }
     __syncthreads();
     unsigned long long *rep = g.hist_rep + (size_t)((blockIdx.x + 7 * blockIdx.y) % HIST_REP) * HIST_LBINS;

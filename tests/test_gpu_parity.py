@@ -427,7 +427,7 @@ def test_histogram_and_pack3_consumers_without_ids(amd, orc, packed, M, N, batch
     assert np.array_equal(eng.get_packed(), o["yz"])
 
 
-@pytest.mark.parametrize("form", ["seq", "table"] + (["fused", "fused_always"] if os.environ.get("PBWTAMD_MEASURE_BUILD") else []))
+@pytest.mark.parametrize("form", ["seq", "table"] + (["fused", "fused_always", "yc"] if os.environ.get("PBWTAMD_MEASURE_BUILD") else []))
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1025, 96, 24, 1), (70001, 80, 40, 1), (2, 40, 8, 1), (257, 64, 64, 1), (300000, 24, 8, 0),
                                             (600100, 24, 8, 1), (150600, 32, 16, 1), (9000, 72, 24, 0), (56001, 48, 16, 1), (511, 40, 8, 1), (512, 40, 8, 0),
                                             (100000, 136, 64, 0), (1000003, 16, 8, 0)])
@@ -442,6 +442,7 @@ def test_packed_fill_every_position(amd, orc, form, M, N, batch, kind, monkeypat
     # that leaves more than 10 % undecided (iid) switches back after its first batches, fused_always never does — which passed here and measured slower
     monkeypatch.setenv("PBWTAMD_FILL_SEQ", "0" if form == "table" else "1")
     monkeypatch.setenv("PBWTAMD_FILL_FUSE", "1" if form.startswith("fused") else "0")
+    monkeypatch.setenv("PBWTAMD_FILL_YC", "1" if form == "yc" else "0")        # yc: the fill emits the sorted allele columns, the sweep reads them first
     if form == "fused_always":
         monkeypatch.setenv("PBWTAMD_FUSE_MAX_FLAGGED", "2")
     monkeypatch.setenv("PBWTAMD_PACKED_CHECKSUM", "1")
