@@ -13,7 +13,7 @@ __device__ __forceinline__ uint64_t h2(uint64_t seed, uint64_t a, uint64_t b) {
 // A thread owns ONE haplotype and walks SYNTH_CPB consecutive columns: what depends on the haplotype alone (its offset into the 2048-site
 // segments) or changes once per segment (its founder) stays in registers, so a (haplotype, site) cell costs one hash — the mutation draw — instead
 // of three; the allele bits of 64 haplotypes leave as one ballot.  Same integer arithmetic cell by cell as the oracle's restatement
-// (oracle/pbwt_oracle.c: orc_synth_bitcols).  grid (ceil(M / 256), ceil(ncols / SYNTH_CPB)).
+// (the test-side restatement of the same generator lives with the checker).  grid (ceil(M / 256), ceil(ncols / SYNTH_CPB)).
 constexpr int SYNTH_CPB = 32;
 __global__ __launch_bounds__(BLOCK) void synth_kernel(uint32_t *bits, int M, int k0, int ncols, int wpc,
                                                      uint64_t seed, int kind) {
