@@ -46,6 +46,10 @@ static inline const char *tune_env(const char *name) { return getenv(name); }
 static inline const char *tune_env(const char *) { return nullptr; }
 #endif
 
+// switches the test-suite toggles from one test to the next inside ONE process (bit-exact code paths, A/B in tests/test_gpu_parity.py): read at
+// every call, not cached in a static (a cached switch silently keeps the first test's value for the rest of the run)
+static inline int env_int(const char *name, int dflt) { const char *s = getenv(name); return s ? atoi(s) : dflt; }
+
 // ------------------------------------------------------------------------------------ device memory
 // PBWTAMD_GUARD=1 (debugging): every device buffer is mapped through the virtual-memory API so that it ENDS (to within its 256-byte
 // alignment) at the end of its mapping with an unmapped granule behind it (=2: STARTS at the mapping's first byte, an unmapped
@@ -138,9 +142,10 @@ struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned o
 // skeleton batches whose consumers need (d, y) of every site but not the haplotype ids (histogram sweep, pack3 through the
 // sweep's bit columns): the fill writes d | y << 31 and no a — half the consumer stream's bytes (they are what slows the chain)
 static inline bool packed_fill(const Pending &p) {
-    static const bool off = getenv("PBWTAMD_NO_PACKED_FILL") != nullptr, no_fuse = tune_env("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
+    static const bool no_fuse = tune_env("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
+    const bool off = getenv("PBWTAMD_NO_PACKED_FILL") != nullptr;
     // PBWTAMD_PACKED_CHECKSUM=1 (test aid): per-site checksums of d and y taken FROM the packed slots, so that the packed fill is checked at every position
-    static const bool packed_csum = getenv("PBWTAMD_PACKED_CHECKSUM") && atoi(getenv("PBWTAMD_PACKED_CHECKSUM"));
+    const bool packed_csum = env_int("PBWTAMD_PACKED_CHECKSUM", 0) != 0;
     const unsigned ids = (packed_csum ? 0u : PBWTAMD_OPT_CHECKSUM) | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_LONG_RECS | 0x100u /* OPT_INTERNAL_KEEP_STATES */;
     return !off && !no_fuse && p.skel && (p.opts & PBWTAMD_OPT_WITHIN_HIST) && !(p.opts & ids);
 }
@@ -214,6 +219,7 @@ struct pbwtamd_engine {
     unsigned *wflags = nullptr; size_t strideF = 0;           // fused fill + maxWithin: one bit per position and slot of a batch = "not decided in the fill" (sweep_resid_kernel clears what it reads)
     unsigned long long *nflag = nullptr, *h_nflag = nullptr; hipEvent_t evFlag = nullptr; bool flagPending = false;   // positions flagged (device total, pinned mirror)
     unsigned long long nflag_prev = 0; double flag_sites = 0; bool fuse_ok = true;      // ... a panel that leaves too many undecided goes back to the streaming sweep
+    unsigned short *p16r = nullptr;                         // 2 rings of B+2 slots of the 16-bit hand-off (stride = strideD elements), allocated with the first batch that takes it
     int2 *fillGB[2] = {nullptr, nullptr};                   // per ring and round: [256] {G, base} per heap entry (skel_fillprep_kernel -> skel_fillseq_kernel)
     int2 *saveR[2] = {nullptr, nullptr}; size_t strideS = 0;  // per ring and round: scan[W][256] {before, carry}, total[256] (stride in int2)
     hipEvent_t tev[16] = {}; long long tev_n = 0; int thr_rounds = 28, thr_depth = 2;   // host throttle: an event every thr_rounds rounds, host at most thr_depth events ahead
@@ -274,7 +280,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); if (e->evRounds[i]) (void)hipEventDestroy(e->evRounds[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->fillGB[0], (void *)e->fillGB[1], (void *)e->wflags, (void *)e->nflag, (void *)e->rankdirS, (void *)e->skT, (void *)e->k2agg, (void *)e->k2cnt, e->cols_stage, e->ycols, e->colBytes, (void *)e->p3regs,
+    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->fillGB[0], (void *)e->fillGB[1], (void *)e->p16r, (void *)e->wflags, (void *)e->nflag, (void *)e->rankdirS, (void *)e->skT, (void *)e->k2agg, (void *)e->k2cnt, e->cols_stage, e->ycols, e->colBytes, (void *)e->p3regs,
                     e->blockCount, e->scal, e->hist, e->hist_rep, e->csum, e->recs, e->yz};
     for (void *p : ptrs) if (p) (void)dev_free(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -582,11 +588,12 @@ static int ensure_blockcount(pbwtamd_engine *e, size_t n) {
 }
 
 // maxWithin sweep over `nsites` slots of (A, D) (sites kbase..) on stream st: histogram or records
-static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int *D, int kbase, int nsites, int final_site, unsigned opts, bool packed = false, bool ycin = false) {
+static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int *D, int kbase, int nsites, int final_site, unsigned opts, bool packed = false, bool ycin = false, const unsigned short *p16 = nullptr) {
     SweepArgs g;
     g.A = A; g.D = D; g.strideA = e->strideA; g.strideD = e->strideD;
     g.M = e->M; g.kbase = kbase; g.final_site = final_site;
     g.blockCount = nullptr; g.recs = nullptr; g.hist = e->hist; g.histlen = e->histlen; g.err = e->ctl + 2;
+    g.P16 = p16; g.stride16 = e->strideD;
     static const bool no_fuse = tune_env("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
     g.ycols = (!no_fuse && final_site < 0 && (opts & PBWTAMD_OPT_PACK3) && (opts & PBWTAMD_OPT_WITHIN_HIST)) ? e->ycols : nullptr; g.wpc64 = e->wpc64;
 #ifdef PBWTAMD_MEASURE
@@ -609,7 +616,8 @@ static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int
             hipLaunchKernelGGL((sweep_hist_kernel<true, true>), dim3((nw + 64 * WAVES - 1) / (64 * WAVES), nsites), dim3(BLOCK), 0, st, g);
         } else
 #endif
-        if (packed) hipLaunchKernelGGL((sweep_hist_kernel<true>), gs, dim3(BLOCK), 0, st, g);
+        if (packed && p16) hipLaunchKernelGGL((sweep_hist_kernel<true, false, true>), gs, dim3(BLOCK), 0, st, g);
+        else if (packed) hipLaunchKernelGGL((sweep_hist_kernel<true>), gs, dim3(BLOCK), 0, st, g);
         else hipLaunchKernelGGL((sweep_hist_kernel<false>), gs, dim3(BLOCK), 0, st, g);
         HIPCHK(hipGetLastError());
     }
@@ -855,6 +863,20 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
 #endif
     const unsigned consumers = PBWTAMD_OPT_CHECKSUM | PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_LONG_RECS | OPT_INTERNAL_KEEP_STATES;
     const bool packed = packed_fill(p);
+    // the 16-bit hand-off (round 4; PBWTAMD_P16=0: the d | y << 31 slots): the sequential fill writes L | y << 15 into a ring of its own, the streaming
+    // sweep reads that — half the bytes on both sides.  PBWTAMD_P16_CLIP=n (tests): lengths from n on escape to the 32-bit slot.
+    const bool p16_on = env_int("PBWTAMD_P16", 1) != 0 && env_int("PBWTAMD_FILL_SEQ", 1) != 0
+#ifdef PBWTAMD_MEASURE
+                               && !env_int("PBWTAMD_FILL_FUSE", 0) && !env_int("PBWTAMD_FILL_YC", 0) && !tune_env("PBWTAMD_OLD_SWEEP")
+#endif
+        ;
+    const int p16_clip = std::min(std::max(env_int("PBWTAMD_P16_CLIP", P16_ESC), 1), (int)P16_ESC);
+    const bool p16 = p16_on && packed && p.skel && e->skEPT <= 2;
+    unsigned short *P16 = nullptr;
+    if (p16) {
+        if (!e->p16r) HIPCHK(dev_alloc((void **)&e->p16r, (size_t)2 * (e->B + 2) * e->strideD * sizeof(unsigned short)));
+        P16 = e->p16r + ((size_t)p.ring * (e->B + 2) + j0) * e->strideD;
+    }
     bool fused = false;                                     // this call's fill has decided most of the -stats sweep and emitted the bit columns
     bool yc = false;                                        // this call's fill has emitted the sorted allele columns (the sweep reads them, pack3 encodes them)
     if ((what & 1) && p.skel && !nofill && (p.opts & consumers)) {   // the 7 states between consecutive skeleton states: all blocks and tiles in one launch
@@ -875,7 +897,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
                       else if (d_only) hipLaunchKernelGGL((skel_fill_kernel<EP, 2>), grid, dim3(BLOCK), dyn, e->s2, f); \
                       else hipLaunchKernelGGL((skel_fill_kernel<EP, 0>), grid, dim3(BLOCK), dyn, e->s2, f); } while (0)
         // the sequential tile-local form (pbwt_fillseq.h) whenever no consumer needs the haplotype ids; PBWTAMD_FILL_SEQ=0: the table form (A/B, bit-exact)
-        static const bool fill_seq = !(getenv("PBWTAMD_FILL_SEQ") && !atoi(getenv("PBWTAMD_FILL_SEQ")));
+        const bool fill_seq = env_int("PBWTAMD_FILL_SEQ", 1) != 0;
         if (fill_seq && (packed || d_only) && e->skEPT <= 2) {
             SkFillPrepArgs pa; pa.scan = f.scan; pa.strideS = f.strideS; pa.nrow = e->prow ? e->W2 : e->Wt; pa.kbase = kb; pa.gb = e->fillGB[p.ring] + (size_t)(j0 / 8) * SKK;
             hipLaunchKernelGGL(skel_fillprep_kernel, dim3(ns / 8), dim3(BLOCK), 0, e->s2, pa);
@@ -891,7 +913,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
             // measurement builds only: built, bit-exact (every-position checksums, histogram, .pbwt bytes on mosaic and iid panels), and SLOWER — the fused
             // fill takes 1.85 ms per 512-site batch at 1 M haplotypes against 0.80 + 0.91 for fill + streaming sweep, the residual sweep 0.89 ms for the 1 %
             // of positions left to it: both consumers are bound by instruction issue, not by the bytes the fusion saves
-            static const bool fuse_env = getenv("PBWTAMD_FILL_FUSE") && atoi(getenv("PBWTAMD_FILL_FUSE"));
+            const bool fuse_env = env_int("PBWTAMD_FILL_FUSE", 0) != 0;
 #else
             constexpr bool fuse_env = false;
 #endif
@@ -904,7 +926,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
             // measurement builds only (PBWTAMD_FILL_YC=1): bit-exact, and a wash — at 1 M haplotypes the fill goes from 0.65 to 0.79 ms per batch, the sweep from
             // 0.79 to 0.56 (it loads a quarter of the groups but its waves are then too short to hide their round trips), 5.47 -> 5.54 us/site end to end;
             // at 100 k 1.525 -> 1.486; on an iid panel (every chunk has ones, runs of a few positions: an atomic pair per run) 4.7 -> 6.0
-            static const bool yc_env = getenv("PBWTAMD_FILL_YC") && atoi(getenv("PBWTAMD_FILL_YC"));
+            const bool yc_env = env_int("PBWTAMD_FILL_YC", 0) != 0;
 #else
             constexpr bool yc_env = false;
 #endif
@@ -914,7 +936,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
             // the 4-byte-per-lane stores take 2.3x as long without the L2 to merge them (fill 0.65 -> 1.48 ms per batch at 1 M, 5.4 -> 6.9 us/site; the
             // sweep reads the uncached ring at the same 0.79 ms); (2) every n-th fill wave writing the L2 back itself when it is done (buffer_wbl2):
             // 5.29 us/site without, 5.42 / 5.69 / 6.50 / 9.13 with n = 256 / 64 / 16 / 4.)
-            q.Dout = q.D;
+            q.Dout = q.D; q.P16 = P16; q.stride16 = e->strideD; q.clip = p16_clip;
             if (yc && !fused) { q.ycols = e->ycols; HIPCHK(hipMemsetAsync(e->ycols, 0, (size_t)ns * e->wpc64 * sizeof(unsigned long long), e->s2)); }
             if (fused) {
                 if (!e->wflags) {
@@ -937,6 +959,8 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
             if (yc) { if (e->skEPT == 1) hipLaunchKernelGGL((skel_fillseq_kernel<4, 1, 1>), gs, dim3(BLOCK), dyn, e->s2, q); else hipLaunchKernelGGL((skel_fillseq_kernel<8, 1, 1>), gs, dim3(BLOCK), dyn, e->s2, q); }
             else
 #endif
+            if (p16) { if (e->skEPT == 1) hipLaunchKernelGGL((skel_fillseq_kernel<4, 3>), gs, dim3(BLOCK), dyn, e->s2, q); else hipLaunchKernelGGL((skel_fillseq_kernel<8, 3>), gs, dim3(BLOCK), dyn, e->s2, q); }
+            else
             if (e->skEPT == 1) { if (packed) hipLaunchKernelGGL((skel_fillseq_kernel<4, 1>), gs, dim3(BLOCK), dyn, e->s2, q); else hipLaunchKernelGGL((skel_fillseq_kernel<4, 2>), gs, dim3(BLOCK), dyn, e->s2, q); }
             // (77 VGPRs, 6 waves per SIMD.  Forced to 64 VGPRs / 8 waves — 12 registers spilled — the fill itself gains 4 % and the chain's rank launch
             // beside it goes from 13.0 to 19.9 us: 5.50 -> 5.74 us/site at 1 M.  Not kept.)
@@ -960,7 +984,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
     if (p.opts & PBWTAMD_OPT_CHECKSUM) {
         unsigned long long *ca = e->csum + (kb - e->k0), *cd = ca + e->csum_sites, *cy = cd + e->csum_sites;
         dim3 grid(std::min(64, (e->M + BLOCK) / BLOCK), ns);
-        hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, sr, A, D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, ns, packed ? 1 : 0);
+        hipLaunchKernelGGL(checksum_kernel, grid, dim3(BLOCK), 0, sr, A, D, e->strideA, e->strideD, e->M, with_d ? 1 : 0, ca, cd, cy, ns, packed ? (p16 ? 2 : 1) : 0, P16, e->strideD, kb);
         HIPCHK(hipGetLastError());
     }
 #ifdef PBWTAMD_MEASURE
@@ -988,7 +1012,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
         }
     } else
 #endif
-    if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, sr, A, D, kb, ns, -1, p.opts, packed, yc));
+    if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, sr, A, D, kb, ns, -1, p.opts, packed, yc, P16));
     if (p.opts & PBWTAMD_OPT_LONG_RECS) {
         CHK(run_long(e, sr, A, D, nullptr, kb, ns, -1));
         // keep the batch's last state (before site kbase+nb-1): it is the stale allele column if the panel ends here
@@ -1240,7 +1264,7 @@ extern "C" int pbwtamd_pass_advance(pbwtamd_engine *e, const void *d_bitcols, in
         const int left = ncols_avail - done;               // columns available from bc on
         const int remaining = e->n_total - e->k_cur;
         const int L = (nb + 1) / 2;
-        static const bool skel_read = !(getenv("PBWTAMD_SKEL_READ") && !atoi(getenv("PBWTAMD_SKEL_READ")));
+        const bool skel_read = env_int("PBWTAMD_SKEL_READ", 1) != 0;
         // the skeleton always carries d (A-only passes run it too: the divergences cost nothing on its critical path)
         const bool skel = e->skel && (nb % 8 == 0) && (sorted ? skel_read && left >= std::min(nb + 1, remaining) : left >= std::min(nb + 8, remaining));
         const bool pair = !skel && e->pair && !sorted && (e->T == 256 || e->T == 1024 || e->T == 2048 || e->T == 4096) && left >= std::min(2 * L + 2, remaining);

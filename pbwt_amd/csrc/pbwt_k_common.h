@@ -16,6 +16,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+// the same as an SGPR (wave-uniform by construction — every kernel here runs 1-D blocks of whole waves — but the compiler cannot know): every tile /
+// slot index and pointer derived from it becomes scalar arithmetic.  Pays where a wave owns its work item (skel_fillseq_kernel: 89 -> 80 VGPRs);
+// measured worse on the chain's hist / rank kernels (scalar branches on the wave index duplicate code: 28 -> 44 VGPRs), which keep wave_id().
+__device__ __forceinline__ int wave_id_s() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // ---- wave64 cross-lane primitives on DPP (row_shr + row_bcast15/31): a 6-op dependent chain of
 // VALU instructions instead of 6 ds_bpermute round trips through the LDS crossbar.
@@ -39,6 +43,23 @@ __device__ __forceinline__ int wave_max(int v) { return __builtin_amdgcn_readlan
 // value of the previous lane (lane 0 gets `id`)
 __device__ __forceinline__ int lane_shr1(int v, int id) {
     return __builtin_amdgcn_update_dpp(id, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+// ---- the 16-bit hand-off between the fill and the -stats sweep (round 4; skel_fillseq_kernel<.., 3> -> sweep_hist_kernel<true, false, true>).
+// Slot s of a batch, position i: L | y << 15 with L = (site of the slot) + 1 - d[i] (the match length with the neighbour above, plus one; 0 for the
+// sentinels) or P16_ESC when L >= clip (clip = P16_ESC; smaller only in tests): then, and only then, d[i] itself stands in the 32-bit ring slot
+// and the reader fetches it from there.
+constexpr int P16_ESC = 0x7fff;
+__device__ __forceinline__ unsigned p16_encode(int site, int d, unsigned y, int clip, bool &esc) {
+    const int L = site + 1 - d;
+    esc = L >= clip;
+    return (unsigned)(esc ? P16_ESC : L) | (y << 15);
+}
+// a word of the 16-bit ring as the d | y << 31 word the sweeps work on (kp1 = the slot's site + 1; x = the position, for the rare escape)
+__device__ __forceinline__ int p16_word(unsigned h, int kp1, const int *d, int x) {
+    const int L = (int)(h & 0x7fffu);
+    const int dv = (L == P16_ESC) ? (__builtin_nontemporal_load(d + x) & 0x7fffffff) : kp1 - L;
+    return dv | (int)((h >> 15) << 31);
 }
 
 __device__ __forceinline__ uint64_t sm64(uint64_t z) {

@@ -71,13 +71,16 @@ struct SkFillSeqArgs {
     unsigned long long *ycols; int wpc64;                   // [site][wpc64], zeroed by the caller: the allele column of every state in sorted order (what pack3 encodes)
     unsigned long long *nflag;                              // += positions flagged (the host falls back to the streaming sweep when a panel leaves too many)
     int *Dout;                                              // where the seven filled states (and, PACKY 1, the packed skeleton state) go: D, or the packed-slot ring of the same geometry
+    // PACKY 3 (round 4): the 16-BIT hand-off (pbwt_k_common.h: p16_encode).  An escaped d is ALSO stored in the 32-bit ring slot (filled states; a skeleton slot
+    // holds its d already).  Half the bytes of the d | y << 31 form on both sides of the hand-off (the fill is bound by its stores).
+    unsigned short *P16; size_t stride16; int clip;
 };
 
 __device__ __forceinline__ void fs_comb(int &b0, int &c0, int b1, int c1) {      // two keys sharing their low bits: counts add, the later last occurrence has the smaller suffix maximum
     b0 += b1; c0 = (c0 < 0) ? c1 : (c1 < 0) ? c0 : min(c0, c1);
 }
 
-// E positions per lane, tile T = 64 E (= the chain's tile: 256 or 512).  PACKY 1: slots get d | y << 31; PACKY 2: d only.
+// E positions per lane, tile T = 64 E (= the chain's tile: 256 or 512).  PACKY 1: slots get d | y << 31; PACKY 2: d only; PACKY 3: the 16-bit ring (SkFillSeqArgs).
 // grid = ceil(W * blocks / 4) workgroups of 4 independent waves; wave -> (block, tile).
 //
 // FUSE — MEASUREMENT BUILDS ONLY: built, bit-exact, slower (see run_consumers in pbwt_engine.hip for the numbers; kept as the record of the experiment).
@@ -92,13 +95,13 @@ __device__ __forceinline__ void fs_comb(int &b0, int &c0, int b1, int c1) {     
 // state) — the column pack3 encodes and, since round 4, the first thing the sweep reads (sweep_hist_kernel<true, YCIN>): per 64 destination-ordered
 // positions one ballot, nothing to do when it is 0 (most sites carry a rare allele), else two 64-bit ORs per stretch of one destination offset.
 // FUSE 2 = the measurement-only full fusion described above (decisions + flags as well).
-template <int E, int PACKY, int FUSE = 0, int WPE = 4>
+template <int E, int PACKY, int FUSE = 0, int WPE = (E == 8 ? 6 : 4)>
 __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs g) {
     constexpr int T = 64 * E;
     __shared__ __attribute__((aligned(16))) int s_dd[WAVES][T];
     __shared__ __attribute__((aligned(16))) unsigned char s_kk[WAVES][T];
     __shared__ int2 s_tabs[WAVES][SKK];                     // heap-indexed {destination offset, ext}
-    const int lane = lane_id(), wv = wave_id();
+    const int lane = lane_id(), wv = wave_id_s();    // (scalar: block, tile and every slot pointer below live in SGPRs)
     const int wgl = g.xcd ? xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;
     const int lg = wgl * WAVES + wv;
     if (lg >= g.W * g.nblk) return;                         // whole waves only; nothing below synchronises across waves
@@ -144,6 +147,20 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
 
 #pragma unroll
     for (int e = 0; e < E; ++e) if (l0 + e >= nvalid) { dc[e] = 0; kc[e] = 0xffu; }    // beyond M: sorts last at every level, never a maximum
+    if (PACKY == 3) {                                       // the skeleton slot itself in the 16-bit form (its d stays where it is: escapes read it there)
+        unsigned short *const q0 = g.P16 + (size_t)(8 * b) * g.stride16;
+        unsigned hv[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { bool esc; hv[e] = p16_encode(k, dc[e], kc[e] & 1u, g.clip, esc); }
+        if (nvalid == T) {
+            if constexpr (E == 8) *reinterpret_cast<uint4 *>(q0 + S + l0) = make_uint4(hv[0] | hv[1] << 16, hv[2] | hv[3] << 16, hv[4] | hv[5] << 16, hv[6] | hv[7] << 16);
+            else *reinterpret_cast<uint2 *>(q0 + S + l0) = make_uint2(hv[0] | hv[1] << 16, hv[2] | hv[3] << 16);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; ++e) if (l0 + e < nvalid) q0[S + l0 + e] = (unsigned short)hv[e];
+        }
+        if (w == g.W - 1 && lane == 0) { bool esc; q0[g.M] = (unsigned short)p16_encode(k, d0[g.M], 0u, g.clip, esc); }
+    }
     if (PACKY == 1) {                                       // the skeleton slot itself, in the packed form of the other seven
         if (nvalid == T) {
             int4 *dp = reinterpret_cast<int4 *>(p0 + S + l0);
@@ -192,7 +209,38 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
 #pragma unroll
     for (int j = (FUSE == 2) ? -1 : 0; j < SKB - 1; ++j) {
         const unsigned m1 = (1u << (j + 1)) - 1u, m0 = (j > 0) ? (1u << j) - 1u : 0u;
-      if (j < 0) {
+        // UNIFORM LEVEL (round 4): no element of the tile carries a 1 at site k + j (most sites carry a rare allele: on a founder-mosaic panel
+        // two tile-levels in three).  The partition is then the identity (c1 = 0: ni = the element's own index), bit j adds nothing to any key, so
+        // every stretch head is the first of its run (H == R) and takes its value from the tables as in the general path, and everything else keeps
+        // its d (pbwtCore.c:497-503: the same-allele predecessor is the neighbour).  No prefix count, no segmented max, nothing moves in LDS but the
+        // heads' values.
+        bool fast = false;
+        if constexpr (FUSE == 0) {
+            if (j >= 0) {
+                unsigned orb = 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) orb |= kc[e];
+                fast = __ballot((orb >> j) & 1u) == 0ULL;
+            }
+        }
+      if (fast) {
+        const unsigned pk = (unsigned)lane_shr1((int)kc[E - 1], 0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const unsigned x = kc[e] ^ (e ? kc[e - 1] : pk);
+            const bool head = ((e == 0) && (lane == 0)) || (x & m0) != 0;
+            if (__ballot(head)) {                           // (wave-uniform skip: a tile holds a handful of runs)
+                if (head) {                                 // first of its (j+1)-bit key in the tile
+                    const int h = (int)(m1 + 1u) + (int)(kc[e] & m1);
+                    const int2 tv = tab[h];
+                    dc[e] = (tv.y & FS_EFLAG) ? max(tv.y & ~FS_EFLAG, dc[e]) : tv.y;
+                    tab[h].x = tv.x - (l0 + e);
+                    if (j > 0) s_d[l0 + e] = dc[e];
+                }
+            }
+            if (j == 0) { s_d[l0 + e] = dc[e]; s_k[l0 + e] = (unsigned char)kc[e]; }     // level 0 stages the tile
+        }
+      } else if (j < 0) {
 #pragma unroll
         for (int e = 0; e < E; ++e) { s_d[l0 + e] = dc[e]; s_k[l0 + e] = (unsigned char)kc[e]; }
         if (lane == 0) tab[1] = make_int2(S, 0);
@@ -261,6 +309,19 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
             if (!g.dbg_nowrite)
 #endif
             {
+                if constexpr (PACKY == 3) {
+                    unsigned short *const dout16 = g.P16 + (size_t)(8 * b + j + 1) * g.stride16;
+#pragma unroll
+                    for (int q = 0; q < E; ++q) {
+                        if (q * 64 + lane < nvalid) {
+                            bool esc;
+                            const unsigned h = p16_encode(k + j + 1, vq[q], (kq[q] >> (j + 1)) & 1u, g.clip, esc);
+                            __builtin_nontemporal_store((unsigned short)h, dout16 + pq[q]);
+                            if (esc) dout[pq[q]] = vq[q];   // (rare: a match of 32 767 sites or more) the sweep reads d itself from the 32-bit slot
+                        }
+                    }
+                    if (w == g.W - 1 && lane == 0) dout16[g.M] = 0;
+                } else
                 if (nvalid == T) {                          // (wave-uniform: all tiles but the panel's last)
 #pragma unroll
                     for (int q = 0; q < E; ++q) __builtin_nontemporal_store((PACKY == 1) ? (vq[q] | (int)(((kq[q] >> (j + 1)) & 1u) << 31)) : vq[q], dout + pq[q]);

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(BLOCK) void synth_kernel(uint32_t *bits, int M, int
 // per-site checksums over ring slots: csum[site] += sum_i sm64(i<<32 | v[i]); grid (tiles, sites)
 __global__ __launch_bounds__(BLOCK) void checksum_kernel(const int *A, const int *D, size_t strideA, size_t strideD,
                                                         int M, int with_d, unsigned long long *ca,
-                                                        unsigned long long *cd, unsigned long long *cy, int y_valid_sites, int packed = 0) {
+                                                        unsigned long long *cd, unsigned long long *cy, int y_valid_sites, int packed = 0,
+                                                        const unsigned short *P16 = nullptr, size_t stride16 = 0, int kbase = 0) {
     __shared__ unsigned long long s_red[WAVES][3];
     const int site = blockIdx.y;
     const int *a = A + (size_t)site * strideA;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(BLOCK) void checksum_kernel(const int *A, const int
     unsigned long long sa = 0, sd = 0, sy = 0;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i <= M; i += gridDim.x * BLOCK) {
         if (packed) {                                       // slots hold d | y << 31 and no ids (PBWTAMD_PACKED_CHECKSUM: the packed fill checked position by position)
-            const int v = d[i];
+            const int v = (packed == 2) ? p16_word(P16[(size_t)site * stride16 + i], kbase + site + 1, d, i) : d[i];     // (2: the 16-bit ring, escapes from d)
             if (i < M) sy += sm64(((uint64_t)i << 32) | ((site < y_valid_sites) ? ((uint32_t)v >> 31) : 0u));
             sd += sm64(((uint64_t)i << 32) | (uint32_t)(i < M ? (v & 0x7fffffff) : v));
             continue;

@@ -23,6 +23,7 @@ struct SweepArgs {
     int nvb;                                // 256-position blocks per site
     unsigned long long *hist_rep;           // streaming form: HIST_REP copies of the first HIST_LBINS bins, folded into hist by hist_fold_kernel
     int iters;                              // streaming form: 1024-position groups per workgroup
+    const unsigned short *P16; size_t stride16;  // streaming form, 16-bit hand-off (skel_fillseq_kernel<.., 3>): slots of L | y << 15, L = site + 1 - d, P16_ESC = "read d from D"
 };
 // Same-address global atomics serialise chip-wide (~12 ns each): a panel whose matches all have similar lengths (iid: every
 // report lands in ~30 bins) would spend seconds there.  So the short lengths are counted in LDS per workgroup first and
@@ -197,11 +198,31 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
 // as coop_walk, 256 positions per step (four independent loads per lane in flight): the long walks of the histogram
 // sweep — a rare allele beside a block of thousands of identical haplotypes carrying the other one — are chains of
 // dependent round trips, so fewer, wider steps.  Only the decision is returned (the histogram needs no stop index).
-template <bool PACKED>
-__device__ __forceinline__ bool coop_walk4(const int *a, const int *d, int from, int dir, int thr, unsigned yi, int M) {
+template <bool PACKED, bool P16 = false>
+__device__ __forceinline__ bool coop_walk4(const int *a, const int *d, int from, int dir, int thr, unsigned yi, int M, const unsigned short *p16 = nullptr, int kp1 = 0) {
     const int lane = lane_id();
     for (;; from += dir * 256) {
         int wd[4], wy[4];
+        if constexpr (P16) {                                // all eight raw words in flight first; escapes (rare) are fetched behind one wave-uniform test
+            unsigned rd[4], ry[4]; bool esc = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = from + dir * (lane + 64 * j), di = (dir < 0) ? p + 1 : p;
+                rd[j] = __builtin_nontemporal_load(p16 + min(max(di, 0), M));
+                ry[j] = (dir < 0) ? (unsigned)__builtin_nontemporal_load(p16 + min(max(p, 0), M)) : rd[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) esc = esc || (rd[j] & 0x7fffu) == 0x7fffu;      // (only the divergences matter; of ry only the allele bit is used)
+            const bool anyesc = __ballot(esc) != 0ULL;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = from + dir * (lane + 64 * j), di = (dir < 0) ? p + 1 : p;
+                const bool inb = (di >= 0) && (di <= M);
+                const int dw = anyesc ? p16_word(rd[j], kp1, d, min(max(di, 0), M)) : ((kp1 - (int)(rd[j] & 0x7fffu)) | (int)((rd[j] >> 15) << 31));
+                wd[j] = inb ? dw : 0x7fffffff;
+                wy[j] = (p >= 0 && p < M) ? (int)((ry[j] >> 15) << 31) : (int)((yi ^ 1u) << 31);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int p = from + dir * (lane + 64 * j);
@@ -209,6 +230,7 @@ __device__ __forceinline__ bool coop_walk4(const int *a, const int *d, int from,
             const bool inb = (di >= 0) && (di <= M);
             wd[j] = inb ? __builtin_nontemporal_load(d + di) : 0x7fffffff;
             wy[j] = (p >= 0 && p < M) ? (PACKED ? ((dir < 0) ? __builtin_nontemporal_load(d + p) : wd[j]) : __builtin_nontemporal_load(a + p)) : (int)((yi ^ 1u) << 31);
+        }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -233,7 +255,9 @@ __device__ __forceinline__ bool coop_walk4(const int *a, const int *d, int from,
 // reads THOSE first, one bit per position: a wave takes 64 column words = 16 groups of 256 positions, finds the groups that are not y-uniform
 // (all four words 0 or all ~0, and the neighbouring bit on either side the same) from ballots of the words, and loads d | y only for them — on a
 // founder-mosaic panel a quarter of the groups.  Everything a loaded group goes through is the code below, unchanged.
-template <bool PACKED, bool YCIN = false>
+// P16 (round 4; with PACKED): the slots are the 16-bit ring of skel_fillseq_kernel<.., 3> — half the bytes; a group's words are converted to the
+// d | y << 31 form when the group is processed (after the y-uniform test, which needs the allele bits only).
+template <bool PACKED, bool YCIN = false, bool P16 = false>
 __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
     constexpr int CH = 4;
     __shared__ unsigned s_hist[HIST_LBINS];
@@ -242,20 +266,32 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
     const int *a = g.A + (size_t)site * g.strideA;
     const int *d = g.D + (size_t)site * g.strideD;
     const int M = g.M, lane = lane_id();
+    const unsigned short *p16 = P16 ? g.P16 + (size_t)site * g.stride16 : nullptr;
+    const int kp1 = k + 1;
     for (int x = threadIdx.x; x < HIST_LBINS; x += BLOCK) s_hist[x] = 0;
     __syncthreads();
     // branch-free loads: every address is clamped into [0, M] (index M holds the sentinel d[M]); words of positions beyond M
     // are never used as anything but a right neighbour of an invalid position
     auto WD = [&](int x) -> int {
         const int xc = min(max(x, 0), M);
+        if constexpr (P16) return (int)__builtin_nontemporal_load(p16 + xc);      // raw: L | y << 15 (converted in process())
         return PACKED ? __builtin_nontemporal_load(d + xc) : (__builtin_nontemporal_load(d + xc) | (__builtin_nontemporal_load(a + min(xc, M - 1)) & (int)0x80000000));
     };
     // the words of a group (own 4 chunks + the two halo words, wave-uniform addresses) are requested TWO iterations ahead of their use, in two
     // register sets: the kernel is bound by the bytes it keeps in flight (8 waves per SIMD x 1.5 KB per wave and group), not by issue — with one
     // group in flight it read 2.5 TB/s whether or not the y-uniform fast path below removed most of its instructions
     struct Grp { int w[CH]; int hl, hr; };
+    // P16: a lane loads PAIRS — two dwords = positions wb + 128 c + 2 lane, + 1 (c = 0, 1) — half the load instructions of the 32-bit form; the allele
+    // test of the y-uniform path works on the pairs as they are, and only a group that is looked at redistributes them (one ds_bpermute per chunk).
+    // Nothing is clamped: a slot is followed by another slot or the ring's padding, and words beyond position M are never used (see below).
     auto request = [&](Grp &q, int wvq) {                   // wvq = index of the 256-position group
         const int wb = wvq * (64 * CH);
+        if constexpr (P16) {
+            const int *pp = reinterpret_cast<const int *>(p16 + wb) + lane;
+            q.w[0] = (wb <= M) ? __builtin_nontemporal_load(pp) : 0; q.w[1] = (wb <= M) ? __builtin_nontemporal_load(pp + 64) : 0;
+            q.hl = (int)__builtin_nontemporal_load(p16 + max(wb - 1, 0)); q.hr = (int)__builtin_nontemporal_load(p16 + min(wb + 64 * CH, M));
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < CH; ++c) q.w[c] = WD(wb + 64 * c + lane);
         q.hl = WD(wb - 1);
@@ -266,19 +302,46 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
     int w[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) w[c] = q.w[c];
-    const int hl = q.hl, hr = q.hr;
+    int hl = P16 ? (int)((unsigned)q.hl << 16) : q.hl, hr = P16 ? (int)((unsigned)q.hr << 16) : q.hr;      // (P16: the allele bit to the sign position, for the test below)
     if (wbase > M) return false;
     // Y-UNIFORM GROUP: when the wave's 256 positions and their two neighbours all carry the same allele, every position has that allele on
     // the side its scan starts from (d[i] <= d[i+1]: y[i-1]; else d[i] >= d[i+1]: y[i+1]), so nothing reports and nothing scans on
     // (pbwtMatch.c:124-129) — four sign tests instead of ~430 instructions.  On a founder-mosaic panel 3 groups in 4 are like that (most sites
     // carry a rare allele); the group holding position 0 or M and the k == N sweep take the general path.
     if (!YCIN && !fin && wbase > 0 && wbase + 64 * CH < M) {
-        const unsigned long long m0 = __ballot(w[0] < 0), m1 = __ballot(w[1] < 0), m2 = __ballot(w[2] < 0), m3 = __ballot(w[3] < 0);
+        bool all0, all1;
         const int h0 = __builtin_amdgcn_readfirstlane(hl), h1 = __builtin_amdgcn_readfirstlane(hr);
-        const bool all0 = (m0 | m1 | m2 | m3) == 0ULL && h0 >= 0 && h1 >= 0, all1 = (m0 & m1 & m2 & m3) == ~0ULL && h0 < 0 && h1 < 0;
+        if constexpr (P16) {                                // both allele bits of every pair
+            const unsigned long long any1 = __ballot(((w[0] | w[1]) & (int)0x80008000) != 0), any0 = __ballot(((w[0] & w[1]) & (int)0x80008000) != (int)0x80008000);
+            all0 = any1 == 0ULL && h0 >= 0 && h1 >= 0; all1 = any0 == 0ULL && h0 < 0 && h1 < 0;
+        } else {
+            const unsigned long long m0 = __ballot(w[0] < 0), m1 = __ballot(w[1] < 0), m2 = __ballot(w[2] < 0), m3 = __ballot(w[3] < 0);
+            all0 = (m0 | m1 | m2 | m3) == 0ULL && h0 >= 0 && h1 >= 0; all1 = (m0 & m1 & m2 & m3) == ~0ULL && h0 < 0 && h1 < 0;
+        }
         if (all0 || all1) {
             if (g.ycols && lane < CH) (g.ycols + (size_t)site * g.wpc64)[wv * CH + lane] = all1 ? ~0ULL : 0ULL;    // wv * CH + 3 < wpc64: the group ends before M
             return true;
+        }
+    }
+    if constexpr (P16) {                                    // pairs -> one position per lane and chunk, then the d | y << 31 words of the group
+        unsigned hw[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int v = __builtin_amdgcn_ds_bpermute(((c & 1) * 32 + (lane >> 1)) << 2, q.w[c >> 1]);
+            hw[c] = (lane & 1) ? ((unsigned)v >> 16) : ((unsigned)v & 0xffffu);
+        }
+        const unsigned uhl = (unsigned)q.hl, uhr = (unsigned)q.hr;
+        bool esc = (uhl & 0x7fffu) == 0x7fffu || (uhr & 0x7fffu) == 0x7fffu;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) esc = esc || (hw[c] & 0x7fffu) == 0x7fffu;
+        if (__ballot(esc)) {                                // (wave-uniform, rare: a match of 32 767 sites or more) escapes fetch d from the 32-bit slot
+#pragma unroll
+            for (int c = 0; c < CH; ++c) w[c] = p16_word(hw[c], kp1, d, min(wbase + 64 * c + lane, M));
+            hl = p16_word(uhl, kp1, d, max(wbase - 1, 0)); hr = p16_word(uhr, kp1, d, min(wbase + 64 * CH, M));
+        } else {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) w[c] = (kp1 - (int)(hw[c] & 0x7fffu)) | (int)((hw[c] >> 15) << 31);
+            hl = (kp1 - (int)(uhl & 0x7fffu)) | (hl & (int)0x80000000); hr = (kp1 - (int)(uhr & 0x7fffu)) | (hr & (int)0x80000000);
         }
     }
     int dI[CH], dN[CH]; unsigned yI[CH];
@@ -327,7 +390,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
                     const unsigned long long any = ms | my;
                     if (any) decided = ((ms >> (63 - __clzll(any))) & 1ULL) ? 2 : 1;
                 }
-                if (!decided) decided = coop_walk4<PACKED>(a, d, wbase - 1, -1, thr, b, M) ? 1 : 2;
+                #ifdef PBWTAMD_MEASURE
+                if (!decided && g.dbg == 3) decided = 2;    // measurement (results WRONG): no walks through memory
+#endif
+                if (!decided) decided = coop_walk4<PACKED, P16>(a, d, wbase - 1, -1, thr, b, M, p16, kp1) ? 1 : 2;
                 if (decided == 1 && lane == src) { rep[c] = false; pendDn[c] = false; }
             }
         }
@@ -350,7 +416,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
                     const unsigned long long any = ms | my;
                     if (any) decided = ((ms >> (__ffsll((long long)any) - 1)) & 1ULL) ? 2 : 1;
                 }
-                if (!decided) decided = coop_walk4<PACKED>(a, d, wbase + 64 * CH, +1, thr, b, M) ? 1 : 2;
+                #ifdef PBWTAMD_MEASURE
+                if (!decided && g.dbg == 3) decided = 2;
+#endif
+                if (!decided) decided = coop_walk4<PACKED, P16>(a, d, wbase + 64 * CH, +1, thr, b, M, p16, kp1) ? 1 : 2;
                 if (decided == 1 && lane == src) rep[c] = false;
             }
         }

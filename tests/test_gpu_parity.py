@@ -427,7 +427,7 @@ def test_histogram_and_pack3_consumers_without_ids(amd, orc, packed, M, N, batch
     assert np.array_equal(eng.get_packed(), o["yz"])
 
 
-@pytest.mark.parametrize("form", ["seq", "table"] + (["fused", "fused_always", "yc"] if os.environ.get("PBWTAMD_MEASURE_BUILD") else []))
+@pytest.mark.parametrize("form", ["seq", "seq_esc", "seq32", "table"] + (["fused", "fused_always", "yc"] if os.environ.get("PBWTAMD_MEASURE_BUILD") else []))
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1025, 96, 24, 1), (70001, 80, 40, 1), (2, 40, 8, 1), (257, 64, 64, 1), (300000, 24, 8, 0),
                                             (600100, 24, 8, 1), (150600, 32, 16, 1), (9000, 72, 24, 0), (56001, 48, 16, 1), (511, 40, 8, 1), (512, 40, 8, 0),
                                             (100000, 136, 64, 0), (1000003, 16, 8, 0)])
@@ -440,6 +440,10 @@ def test_packed_fill_every_position(amd, orc, form, M, N, batch, kind, monkeypat
     # seq: sequential fill + streaming sweep (the shipped path); table: skel_fill_kernel.  Measurement builds (PBWTAMD_MEASURE_BUILD=1) also run the fused
     # forms — the sequential fill deciding the first step of the -stats sweep and emitting the bit columns, the rest through sweep_resid_kernel; a panel
     # that leaves more than 10 % undecided (iid) switches back after its first batches, fused_always never does — which passed here and measured slower
+    # seq: the 16-bit hand-off (L | y << 15 slots, the shipped path); seq_esc: the same with lengths from 3 on escaping to the 32-bit slot (what a match of
+    # 32 767 sites or more does in production: here most positions take that path); seq32: the d | y << 31 slots (PBWTAMD_P16=0)
+    monkeypatch.setenv("PBWTAMD_P16", "0" if form == "seq32" else "1")
+    monkeypatch.setenv("PBWTAMD_P16_CLIP", "3" if form == "seq_esc" else "32767")
     monkeypatch.setenv("PBWTAMD_FILL_SEQ", "0" if form == "table" else "1")
     monkeypatch.setenv("PBWTAMD_FILL_FUSE", "1" if form.startswith("fused") else "0")
     monkeypatch.setenv("PBWTAMD_FILL_YC", "1" if form == "yc" else "0")        # yc: the fill emits the sorted allele columns, the sweep reads them first
@@ -463,6 +467,34 @@ def test_packed_fill_every_position(amd, orc, form, M, N, batch, kind, monkeypat
     assert np.array_equal(cd[:N], o["csum_d"][:N]), "d[] differs first at site %d" % int(np.argmax(cd[:N] != o["csum_d"][:N]))
     assert np.array_equal(cy[:N], sw["csum_y"][:N]), "y[] differs first at site %d" % int(np.argmax(cy[:N] != sw["csum_y"][:N]))
     assert full >= 0
+    assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
+    assert np.array_equal(eng.get_packed(), o["yz"])
+
+
+def test_p16_matches_longer_than_32766_sites(amd, orc, monkeypatch):
+    """the 16-bit hand-off at its own escape threshold: a panel with duplicated haplotypes over 34 000 sites — their divergences stay at 0 for the
+    whole panel, so from site 32 766 on those positions overflow the 15-bit length and take the escape (d from the 32-bit slot).  Every position
+    of every site (checksums from the slots), the histogram and the .pbwt bytes against the oracle."""
+    import torch
+    M, N, batch = 700, 34000, 512
+    hap = orc.unpack_bitcols(orc.synth_bitcols(M, N, seed=77, kind=1), M)
+    hap[:, 1] = hap[:, 0]; hap[:, 301] = hap[:, 300]; hap[:, 699] = hap[:, 5]; hap[:, 6] = hap[:, 5]
+    hap[20000:, 400] = hap[20000:, 401]                      # (a match that starts mid-panel: no overflow before the end)
+    bits = np.ascontiguousarray(orc.pack_bitcols(hap))
+    o = orc.build_bitcols(bits, M, with_d=True)
+    sw = orc.sweep_AD(o["yz"], M, N)
+    monkeypatch.setenv("PBWTAMD_PACKED_CHECKSUM", "1")
+    eng = amd.Engine(M, batch_sites=batch)
+    assert bits.shape[1] == eng.wpc
+    buf = torch.from_numpy(bits.view(np.int32)).cuda()
+    torch.cuda.synchronize()
+    opts = amd.OPT_WITH_D | amd.OPT_WITHIN_HIST | amd.OPT_PACK3 | amd.OPT_CHECKSUM
+    eng.pass_begin(N)
+    eng.pass_advance(buf.data_ptr(), N, N, opts)
+    eng.pass_end(opts)
+    _, cd, cy = eng.get_checksums(0, N)
+    assert np.array_equal(cd[:N], o["csum_d"][:N]), "d[] differs first at site %d" % int(np.argmax(cd[:N] != o["csum_d"][:N]))
+    assert np.array_equal(cy[:N], sw["csum_y"][:N]), "y[] differs first at site %d" % int(np.argmax(cy[:N] != sw["csum_y"][:N]))
     assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
     assert np.array_equal(eng.get_packed(), o["yz"])
 
