@@ -241,6 +241,14 @@ struct pbwtamd_engine {
 };
 
 extern "C" int pbwtamd_abi_version(void) { return PBWTAMD_ABI_VERSION; }
+#ifdef PBWTAMD_MEASURE
+extern "C" int pbwtamd_measure_walkstat(unsigned long long *out, int reset) {      // measurement builds: the sweep's walk counters (pbwt_k_sweep.h: g_walkstat)
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(pbwtk::g_walkstat), sizeof(unsigned long long) * 16));
+    if (reset) { unsigned long long z[16] = {}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(pbwtk::g_walkstat), z, sizeof z)); }
+    return 0;
+}
+#endif
 extern "C" const char *pbwtamd_last_error(void) { return g_err.c_str(); }
 extern "C" int pbwtamd_device_count(void) {
     int n = 0;
@@ -588,12 +596,12 @@ static int ensure_blockcount(pbwtamd_engine *e, size_t n) {
 }
 
 // maxWithin sweep over `nsites` slots of (A, D) (sites kbase..) on stream st: histogram or records
-static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int *D, int kbase, int nsites, int final_site, unsigned opts, bool packed = false, bool ycin = false, const unsigned short *p16 = nullptr) {
+static int run_within(pbwtamd_engine *e, hipStream_t st, const int *A, const int *D, int kbase, int nsites, int final_site, unsigned opts, bool packed = false, bool ycin = false, const unsigned short *p16 = nullptr, int p16_clip = P16_ESC) {
     SweepArgs g;
     g.A = A; g.D = D; g.strideA = e->strideA; g.strideD = e->strideD;
     g.M = e->M; g.kbase = kbase; g.final_site = final_site;
     g.blockCount = nullptr; g.recs = nullptr; g.hist = e->hist; g.histlen = e->histlen; g.err = e->ctl + 2;
-    g.P16 = p16; g.stride16 = e->strideD;
+    g.P16 = p16; g.stride16 = e->strideD; g.clip = p16_clip;
     static const bool no_fuse = tune_env("PBWTAMD_NO_YCOLS_FUSION") != nullptr;
     g.ycols = (!no_fuse && final_site < 0 && (opts & PBWTAMD_OPT_PACK3) && (opts & PBWTAMD_OPT_WITHIN_HIST)) ? e->ycols : nullptr; g.wpc64 = e->wpc64;
 #ifdef PBWTAMD_MEASURE
@@ -865,7 +873,11 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
     const bool packed = packed_fill(p);
     // the 16-bit hand-off (round 4; PBWTAMD_P16=0: the d | y << 31 slots): the sequential fill writes L | y << 15 into a ring of its own, the streaming
     // sweep reads that — half the bytes on both sides.  PBWTAMD_P16_CLIP=n (tests): lengths from n on escape to the 32-bit slot.
-    const bool p16_on = env_int("PBWTAMD_P16", 1) != 0 && env_int("PBWTAMD_FILL_SEQ", 1) != 0
+    // Measured (interleaved A/B, founder-mosaic panels): -0.5 % at 200 k haplotypes, -4.8 % at 350 k, -2.3 % at 600 k, -5..-6.5 % at 1 M; +1.5 % at 100 k,
+    // where the consumers hide behind the chain's launches and only their footprint beside a chain workgroup counts: on from 180 000 haplotypes
+    // (PBWTAMD_P16=1: at every width — the parity tests; =0: never).
+    const int p16_env = env_int("PBWTAMD_P16", -1);
+    const bool p16_on = (p16_env < 0 ? e->M >= 180000 : p16_env != 0) && env_int("PBWTAMD_FILL_SEQ", 1) != 0
 #ifdef PBWTAMD_MEASURE
                                && !env_int("PBWTAMD_FILL_FUSE", 0) && !env_int("PBWTAMD_FILL_YC", 0) && !tune_env("PBWTAMD_OLD_SWEEP")
 #endif
@@ -1012,7 +1024,7 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
         }
     } else
 #endif
-    if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, sr, A, D, kb, ns, -1, p.opts, packed, yc, P16));
+    if (p.opts & (PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_WITHIN_RECS)) CHK(run_within(e, sr, A, D, kb, ns, -1, p.opts, packed, yc, P16, p16_clip));
     if (p.opts & PBWTAMD_OPT_LONG_RECS) {
         CHK(run_long(e, sr, A, D, nullptr, kb, ns, -1));
         // keep the batch's last state (before site kbase+nb-1): it is the stale allele column if the panel ends here

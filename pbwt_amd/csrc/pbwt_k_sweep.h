@@ -23,12 +23,19 @@ struct SweepArgs {
     int nvb;                                // 256-position blocks per site
     unsigned long long *hist_rep;           // streaming form: HIST_REP copies of the first HIST_LBINS bins, folded into hist by hist_fold_kernel
     int iters;                              // streaming form: 1024-position groups per workgroup
+    int clip;                               // P16: lengths from clip on are escapes (P16_ESC; smaller in tests)
     const unsigned short *P16; size_t stride16;  // streaming form, 16-bit hand-off (skel_fillseq_kernel<.., 3>): slots of L | y << 15, L = site + 1 - d, P16_ESC = "read d from D"
 };
 // Same-address global atomics serialise chip-wide (~12 ns each): a panel whose matches all have similar lengths (iid: every
 // report lands in ~30 bins) would spend seconds there.  So the short lengths are counted in LDS per workgroup first and
 // flushed to one of HIST_REP replicas of the low bins; long lengths (spread over many bins) go straight to hist.
 constexpr int HIST_LBINS = 2048, HIST_REP = 32;
+#ifdef PBWTAMD_MEASURE
+__device__ unsigned long long g_walkstat[16];               // [0] LDS walks [1] their 256-position steps [2] memory walks [3] their steps [4..11] LDS walks by steps: 1, 2, 3-4, 5-8, 9-16, 17-32, > 32 ; [12] pending up [13] pending down
+#define WALKSTAT(i, n) do { if (lane_id() == 0) atomicAdd(&g_walkstat[i], (unsigned long long)(n)); } while (0)
+#else
+#define WALKSTAT(i, n) do { } while (0)
+#endif
 __global__ void hist_fold_kernel(unsigned long long *hist, unsigned long long *rep, int histlen) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= HIST_LBINS) return;
@@ -201,7 +208,9 @@ __global__ __launch_bounds__(BLOCK) void sweep_within_kernel(SweepArgs g) {
 template <bool PACKED, bool P16 = false>
 __device__ __forceinline__ bool coop_walk4(const int *a, const int *d, int from, int dir, int thr, unsigned yi, int M, const unsigned short *p16 = nullptr, int kp1 = 0) {
     const int lane = lane_id();
+    WALKSTAT(2, 1);
     for (;; from += dir * 256) {
+        WALKSTAT(3, 1);
         int wd[4], wy[4];
         if constexpr (P16) {                                // all eight raw words in flight first; escapes (rare) are fetched behind one wave-uniform test
             unsigned rd[4], ry[4]; bool esc = false;
@@ -260,7 +269,14 @@ __device__ __forceinline__ bool coop_walk4(const int *a, const int *d, int from,
 template <bool PACKED, bool YCIN = false, bool P16 = false>
 __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
     constexpr int CH = 4;
-    __shared__ unsigned s_hist[HIST_LBINS];
+    // (P16: two 16-bit counters per word — a workgroup has at most 8192 positions, so no bin can reach 65 536 — 4 KB instead of 8: the LDS copy
+    // of the range below must leave the chain's workgroups room beside this kernel)
+    __shared__ unsigned s_hist[P16 ? HIST_LBINS / 2 : HIST_LBINS];
+    // P16: the workgroup's whole range — iters x 4 groups = up to 8192 consecutive positions, 16 KB — is staged in LDS first (16-byte loads, all in flight
+    // at once), and the scans that leave a wave's own 256 words WALK THE LDS COPY: the walks through memory were 40 % of this kernel (chains of
+    // dependent round trips of ~2 us, one pending position after the other); only a walk that leaves the workgroup's range still goes to memory.
+    constexpr int RANGE = P16 ? 8192 : 8;
+    __shared__ __attribute__((aligned(16))) unsigned short s_w[RANGE + 8];
     const int site = blockIdx.y, k = g.kbase + site;
     const bool fin = (site == g.final_site);
     const int *a = g.A + (size_t)site * g.strideA;
@@ -268,7 +284,14 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
     const int M = g.M, lane = lane_id();
     const unsigned short *p16 = P16 ? g.P16 + (size_t)site * g.stride16 : nullptr;
     const int kp1 = k + 1;
-    for (int x = threadIdx.x; x < HIST_LBINS; x += BLOCK) s_hist[x] = 0;
+    for (int x = threadIdx.x; x < (P16 ? HIST_LBINS / 2 : HIST_LBINS); x += BLOCK) s_hist[x] = 0;
+    const int r0 = blockIdx.x * g.iters * WAVES * (64 * CH), rn = min(g.iters * WAVES * (64 * CH), RANGE);       // the workgroup's positions [r0, r0 + rn)
+    int edgeL = 0, edgeR = 0;                               // P16: the words just outside the range
+    if constexpr (P16) {
+        for (int x = threadIdx.x * 8; x < rn; x += BLOCK * 8)
+            if (r0 + x <= M) *reinterpret_cast<uint4 *>(s_w + x) = *reinterpret_cast<const uint4 *>(p16 + r0 + x);     // (a slot is followed by another slot or the ring's padding)
+        edgeL = (int)__builtin_nontemporal_load(p16 + max(r0 - 1, 0)); edgeR = (int)__builtin_nontemporal_load(p16 + min(r0 + rn, M));
+    }
     __syncthreads();
     // branch-free loads: every address is clamped into [0, M] (index M holds the sentinel d[M]); words of positions beyond M
     // are never used as anything but a right neighbour of an invalid position
@@ -286,23 +309,43 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
     // Nothing is clamped: a slot is followed by another slot or the ring's padding, and words beyond position M are never used (see below).
     auto request = [&](Grp &q, int wvq) {                   // wvq = index of the 256-position group
         const int wb = wvq * (64 * CH);
-        if constexpr (P16) {
-            const int *pp = reinterpret_cast<const int *>(p16 + wb) + lane;
-            q.w[0] = (wb <= M) ? __builtin_nontemporal_load(pp) : 0; q.w[1] = (wb <= M) ? __builtin_nontemporal_load(pp + 64) : 0;
-            q.hl = (int)__builtin_nontemporal_load(p16 + max(wb - 1, 0)); q.hr = (int)__builtin_nontemporal_load(p16 + min(wb + 64 * CH, M));
-            return;
-        }
 #pragma unroll
         for (int c = 0; c < CH; ++c) q.w[c] = WD(wb + 64 * c + lane);
         q.hl = WD(wb - 1);
         q.hr = WD(wb + 64 * CH);
     };
-    auto process = [&](const Grp &q, int wv) -> bool {      // false: beyond the panel, stop
+    // P16: the scans of pbwtMatch.c:124-129 over the LDS copy, 256 candidates per step, in the L domain (d > thr <=> L < kp1 - thr; an escaped L is
+    // >= clip, so it never ends a block as long as kp1 - thr <= clip — the caller goes to memory otherwise).  Returns 1 = the same allele
+    // turned up (not reported), 2 = the block ended first, 0 = the range ended first: `from` is then the first candidate outside it.
+    auto walk_lds = [&](int &from, int dir, int thr, unsigned b) -> int {
+        const int Lthr = kp1 - thr;
+        int nst = 0;
+        auto fin_stat = [&]() { WALKSTAT(0, 1); WALKSTAT(1, nst); WALKSTAT(4 + (nst <= 1 ? 0 : nst == 2 ? 1 : nst <= 4 ? 2 : nst <= 8 ? 3 : nst <= 16 ? 4 : nst <= 32 ? 5 : 6), 1); };
+        for (;;) {
+            if (dir < 0 ? (from < r0) : (from >= r0 + rn)) { fin_stat(); return 0; }
+            ++nst;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = from + dir * (lane + 64 * j), rq = q - r0;
+                const bool in = (dir < 0) ? (rq >= 0) : (rq < rn && q <= M);
+                // up: candidate q stops the scan when d[q + 1] > thr, skips i when y[q] == b; down: d[q] > thr (d[M] is the sentinel), y[q] == b (q < M)
+                const unsigned hd = in ? (unsigned)s_w[(dir < 0) ? rq + 1 : rq] : 0u, hy = (dir < 0) ? (in ? (unsigned)s_w[rq] : 0u) : hd;
+                const bool bound = in && (int)(hd & 0x7fffu) < Lthr;
+                const bool same = in && !bound && (dir < 0 || q < M) && (hy >> 15) == b;
+                const unsigned long long mb = __ballot(bound), ms = __ballot(same), any = mb | ms;
+                if (any) { fin_stat(); return ((ms >> (__ffsll((long long)any) - 1)) & 1ULL) ? 1 : 2; }
+                if (__ballot(!in)) { from = (dir < 0) ? r0 - 1 : r0 + rn; fin_stat(); return 0; }      // the step crossed the end of the range undecided
+            }
+            from += dir * 256;
+        }
+    };
+    auto process = [&](int qw0, int qw1, int qw2, int qw3, int qhl, int qhr, int wv) -> bool {      // false: beyond the panel, stop  (the group's words by value: no struct through memory)
+    const int qw[CH] = {qw0, qw1, qw2, qw3};
     const int wbase = wv * (64 * CH);
     int w[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) w[c] = q.w[c];
-    int hl = P16 ? (int)((unsigned)q.hl << 16) : q.hl, hr = P16 ? (int)((unsigned)q.hr << 16) : q.hr;      // (P16: the allele bit to the sign position, for the test below)
+    for (int c = 0; c < CH; ++c) w[c] = qw[c];
+    int hl = P16 ? (int)((unsigned)qhl << 16) : qhl, hr = P16 ? (int)((unsigned)qhr << 16) : qhr;      // (P16: the allele bit to the sign position, for the test below)
     if (wbase > M) return false;
     // Y-UNIFORM GROUP: when the wave's 256 positions and their two neighbours all carry the same allele, every position has that allele on
     // the side its scan starts from (d[i] <= d[i+1]: y[i-1]; else d[i] >= d[i+1]: y[i+1]), so nothing reports and nothing scans on
@@ -327,10 +370,10 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
         unsigned hw[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int v = __builtin_amdgcn_ds_bpermute(((c & 1) * 32 + (lane >> 1)) << 2, q.w[c >> 1]);
+            const int v = __builtin_amdgcn_ds_bpermute(((c & 1) * 32 + (lane >> 1)) << 2, qw[c >> 1]);
             hw[c] = (lane & 1) ? ((unsigned)v >> 16) : ((unsigned)v & 0xffffu);
         }
-        const unsigned uhl = (unsigned)q.hl, uhr = (unsigned)q.hr;
+        const unsigned uhl = (unsigned)qhl, uhr = (unsigned)qhr;
         bool esc = (uhl & 0x7fffu) == 0x7fffu || (uhr & 0x7fffu) == 0x7fffu;
 #pragma unroll
         for (int c = 0; c < CH; ++c) esc = esc || (hw[c] & 0x7fffu) == 0x7fffu;
@@ -376,6 +419,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             for (unsigned long long pend = __ballot(pendUp[c]); pend; pend &= pend - 1) {
+                WALKSTAT(12, 1);
                 const int src = __ffsll((long long)pend) - 1;
                 const int thr = __builtin_amdgcn_readlane(dI[c], src);
                 const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)yI[c], src);
@@ -390,10 +434,12 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
                     const unsigned long long any = ms | my;
                     if (any) decided = ((ms >> (63 - __clzll(any))) & 1ULL) ? 2 : 1;
                 }
-                #ifdef PBWTAMD_MEASURE
+#ifdef PBWTAMD_MEASURE
                 if (!decided && g.dbg == 3) decided = 2;    // measurement (results WRONG): no walks through memory
 #endif
-                if (!decided) decided = coop_walk4<PACKED, P16>(a, d, wbase - 1, -1, thr, b, M, p16, kp1) ? 1 : 2;
+                int from = wbase - 1;
+                if constexpr (P16) { if (!decided && kp1 - thr <= g.clip) decided = walk_lds(from, -1, thr, b); }
+                if (!decided) decided = coop_walk4<PACKED, P16>(a, d, from, -1, thr, b, M, p16, kp1) ? 1 : 2;
                 if (decided == 1 && lane == src) { rep[c] = false; pendDn[c] = false; }
             }
         }
@@ -402,6 +448,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             for (unsigned long long pend = __ballot(pendDn[c]); pend; pend &= pend - 1) {
+                WALKSTAT(13, 1);
                 const int src = __ffsll((long long)pend) - 1;
                 const int thr = __builtin_amdgcn_readlane(dN[c], src);
                 const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)yI[c], src);
@@ -416,10 +463,12 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
                     const unsigned long long any = ms | my;
                     if (any) decided = ((ms >> (__ffsll((long long)any) - 1)) & 1ULL) ? 2 : 1;
                 }
-                #ifdef PBWTAMD_MEASURE
+#ifdef PBWTAMD_MEASURE
                 if (!decided && g.dbg == 3) decided = 2;
 #endif
-                if (!decided) decided = coop_walk4<PACKED, P16>(a, d, wbase + 64 * CH, +1, thr, b, M, p16, kp1) ? 1 : 2;
+                int from = wbase + 64 * CH;
+                if constexpr (P16) { if (!decided && kp1 - thr <= g.clip) decided = walk_lds(from, +1, thr, b); }
+                if (!decided) decided = coop_walk4<PACKED, P16>(a, d, from, +1, thr, b, M, p16, kp1) ? 1 : 2;
                 if (decided == 1 && lane == src) rep[c] = false;
             }
         }
@@ -429,7 +478,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
         if (rep[c]) {
             const int len = k - min(dI[c], dN[c]);          // (d[i] < d[i+1]) ? k - d[i] : k - d[i+1]   (pbwtMatch.c:131)
             if (len < 0 || len >= g.histlen) atomicExch(g.err, 1);
-            else if (len < HIST_LBINS) atomicAdd(&s_hist[len], 1u);
+            else if (len < HIST_LBINS) atomicAdd(&s_hist[P16 ? (len >> 1) : len], P16 ? (1u << (16 * (len & 1))) : 1u);
             else atomicAdd(g.hist + len, 1ULL);
         }
     }
@@ -463,23 +512,34 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
         int ca = next(); if (ca >= 0) request(ga, ca);
         int cb = next(); if (cb >= 0) request(gb, cb);
         while (ca >= 0 || cb >= 0) {
-            if (ca >= 0) { process(ga, ca); ca = next(); if (ca >= 0) request(ga, ca); }
-            if (cb >= 0) { process(gb, cb); cb = next(); if (cb >= 0) request(gb, cb); }
+            if (ca >= 0) { process(ga.w[0], ga.w[1], ga.w[2], ga.w[3], ga.hl, ga.hr, ca); ca = next(); if (ca >= 0) request(ga, ca); }
+            if (cb >= 0) { process(gb.w[0], gb.w[1], gb.w[2], gb.w[3], gb.hl, gb.hr, cb); cb = next(); if (cb >= 0) request(gb, cb); }
         }
     } else {
-    const int wv0 = blockIdx.x * g.iters * WAVES + wave_id();   // group of iteration it: wv0 + it * WAVES
+    const int wv0 = blockIdx.x * g.iters * WAVES + (P16 ? wave_id_s() : wave_id());   // group of iteration it: wv0 + it * WAVES  (P16: in an SGPR — scalar control flow below)
+    if constexpr (P16) {                                    // (the words come from LDS: nothing to request ahead)
+#pragma nounroll
+        for (int it = 0; it < g.iters; ++it) {
+            const int wvq = wv0 + it * WAVES, rb = wvq * (64 * CH) - r0;       // (inside the workgroup's range by construction)
+            if (rb + 64 * CH > rn) break;
+            const int *pp = reinterpret_cast<const int *>(s_w + rb) + lane;
+            const int hl = (rb > 0) ? (int)s_w[rb - 1] : edgeL, hr = (rb + 64 * CH < rn) ? (int)s_w[rb + 64 * CH] : edgeR;
+            if (!process(pp[0], pp[64], 0, 0, hl, hr, wvq)) break;
+        }
+    } else {
     request(ga, wv0); request(gb, wv0 + WAVES);
     for (int it = 0; it < g.iters; it += 2) {
-        if (!process(ga, wv0 + it * WAVES)) break;
+        if (!process(ga.w[0], ga.w[1], ga.w[2], ga.w[3], ga.hl, ga.hr, wv0 + it * WAVES)) break;
         request(ga, wv0 + (it + 2) * WAVES);
         if (it + 1 >= g.iters) break;
-        if (!process(gb, wv0 + (it + 1) * WAVES)) break;
+        if (!process(gb.w[0], gb.w[1], gb.w[2], gb.w[3], gb.hl, gb.hr, wv0 + (it + 1) * WAVES)) break;
         request(gb, wv0 + (it + 3) * WAVES);
+    }
     }
     }
     __syncthreads();
     unsigned long long *rep = g.hist_rep + (size_t)((blockIdx.x + 7 * blockIdx.y) % HIST_REP) * HIST_LBINS;
-    for (int x = threadIdx.x; x < HIST_LBINS; x += BLOCK) { const unsigned v = s_hist[x]; if (v) atomicAdd(rep + x, (unsigned long long)v); }
+    for (int x = threadIdx.x; x < HIST_LBINS; x += BLOCK) { const unsigned v = P16 ? ((s_hist[x >> 1] >> (16 * (x & 1))) & 0xffffu) : s_hist[x]; if (v) atomicAdd(rep + x, (unsigned long long)v); }
 }
 
 // matchLongWithin2 (pbwtMatch.c:85-113, -longWithin L) over ring slots: positions are cut into

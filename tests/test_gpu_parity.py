@@ -484,6 +484,7 @@ def test_p16_matches_longer_than_32766_sites(amd, orc, monkeypatch):
     o = orc.build_bitcols(bits, M, with_d=True)
     sw = orc.sweep_AD(o["yz"], M, N)
     monkeypatch.setenv("PBWTAMD_PACKED_CHECKSUM", "1")
+    monkeypatch.setenv("PBWTAMD_P16", "1")                   # (by default the 16-bit hand-off starts at 180 000 haplotypes)
     eng = amd.Engine(M, batch_sites=batch)
     assert bits.shape[1] == eng.wpc
     buf = torch.from_numpy(bits.view(np.int32)).cuda()
