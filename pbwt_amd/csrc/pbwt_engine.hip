@@ -873,11 +873,10 @@ static int run_consumers(pbwtamd_engine *e, const Pending &p, int j0, int ns, in
     const bool packed = packed_fill(p);
     // the 16-bit hand-off (round 4; PBWTAMD_P16=0: the d | y << 31 slots): the sequential fill writes L | y << 15 into a ring of its own, the streaming
     // sweep reads that — half the bytes on both sides.  PBWTAMD_P16_CLIP=n (tests): lengths from n on escape to the 32-bit slot.
-    // Measured (interleaved A/B, founder-mosaic panels): -0.5 % at 200 k haplotypes, -4.8 % at 350 k, -2.3 % at 600 k, -5..-6.5 % at 1 M; +1.5 % at 100 k,
-    // where the consumers hide behind the chain's launches and only their footprint beside a chain workgroup counts: on from 180 000 haplotypes
-    // (PBWTAMD_P16=1: at every width — the parity tests; =0: never).
-    const int p16_env = env_int("PBWTAMD_P16", -1);
-    const bool p16_on = (p16_env < 0 ? e->M >= 180000 : p16_env != 0) && env_int("PBWTAMD_FILL_SEQ", 1) != 0
+    // Measured (interleaved A/B, founder-mosaic panels, with the four-per-lane stores of the fill and the LDS-staged sweep): -9 % at 1 M haplotypes
+    // (5.35 -> 4.87 us/site), -2.3..-2.6 % at 100 k, -3.4 % at 50 k; an iid panel (every level of every tile moves elements, every group of the sweep has
+    // pending scans) +9 % at 100 k.  On at every width (PBWTAMD_P16=0: off).
+    const bool p16_on = env_int("PBWTAMD_P16", 1) != 0 && env_int("PBWTAMD_FILL_SEQ", 1) != 0
 #ifdef PBWTAMD_MEASURE
                                && !env_int("PBWTAMD_FILL_FUSE", 0) && !env_int("PBWTAMD_FILL_YC", 0) && !tune_env("PBWTAMD_OLD_SWEEP")
 #endif

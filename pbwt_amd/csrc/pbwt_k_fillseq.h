@@ -295,6 +295,91 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
         asm volatile("" ::: "memory");
         // ---- the level's outputs, destination order: lanes = consecutive local indices = consecutive destinations inside a run
         int *const dout = g.Dout + (size_t)(8 * b + j + 1) * g.strideD;
+        // FOUR per lane and store (round 4): a wave64 vector-memory instruction costs the address path its 16 cycles whatever it carries, and the
+        // fill was bound by exactly that — 64 stores of 128-256 bytes per wave (without its stores the kernel takes half the time).  A lane takes four
+        // consecutive local indices; when they belong to one run (one destination offset — the rule on a panel whose sites carry rare alleles) they
+        // leave as ONE store of 8 (16-bit slots; 2-byte aligned: the address mode of this stack takes it) or 16 bytes; a lane at a run boundary
+        // stores its four one by one.  Tables and LDS reads shrink alike: one offset lookup, one 4-byte and one 16-byte read per four outputs.
+        bool vec_done = false;
+        if constexpr (FUSE == 0) {
+#ifdef PBWTAMD_MEASURE
+          if (!g.dbg_nowrite)
+#endif
+          if (j >= 0 && nvalid == T) {
+            vec_done = true;
+            unsigned short *const dout16 = (PACKY == 3) ? g.P16 + (size_t)(8 * b + j + 1) * g.stride16 : nullptr;
+            const int site = k + j + 1;
+#pragma unroll
+            for (int q = 0; q < E / 4; ++q) {
+                const int x = 4 * (q * 64 + lane);
+                const unsigned k4 = *reinterpret_cast<const unsigned *>(s_k + x);
+                const int4 d4 = *reinterpret_cast<const int4 *>(s_d + x);
+                int v[4] = {d4.x, d4.y, d4.z, d4.w};
+                const unsigned kp[4] = {k4 & m1, (k4 >> 8) & m1, (k4 >> 16) & m1, (k4 >> 24) & m1};
+                const unsigned yb[4] = {(k4 >> (j + 1)) & 1u, (k4 >> (j + 9)) & 1u, (k4 >> (j + 17)) & 1u, (k4 >> (j + 25)) & 1u};
+                const int off0 = tab[(int)(m1 + 1u) + (int)kp[0]].x;
+                if (kp[1] == kp[0] && kp[2] == kp[0] && kp[3] == kp[0]) {
+                    const int dest = x + off0;
+                    if (dest == 0) v[0] = site + 1;         // sentinel (pbwtCore.c:507)
+                    if constexpr (PACKY == 3) {
+                        bool e0, e1, e2, e3;
+                        const unsigned h0 = p16_encode(site, v[0], yb[0], g.clip, e0), h1 = p16_encode(site, v[1], yb[1], g.clip, e1);
+                        const unsigned h2 = p16_encode(site, v[2], yb[2], g.clip, e2), h3 = p16_encode(site, v[3], yb[3], g.clip, e3);
+                        struct __attribute__((packed, aligned(2))) U64A2 { unsigned long long u; };
+                        reinterpret_cast<U64A2 *>(dout16 + dest)->u = (unsigned long long)(h0 | h1 << 16) | ((unsigned long long)(h2 | h3 << 16) << 32);
+                        if (e0 | e1 | e2 | e3) {            // (rare: a match of 32 767 sites or more) the sweep reads d itself from the 32-bit slot
+                            if (e0) dout[dest] = v[0];
+                            if (e1) dout[dest + 1] = v[1];
+                            if (e2) dout[dest + 2] = v[2];
+                            if (e3) dout[dest + 3] = v[3];
+                        }
+                    } else {
+                        struct __attribute__((packed, aligned(4))) I128A4 { int4 u; };
+                        I128A4 t;
+                        if constexpr (PACKY == 1) t.u = make_int4(v[0] | (int)(yb[0] << 31), v[1] | (int)(yb[1] << 31), v[2] | (int)(yb[2] << 31), v[3] | (int)(yb[3] << 31));
+                        else t.u = make_int4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<I128A4 *>(dout + dest) = t;
+                    }
+                } else {                                    // a run boundary inside the four
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int dest = x + e + ((e && kp[e] != kp[0]) ? tab[(int)(m1 + 1u) + (int)kp[e]].x : off0);
+                        const int vv = (dest == 0) ? site + 1 : v[e];
+                        if constexpr (PACKY == 3) {
+                            bool esc;
+                            const unsigned h = p16_encode(site, vv, yb[e], g.clip, esc);
+                            dout16[dest] = (unsigned short)h;
+                            if (esc) dout[dest] = vv;
+                        } else dout[dest] = (PACKY == 1) ? (vv | (int)(yb[e] << 31)) : vv;
+                    }
+                }
+            }
+            if (w == g.W - 1 && lane == 0) { dout[g.M] = k + j + 2; if constexpr (PACKY == 3) dout16[g.M] = 0; }
+          }
+        }
+        if constexpr (FUSE == 0) {
+          if (!vec_done && j >= 0) {                        // the panel's ragged last tile: one by one
+#ifdef PBWTAMD_MEASURE
+            if (!g.dbg_nowrite)
+#endif
+#pragma nounroll
+            for (int q = 0; q < E; ++q) {
+                const int x = q * 64 + lane;
+                if (x >= nvalid) continue;
+                const unsigned kx = s_k[x];
+                const int dest = x + tab[(int)(m1 + 1u) + (int)(kx & m1)].x;
+                const int vv = (dest == 0) ? k + j + 2 : s_d[x];
+                const unsigned yb = (kx >> (j + 1)) & 1u;
+                if constexpr (PACKY == 3) {
+                    bool esc;
+                    const unsigned h = p16_encode(k + j + 1, vv, yb, g.clip, esc);
+                    (g.P16 + (size_t)(8 * b + j + 1) * g.stride16)[dest] = (unsigned short)h;
+                    if (esc) dout[dest] = vv;
+                } else dout[dest] = (PACKY == 1) ? (vv | (int)(yb << 31)) : vv;
+            }
+            if (w == g.W - 1 && lane == 0) { dout[g.M] = k + j + 2; if constexpr (PACKY == 3) (g.P16 + (size_t)(8 * b + j + 1) * g.stride16)[g.M] = 0; }
+          }
+        } else {
         int vq[E], pq[E]; unsigned kq[E];
 #pragma unroll
         for (int q = 0; q < E; ++q) {
@@ -380,6 +465,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
                 }
             }
         }
+        }                                                   // (!vec_done)
         if (j < SKB - 2) {
             const int4 *dp = reinterpret_cast<const int4 *>(s_d + l0);
 #pragma unroll

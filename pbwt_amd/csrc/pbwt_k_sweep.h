@@ -523,8 +523,9 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
             const int wvq = wv0 + it * WAVES, rb = wvq * (64 * CH) - r0;       // (inside the workgroup's range by construction)
             if (rb + 64 * CH > rn) break;
             const int *pp = reinterpret_cast<const int *>(s_w + rb) + lane;
-            const int hl = (rb > 0) ? (int)s_w[rb - 1] : edgeL, hr = (rb + 64 * CH < rn) ? (int)s_w[rb + 64 * CH] : edgeR;
-            if (!process(pp[0], pp[64], 0, 0, hl, hr, wvq)) break;
+            const int hlv = (int)s_w[max(rb - 1, 0)], hrv = (int)s_w[min(rb + 64 * CH, rn - 1)], w0 = pp[0], w1 = pp[64];     // (four LDS reads in flight, branch-free)
+            const int hl = (rb > 0) ? hlv : edgeL, hr = (rb + 64 * CH < rn) ? hrv : edgeR;
+            if (!process(w0, w1, 0, 0, hl, hr, wvq)) break;
         }
     } else {
     request(ga, wv0); request(gb, wv0 + WAVES);
