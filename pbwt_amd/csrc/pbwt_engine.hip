@@ -398,6 +398,9 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
                 ALLOC(e->saveR[i], (size_t)rounds * e->strideS * sizeof(int2));
                 ALLOC(e->fillGB[i], (size_t)rounds * SKK * sizeof(int2));
             }
+            // the 16-bit hand-off ring (run_consumers): 2 x (B + 2) slots of strideD 16-bit words — here rather than with the first batch that takes it
+            // (a 0.2-2 GB hipMalloc inside a pass showed up as a 10 % outlier in one run out of four at 100 k haplotypes)
+            if (e->skEPT <= 2 && env_int("PBWTAMD_P16", 1) != 0) ALLOC(e->p16r, (size_t)2 * (e->B + 2) * e->strideD * sizeof(unsigned short));
         }
         ALLOC(e->skT, (size_t)(e->Wt + 1) * SKK * sizeof(int2));
         ALLOC(e->k2agg, (size_t)64 * SKK * sizeof(unsigned long long));

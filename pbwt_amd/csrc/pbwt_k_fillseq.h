@@ -318,7 +318,10 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
                 const unsigned kp[4] = {k4 & m1, (k4 >> 8) & m1, (k4 >> 16) & m1, (k4 >> 24) & m1};
                 const unsigned yb[4] = {(k4 >> (j + 1)) & 1u, (k4 >> (j + 9)) & 1u, (k4 >> (j + 17)) & 1u, (k4 >> (j + 25)) & 1u};
                 const int off0 = tab[(int)(m1 + 1u) + (int)kp[0]].x;
-                if (kp[1] == kp[0] && kp[2] == kp[0] && kp[3] == kp[0]) {
+                // (a wave in which most lanes straddle a run boundary — an iid panel at the deep levels — skips the attempt: both branches would run in full)
+                const bool one_run = kp[1] == kp[0] && kp[2] == kp[0] && kp[3] == kp[0];
+                const bool try_vec = __popcll(__ballot(one_run)) >= 40;
+                if (try_vec && one_run) {
                     const int dest = x + off0;
                     if (dest == 0) v[0] = site + 1;         // sentinel (pbwtCore.c:507)
                     if constexpr (PACKY == 3) {

@@ -314,6 +314,9 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
         q.hl = WD(wb - 1);
         q.hr = WD(wb + 64 * CH);
     };
+    // P16: a wave takes iters CONSECUTIVE groups, so the words of the site's sorted bit column it produces are consecutive too: they collect in a
+    // register (lane = word) and leave as ONE store per wave instead of one per y-uniform group and four per other group (§2's 16-cycle rule)
+    unsigned long long ycacc = 0ULL; int ycslot = 0;
     // P16: the scans of pbwtMatch.c:124-129 over the LDS copy, 256 candidates per step, in the L domain (d > thr <=> L < kp1 - thr; an escaped L is
     // >= clip, so it never ends a block as long as kp1 - thr <= clip — the caller goes to memory otherwise).  Returns 1 = the same allele
     // turned up (not reported), 2 = the block ended first, 0 = the range ended first: `from` is then the first candidate outside it.
@@ -362,6 +365,8 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
             all0 = (m0 | m1 | m2 | m3) == 0ULL && h0 >= 0 && h1 >= 0; all1 = (m0 & m1 & m2 & m3) == ~0ULL && h0 < 0 && h1 < 0;
         }
         if (all0 || all1) {
+            if constexpr (P16) { if ((lane >> 2) == (ycslot >> 2)) ycacc = all1 ? ~0ULL : 0ULL; }
+            else
             if (g.ycols && lane < CH) (g.ycols + (size_t)site * g.wpc64)[wv * CH + lane] = all1 ? ~0ULL : 0ULL;    // wv * CH + 3 < wpc64: the group ends before M
             return true;
         }
@@ -408,6 +413,8 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
         if (!YCIN && g.ycols) {                             // this site's sorted bit column (what pack3 encodes)
             const unsigned long long mk = __ballot(valid && yI[c]);
             const int wd = wv * CH + c;
+            if constexpr (P16) { if (lane == ycslot + c) ycacc = mk; }
+            else
             if (lane == 0 && wd < g.wpc64) (g.ycols + (size_t)site * g.wpc64)[wd] = mk;
         }
         mPendUp |= __ballot(pendUp[c]); mPendDn |= __ballot(pendDn[c]);
@@ -516,17 +523,19 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
             if (cb >= 0) { process(gb.w[0], gb.w[1], gb.w[2], gb.w[3], gb.hl, gb.hr, cb); cb = next(); if (cb >= 0) request(gb, cb); }
         }
     } else {
-    const int wv0 = blockIdx.x * g.iters * WAVES + (P16 ? wave_id_s() : wave_id());   // group of iteration it: wv0 + it * WAVES  (P16: in an SGPR — scalar control flow below)
+    const int wv0 = blockIdx.x * g.iters * WAVES + (P16 ? wave_id_s() * g.iters : wave_id());   // group of iteration it: wv0 + it * WAVES  (P16: wv0 + it, in an SGPR — scalar control flow below)
     if constexpr (P16) {                                    // (the words come from LDS: nothing to request ahead)
 #pragma nounroll
         for (int it = 0; it < g.iters; ++it) {
-            const int wvq = wv0 + it * WAVES, rb = wvq * (64 * CH) - r0;       // (inside the workgroup's range by construction)
+            const int wvq = wv0 + it, rb = wvq * (64 * CH) - r0;       // (inside the workgroup's range by construction)
             if (rb + 64 * CH > rn) break;
+            ycslot = it * CH;
             const int *pp = reinterpret_cast<const int *>(s_w + rb) + lane;
             const int hlv = (int)s_w[max(rb - 1, 0)], hrv = (int)s_w[min(rb + 64 * CH, rn - 1)], w0 = pp[0], w1 = pp[64];     // (four LDS reads in flight, branch-free)
             const int hl = (rb > 0) ? hlv : edgeL, hr = (rb + 64 * CH < rn) ? hrv : edgeR;
             if (!process(w0, w1, 0, 0, hl, hr, wvq)) break;
         }
+        if (g.ycols && lane < g.iters * CH && wv0 * CH + lane < g.wpc64) (g.ycols + (size_t)site * g.wpc64)[wv0 * CH + lane] = ycacc;     // (groups beyond M leave zeros: padding words)
     } else {
     request(ga, wv0); request(gb, wv0 + WAVES);
     for (int it = 0; it < g.iters; it += 2) {
