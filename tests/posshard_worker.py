@@ -23,11 +23,15 @@ def main():
     kind, step = int(os.environ.get("PS_KIND", "0")), int(os.environ.get("PS_STEP", "8192"))
     with_csum = int(os.environ.get("PS_CSUM", "1"))
     trace = (lambda m: print("[worker %d] %s" % (rank, m), file=sys.stderr, flush=True)) if os.environ.get("PS_TRACE") else (lambda m: None)
-    eng = amd.Engine(M, batch_sites=B, device=0)
-    trace("engine up")
+    # PS_SPREAD=1 (tests/test_gpu_multi.py::test_position_sharded_across_devices, multi-GPU nodes only): rank r on device r mod device_count — the
+    # peer stores, the flag barriers and the hipIpc mappings then really cross xGMI; default: every rank on device 0
+    dev = (rank % max(torch.cuda.device_count(), 1)) if os.environ.get("PS_SPREAD") == "1" else 0
+    torch.cuda.set_device(dev)
+    eng = amd.Engine(M, batch_sites=B, device=dev)
+    trace("engine up on device %d" % dev)
     ps.setup(eng, rank, world)
     trace("shard connected")
-    panel = torch.empty((N, eng.wpc), dtype=torch.int32, device="cuda:0")
+    panel = torch.empty((N, eng.wpc), dtype=torch.int32, device="cuda:%d" % dev)
     torch.cuda.synchronize()
     eng.synth_device(panel.data_ptr(), 0, N, seed=0x9051, kind=kind)       # every rank holds the same columns
     eng.sync()
@@ -43,7 +47,7 @@ def main():
     yz = ps.gather_packed(eng)
     a, d = eng.get_state()
     trace("results gathered")
-    res = {"rank": rank, "range": list(eng.shard_range(rank)), "seconds": dt, "blocks": int(len(eng.shard_blocks()[0]))}
+    res = {"rank": rank, "device": dev, "range": list(eng.shard_range(rank)), "seconds": dt, "blocks": int(len(eng.shard_blocks()[0]))}
     if rank == 0:
         import oracle
         bits = panel.cpu().numpy().view(np.uint32)

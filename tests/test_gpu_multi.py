@@ -187,6 +187,33 @@ def test_position_sharded_chain_ranks_one_gpu(world, M, N, B, kind, step, csum, 
     assert outs[0]["range"][0] == 0 and outs[-1]["range"][1] == M
 
 
+def _device_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs a node with at least two MI355X: every box this build has seen so far has ONE GPU, so the position-sharded "
+                                                "path is single-device-validated only (DESIGN.md section 6.3) — this is the first thing to run on a multi-GPU node")
+@pytest.mark.parametrize("M,N,B,kind,csum", [(70000, 264, 128, 0, 1), (300000, 136, 64, 1, 0), (1000000, 1024, 512, 0, 0)])
+def test_position_sharded_across_devices(M, N, B, kind, csum, tmp_path):
+    """the same check as test_position_sharded_chain_ranks_one_gpu with rank r on DEVICE r (world = min(device_count, 8)): peer stores into hipIpc
+    mappings of another GPU's rings, the flag barriers and the per-round row exchange over xGMI.  What one shared GPU cannot show — a peer store that
+    is late or stale in the owner's L2 — fails here as a checksum mismatch at the first site it touches."""
+    world = min(_device_count(), 8)
+    env = dict(os.environ, OUT_DIR=str(tmp_path), PS_M=str(M), PS_N=str(N), PS_B=str(B), PS_KIND=str(kind), PS_STEP="8192", PS_CSUM=str(csum), PS_SPREAD="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "posshard_worker.py")],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    outs = [json.load(open(tmp_path / ("ps%d.json" % rk))) for rk in range(world)]
+    assert all(o["ok"] for o in outs), outs
+    assert sorted(o["device"] for o in outs) == list(range(world))
+
+
 QS_WORKER = textwrap.dedent("""
     import json, os, sys
     import numpy as np
