@@ -241,7 +241,7 @@ struct pbwtamd_engine {
 };
 
 extern "C" int pbwtamd_abi_version(void) { return PBWTAMD_ABI_VERSION; }
-#ifdef PBWTAMD_MEASURE
+#ifdef PBWTAMD_WALKSTAT
 extern "C" int pbwtamd_measure_walkstat(unsigned long long *out, int reset) {      // measurement builds: the sweep's walk counters (pbwt_k_sweep.h: g_walkstat)
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(pbwtk::g_walkstat), sizeof(unsigned long long) * 16));

@@ -485,8 +485,14 @@ __device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut
     __shared__ short s_cnt[NC][SKK];                        // per chunk: count -> base (exclusive over chunks)
     __shared__ short s_lastp[NC][SKK];                      // per chunk: last local position of the key -> previous one before the chunk
     __shared__ int s_tbl[NL][T];                            // s_tbl[l][i] = max d over (i-2^l, i]
-    __shared__ int s_before[SKK], s_carry[SKK], s_G[SKK], s_lower[SKK];
-    __shared__ int s_gw[WAVES], s_lw[WAVES];
+    // (round 4) 20 480 bytes at 512 positions, so that EIGHT workgroups fit a CU's 160 KB (22 560 held seven: at 1 M haplotypes 1 792 of the 1 954 tiles
+    // were resident and the rest made a second, nearly empty round of the chip): per key ONE destination base (bucket base + keys before the tile) and ONE
+    // first-occurrence word (carry | SK_EFLAG, or the final value); the cross-wave scan of the totals borrows eight words of the sparse table's top level
+    // that no query reads (a window of 4^(NL-1) positions never ends below index 4^(NL-1) - 1; those eight are not written there either).
+    __shared__ int s_base[SKK], s_ext[SKK];
+    constexpr int SK_EFLAG = 0x40000000;
+    int *const s_gw = R4 ? &s_tbl[NL - 1][0] : nullptr, *const s_lw = R4 ? &s_tbl[NL - 1][WAVES] : nullptr;
+    __shared__ int s_gwx[R4 ? 1 : WAVES], s_lwx[R4 ? 1 : WAVES];
     __shared__ int *s_pa[SHARD ? SHARD_MAX : 1], *s_pd[SHARD ? SHARD_MAX : 1]; __shared__ unsigned char *s_pk[SHARD ? SHARD_MAX : 1];
     __shared__ int s_pb[SHARD ? SHARD_MAX : 1];
     __shared__ int s_failed;
@@ -563,7 +569,7 @@ __device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut
                 if (i - wq >= 0) m = max(m, s_tbl[l - 1][i - wq]);
                 if (i - 2 * wq >= 0) m = max(m, s_tbl[l - 1][i - 2 * wq]);
                 if (i - 3 * wq >= 0) m = max(m, s_tbl[l - 1][i - 3 * wq]);
-                s_tbl[l][i] = m;
+                if (l < NL - 1 || i >= 2 * WAVES) s_tbl[l][i] = m;        // (the top level's first eight words carry the totals' scan, see above)
             } else {
                 const int j = i - (1 << (l - 1));
                 s_tbl[l][i] = (j >= 0) ? max(s_tbl[l - 1][i], s_tbl[l - 1][j]) : s_tbl[l - 1][i];
@@ -582,13 +588,15 @@ __device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut
     }
     // bucket bases G (exclusive prefix of the key totals) and the nearest lower non-empty key
     const int ginc = wave_iscan_sum(tq), linc = wave_iscan_max(tq ? t + 1 : 0);
-    if (lane == 63) { s_gw[wv] = ginc; s_lw[wv] = linc; }
+    int *const gwp = R4 ? s_gw : s_gwx, *const lwp = R4 ? s_lw : s_lwx;
+    if (lane == 63) { gwp[wv] = ginc; lwp[wv] = linc; }
     const int lexc = lane_shr1(linc, 0);
     lds_barrier();
     int Gq = ginc - tq, lq = lexc;
-    for (int x = 0; x < wv; ++x) { Gq += s_gw[x]; lq = max(lq, s_lw[x]); }
+    for (int x = 0; x < wv; ++x) { Gq += gwp[x]; lq = max(lq, lwp[x]); }
     lq -= 1;
-    s_before[t] = bq; s_carry[t] = cq; s_G[t] = Gq; s_lower[t] = lq;
+    s_base[t] = Gq + bq;
+    s_ext[t] = (cq >= 0) ? (cq | SK_EFLAG) : (lq >= 0 ? g.k + 1 + (31 - __clz(t ^ lq)) : 0);      // a first occurrence in the tile: the carry (max with the local maximum) or the key-difference value
     lds_barrier();
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
@@ -608,10 +616,8 @@ __device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut
         }
         int dd;
         if (p >= 0) dd = rm;
-        else if (s_carry[ky] >= 0) dd = max(s_carry[ky], rm);
-        else if (s_lower[ky] >= 0) dd = g.k + 1 + (31 - __clz(ky ^ s_lower[ky]));
-        else dd = 0;
-        const int pos = s_G[ky] + s_before[ky] + rank;
+        else { const int ex = s_ext[ky]; dd = (ex & SK_EFLAG) ? max(ex & ~SK_EFLAG, rm) : ex; }
+        const int pos = s_base[ky] + rank;
         if (pos == 0) dd = g.k + SKB + 1;                  // sentinel (pbwtCore.c:507 after the 8th site)
         if constexpr (SHARD) {                              // the owner of the destination: pb[o] <= pos < pb[o+1] (s_pb holds pb[1..]; unused entries INT_MAX)
             int o = 0;

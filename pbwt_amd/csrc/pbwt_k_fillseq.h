@@ -337,10 +337,10 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
                             if (e3) dout[dest + 3] = v[3];
                         }
                     } else {
-                        struct __attribute__((packed, aligned(4))) I128A4 { int4 u; };
+                        struct __attribute__((aligned(4))) I128A4 { int x, y, z, w; };     // (16 bytes at a 4-byte aligned address: one global_store_dwordx4)
                         I128A4 t;
-                        if constexpr (PACKY == 1) t.u = make_int4(v[0] | (int)(yb[0] << 31), v[1] | (int)(yb[1] << 31), v[2] | (int)(yb[2] << 31), v[3] | (int)(yb[3] << 31));
-                        else t.u = make_int4(v[0], v[1], v[2], v[3]);
+                        if constexpr (PACKY == 1) t = I128A4{v[0] | (int)(yb[0] << 31), v[1] | (int)(yb[1] << 31), v[2] | (int)(yb[2] << 31), v[3] | (int)(yb[3] << 31)};
+                        else t = I128A4{v[0], v[1], v[2], v[3]};
                         *reinterpret_cast<I128A4 *>(dout + dest) = t;
                     }
                 } else {                                    // a run boundary inside the four

@@ -30,7 +30,7 @@ struct SweepArgs {
 // report lands in ~30 bins) would spend seconds there.  So the short lengths are counted in LDS per workgroup first and
 // flushed to one of HIST_REP replicas of the low bins; long lengths (spread over many bins) go straight to hist.
 constexpr int HIST_LBINS = 2048, HIST_REP = 32;
-#ifdef PBWTAMD_MEASURE
+#ifdef PBWTAMD_WALKSTAT                                     // (its own switch: the counters' atomics slow a measurement build fivefold)
 __device__ unsigned long long g_walkstat[16];               // [0] LDS walks [1] their 256-position steps [2] memory walks [3] their steps [4..11] LDS walks by steps: 1, 2, 3-4, 5-8, 9-16, 17-32, > 32 ; [12] pending up [13] pending down
 #define WALKSTAT(i, n) do { if (lane_id() == 0) atomicAdd(&g_walkstat[i], (unsigned long long)(n)); } while (0)
 #else
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(BLOCK) void sweep_hist_kernel(SweepArgs g) {
     // turned up (not reported), 2 = the block ended first, 0 = the range ended first: `from` is then the first candidate outside it.
     auto walk_lds = [&](int &from, int dir, int thr, unsigned b) -> int {
         const int Lthr = kp1 - thr;
-        int nst = 0;
+        int nst = 0; (void)nst;
         auto fin_stat = [&]() { WALKSTAT(0, 1); WALKSTAT(1, nst); WALKSTAT(4 + (nst <= 1 ? 0 : nst == 2 ? 1 : nst <= 4 ? 2 : nst <= 8 ? 3 : nst <= 16 ? 4 : nst <= 32 ? 5 : 6), 1); };
         for (;;) {
             if (dir < 0 ? (from < r0) : (from >= r0 + rn)) { fin_stat(); return 0; }

@@ -1,4 +1,4 @@
-"""measurement build only: how long are the scans of the -stats sweep that leave a wave's own 256 positions?  python tools/walkstat.py [M] [sites] [kind]"""
+"""build with -DPBWTAMD_WALKSTAT (hipcc ... -DPBWTAMD_WALKSTAT -o pbwt_amd/libpbwtgpu_walkstat.so; PBWTAMD_LIB=that): how long are the scans of the -stats sweep that leave a wave's own 256 positions?  python tools/walkstat.py [M] [sites] [kind]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, pbwt_amd as amd
