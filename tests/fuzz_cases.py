@@ -20,7 +20,7 @@ def run_cases(seed, ncases=None, budget_s=None, verbose=False):
         bits = orc.synth_bitcols(M, N, seed=int(rng.integers(1, 1 << 30)), kind=kind)
         o = orc.build_bitcols(bits, M, with_d=True)
         eng = amd.Engine(M, batch_sites=B)
-        mode = int(rng.integers(0, 5))
+        mode = int(rng.integers(0, 6))
         ok = True
         try:
             if mode == 0:      # device pass API, every site, split into random advances
@@ -42,6 +42,29 @@ def run_cases(seed, ncases=None, budget_s=None, verbose=False):
                 opts = amd.OPT_WITH_D | amd.OPT_WITHIN_HIST | amd.OPT_PACK3
                 eng.pass_begin(N); eng.pass_advance(buf.data_ptr(), N, N, opts); eng.pass_end(opts)
                 ok = np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1]) and np.array_equal(eng.get_packed(), o["yz"])
+            elif mode == 5:    # packed consumers checked at EVERY position: checksums of d and y taken from the hand-off slots (16-bit with a random escape threshold, or 32-bit)
+                import os
+                saved = {k: os.environ.get(k) for k in ("PBWTAMD_PACKED_CHECKSUM", "PBWTAMD_P16", "PBWTAMD_P16_CLIP")}
+                os.environ["PBWTAMD_PACKED_CHECKSUM"] = "1"
+                os.environ["PBWTAMD_P16"] = "1" if rng.random() < 0.8 else "0"
+                os.environ["PBWTAMD_P16_CLIP"] = str(int(rng.choice([1, 2, 5, 37, 32767])))
+                try:
+                    buf = torch.from_numpy(bits.view(np.int32)).cuda()
+                    opts = amd.OPT_WITH_D | amd.OPT_WITHIN_HIST | amd.OPT_PACK3 | amd.OPT_CHECKSUM
+                    eng.pass_begin(N)
+                    k = 0
+                    while k < N:
+                        step = int(min(N - k, rng.choice([8, 16, 64, 1000])))
+                        eng.pass_advance(buf.data_ptr() + k * eng.wpc * 4, step, int(min(N - k, step + 8)), opts); k += step
+                    eng.pass_end(opts)
+                    _, cd, cy = eng.get_checksums(0, N)
+                    sw = orc.sweep_AD(o["yz"], M, N)
+                    ok = np.array_equal(cd[:N], o["csum_d"][:N]) and np.array_equal(cy[:N], sw["csum_y"][:N])
+                    ok = ok and np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1]) and np.array_equal(eng.get_packed(), o["yz"])
+                finally:
+                    for k2, v in saved.items():
+                        if v is None: os.environ.pop(k2, None)
+                        else: os.environ[k2] = v
             elif mode == 2:    # host build + read side
                 b = eng.build(bits, with_d=bool(rng.integers(0, 2)))
                 ok = np.array_equal(b["yz"], o["yz"]) and np.array_equal(b["aFend"], o["aFend"])
