@@ -1419,7 +1419,7 @@ static void launch_round_many(pbwtamd_engine *e0, const SkArgs *dargs, int P, in
     }
     if (W <= 256) hipLaunchKernelGGL((skel_k2_many_kernel<4, 4>), dim3(SKK / 4, P), dim3(BLOCK), 0, st, dargs);
     else hipLaunchKernelGGL((skel_k2_many_kernel<4, 16>), dim3(SKK / 4, P), dim3(BLOCK), 0, st, dargs);
-    hipLaunchKernelGGL((skel_rank_many_kernel<EPT, 0>), dim3(W, P), dim3(BLOCK), 0, st, dargs);
+    hipLaunchKernelGGL((skel_rank_many_kernel<EPT, 0, true>), dim3(W, P), dim3(BLOCK), 0, st, dargs);     // (the radix-4 form, 20 KB of LDS: as the single-panel round)
 }
 
 extern "C" int pbwtamd_pass_advance_many(pbwtamd_engine **es, int P, const void *const *d_bitcols, int wpc, int ncols, int ncols_avail, unsigned opts) {

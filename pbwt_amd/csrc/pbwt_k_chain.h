@@ -690,8 +690,8 @@ __global__ __launch_bounds__(KPW * 64) void skel_k2_many_kernel(const SkArgs *ar
     Sk2Args k; k.tbl = g.tbl; k.scan = g.scan; k.total = g.total; k.W = g.W;
     skel_k2_body<KPW, TPL>(k);
 }
-template <int EPT, int TR>
-__global__ __launch_bounds__(BLOCK) void skel_rank_many_kernel(const SkArgs *args) { const SkArgs g = args[blockIdx.y]; skel_rank_body<EPT, TR, false, false>(g, nullptr); }
+template <int EPT, int TR, bool R4 = false>
+__global__ __launch_bounds__(BLOCK) void skel_rank_many_kernel(const SkArgs *args) { const SkArgs g = args[blockIdx.y]; skel_rank_body<EPT, TR, R4, false>(g, nullptr); }
 
 // READ SIDE: the columns arrive in PBWT order (y_k by position), so the 8-bit key of position i of the
 // state before site k follows the LF-mapping through the 8 columns: bit j = y_{k+j}[p_j], p_0 = i,
