@@ -1141,8 +1141,8 @@ static void launch_skel_round(pbwtamd_engine *e, SkArgs &g, bool two_launch, int
     // the 22 KB rank workgroup (radix-4 range maxima) from two workgroups per CU on, whatever the scan: end to end 2.68 -> 2.56 us/site at
     // 300 k haplotypes (586 tiles), 3.13 -> 2.94 at 400 k; nothing up to 250 k (489 tiles)
     // (round 4) the radix-4 form at EVERY width of the three-launch round: 20 KB of LDS instead of 28.7.  Alone it is as fast as the radix-2 form below 512 tiles
-    // (1.495 against 1.499 us/site at 100 k); beside the sweep of the 16-bit slots (20.5 KB per workgroup, seven per CU) the 28.7 KB workgroup did not fit the
-    // hole a retiring sweep workgroup leaves, and one run in three of the 100 k bench went 11 % slower (1.66 against 1.50 us/site: section 2's rule).
+    // (1.495 against 1.499 us/site at 100 k), and beside the sweep of the 16-bit slots (20.5 KB per workgroup, seven per CU) it fits the hole a retiring sweep
+    // workgroup leaves, which the 28.7 KB workgroup does not (section 2's rule).
     static const int r4_from = tune_env("PBWTAMD_RANK_R4_FROM") ? atoi(tune_env("PBWTAMD_RANK_R4_FROM")) : 0;
     if ((wide && (e->prow || rank_r4)) || W >= r4_from) hipLaunchKernelGGL((skel_rank_kernel<EPT, 0, true>), dim3(W), dim3(BLOCK), 0, e->stream, g);    // more tiles than one round of the chip: occupancy counts
     else hipLaunchKernelGGL((skel_rank_kernel<EPT, 0>), dim3(W), dim3(BLOCK), 0, e->stream, g);
