@@ -4,7 +4,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["csrc/pbwt_engine.hip"]
-DEPS = ["csrc/pbwt_engine.hip", "csrc/pbwt_shard.inc", "../include/pbwt_amd.h"] + sorted("csrc/" + f for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith(".h"))
+DEPS = ["csrc/pbwt_engine.hip", "../include/pbwt_amd.h"] + sorted("csrc/" + f for f in os.listdir(os.path.join(_HERE, "csrc")) if f.endswith((".h", ".inc")))
 OUT = os.path.join(_HERE, "libpbwtgpu.so")
 
 
