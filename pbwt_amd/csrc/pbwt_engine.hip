@@ -227,6 +227,7 @@ struct pbwtamd_engine {
     bool keys_ready[2] = {false, false};     // slot-0 keys of the ring delivered by the previous batch's last round
     int q_lo = 0, q_hi = 0x7fffffff; bool q_part = false;   // query sweeps: only queries q_lo <= jj < q_hi (pbwtamd_set_query_range)
     bool prow = false; int W2 = 0;          // pair rows: skel_hist_kernel<4, true> + the scan on W2 = ceil(Wt / 2) rows
+    bool k2local = false; int k2tpw = 32; size_t aggx_off = 0;   // wide panels: local-prefix scan (skel_k2_local_kernel), rows per scan workgroup, offset of the aggregate rows in a round's block of saveR (int2)
     int Wt = 0, skEPT = 4;                  // skeleton tiles: 256*skEPT positions, Wt of them; PBWTAMD_SKT=512|1024
     int skn_maxw = 48;                      // two-launch round (rank scans the tile table itself) up to this many tiles (measured: 5 k -28 %, 8 k -26 %, 10 k -9 %, 12 k -6 %, 16 k 0); PBWTAMD_SKN_MAXW
     bool summ_pair = false;                 // format of the current tile summaries (two-site keys or single site)
@@ -393,6 +394,17 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             e->prow = pair_rows && (e->skEPT == 2 || (e->skEPT == 1 && prow_ept1)) && e->W2 > prow_min && e->W2 <= prow_max;
             if (e->skEPT == 2 && e->Wt > 2048 && !e->prow) { const int r = fail("pbwtamd_engine_create: %d tiles of 512 positions need pair rows", e->Wt); pbwtamd_engine_destroy(e); return r; }
             e->strideS = e->prow ? (size_t)SKK * e->W2 * 2 + SKK / 2 : (size_t)SKK * e->Wt + SKK / 2;
+            // wide panels (more than 512 scan rows): the scan in its local form (skel_k2_local_kernel) — one exclusive aggregate row per scan workgroup
+            // (<= 64 of them) behind the round's other tables; PBWTAMD_K2_LOCAL=0: the two-pass form (skel_k2_wide_kernel)
+            {
+                const int rows = e->prow ? e->W2 : e->Wt;
+                // (interleaved A/B, end to end: -5.4 % at 600 k haplotypes, -2.6 % at 1 M — the chain alone 3.53 -> 3.27 us/site; +3 % at 2 M, where 62 scan
+                // workgroups make the last arriver's fold long and the consumers, not the chain, set the pace: up to 1024 rows)
+                e->k2local = rows > 512 && rows <= 1024 && env_int("PBWTAMD_K2_LOCAL", 1) != 0;
+                e->k2tpw = rows > 2048 ? 64 : 32;
+                e->aggx_off = e->k2local ? e->strideS : 0;
+                if (e->k2local) e->strideS += (size_t)64 * SKK;
+            }
             for (int i = 0; i < 2; ++i) {
                 ALLOC(e->keysR[i], (size_t)(rounds + 1) * e->Mpad);
                 ALLOC(e->saveR[i], (size_t)rounds * e->strideS * sizeof(int2));

@@ -76,7 +76,15 @@ struct SkArgs {
     int M, W, k;                                                // k = site of the input state; W = tiles of this launch
     int xcd;                                                    // bit 1: rank, bit 2: hist — XCD-contiguous tiles (xcd_tile)
     int w0, Wtot;                                               // position sharding: this launch covers tiles w0 .. w0+W-1 of Wtot (one GPU: 0, W)
+    // (round 4) wide panels, skel_k2_local_kernel: scan[] holds prefixes LOCAL to the scan workgroup of aggx_tpw rows, and aggx[row / aggx_tpw][key] the
+    // exclusive fold of the workgroups before it; whoever reads a row folds the two (sk_fold_aggx).  nullptr: scan[] holds the global prefixes.
+    const int2 *aggx = nullptr; int aggx_tpw = 0;
 };
+// the global (keys before, carry) of a row from the aggregate of the scan workgroups before its own (L) and its prefix local to that workgroup (R):
+// skel_k2_kernel's combine, with the carry of "no earlier occurrence" = -1 on the way out
+__device__ __forceinline__ int2 sk_fold_aggx(int2 L, int2 R) {
+    return make_int2(L.x + R.x, R.x ? R.y : (L.x ? max(L.y, R.y) : -1));
+}
 
 // Position sharding: the ranks of one panel own contiguous ranges of TILES of the sorted order.  Every rank keeps
 // full-width ring slots; the chain of rank g reads and writes positions pb[g] .. pb[g+1]-1 of them only, and its rank kernel
@@ -239,7 +247,55 @@ __global__ __launch_bounds__(KPW * 64) void skel_k2_kernel(Sk2Args g) { skel_k2_
 // All of them are resident at once (W / TPW <= 64 workgroups).  Cross-workgroup visibility: 8-byte agent-scope relaxed
 // atomics on both sides (write-through stores, L1-bypassing loads), `s_waitcnt vmcnt(0)` before the arrival — the
 // granule form of MI355X_MICROARCH.md "Workgroup dispatch ... inter-workgroup visibility".
-struct Sk2WArgs { const int2 *tbl; int2 *scan; int *total; int W; unsigned long long *agg; unsigned *counter; unsigned target; int *err; };
+struct Sk2WArgs { const int2 *tbl; int2 *scan; int *total; int W; unsigned long long *agg; unsigned *counter; unsigned target; int *err; int2 *aggx; };
+
+// (round 4) The same scan WITHOUT its second half.  skel_k2_wide_kernel is a chain of eight dependent round trips: two batches of rows, the aggregate out,
+// the arrival and the wait for everybody, the error word, the aggregates in, the rows again, the prefixes out — and every one of them stretches beside the
+// consumers.  Here a workgroup writes, in its first and only pass over its rows, the prefixes LOCAL to itself (raw: count and running tail, the tail of
+// a key not yet seen being the maximum so far), publishes its aggregate and arrives; nobody waits: the workgroup that arrives LAST folds the <= 64
+// aggregates into one exclusive row per workgroup (aggx) and the totals.  The rank and fill workgroups fold aggx[row / TPW] in front of their row with
+// one more 8-byte load per thread (sk_fold_aggx), issued together with the row's.  Five round trips, the last two in one workgroup only.
+template <int TPW, int CH = 16>
+__global__ __launch_bounds__(SKK) void skel_k2_local_kernel(Sk2WArgs g) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    __shared__ int s_last;
+    const int t = threadIdx.x, j = blockIdx.x, w0 = j * TPW;
+    int lc = 0, lt = 0;                                      // running local prefix for key t (d >= 0: 0 is the identity of the tails' maximum)
+#pragma unroll 1
+    for (int x0 = 0; x0 < TPW; x0 += CH) {
+        int2 v[CH];
+#pragma unroll
+        for (int x = 0; x < CH; ++x) v[x] = (w0 + x0 + x < g.W) ? g.tbl[(size_t)(w0 + x0 + x) * SKK + t] : make_int2(0, 0);
+#pragma unroll
+        for (int x = 0; x < CH; ++x) {
+            if (w0 + x0 + x < g.W) g.scan[(size_t)(w0 + x0 + x) * SKK + t] = make_int2(lc, lt);
+            lt = v[x].x ? v[x].y : max(lt, v[x].y); lc += v[x].x;
+        }
+    }
+    __hip_atomic_store(g.agg + (size_t)j * SKK + t, ((unsigned long long)(unsigned)lt << 32) | (unsigned)lc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) s_last = (__hip_atomic_fetch_add(g.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == g.target) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    const int nwg = (int)gridDim.x;                          // <= 64
+    int ec = 0, et = 0;
+#pragma unroll 1
+    for (int i0 = 0; i0 < nwg; i0 += 32) {
+        unsigned long long pv[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) pv[i] = (i0 + i < nwg) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (i0 + i < nwg) g.aggx[(size_t)(i0 + i) * SKK + t] = make_int2(ec, et);
+            const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32);
+            et = vc ? vt : max(et, vt); ec += vc;
+        }
+    }
+    g.total[t] = ec;
+}
 // 16 rows / 32 aggregates in flight per lane, and the rows are read a second time (from L2) for the output pass.  The first
 // form of this kernel held all 32 rows + 64 aggregates in 200 VGPRs (one round trip each, 8.0 us alone).  A 200-VGPR wave fits
 // on no SIMD while a consumer kernel is at full occupancy (sweep: 8 waves x 56 VGPRs, fill: 6 x 56), and the 56 registers a
@@ -513,7 +569,9 @@ __device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut
 #pragma unroll
         for (int r = 0; r < TR; ++r) row[r] = (r < g.W) ? g.tbl[(size_t)r * SKK + t] : make_int2(0, 0);
     } else {
-        int2 sv = g.scan[(size_t)(g.pair ? (w >> 1) : w) * SKK + t];
+        const int srow = g.pair ? (w >> 1) : w;
+        int2 sv = g.scan[(size_t)srow * SKK + t];
+        if (g.aggx) sv = sk_fold_aggx(g.aggx[(size_t)(srow / g.aggx_tpw) * SKK + t], sv);      // (both loads in flight together)
         if (g.pair && (w & 1)) {                            // second tile of its pair: fold the first one's row in
             const int2 r0 = g.tbl0[(size_t)(w >> 1) * SKK + t];
             sv.y = r0.x ? r0.y : (sv.x ? max(sv.y, r0.y) : -1);

@@ -22,6 +22,7 @@ struct SkFillArgs {
     int pack_y;                                             // write d | y << 31 only (no a): for consumers that need (d, y) but not the haplotype ids
     int xcd;                                                // XCD-contiguous (round, tile) pairs (xcd_tile)
     int pair, W2;                                           // pair rows: scan[W2][256], total, then the first halves' rows tbl0[W2][256] per round
+    int aggx_off, aggx_tpw;                                 // > 0: the rows are local to scan workgroups of aggx_tpw rows; their exclusive aggregates stand aggx_off int2 into the round's block (SkArgs::aggx)
 };
 
 // PACKY 1: the consumers need (d, y) of every site but not the haplotype ids — a[] is neither read nor written, slots hold d | y << 31
@@ -76,7 +77,9 @@ __global__ __launch_bounds__(BLOCK) void skel_fill_kernel(SkFillArgs g) {
     }
     {
         const int nrow = g.pair ? g.W2 : g.W;
-        int2 v = sv[(size_t)(g.pair ? (w >> 1) : w) * SKK + t];
+        const int srow = g.pair ? (w >> 1) : w;
+        int2 v = sv[(size_t)srow * SKK + t];
+        if (g.aggx_off) v = sk_fold_aggx(sv[(size_t)g.aggx_off + (size_t)(srow / g.aggx_tpw) * SKK + t], v);
         if (g.pair && (w & 1)) {                            // second tile of its pair: fold the first one's row in (skel_k2_kernel's combine)
             const int2 r0 = (sv + (size_t)nrow * SKK + SKK / 2)[(size_t)(w >> 1) * SKK + t];
             v.y = r0.x ? r0.y : (v.x ? max(v.y, r0.y) : -1);

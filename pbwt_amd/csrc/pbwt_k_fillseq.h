@@ -63,6 +63,7 @@ struct SkFillSeqArgs {
     int M, W, kbase, nblk;
     int xcd;                                                // XCD-contiguous workgroups (xcd_tile)
     int pair, W2;                                           // pair rows: scan[W2][256], total, then the first halves' rows tbl0[W2][256] per block
+    int aggx_off, aggx_tpw;                                 // as SkFillArgs
 #ifdef PBWTAMD_MEASURE
     int dbg_nowrite;
 #endif
@@ -133,7 +134,11 @@ __global__ __launch_bounds__(BLOCK, WPE) void skel_fillseq_kernel(SkFillSeqArgs 
         const int nrow = g.pair ? g.W2 : g.W;
         const int2 *row = sv + (size_t)(g.pair ? (w >> 1) : w) * SKK;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int2 v = row[lane + 64 * q]; bq[q] = v.x; cq[q] = v.y; }
+        for (int q = 0; q < 4; ++q) {
+            int2 v = row[lane + 64 * q];
+            if (g.aggx_off) v = sk_fold_aggx(sv[(size_t)g.aggx_off + (size_t)((g.pair ? (w >> 1) : w) / g.aggx_tpw) * SKK + lane + 64 * q], v);
+            bq[q] = v.x; cq[q] = v.y;
+        }
         if (g.pair && (w & 1)) {                            // second tile of its pair: fold the first one's row in (skel_k2_kernel's combine)
             const int2 *r0p = sv + (size_t)nrow * SKK + SKK / 2 + (size_t)(w >> 1) * SKK;
 #pragma unroll
