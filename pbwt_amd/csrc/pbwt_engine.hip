@@ -400,7 +400,9 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
                 const int rows = e->prow ? e->W2 : e->Wt;
                 // (interleaved A/B, end to end: -5.4 % at 600 k haplotypes, -2.6 % at 1 M — the chain alone 3.53 -> 3.27 us/site; +3 % at 2 M, where 62 scan
                 // workgroups make the last arriver's fold long and the consumers, not the chain, set the pace: up to 1024 rows)
-                e->k2local = rows > 512 && rows <= 1024 && env_int("PBWTAMD_K2_LOCAL", 1) != 0;
+                // Below 513 rows the one-level scan (skel_k2_kernel) stays ahead: 2.88 against 3.15 us/site at 500 k, 2.48 / 2.74 at 350 k, 1.90 / 2.28 at 200 k
+                // (PBWTAMD_K2_LOCAL_MIN=n, A/B and parity runs only: the local form from n + 1 rows on).
+                e->k2local = rows > env_int("PBWTAMD_K2_LOCAL_MIN", 512) && rows <= 1024 && env_int("PBWTAMD_K2_LOCAL", 1) != 0;
                 e->k2tpw = rows > 2048 ? 64 : 32;
                 e->aggx_off = e->k2local ? e->strideS : 0;
                 if (e->k2local) e->strideS += (size_t)64 * SKK;
