@@ -109,3 +109,42 @@ def test_sequential_fill_model_matches_oracle(orc, M, N, kind, T, B):
             assert np.array_equal(aj, o["a_dump"][k + j]), "a at site %d" % (k + j)
             assert np.array_equal(dj, o["d_dump"][k + j]), "d at site %d" % (k + j)
         a, d = stepB_tiles(a, d, key, k, B, T)
+
+
+def test_local_scan_fold_equals_global_scan():
+    """skel_k2_local_kernel + sk_fold_aggx (pbwt_k_chain.h) restated in numpy: the per-key scan over the tiles' (count, tail) rows done in
+    workgroups of TPW rows — raw prefixes local to the workgroup, one exclusive aggregate row per workgroup — and folded by the reader gives the
+    rows skel_k2_wide_kernel writes: (keys before the tile, carry = max d since the key's last earlier occurrence, -1 without one)."""
+    rng = np.random.default_rng(5)
+    for W, K, TPW in [(70, 16, 32), (33, 8, 32), (129, 4, 64), (5, 32, 32)]:
+        cnt = (rng.random((W, K)) < 0.4) * rng.integers(1, 5, (W, K))
+        tail = rng.integers(0, 1000, (W, K))                # (a row without the key: its tail is the maximum of the whole tile)
+        # global scan (skel_k2_wide_kernel's second pass)
+        want = np.zeros((W, K, 2), np.int64)
+        for q in range(K):
+            ec, et = 0, 0
+            for w in range(W):
+                want[w, q] = (ec, et if ec else -1)
+                et = tail[w, q] if cnt[w, q] else max(et, tail[w, q]); ec += cnt[w, q]
+        # local form
+        nwg = (W + TPW - 1) // TPW
+        loc = np.zeros((W, K, 2), np.int64); agg = np.zeros((nwg, K, 2), np.int64)
+        for j in range(nwg):
+            for q in range(K):
+                lc, lt = 0, 0
+                for w in range(j * TPW, min(W, (j + 1) * TPW)):
+                    loc[w, q] = (lc, lt)
+                    lt = tail[w, q] if cnt[w, q] else max(lt, tail[w, q]); lc += cnt[w, q]
+                agg[j, q] = (lc, lt)
+        aggx = np.zeros((nwg, K, 2), np.int64)              # the last arriver's fold
+        for q in range(K):
+            ec, et = 0, 0
+            for j in range(nwg):
+                aggx[j, q] = (ec, et)
+                et = agg[j, q, 1] if agg[j, q, 0] else max(et, agg[j, q, 1]); ec += agg[j, q, 0]
+        got = np.zeros_like(want)
+        for w in range(W):
+            for q in range(K):
+                L, R = aggx[w // TPW, q], loc[w, q]          # sk_fold_aggx
+                got[w, q] = (L[0] + R[0], R[1] if R[0] else (max(L[1], R[1]) if L[0] else -1))
+        assert np.array_equal(got, want), (W, K, TPW)
