@@ -403,7 +403,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
                 // Below 513 rows the one-level scan (skel_k2_kernel) stays ahead: 2.88 against 3.15 us/site at 500 k, 2.48 / 2.74 at 350 k, 1.90 / 2.28 at 200 k
                 // (PBWTAMD_K2_LOCAL_MIN=n, A/B and parity runs only: the local form from n + 1 rows on).
                 e->k2local = rows > env_int("PBWTAMD_K2_LOCAL_MIN", 512) && rows <= env_int("PBWTAMD_K2_LOCAL_MAX", 1024) && env_int("PBWTAMD_K2_LOCAL", 1) != 0;
-                e->k2tpw = rows > 1024 ? 64 : 32;           // (PBWTAMD_K2_LOCAL_MAX=2048, A/B: 64-row workgroups there — 6.34 against 6.36 us/site at 1.5 M, 8.20 against 8.04 at 2 M: not taken)
+                e->k2tpw = rows > 1024 ? 64 : 32;           // (16 rows per scan workgroup, twice the arrivals: 4.70 against 4.57 us/site at 1 M, 3.60 / 3.53 at 600 k; PBWTAMD_K2_LOCAL_MAX=2048, A/B: 64-row workgroups there — 6.34 against 6.36 us/site at 1.5 M, 8.20 against 8.04 at 2 M: not taken)
                 e->aggx_off = e->k2local ? e->strideS : 0;
                 if (e->k2local) e->strideS += (size_t)64 * SKK;
             }
