@@ -646,15 +646,22 @@ def main():
         # 1 M-haplotype panel with the recurrence position-sharded over the ranks (BASELINE configs[3]) — and attaches it as `position_sharded`.
         # Never `value`.  It has only ever run with the ranks sharing one GPU, so it is fenced: a small self-check against the plain engine first,
         # exceptions caught, and a watchdog that prints the line without it if it does not come back.
+        import copy
         import threading
         done = threading.Event()
+        fallback = copy.deepcopy(out)                       # the line as it stands now: the watchdog never touches `out` while the main thread fills it in
 
         def watchdog():
-            if not done.wait(args.ps_timeout):
+            if done.wait(args.ps_timeout):
+                return
+            code = 3                                         # the attached job hung (a collective or a peer wait that never came back): not a clean exit
+            try:
                 if rank == 0:
-                    out["position_sharded"] = {"error": "gave up after %.0f s (--ps-timeout)" % args.ps_timeout}
-                    print(json.dumps(out), flush=True)
-                os._exit(0)
+                    fallback["position_sharded"] = {"error": "gave up after %.0f s (--ps-timeout)" % args.ps_timeout}
+                    print(json.dumps(fallback), flush=True)
+                    code = 0                                 # rank 0 printed the replicas line (a valid measurement, with the failure of the attachment in it)
+            finally:
+                os._exit(code)
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             del panel

@@ -404,6 +404,9 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
                 // (PBWTAMD_K2_LOCAL_MIN=n, A/B and parity runs only: the local form from n + 1 rows on).
                 e->k2local = rows > env_int("PBWTAMD_K2_LOCAL_MIN", 512) && rows <= env_int("PBWTAMD_K2_LOCAL_MAX", 1024) && env_int("PBWTAMD_K2_LOCAL", 1) != 0;
                 e->k2tpw = rows > 1024 ? 64 : 32;           // (16 rows per scan workgroup, twice the arrivals: 4.70 against 4.57 us/site at 1 M, 3.60 / 3.53 at 600 k; PBWTAMD_K2_LOCAL_MAX=2048, A/B: 64-row workgroups there — 6.34 against 6.36 us/site at 1.5 M, 8.20 against 8.04 at 2 M: not taken)
+                // the local form's capacity: aggx and k2agg hold 64 rows (one per scan workgroup), so rows <= 64 * k2tpw — odd PBWTAMD_K2_LOCAL_MIN / _MAX
+                // combinations fall back to the other scans instead of writing past them
+                if ((rows + e->k2tpw - 1) / e->k2tpw > 64) e->k2local = false;
                 e->aggx_off = e->k2local ? e->strideS : 0;
                 if (e->k2local) e->strideS += (size_t)64 * SKK;
             }
@@ -412,9 +415,9 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
                 ALLOC(e->saveR[i], (size_t)rounds * e->strideS * sizeof(int2));
                 ALLOC(e->fillGB[i], (size_t)rounds * SKK * sizeof(int2));
             }
-            // the 16-bit hand-off ring (run_consumers): 2 x (B + 2) slots of strideD 16-bit words — here rather than with the first batch that takes it
-            // (a 0.2-2 GB hipMalloc inside a pass showed up as a 10 % outlier in one run out of four at 100 k haplotypes)
-            if (e->skEPT <= 2 && env_int("PBWTAMD_P16", 1) != 0) ALLOC(e->p16r, (size_t)2 * (e->B + 2) * e->strideD * sizeof(unsigned short));
+            // (the 16-bit hand-off ring, 2 x (B + 2) slots of strideD 16-bit words — 2 GB at 1 M haplotypes — is allocated by run_consumers with the first
+            // batch that takes the packed path: query-sweep engines, record / checksum option sets, sharded ranks and the P engines of
+            // pbwtamd_pass_advance_many that never take it do not pay for it)
         }
         ALLOC(e->skT, (size_t)(e->Wt + 1) * SKK * sizeof(int2));
         ALLOC(e->k2agg, (size_t)64 * SKK * sizeof(unsigned long long));

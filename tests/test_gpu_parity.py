@@ -359,7 +359,8 @@ def test_malformed_packed_panel_is_rejected(amd, orc):
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1024, 130, 32, 1), (1025, 96, 24, 0), (70001, 80, 40, 0),
                                             (300000, 40, 16, 0), (600100, 24, 8, 0), (1500, 41, 8, 1), (5, 64, 16, 1), (1, 16, 8, 0),
                                             (150600, 40, 16, 0), (524288, 24, 8, 1),    # pair rows with the one-level scan: 148 rows (odd tile count), 512 rows
-                                            (9000, 136, 64, 0), (12288, 96, 32, 1), (8193, 72, 24, 0)])   # two launches per round on 512-position tiles (17-24 tiles)
+                                            (9000, 136, 64, 0), (12288, 96, 32, 1), (8193, 72, 24, 0),    # two launches per round on 512-position tiles (17-24 tiles)
+                                            (525000, 16, 8, 0), (1048576, 16, 8, 1)])   # the local scan launch (skel_k2_local_kernel) at both ends of its range: 513 and 1 024 scan rows
 def test_both_chains_every_site(amd, orc, skel, M, N, batch, kind, monkeypatch):
     """the two chain implementations — skeleton (8-bit radix step every 8 sites, K1/K2/K3, with the
     seven states between filled by batched single-site kernels) and the two-site chain — against the
@@ -399,7 +400,8 @@ def test_both_chains_every_site(amd, orc, skel, M, N, batch, kind, monkeypatch):
 
 @pytest.mark.parametrize("packed", ["1", "0"])
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1025, 96, 24, 0), (70001, 80, 40, 1), (2, 40, 8, 1), (300000, 24, 8, 0),
-                                            (600100, 24, 8, 1), (150600, 32, 16, 1), (139300, 24, 8, 0)])     # 600 100: pair rows with an odd number of tiles (1173); 150 600 / 139 300: pair rows, one-level scan (the narrowest: 137 rows)
+                                            (600100, 24, 8, 1), (150600, 32, 16, 1), (139300, 24, 8, 0),      # 600 100: pair rows with an odd number of tiles (1173); 150 600 / 139 300: pair rows, one-level scan (the narrowest: 137 rows)
+                                            (525000, 16, 8, 1), (1048576, 16, 8, 0)])   # 513 and 1 024 scan rows: the first and the last width of the local scan launch (aggx folded by rank and both fills)
 def test_histogram_and_pack3_consumers_without_ids(amd, orc, packed, M, N, batch, kind, monkeypatch):
     """the bench configuration (divergence + maxWithin histogram + pack3, no per-site checksums): on the
     skeleton path the fill then writes d | y << 31 and no haplotype ids, the sweep reads that and emits
@@ -484,7 +486,7 @@ def test_p16_matches_longer_than_32766_sites(amd, orc, monkeypatch):
     o = orc.build_bitcols(bits, M, with_d=True)
     sw = orc.sweep_AD(o["yz"], M, N)
     monkeypatch.setenv("PBWTAMD_PACKED_CHECKSUM", "1")
-    monkeypatch.setenv("PBWTAMD_P16", "1")                   # (by default the 16-bit hand-off starts at 180 000 haplotypes)
+    monkeypatch.setenv("PBWTAMD_P16", "1")                   # (the default at every width; pinned here so that this test keeps testing the 16-bit hand-off if that changes)
     eng = amd.Engine(M, batch_sites=batch)
     assert bits.shape[1] == eng.wpc
     buf = torch.from_numpy(bits.view(np.int32)).cuda()

@@ -52,7 +52,7 @@ for p, k, c, n, m in rows:
     if k.startswith("calib_copy4"):
         cal[c] = (256 << 20) * 4 / 1024.0 / m                      # known bytes (1 GiB copy, 4 B/lane) / reported KiB
 cf, cw = cal.get("FETCH_SIZE", 2.0), cal.get("WRITE_SIZE", 1.0)
-CHAIN = ("skel_hist_kernel", "skel_k2_kernel", "skel_k2_wide_kernel", "skel_rank_kernel")
+CHAIN = ("skel_hist_kernel", "skel_k2_kernel", "skel_k2_local_kernel", "skel_k2_wide_kernel", "skel_rank_kernel", "skel_team_kernel")
 CONS = ("skel_fill_kernel", "skel_fillseq_kernel", "skel_fillprep_kernel", "sweep_hist_kernel", "p3r_scan_kernel", "p3r_combine_kernel", "p3r_emit_kernel", "transpose32_kernel")
 
 
