@@ -177,6 +177,8 @@ struct pbwtamd_engine {
     int2 *qs_bsum[2] = {nullptr, nullptr}; int qs_nblk = 0;   // query sweep: per ring, block summaries of every state of the batch (qs_blocksum_kernel), written by the batch's consumers
     int qs_bsum_sites[2] = {0, 0};          // ... and how many leading sites of the ring's batch they have summarised so far
     SkArgs *margs = nullptr, *margs_host = nullptr; size_t margs_cap = 0; int margs_half = 0; hipEvent_t evMargs[2] = {nullptr, nullptr};   // pbwtamd_pass_advance_many (panel 0 owns them)
+    unsigned long long *teamprof = nullptr;                 // PBWTAMD_TEAM_PROF=1: member 0's wall-clock stamps per round and phase
+    unsigned *teamctl = nullptr; unsigned team_round = 0; int team_cap = 0;   // team-persistent chain (skel_team_kernel): tickets + flag words per XCD, barriers passed so far (the first engine of a group owns them)
     bool persist = false;                   // small panels (two-launch regime): all rounds of a batch in ONE launch (skel_persist_kernel) — set for the query cursor of the query sweep
     SkArgs *pargs = nullptr, *pargs_host = nullptr; unsigned *pbar = nullptr; unsigned pbar_epoch = 0; int pargs_half = 0; hipEvent_t evPargs[2] = {nullptr, nullptr};
     hipEvent_t evPreKeys = nullptr;         // read side: the next skeleton batch's rank directories and keys were derived ahead of time on another stream (query sweep); wait for this event instead
@@ -283,6 +285,8 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (e->pargs_host) (void)hipHostFree(e->pargs_host);
     if (e->pargs) (void)dev_free(e->pargs);
     if (e->pbar) (void)dev_free(e->pbar);
+    if (e->teamctl) (void)dev_free(e->teamctl);
+    if (e->teamprof) (void)dev_free(e->teamprof);
     if (e->h_used) (void)hipHostFree(e->h_used);
     if (e->h_nflag) (void)hipHostFree(e->h_nflag);
     if (e->evFlag) (void)hipEventDestroy(e->evFlag);

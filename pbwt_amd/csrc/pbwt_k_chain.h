@@ -86,6 +86,36 @@ __device__ __forceinline__ int2 sk_fold_aggx(int2 L, int2 R) {
     return make_int2(L.x + R.x, R.x ? R.y : (L.x ? max(L.y, R.y) : -1));
 }
 
+// How a chain kernel reads what ANOTHER workgroup of the SAME launch has written (the persistent forms below; DESIGN.md section 2, profiles/r04_latprobe4.txt):
+//   SKM_LAUNCH  the three-launch round: producer and consumer are different launches, plain loads;
+//   SKM_TEAM    a team of workgroups on ONE XCD (skel_team_kernel): producers store plainly (the data stays in that XCD's L2, the team's coherence
+//               point), consumers bypass their CU's L1 with nontemporal loads — plain loads hit stale L1 lines (37-43 % in the probe);
+//   SKM_SPREAD  teams on several XCDs: write-through (sc1) stores and sc1 loads on both sides (agent-scope relaxed atomics).
+constexpr int SKM_LAUNCH = 0, SKM_TEAM = 1, SKM_SPREAD = 2;
+template <int MODE, typename T>
+__device__ __forceinline__ T skm_ld(const T *p) {
+    if constexpr (MODE == SKM_LAUNCH) return *p;
+#ifndef SKM_TEAM_SC1
+    else if constexpr (MODE == SKM_TEAM) return __builtin_nontemporal_load(p);
+#endif
+    else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int MODE>
+__device__ __forceinline__ int2 skm_ld2(const void *p) {      // 8 bytes, 8-byte aligned
+    if constexpr (MODE == SKM_LAUNCH) return *reinterpret_cast<const int2 *>(p);
+    else { const unsigned long long v = skm_ld<MODE>(reinterpret_cast<const unsigned long long *>(p)); return make_int2((int)(unsigned)v, (int)(v >> 32)); }
+}
+template <int MODE, typename T>
+__device__ __forceinline__ void skm_st(T *p, T v) {
+    if constexpr (MODE == SKM_SPREAD) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <int MODE>
+__device__ __forceinline__ void skm_st2(int2 *p, int2 v) {
+    if constexpr (MODE == SKM_SPREAD) __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), ((unsigned long long)(unsigned)v.y << 32) | (unsigned)v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 // Position sharding: the ranks of one panel own contiguous ranges of TILES of the sorted order.  Every rank keeps
 // full-width ring slots; the chain of rank g reads and writes positions pb[g] .. pb[g+1]-1 of them only, and its rank kernel
 // stores each (a | tag, d', key) into the slot of the position's OWNER through the peers' mapped ring pointers (hipIpc).
@@ -101,8 +131,9 @@ struct SkShardOut {
 // first half; the scan over the tiles then runs on half as many rows (the scan launch is what a wide panel pays most for beside
 // the consumers: 22.7 us per round at 1954 rows, 14 at 977), and the rank / fill workgroup of an odd tile folds the first half's
 // row into its pair's prefix (skel_k2_kernel's combine).  Waves 2, 3 hold the first half.
-template <int EPT, bool HALF>
-__device__ __forceinline__ void skel_hist_body(const SkArgs &g) {
+template <int EPT, bool HALF, int MODE = SKM_LAUNCH>
+__device__ __forceinline__ void skel_hist_body(const SkArgs &g, int wsel = -1) {
+    static_assert(MODE == SKM_LAUNCH || EPT <= 2, "the persistent forms run 256- and 512-position tiles");
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
 #endif
@@ -111,7 +142,7 @@ __device__ __forceinline__ void skel_hist_body(const SkArgs &g) {
     __shared__ int s_suf[T];
     __shared__ int s_w[WAVES];
     __shared__ int h_cnt0[HALF ? SKK : 1], h_last0[HALF ? SKK : 1], s_suf0[HALF ? T / 2 : 1];
-    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = g.w0 + ((g.xcd & 4) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x);
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = (wsel >= 0) ? wsel : g.w0 + ((g.xcd & 4) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x);
     const int rb = BLOCK - 1 - t;
     const int l0 = rb * EPT, i0 = w * T + l0;
     unsigned packed;
@@ -121,11 +152,11 @@ __device__ __forceinline__ void skel_hist_body(const SkArgs &g) {
         const int4 vd = *reinterpret_cast<const int4 *>(g.d + i0);
         dv[0] = vd.x; dv[1] = vd.y; dv[2] = vd.z; dv[3] = vd.w;
     } else if constexpr (EPT == 2) {
-        packed = *reinterpret_cast<const unsigned short *>(g.keys + i0);
-        const int2 vd = *reinterpret_cast<const int2 *>(g.d + i0);
+        packed = skm_ld<MODE>(reinterpret_cast<const unsigned short *>(g.keys + i0));
+        const int2 vd = skm_ld2<MODE>(g.d + i0);
         dv[0] = vd.x; dv[1] = vd.y;
     } else {
-        packed = g.keys[i0]; dv[0] = g.d[i0];
+        packed = skm_ld<MODE>(g.keys + i0); dv[0] = skm_ld<MODE>(g.d + i0);
     }
     h_cnt[t] = 0; h_last[t] = -1;
     if (HALF) { h_cnt0[t] = 0; h_last0[t] = -1; }
@@ -168,7 +199,7 @@ __device__ __forceinline__ void skel_hist_body(const SkArgs &g) {
     for (int q = 0; q < WAVES; ++q) tilemax = max(tilemax, s_w[q]);
     lds_barrier();
     const int c = h_cnt[t], tl = c ? s_suf[h_last[t]] : tilemax;
-    g.tbl[(size_t)w * SKK + t] = make_int2(c, tl);         // row-major: one coalesced 2 KB row per tile
+    skm_st2<MODE>(g.tbl + (size_t)w * SKK + t, make_int2(c, tl));      // row-major: one coalesced 2 KB row per tile
     if (HALF) {
         const int c0 = h_cnt0[t], tl0 = c0 ? s_suf0[h_last0[t]] : max(s_w[2], s_w[3]);
         g.tbl0[(size_t)w * SKK + t] = make_int2(c0, tl0);
@@ -185,21 +216,21 @@ __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) { skel_hist_
 // the same way.  Output scan[tile][key] = {keys before the tile, carry (-1: no earlier occurrence)},
 // total[key].  grid = 256 / KPW workgroups of KPW waves.
 struct Sk2Args { const int2 *tbl; int2 *scan; int *total; int W; };
-template <int KPW, int TPL>
-__device__ __forceinline__ void skel_k2_body(const Sk2Args &g) {
+template <int KPW, int TPL, int MODE = SKM_LAUNCH>
+__device__ __forceinline__ void skel_k2_body(const Sk2Args &g, int kblk = -1) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
     constexpr int NT = KPW * 64;                            // one wave per key
     constexpr int WP = 64 * (TPL + 1);                      // a lane's TPL tiles + one pad entry: lane stride TPL+1 is odd, no LDS bank conflicts
     __shared__ int2 s_v[KPW][WP];
-    const int t = threadIdx.x, lane = lane_id(), kk = t >> 6, key0 = blockIdx.x * KPW;
+    const int t = threadIdx.x, lane = lane_id(), kk = t >> 6, key0 = ((kblk >= 0) ? kblk : (int)blockIdx.x) * KPW;
     constexpr int NIT = 64 * TPL * KPW / NT;                // = TPL: all loads in flight at once (one round trip, not NIT)
     int2 ld[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
         const int idx = t + i * NT, r = idx / KPW, kq = idx % KPW;
-        ld[i] = (r < g.W) ? g.tbl[(size_t)r * SKK + key0 + kq] : make_int2(0, 0);
+        ld[i] = (r < g.W) ? skm_ld2<MODE>(g.tbl + (size_t)r * SKK + key0 + kq) : make_int2(0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
@@ -228,12 +259,12 @@ __device__ __forceinline__ void skel_k2_body(const Sk2Args &g) {
             if (w < g.W) s_v[kk][lane * (TPL + 1) + x] = make_int2(ec, ec ? et : -1);
             et = c[x] ? tt[x] : max(et, tt[x]); ec += c[x];
         }
-        if (lane == 63) g.total[key0 + kk] = ic;
+        if (lane == 63) skm_st<MODE>(g.total + key0 + kk, ic);
     }
     __syncthreads();
     for (int idx = t; idx < g.W * KPW; idx += NT) {
         const int r = idx / KPW, kq = idx % KPW;
-        g.scan[(size_t)r * SKK + key0 + kq] = s_v[kq][r + r / TPL];
+        skm_st2<MODE>(g.scan + (size_t)r * SKK + key0 + kq, s_v[kq][r + r / TPL]);
     }
 }
 template <int KPW, int TPL>
@@ -531,8 +562,9 @@ constexpr int SKN_MAXW = 128;
 // R4 (wide panels: more tiles than fit the chip at once): the range maxima come from a radix-4 sparse table (windows 1, 4, 16, 64,
 // 256; <= 4 reads per query instead of 2) — 10 KB instead of 18 at T = 512, 22 KB per workgroup instead of 30: 7 workgroups per
 // CU instead of 5, so the 1954 tiles of M = 1 M almost fit in one round (1792 resident) instead of needing two (1280).
-template <int EPT, int TR, bool R4, bool SHARD>
-__device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut *so) {
+template <int EPT, int TR, bool R4, bool SHARD, int MODE = SKM_LAUNCH>
+__device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut *so, int wsel = -1) {
+    static_assert(MODE == SKM_LAUNCH || (TR == 0 && !SHARD), "the persistent forms take the scanned tables");
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
 #endif
@@ -552,7 +584,7 @@ __device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut
     __shared__ int *s_pa[SHARD ? SHARD_MAX : 1], *s_pd[SHARD ? SHARD_MAX : 1]; __shared__ unsigned char *s_pk[SHARD ? SHARD_MAX : 1];
     __shared__ int s_pb[SHARD ? SHARD_MAX : 1];
     __shared__ int s_failed;
-    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = g.w0 + ((g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x);
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = (wsel >= 0) ? wsel : g.w0 + ((g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x);
     const int S = w * T;
     if constexpr (SHARD) { if (t == 0) s_failed = __hip_atomic_load(so->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // read by all after the first barrier
     if constexpr (SHARD) { if (t < SHARD_MAX) { s_pa[t] = so->a[t]; s_pd[t] = so->d[t]; s_pk[t] = so->k[t]; s_pb[t] = so->pb[t + 1]; } }   // visible after the barriers below
@@ -561,7 +593,7 @@ __device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {                         // striped: chunk r*4+wv = 64 consecutive positions
         const int i = S + r * BLOCK + t;
-        av[r] = g.a[i]; dv[r] = g.d[i]; key[r] = (int)g.keys[i];
+        av[r] = skm_ld<MODE>(g.a + i); dv[r] = skm_ld<MODE>(g.d + i); key[r] = (int)skm_ld<MODE>(g.keys + i);
     }
     int2 row[TR > 0 ? TR : 1];
     int bq = 0, cq = -1, tq = 0;
@@ -570,14 +602,14 @@ __device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut
         for (int r = 0; r < TR; ++r) row[r] = (r < g.W) ? g.tbl[(size_t)r * SKK + t] : make_int2(0, 0);
     } else {
         const int srow = g.pair ? (w >> 1) : w;
-        int2 sv = g.scan[(size_t)srow * SKK + t];
-        if (g.aggx) sv = sk_fold_aggx(g.aggx[(size_t)(srow / g.aggx_tpw) * SKK + t], sv);      // (both loads in flight together)
+        int2 sv = skm_ld2<MODE>(g.scan + (size_t)srow * SKK + t);
+        if (g.aggx) sv = sk_fold_aggx(skm_ld2<MODE>(g.aggx + (size_t)(srow / g.aggx_tpw) * SKK + t), sv);      // (both loads in flight together)
         if (g.pair && (w & 1)) {                            // second tile of its pair: fold the first one's row in
-            const int2 r0 = g.tbl0[(size_t)(w >> 1) * SKK + t];
+            const int2 r0 = skm_ld2<MODE>(g.tbl0 + (size_t)(w >> 1) * SKK + t);
             sv.y = r0.x ? r0.y : (sv.x ? max(sv.y, r0.y) : -1);
             sv.x += r0.x;
         }
-        bq = sv.x; cq = sv.y; tq = g.total[t];
+        bq = sv.x; cq = sv.y; tq = skm_ld<MODE>(g.total + t);
     }
     for (int x = t; x < NC * SKK / 2; x += BLOCK) { reinterpret_cast<int *>(&s_cnt[0][0])[x] = 0; reinterpret_cast<int *>(&s_lastp[0][0])[x] = -1; }
 #pragma unroll
@@ -689,14 +721,14 @@ __device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut
             g.a_out[pos] = av[r] | (int)(tg << 31);
             g.d_out[pos] = dd;
         } else {
-            g.a_out[pos] = av[r] | (int)((nk[r] & 1u) << 31);
-            g.d_out[pos] = dd;
-            g.keys_out[pos] = (unsigned char)nk[r];
+            skm_st<MODE>(g.a_out + pos, av[r] | (int)((nk[r] & 1u) << 31));
+            skm_st<MODE>(g.d_out + pos, dd);
+            skm_st<MODE>(g.keys_out + pos, (unsigned char)nk[r]);
         }
     }
     if (w == g.Wtot - 1 && t == 0) {
         if constexpr (SHARD) so->d[so->n - 1][g.M] = g.k + SKB + 1;      // d[M] lives with the last rank
-        else g.d_out[g.M] = g.k + SKB + 1;
+        else skm_st<MODE>(g.d_out + g.M, g.k + SKB + 1);
     }
 }
 template <int EPT, int TR, bool R4 = false>
@@ -734,6 +766,81 @@ __global__ __launch_bounds__(BLOCK) void skel_persist_kernel(const SkArgs *round
         skel_rank_body<EPT, TR, false, false>(g, nullptr);
         target += nwg; skel_grid_barrier(counter, target, err);          // the new state (a, d, keys) is complete
     }
+}
+
+// TEAM-PERSISTENT chain (round 5; the probe is tools/latprobe4.hip section 5, profiles/r04_latprobe4.txt): ALL rounds of a batch in
+// ONE launch, hist -> per-key scan -> rank of every round separated by barriers among the workgroups of ONE XCD instead of by kernel boundaries.  A
+// dependent launch costs 3.5-3.9 us whatever it carries; inside one XCD the same dependency is a flag-word barrier through that XCD's L2 — no far
+// atomics, no fences: arrive = plain store of the round number into the member's own flag word (it lands in the XCD's L2, the coherence point of
+// every CU of the team), poll = sc1 loads of all K words by one wave (they bypass the CU's L1 and are served by that L2), payload = plain stores read
+// back with nontemporal loads (SKM_TEAM) — 0.45 us per barrier, 0.75-0.95 us with a 256 KB hand-off in the probe.
+// Launch: 8 (K + slack) workgroups; a workgroup reads HW_REG_XCC_ID, leaves unless its XCD carries a panel (panel p lives on XCD x0 + p: eight
+// chromosomes of one cohort side by side, pbwtIO.c:477-483 once per panel), takes a ticket in its XCD's team and leaves if the team is full.  Member m
+// takes the tiles m, m + K, ... of its panel and the key groups m, m + K, ... of the scan.  Placement is read, not assumed: a team that does not fill
+// (the observed "block b runs on XCD b mod 8" not holding) runs into the barrier's bounded wait and fails the pass (device error 10).
+// rounds[s * P + p] = the arguments of round s of panel p.  The flag words only grow: barrier i of this launch carries the round number round0 + i + 1.
+constexpr int TEAM_MAXK = 256;                              // members per team (flag words per XCD)
+constexpr int TEAM_TICKETS = 64;                            // words in front of the flags: [x] = tickets taken on XCD x in this launch (zeroed before every launch)
+__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15; }     // HW_REG_XCC_ID[3:0]
+
+__device__ __forceinline__ bool team_barrier(unsigned *flags, int m, int K, unsigned round, int *err, int *s_abort) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's stores acknowledged by the L2 ...
+    __syncthreads();                                        // ... before the member's flag says so
+    if (threadIdx.x < 64) {
+        if (threadIdx.x == 0) __hip_atomic_store(flags + m, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_s_setprio(0);                      // a polling wave yields to whatever shares its SIMD
+        const unsigned long long t0 = wall_clock64();       // 100 MHz
+        int spins = 0;
+        for (;;) {
+            bool ok = true;
+            for (int i = threadIdx.x; i < K; i += 64) ok &= (int)(__hip_atomic_load(flags + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - round) >= 0;
+            if (__all(ok)) break;
+            // bounded (4 s of wall clock): members wait here for the last of them to be placed beside the consumer kernels, never for ever
+            if ((++spins & 255) == 0 && (wall_clock64() - t0 > 400000000ULL || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                if (threadIdx.x == 0) { atomicCAS(err, 0, 10); *s_abort = 1; }
+                break;
+            }
+        }
+        __builtin_amdgcn_s_setprio(3);
+    }
+    __syncthreads();
+    return *s_abort == 0;
+}
+
+// prof (PBWTAMD_TEAM_PROF=1, nullptr otherwise): member 0 of panel 0 stamps the wall clock (100 MHz) before and after every barrier of every round: [round][8]
+template <int EPT, int KPW, int TPL>
+__global__ __launch_bounds__(BLOCK) void skel_team_kernel(const SkArgs *rounds, int nr, int P, int x0, int K, unsigned *ctl, unsigned round0, int *err, unsigned long long *prof) {
+    __shared__ int s_m, s_abort;
+    const int x = xcc_id(), p = x - x0;
+    if (p < 0 || p >= P) return;
+    if (threadIdx.x == 0) { s_m = (int)__hip_atomic_fetch_add(ctl + x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 0; }
+    __syncthreads();
+    const int m = s_m;
+    if (m >= K) return;
+    unsigned *flags = ctl + TEAM_TICKETS + (size_t)x * TEAM_MAXK;
+    unsigned round = round0;
+    const bool stamp = prof && p == 0 && m == 0 && threadIdx.x == 0;
+#define TEAM_STAMP(i) do { if (stamp) prof[(size_t)s * 8 + (i)] = wall_clock64(); } while (0)
+    for (int s = 0; s < nr; ++s) {
+        const SkArgs g = rounds[(size_t)s * P + p];
+        TEAM_STAMP(0);
+        for (int w = m; w < g.W; w += K) { skel_hist_body<EPT, false, SKM_TEAM>(g, w); lds_barrier(); }
+        TEAM_STAMP(1);
+        if (!team_barrier(flags, m, K, ++round, err, &s_abort)) return;            // every tile's row is in the table
+        TEAM_STAMP(2);
+        {
+            Sk2Args k2; k2.tbl = g.tbl; k2.scan = g.scan; k2.total = g.total; k2.W = g.W;
+            for (int kb = m; kb < SKK / KPW; kb += K) { skel_k2_body<KPW, TPL, SKM_TEAM>(k2, kb); __syncthreads(); }
+        }
+        TEAM_STAMP(3);
+        if (!team_barrier(flags, m, K, ++round, err, &s_abort)) return;            // every key's prefixes and total are out
+        TEAM_STAMP(4);
+        for (int w = m; w < g.W; w += K) { skel_rank_body<EPT, 0, true, false, SKM_TEAM>(g, nullptr, w); lds_barrier(); }
+        TEAM_STAMP(5);
+        if (!team_barrier(flags, m, K, ++round, err, &s_abort)) return;            // the new state (a, d, keys) is complete
+        TEAM_STAMP(6);
+    }
+#undef TEAM_STAMP
 }
 
 // MANY PANELS PER LAUNCH (pbwtamd_pass_advance_many): P independent panels of the same width — chromosomes side by side — advance through the

@@ -398,6 +398,45 @@ def test_both_chains_every_site(amd, orc, skel, M, N, batch, kind, monkeypatch):
         assert np.array_equal(eng.max_within(o["yz"], N, mode="records"), orc.max_within(o["yz"], M, N))
 
 
+@pytest.mark.parametrize("M,N,batch,kind,K", [(70001, 80, 40, 0, 0), (100000, 136, 64, 0, 0), (100000, 72, 24, 1, 7), (20000, 136, 64, 1, 79), (139000, 40, 16, 0, 128),
+                                              (30000, 520, 256, 0, 33), (131072, 24, 8, 1, 64)])
+def test_team_chain_every_site(amd, orc, M, N, batch, kind, K, monkeypatch):
+    """the third chain form (PBWTAMD_TEAM=1, skel_team_kernel): all rounds of a batch in ONE launch, hist / scan / rank separated by flag-word barriers
+    among the workgroups of one XCD instead of by kernel boundaries — against the oracle at EVERY site (checksums of a and d), plus the consumers
+    fed from those states (histogram, .pbwt bytes), with one tile per member, several tiles per member (K = 7) and odd team sizes."""
+    import torch
+    monkeypatch.setenv("PBWTAMD_TEAM", "1")
+    if K:
+        monkeypatch.setenv("PBWTAMD_TEAM_K", str(K))
+    eng = amd.Engine(M, batch_sites=batch)
+    buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    eng.synth_device(buf.data_ptr(), 0, N, seed=1700 + M, kind=kind)
+    eng.sync()
+    bits = buf.cpu().numpy().view(np.uint32)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    opts = amd.OPT_WITH_D | amd.OPT_CHECKSUM | amd.OPT_WITHIN_HIST
+    eng.pass_begin(N)
+    half = (N // 2) // 8 * 8                   # two advances: the second starts from a carried cursor
+    eng.pass_advance(buf.data_ptr(), half, N, opts)
+    eng.pass_advance(buf.data_ptr() + half * eng.wpc * 4, N - half, N - half, opts)
+    eng.pass_end(opts)
+    a, d = eng.get_state()
+    ca, cd, _ = eng.get_checksums(0, N + 1)
+    assert np.array_equal(ca, o["csum_a"]), "a[] differs first at site %d" % int(np.argmax(ca != o["csum_a"]))
+    assert np.array_equal(cd, o["csum_d"]), "d[] differs first at site %d" % int(np.argmax(cd != o["csum_d"]))
+    assert np.array_equal(a, o["aFend"]) and np.array_equal(d, o["d_final"])
+    assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
+    ms, n = eng.chain_timing()
+    assert n <= (N + 7) // 8 + 2 * (N % batch) + 8, "the team form did not take the batches (%d chain launches for %d sites)" % (n, N)
+    opts = amd.OPT_WITH_D | amd.OPT_WITHIN_HIST | amd.OPT_PACK3          # the bench option set: packed fill, 16-bit hand-off, pack3 from the sweep's columns
+    eng.pass_begin(N)
+    eng.pass_advance(buf.data_ptr(), N, N, opts)
+    eng.pass_end(opts)
+    assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
+    assert np.array_equal(eng.get_packed(), o["yz"])
+
+
 @pytest.mark.parametrize("packed", ["1", "0"])
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1025, 96, 24, 0), (70001, 80, 40, 1), (2, 40, 8, 1), (300000, 24, 8, 0),
                                             (600100, 24, 8, 1), (150600, 32, 16, 1), (139300, 24, 8, 0),      # 600 100: pair rows with an odd number of tiles (1173); 150 600 / 139 300: pair rows, one-level scan (the narrowest: 137 rows)
@@ -577,12 +616,17 @@ def test_no_match_events_beyond_the_cap_keep_the_log_order(amd, orc):
     assert np.array_equal(ev[:, 0], idx % Mq) and np.all(ev[:, 1] == 1) and np.all(ev[:, 3] == 0)   # identical queries keep their original order in the query PBWT
 
 
-@pytest.mark.parametrize("P,M,N,B", [(3, 5000, 602, 256), (4, 30000, 520, 256), (2, 100000, 264, 128), (2, 600100, 24, 8)])
-def test_many_panels_per_launch(amd, orc, P, M, N, B):
+@pytest.mark.parametrize("team", ["0", "1"])
+@pytest.mark.parametrize("P,M,N,B", [(3, 5000, 602, 256), (4, 30000, 520, 256), (2, 100000, 264, 128), (2, 600100, 24, 8), (8, 60000, 264, 128), (11, 20000, 136, 64)])
+def test_many_panels_per_launch(amd, orc, P, M, N, B, team, monkeypatch):
     """pbwtamd_pass_advance_many: P independent panels (chromosomes) of one width advance through fused chain launches (grid.y = panel;
     two launches per round at 5 000 haplotypes, three at 30 000 / 100 000; the 600 100-wide case and the ragged tails take the per-engine
     fallback).  Every panel's .pbwt bytes, final a / d and -stats histogram equal the oracle's for that panel alone."""
     import torch
+    # team = "1": panel p on XCD p, all rounds of a batch in one launch (skel_team_kernel), eight panels at a time (the 11-panel case: 8 + 3)
+    if team == "1" and (M <= 12288 or M > 139000):
+        pytest.skip("the team form takes the widths of the three-launch round without pair rows")
+    monkeypatch.setenv("PBWTAMD_TEAM", team)
     st = torch.cuda.Stream()
     engs = [amd.Engine(M, batch_sites=B, stream=st.cuda_stream) for _ in range(P)]
     bufs = [torch.zeros((N, engs[0].wpc), dtype=torch.int32, device="cuda") for _ in range(P)]

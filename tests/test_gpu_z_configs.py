@@ -37,8 +37,10 @@ def bench_pass(amd, eng, buf, N, step=8192):
     return eng.get_hist(N + 1), eng.get_packed(), a, d
 
 
-def test_config2_bench_path_32768_sites(gpu_lib, orc):
+@pytest.mark.parametrize("team", ["0", "1"])
+def test_config2_bench_path_32768_sites(gpu_lib, orc, team, monkeypatch):
     amd = gpu_lib
+    monkeypatch.setenv("PBWTAMD_TEAM", team)               # "1": the team-persistent chain (one launch per batch, skel_team_kernel)
     M, N = 100000, 32768
     eng = amd.Engine(M, batch_sites=512)
     buf = device_panel(eng, N, seed=0x5EED0001)
