@@ -177,6 +177,8 @@ struct pbwtamd_engine {
     int2 *qs_bsum[2] = {nullptr, nullptr}; int qs_nblk = 0;   // query sweep: per ring, block summaries of every state of the batch (qs_blocksum_kernel), written by the batch's consumers
     int qs_bsum_sites[2] = {0, 0};          // ... and how many leading sites of the ring's batch they have summarised so far
     SkArgs *margs = nullptr, *margs_host = nullptr; size_t margs_cap = 0; int margs_half = 0; hipEvent_t evMargs[2] = {nullptr, nullptr};   // pbwtamd_pass_advance_many (panel 0 owns them)
+    // the one-launch round (skel_onepass_kernel; PBWTAMD_ONEPASS): tagged row / group-row granules, tiles per group, launches so far (the tag)
+    bool onepass = false; unsigned long long *op_rows = nullptr, *op_grows = nullptr; int op_g1 = 0; unsigned op_epoch = 0;
     unsigned long long *teamprof = nullptr;                 // PBWTAMD_TEAM_PROF=1: member 0's wall-clock stamps per round and phase
     unsigned *teamctl = nullptr; unsigned team_round = 0; int team_cap = 0;   // team-persistent chain (skel_team_kernel): tickets + flag words per XCD, barriers passed so far (the first engine of a group owns them)
     bool persist = false;                   // small panels (two-launch regime): all rounds of a batch in ONE launch (skel_persist_kernel) — set for the query cursor of the query sweep
@@ -287,6 +289,8 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (e->pbar) (void)dev_free(e->pbar);
     if (e->teamctl) (void)dev_free(e->teamctl);
     if (e->teamprof) (void)dev_free(e->teamprof);
+    if (e->op_rows) (void)dev_free(e->op_rows);
+    if (e->op_grows) (void)dev_free(e->op_grows);
     if (e->h_used) (void)hipHostFree(e->h_used);
     if (e->h_nflag) (void)hipHostFree(e->h_nflag);
     if (e->evFlag) (void)hipEventDestroy(e->evFlag);
@@ -392,10 +396,20 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             // (139 k < M <= 524 k): the one-level scan on half the rows — measured -2 % at 140 k, -3 % at 160-250 k, -12 % at 300 k, -8 % at
             // 400 k, -6 % at 500 k end to end; +4..6 % at 100-120 k, where the hist workgroup of two tiles costs more than the shorter scan saves
             static const bool pair_rows = !(tune_env("PBWTAMD_PAIR_ROWS") && !atoi(tune_env("PBWTAMD_PAIR_ROWS")));
+            // the one-launch round (pbwt_k_chain.h, skel_onepass_kernel): every tile of a launch must be able to become resident (a tile waits for the rows of tiles
+            // before it), so at most 1024 tiles and no more than the device holds at once; it needs neither pair rows nor the two-level scan
+            e->onepass = env_int("PBWTAMD_ONEPASS", 0) != 0 && e->skEPT <= 2 && e->Wt <= 1024;
+            if (e->onepass) {
+                int per_cu = 0, ncu = 0;
+                const hipError_t r1 = (e->skEPT == 1) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<1>, BLOCK, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<2>, BLOCK, 0);
+                if (r1 != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+                if ((long long)std::min(per_cu, 6) * ncu < e->Wt) e->onepass = false;      // (6: what the hardware admits of a kernel with ~100 SGPRs whatever the API says)
+            }
+            if (e->onepass) { e->op_g1 = 1; while (e->op_g1 * e->op_g1 < e->Wt) ++e->op_g1; }     // groups of ceil(sqrt(W)) tiles: as many groups as tiles per group
             e->W2 = (e->Wt + 1) / 2;
             static const int prow_min = tune_env("PBWTAMD_PROW_MIN") ? atoi(tune_env("PBWTAMD_PROW_MIN")) : 136;
             static const bool prow_ept1 = tune_env("PBWTAMD_PROW_EPT1") && atoi(tune_env("PBWTAMD_PROW_EPT1"));   // measurement builds: pairs of 256-position tiles
-            e->prow = pair_rows && (e->skEPT == 2 || (e->skEPT == 1 && prow_ept1)) && e->W2 > prow_min && e->W2 <= prow_max;
+            e->prow = !e->onepass && pair_rows && (e->skEPT == 2 || (e->skEPT == 1 && prow_ept1)) && e->W2 > prow_min && e->W2 <= prow_max;
             if (e->skEPT == 2 && e->Wt > 2048 && !e->prow) { const int r = fail("pbwtamd_engine_create: %d tiles of 512 positions need pair rows", e->Wt); pbwtamd_engine_destroy(e); return r; }
             e->strideS = e->prow ? (size_t)SKK * e->W2 * 2 + SKK / 2 : (size_t)SKK * e->Wt + SKK / 2;
             // wide panels (more than 512 scan rows): the scan in its local form (skel_k2_local_kernel) — one exclusive aggregate row per scan workgroup
@@ -406,7 +420,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
                 // workgroups make the last arriver's fold long and the consumers, not the chain, set the pace: up to 1024 rows)
                 // Below 513 rows the one-level scan (skel_k2_kernel) stays ahead: 2.88 against 3.15 us/site at 500 k, 2.48 / 2.74 at 350 k, 1.90 / 2.28 at 200 k
                 // (PBWTAMD_K2_LOCAL_MIN=n, A/B and parity runs only: the local form from n + 1 rows on).
-                e->k2local = rows > env_int("PBWTAMD_K2_LOCAL_MIN", 512) && rows <= env_int("PBWTAMD_K2_LOCAL_MAX", 1024) && env_int("PBWTAMD_K2_LOCAL", 1) != 0;
+                e->k2local = !e->onepass && rows > env_int("PBWTAMD_K2_LOCAL_MIN", 512) && rows <= env_int("PBWTAMD_K2_LOCAL_MAX", 1024) && env_int("PBWTAMD_K2_LOCAL", 1) != 0;
                 e->k2tpw = rows > 1024 ? 64 : 32;           // (16 rows per scan workgroup, twice the arrivals: 4.70 against 4.57 us/site at 1 M, 3.60 / 3.53 at 600 k; PBWTAMD_K2_LOCAL_MAX=2048, A/B: 64-row workgroups there — 6.34 against 6.36 us/site at 1.5 M, 8.20 against 8.04 at 2 M: not taken)
                 // the local form's capacity: aggx and k2agg hold 64 rows (one per scan workgroup), so rows <= 64 * k2tpw — odd PBWTAMD_K2_LOCAL_MIN / _MAX
                 // combinations fall back to the other scans instead of writing past them
@@ -424,6 +438,13 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             // pbwtamd_pass_advance_many that never take it do not pay for it)
         }
         ALLOC(e->skT, (size_t)(e->Wt + 1) * SKK * sizeof(int2));
+        if (e->onepass) {
+            const int ngrp = (e->Wt + e->op_g1 - 1) / e->op_g1;
+            ALLOC(e->op_rows, (size_t)e->Wt * SKK * sizeof(unsigned long long));
+            ALLOC(e->op_grows, (size_t)ngrp * SKK * sizeof(unsigned long long));
+            ECHK(hipMemsetAsync(e->op_rows, 0, (size_t)e->Wt * SKK * sizeof(unsigned long long), e->stream));        // tag 0: no launch has published yet (the first launch's tag is 1)
+            ECHK(hipMemsetAsync(e->op_grows, 0, (size_t)ngrp * SKK * sizeof(unsigned long long), e->stream));
+        }
         ALLOC(e->k2agg, (size_t)64 * SKK * sizeof(unsigned long long));
         ALLOC(e->k2cnt, 64);
         ECHK(hipMemsetAsync(e->k2cnt, 0, 64, e->stream));

@@ -79,6 +79,9 @@ struct SkArgs {
     // (round 4) wide panels, skel_k2_local_kernel: scan[] holds prefixes LOCAL to the scan workgroup of aggx_tpw rows, and aggx[row / aggx_tpw][key] the
     // exclusive fold of the workgroups before it; whoever reads a row folds the two (sk_fold_aggx).  nullptr: scan[] holds the global prefixes.
     const int2 *aggx = nullptr; int aggx_tpw = 0;
+    // (round 5) the ONE-LAUNCH round (skel_onepass_kernel): rows[tile][key] / grows[group][key] = tagged {count, tail} granules published by the tiles / by the
+    // last tile of every group of g1 consecutive tiles; tag = this launch's epoch (11 bits); total[] is precomputed (skel_totals_kernel)
+    unsigned long long *rows = nullptr, *grows = nullptr; int g1 = 0; unsigned tag = 0; int *err = nullptr;
 };
 // the global (keys before, carry) of a row from the aggregate of the scan workgroups before its own (L) and its prefix local to that workgroup (R):
 // skel_k2_kernel's combine, with the carry of "no earlier occurrence" = -1 on the way out
@@ -736,6 +739,215 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_kernel(SkArgs g) { skel_rank_
 // position-sharded form: tiles w0 .. w0+W-1, scatter through the owners' table
 template <int EPT, bool R4>
 __global__ __launch_bounds__(BLOCK) void skel_rank_shard_kernel(SkArgs g, SkShardOut so) { skel_rank_body<EPT, 0, R4, true>(g, &so); }
+
+// ---------------------------------------------------------------------------------------------
+// THE ONE-LAUNCH ROUND (round 5).  The three-launch round pays three device-wide dependencies per 8 sites (hist -> scan -> rank: 3.6-3.9 us each at
+// <= 100 k haplotypes, 0.5 us of data).  Two observations remove two of them:
+//  (1) total[key] of a round — and with it every bucket base and the "nearest lower non-empty key" — does not depend on the ORDER: it is the number of
+//      haplotypes whose alleles at the round's 8 sites spell that key, a histogram of one byte plane of the transposed panel.  skel_totals_kernel
+//      computes it for every round of a batch at once, off the chain.
+//  (2) what is left of the scan — per tile and key the keys before the tile and the carry — is a prefix over the tiles IN ORDER, and a tile can
+//      fetch it from its predecessors inside the launch (decoupled look-back, two levels): a tile publishes its {count, tail} row as 256 tagged 8-byte
+//      granules (ONE sc1 store each: the data is its own flag — MI355X_MICROARCH.md, the R2 form), folds the rows of the tiles before it in its group of
+//      g1 tiles; the LAST tile of a group publishes the group's aggregate row; every tile folds the aggregates of the groups before its own.  Two
+//      hand-offs of <= g1 - 1 and <= W / g1 - 1 rows (13 + 13 at 196 tiles) instead of two kernel boundaries and two passes over a 400 KB table.
+// The kernel is skel_rank_body with the tile's own row derived from tables it builds anyway (per-key count and last position from the chunk scan, the
+// tail as a range maximum from the sparse table) and the look-back in front of the bucket bases.  Waits are bounded by the wall clock (error 11); every
+// workgroup of the launch must be able to become resident (W <= 1024 and the occupancy check in pbwtamd_engine_create): a tile waits for tiles
+// before it, which the xcd_tile dealing does not dispatch in tile order.
+// Granule: count [0, 22) | tail [22, 53) | tag [53, 64).
+__device__ __forceinline__ unsigned long long sk1_enc(int c, int tl, unsigned tag) { return (unsigned long long)(unsigned)c | ((unsigned long long)(unsigned)tl << 22) | ((unsigned long long)(tag & 2047u) << 53); }
+// fold the n rows base[i * SKK + t], i = 0 .. n - 1 (in that order) onto (c, tl) with the scan's combine; false: the bounded wait ran out
+template <int CH>
+__device__ __forceinline__ bool sk1_fold_rows(const unsigned long long *base, int n, unsigned tag, int &c, int &tl, int *err, int code) {
+    const int t = threadIdx.x;
+    const unsigned long long want = (unsigned long long)(tag & 2047u);
+#pragma unroll 1
+    for (int i0 = 0; i0 < n; i0 += CH) {
+        unsigned long long v[CH];
+        int spins = 0; unsigned long long t0 = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) v[i] = (i0 + i < n) ? __hip_atomic_load(base + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (want << 53);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) ok &= (v[i] >> 53) == want;
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63) == 0) {                      // bounded (2 s of wall clock, 100 MHz): a predecessor that never ran must not hang the GPU
+                const unsigned long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                if (now - t0 > 200000000ULL || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicCAS(err, 0, code); return false; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int vc = (int)(v[i] & 0x3fffffu), vt = (int)((v[i] >> 22) & 0x7fffffffu);     // beyond n: (0, 0), the identity
+            tl = vc ? vt : max(tl, vt); c += vc;
+        }
+    }
+    return true;
+}
+
+// totals of every round of a batch: tot[r * strideT + key] = number of entries of src[r * strideSrc + 0 .. M) equal to key.  src = the byte planes of the
+// transposed panel (keys by haplotype, build side) or the rounds' key rows (by position, read side).  grid (chunks of 65536 entries, rounds); more than one
+// chunk per round: atomics onto totals zeroed by skel_totals_zero_kernel.
+__global__ __launch_bounds__(BLOCK) void skel_totals_zero_kernel(int *tot, size_t strideT) { tot[(size_t)blockIdx.x * strideT + threadIdx.x] = 0; }
+__global__ __launch_bounds__(BLOCK) void skel_totals_kernel(const unsigned char *src, size_t strideSrc, int M, int *tot, size_t strideT) {
+    __shared__ int h[WAVES][SKK];                           // a private histogram per wave: LDS atomics of different waves do not collide
+    const int t = threadIdx.x, wv = wave_id(), r = blockIdx.y;
+    const unsigned char *p = src + (size_t)r * strideSrc;
+    for (int x = t; x < WAVES * SKK; x += BLOCK) (&h[0][0])[x] = 0;
+    lds_barrier();
+    const int lo = blockIdx.x * 65536, hi = min(M, lo + 65536);
+    for (int i0 = lo + t * 16; i0 < hi; i0 += BLOCK * 16) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(p + i0);                      // rows are padded to 4096 entries: whole 16-byte pieces
+        const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) if (i0 + 4 * q + b < hi) atomicAdd(&h[wv][(wd[q] >> (8 * b)) & 0xffu], 1);
+    }
+    lds_barrier();
+    const int c = h[0][t] + h[1][t] + h[2][t] + h[3][t];
+    if (gridDim.x == 1) tot[(size_t)r * strideT + t] = c;
+    else if (c) atomicAdd(tot + (size_t)r * strideT + t, c);
+}
+
+template <int EPT>
+__device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    constexpr int T = BLOCK * EPT, NC = EPT * WAVES;
+    constexpr int NL = (EPT == 1) ? 4 : 5;                  // radix-4 sparse table: windows 1 .. 4^(NL-1) (EPT <= 2)
+    static_assert(EPT <= 2, "the one-launch round runs 256- and 512-position tiles");
+    __shared__ short s_cnt[NC][SKK];
+    __shared__ short s_lastp[NC][SKK];
+    __shared__ int s_tbl[NL][T];
+    __shared__ int s_base[SKK], s_ext[SKK];
+    __shared__ int s_failed;
+    constexpr int SK_EFLAG = 0x40000000;
+    int *const s_gw = &s_tbl[NL - 1][0], *const s_lw = &s_tbl[NL - 1][WAVES];   // (eight words of the top level no query reads: skel_rank_body)
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = (g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
+    const int S = w * T;
+    int av[EPT], dv[EPT], key[EPT];
+    unsigned nk[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) { const int i = S + r * BLOCK + t; av[r] = g.a[i]; dv[r] = g.d[i]; key[r] = (int)g.keys[i]; }
+    const int tq = g.total[t];                              // precomputed (skel_totals_kernel)
+    if (t == 0) s_failed = 0;
+    for (int x = t; x < NC * SKK / 2; x += BLOCK) { reinterpret_cast<int *>(&s_cnt[0][0])[x] = 0; reinterpret_cast<int *>(&s_lastp[0][0])[x] = -1; }
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        const int l = r * BLOCK + t;
+        const bool valid = S + l < g.M;
+        av[r] &= AMASK; if (!valid) { dv[r] = 0; key[r] = -1; }
+        s_tbl[0][l] = dv[r];
+        nk[r] = (g.has_next && valid && !g.ycnext) ? (unsigned)g.kbnext[av[r]] : 0u;
+    }
+    int rk[EPT], pl[EPT];
+    const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        unsigned long long same = __ballot(key[r] >= 0);
+#pragma unroll
+        for (int b = 0; b < SKB; ++b) { const unsigned long long bal = __ballot((key[r] >> b) & 1); same &= ((key[r] >> b) & 1) ? bal : ~bal; }
+        const unsigned long long before = same & lt;
+        rk[r] = __popcll(before);
+        pl[r] = before ? (r * 4 + wv) * 64 + (63 - __clzll(before)) : -1;
+        if (key[r] >= 0 && !before) {
+            s_cnt[r * 4 + wv][key[r]] = (short)__popcll(same);
+            s_lastp[r * 4 + wv][key[r]] = (short)((r * 4 + wv) * 64 + (63 - __clzll(same)));
+        }
+    }
+    lds_barrier();
+    int cnt_t = 0, last_t = -1;                             // thread = key: the key's count and last position in this tile
+    {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int cn = s_cnt[c][t], lp = s_lastp[c][t];
+            s_cnt[c][t] = (short)cnt_t; s_lastp[c][t] = (short)last_t;
+            cnt_t += cn; if (cn) last_t = lp;
+        }
+    }
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const int i = r * BLOCK + t;
+            const int wq = 1 << (2 * (l - 1));
+            int m = s_tbl[l - 1][i];
+            if (i - wq >= 0) m = max(m, s_tbl[l - 1][i - wq]);
+            if (i - 2 * wq >= 0) m = max(m, s_tbl[l - 1][i - 2 * wq]);
+            if (i - 3 * wq >= 0) m = max(m, s_tbl[l - 1][i - 3 * wq]);
+            if (l < NL - 1 || i >= 2 * WAVES) s_tbl[l][i] = m;
+        }
+    }
+    lds_barrier();
+    auto range_max = [&](int p, int l) -> int {             // max of d over (p, l], p >= -1
+        const int len = l - p;
+        const int lv = min((31 - __clz(len)) >> 1, NL - 1), wq = 1 << (2 * lv);
+        return max(max(s_tbl[lv][l], s_tbl[lv][p + wq]), max(s_tbl[lv][len > 2 * wq ? l - wq : l], s_tbl[lv][len > 3 * wq ? l - 2 * wq : l]));
+    };
+    // this tile's row: the key's count and the maximum of d after its last occurrence (the whole tile's for an absent key) — what skel_hist_kernel emits
+    const int tail_t = range_max(last_t, T - 1);
+    __hip_atomic_store(g.rows + (size_t)w * SKK + t, sk1_enc(cnt_t, tail_t, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // look-back, level 1: the tiles before this one in its group; the group's last tile publishes the group's aggregate
+    const int grp = w / g.g1, first = grp * g.g1, lastw = min(first + g.g1, g.W) - 1;
+    int pc = 0, pt = 0;
+    bool ok = sk1_fold_rows<16>(g.rows + (size_t)first * SKK, w - first, g.tag, pc, pt, g.err, 11);
+    if (ok && w == lastw) {
+        const int ac = pc + cnt_t, at = cnt_t ? tail_t : max(pt, tail_t);
+        __hip_atomic_store(g.grows + (size_t)grp * SKK + t, sk1_enc(ac, at, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // level 2: the groups before this tile's
+    int qc = 0, qt = 0;
+    ok = ok && sk1_fold_rows<16>(g.grows, grp, g.tag, qc, qt, g.err, 11);
+    if (!ok) s_failed = 1;
+    const int bq = qc + pc, cq = pc ? pt : (qc ? max(qt, pt) : -1);      // keys before the tile, carry (-1: no earlier occurrence)
+    g.scan[(size_t)w * SKK + t] = make_int2(bq, cq);       // kept for the fill
+    const int ginc = wave_iscan_sum(tq), linc = wave_iscan_max(tq ? t + 1 : 0);
+    if (lane == 63) { s_gw[wv] = ginc; s_lw[wv] = linc; }
+    const int lexc = lane_shr1(linc, 0);
+    lds_barrier();
+    if (s_failed) return;                                   // a bounded wait ran out: nothing is scattered from tables that are not there
+    int Gq = ginc - tq, lq = lexc;
+    for (int x = 0; x < wv; ++x) { Gq += s_gw[x]; lq = max(lq, s_lw[x]); }
+    lq -= 1;
+    s_base[t] = Gq + bq;
+    s_ext[t] = (cq >= 0) ? (cq | SK_EFLAG) : (lq >= 0 ? g.k + 1 + (31 - __clz(t ^ lq)) : 0);
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        if (key[r] < 0) continue;
+        const int l = r * BLOCK + t, c = r * 4 + wv, ky = key[r];
+        const int rank = s_cnt[c][ky] + rk[r];
+        const int p = (pl[r] >= 0) ? pl[r] : s_lastp[c][ky];
+        const int rm = range_max(p, l);
+        int dd;
+        if (p >= 0) dd = rm;
+        else { const int ex = s_ext[ky]; dd = (ex & SK_EFLAG) ? max(ex & ~SK_EFLAG, rm) : ex; }
+        const int pos = s_base[ky] + rank;
+        if (pos == 0) dd = g.k + SKB + 1;
+        if (g.ycnext) {
+            const unsigned tg = g.has_next ? (unsigned)((g.ycnext[pos >> 6] >> (pos & 63)) & 1ULL) : 0u;
+            g.a_out[pos] = av[r] | (int)(tg << 31);
+            g.d_out[pos] = dd;
+        } else {
+            g.a_out[pos] = av[r] | (int)((nk[r] & 1u) << 31);
+            g.d_out[pos] = dd;
+            g.keys_out[pos] = (unsigned char)nk[r];
+        }
+    }
+    if (w == g.Wtot - 1 && t == 0) g.d_out[g.M] = g.k + SKB + 1;
+}
+template <int EPT>
+__global__ __launch_bounds__(BLOCK) void skel_onepass_kernel(SkArgs g) { skel_onepass_body<EPT>(g); }
+template <int EPT>
+__global__ __launch_bounds__(BLOCK) void skel_onepass_many_kernel(const SkArgs *args) { const SkArgs g = args[blockIdx.y]; skel_onepass_body<EPT>(g); }
 
 // PERSISTENT chain of a small panel (<= TR tiles: the two-launch regime): ALL rounds of a batch in ONE launch, hist and rank of every
 // round separated by barriers over the launch's <= 128 co-resident workgroups instead of by kernel boundaries.  Such a barrier costs MORE

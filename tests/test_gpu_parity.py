@@ -355,7 +355,7 @@ def test_malformed_packed_panel_is_rejected(amd, orc):
     assert np.array_equal(eng.max_within(yz, N, mode="hist"), orc.max_within_hist(yz, M, N)[: N + 1])   # the engine is still usable
 
 
-@pytest.mark.parametrize("skel", ["1", "0"])
+@pytest.mark.parametrize("skel", ["1", "0", "onepass"])
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1024, 130, 32, 1), (1025, 96, 24, 0), (70001, 80, 40, 0),
                                             (300000, 40, 16, 0), (600100, 24, 8, 0), (1500, 41, 8, 1), (5, 64, 16, 1), (1, 16, 8, 0),
                                             (150600, 40, 16, 0), (524288, 24, 8, 1),    # pair rows with the one-level scan: 148 rows (odd tile count), 512 rows
@@ -366,7 +366,12 @@ def test_both_chains_every_site(amd, orc, skel, M, N, batch, kind, monkeypatch):
     seven states between filled by batched single-site kernels) and the two-site chain — against the
     oracle at EVERY site (checksums of a and d), plus the consumers fed from those states (hist, pack3)"""
     import torch
-    monkeypatch.setenv("PBWTAMD_SKEL", skel)
+    # "onepass": the skeleton with ONE launch per round of 8 sites (skel_onepass_kernel: totals precomputed, two-level look-back inside the launch) instead of
+    # three (two below 12 289 haplotypes); it takes every width up to 1 024 tiles of 512 positions
+    if skel == "onepass" and M > 524288:
+        pytest.skip("the one-launch round takes up to 1 024 tiles")
+    monkeypatch.setenv("PBWTAMD_SKEL", "0" if skel == "0" else "1")
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if skel == "onepass" else "0")
     eng = amd.Engine(M, batch_sites=batch)
     buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()               # the engine enqueues on its own stream: the fill must have landed
@@ -392,6 +397,8 @@ def test_both_chains_every_site(amd, orc, skel, M, N, batch, kind, monkeypatch):
     n = eng.chain_timing()[1]
     if skel == "1" and N >= batch and batch % 8 == 0:
         assert n < (N + 1) // 2                # at least one batch went through the skeleton (3 launches per 8 sites)
+    if skel == "onepass" and batch % 8 == 0:
+        assert n <= N // 8 + 2 * (N % batch) + 2, "the one-launch round did not take the batches (%d chain launches for %d sites)" % (n, N)
     b = eng.build(bits, with_d=True)           # host entry point: pack3 stream + records sink
     assert np.array_equal(b["yz"], o["yz"]) and np.array_equal(b["dFend"], o["d_final"])
     if 1 < M <= 3000:
@@ -437,7 +444,7 @@ def test_team_chain_every_site(amd, orc, M, N, batch, kind, K, monkeypatch):
     assert np.array_equal(eng.get_packed(), o["yz"])
 
 
-@pytest.mark.parametrize("packed", ["1", "0"])
+@pytest.mark.parametrize("packed", ["1", "0", "onepass"])
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1025, 96, 24, 0), (70001, 80, 40, 1), (2, 40, 8, 1), (300000, 24, 8, 0),
                                             (600100, 24, 8, 1), (150600, 32, 16, 1), (139300, 24, 8, 0),      # 600 100: pair rows with an odd number of tiles (1173); 150 600 / 139 300: pair rows, one-level scan (the narrowest: 137 rows)
                                             (525000, 16, 8, 1), (1048576, 16, 8, 0)])   # 513 and 1 024 scan rows: the first and the last width of the local scan launch (aggx folded by rank and both fills)
@@ -449,6 +456,9 @@ def test_histogram_and_pack3_consumers_without_ids(amd, orc, packed, M, N, batch
     import torch
     if packed == "0":
         monkeypatch.setenv("PBWTAMD_NO_PACKED_FILL", "1")
+    if packed == "onepass" and M > 524288:
+        pytest.skip("the one-launch round takes up to 1 024 tiles")
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if packed == "onepass" else "0")     # the packed consumers behind the one-launch round (no pair rows at any width)
     eng = amd.Engine(M, batch_sites=batch)
     buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()               # the engine enqueues on its own stream: the fill must have landed
@@ -468,7 +478,7 @@ def test_histogram_and_pack3_consumers_without_ids(amd, orc, packed, M, N, batch
     assert np.array_equal(eng.get_packed(), o["yz"])
 
 
-@pytest.mark.parametrize("form", ["seq", "seq_esc", "seq32", "table"] + (["fused", "fused_always", "yc"] if os.environ.get("PBWTAMD_MEASURE_BUILD") else []))
+@pytest.mark.parametrize("form", ["seq", "seq_esc", "seq32", "table", "onepass", "onepass_table"] + (["fused", "fused_always", "yc"] if os.environ.get("PBWTAMD_MEASURE_BUILD") else []))
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1025, 96, 24, 1), (70001, 80, 40, 1), (2, 40, 8, 1), (257, 64, 64, 1), (300000, 24, 8, 0),
                                             (600100, 24, 8, 1), (150600, 32, 16, 1), (9000, 72, 24, 0), (56001, 48, 16, 1), (511, 40, 8, 1), (512, 40, 8, 0),
                                             (100000, 136, 64, 0), (1000003, 16, 8, 0)])
@@ -483,9 +493,12 @@ def test_packed_fill_every_position(amd, orc, form, M, N, batch, kind, monkeypat
     # that leaves more than 10 % undecided (iid) switches back after its first batches, fused_always never does — which passed here and measured slower
     # seq: the 16-bit hand-off (L | y << 15 slots, the shipped path); seq_esc: the same with lengths from 3 on escaping to the 32-bit slot (what a match of
     # 32 767 sites or more does in production: here most positions take that path); seq32: the d | y << 31 slots (PBWTAMD_P16=0)
+    if form.startswith("onepass") and M > 524288:
+        pytest.skip("the one-launch round takes up to 1 024 tiles")
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if form.startswith("onepass") else "0")     # both fills behind the one-launch round's tables
     monkeypatch.setenv("PBWTAMD_P16", "0" if form == "seq32" else "1")
     monkeypatch.setenv("PBWTAMD_P16_CLIP", "3" if form == "seq_esc" else "32767")
-    monkeypatch.setenv("PBWTAMD_FILL_SEQ", "0" if form == "table" else "1")
+    monkeypatch.setenv("PBWTAMD_FILL_SEQ", "0" if form in ("table", "onepass_table") else "1")
     monkeypatch.setenv("PBWTAMD_FILL_FUSE", "1" if form.startswith("fused") else "0")
     monkeypatch.setenv("PBWTAMD_FILL_YC", "1" if form == "yc" else "0")        # yc: the fill emits the sorted allele columns, the sweep reads them first
     if form == "fused_always":
@@ -616,7 +629,7 @@ def test_no_match_events_beyond_the_cap_keep_the_log_order(amd, orc):
     assert np.array_equal(ev[:, 0], idx % Mq) and np.all(ev[:, 1] == 1) and np.all(ev[:, 3] == 0)   # identical queries keep their original order in the query PBWT
 
 
-@pytest.mark.parametrize("team", ["0", "1"])
+@pytest.mark.parametrize("team", ["0", "1", "onepass"])
 @pytest.mark.parametrize("P,M,N,B", [(3, 5000, 602, 256), (4, 30000, 520, 256), (2, 100000, 264, 128), (2, 600100, 24, 8), (8, 60000, 264, 128), (11, 20000, 136, 64)])
 def test_many_panels_per_launch(amd, orc, P, M, N, B, team, monkeypatch):
     """pbwtamd_pass_advance_many: P independent panels (chromosomes) of one width advance through fused chain launches (grid.y = panel;
@@ -626,7 +639,10 @@ def test_many_panels_per_launch(amd, orc, P, M, N, B, team, monkeypatch):
     # team = "1": panel p on XCD p, all rounds of a batch in one launch (skel_team_kernel), eight panels at a time (the 11-panel case: 8 + 3)
     if team == "1" and (M <= 12288 or M > 139000):
         pytest.skip("the team form takes the widths of the three-launch round without pair rows")
-    monkeypatch.setenv("PBWTAMD_TEAM", team)
+    monkeypatch.setenv("PBWTAMD_TEAM", "1" if team == "1" else "0")
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if team == "onepass" else "0")        # grid.y = panel on the one-launch round
+    if team == "onepass" and M > 524288:
+        pytest.skip("the one-launch round takes up to 1 024 tiles")
     st = torch.cuda.Stream()
     engs = [amd.Engine(M, batch_sites=B, stream=st.cuda_stream) for _ in range(P)]
     bufs = [torch.zeros((N, engs[0].wpc), dtype=torch.int32, device="cuda") for _ in range(P)]
@@ -672,13 +688,16 @@ def test_match_sweep_sparse_golden_and_no_match_branch(amd, orc):
         amd.Engine(M - Mq, batch_sites=4).match_sweep_sparse(m["pz"], N, m["qz"], Mq, 9)
 
 
-@pytest.mark.parametrize("skel_read", ["1", "0"])
+@pytest.mark.parametrize("skel_read", ["1", "0", "onepass"])
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 200, 64, 0), (1025, 96, 24, 1), (70001, 80, 40, 0), (2, 33, 8, 1), (300000, 24, 8, 0), (600100, 16, 8, 0)])
 def test_read_side_both_chains(amd, orc, skel_read, M, N, batch, kind, monkeypatch):
     """the read side (ForwardsReadAD over a packed panel, the reference's -read ... -maxWithin path): the skeleton chain
     with keys derived from the sorted columns through the LF-mapping (default) and the one-site-per-launch chain
     (PBWTAMD_SKEL_READ=0) — a, d, y at every site, histogram, records, -longWithin against the oracle"""
-    monkeypatch.setenv("PBWTAMD_SKEL_READ", skel_read)
+    if skel_read == "onepass" and M > 524288:
+        pytest.skip("the one-launch round takes up to 1 024 tiles")
+    monkeypatch.setenv("PBWTAMD_SKEL_READ", "0" if skel_read == "0" else "1")
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if skel_read == "onepass" else "0")    # the one-launch round on the read side: totals from the LF-mapped key rows
     bits = orc.synth_bitcols(M, N, seed=3000 + M, kind=kind)
     yz = orc.build_bitcols(bits, M, with_d=False)["yz"]
     eng = amd.Engine(M, batch_sites=batch)
