@@ -178,7 +178,7 @@ struct pbwtamd_engine {
     int qs_bsum_sites[2] = {0, 0};          // ... and how many leading sites of the ring's batch they have summarised so far
     SkArgs *margs = nullptr, *margs_host = nullptr; size_t margs_cap = 0; int margs_half = 0; hipEvent_t evMargs[2] = {nullptr, nullptr};   // pbwtamd_pass_advance_many (panel 0 owns them)
     // the one-launch round (skel_onepass_kernel; PBWTAMD_ONEPASS): tagged row / group-row granules, tiles per group, launches so far (the tag)
-    bool onepass = false; unsigned long long *op_rows = nullptr, *op_grows = nullptr; int op_g1 = 0; unsigned op_epoch = 0;
+    bool onepass = false; unsigned long long *op_rows = nullptr, *op_grows = nullptr; int op_g1 = 0; unsigned op_epoch = 0; unsigned long long *op_prof = nullptr;
     unsigned long long *teamprof = nullptr;                 // PBWTAMD_TEAM_PROF=1: member 0's wall-clock stamps per round and phase
     unsigned *teamctl = nullptr; unsigned team_round = 0; int team_cap = 0;   // team-persistent chain (skel_team_kernel): tickets + flag words per XCD, barriers passed so far (the first engine of a group owns them)
     bool persist = false;                   // small panels (two-launch regime): all rounds of a batch in ONE launch (skel_persist_kernel) — set for the query cursor of the query sweep
@@ -275,6 +275,18 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->s2) (void)hipStreamSynchronize(e->s2);
+    if (e->op_prof) {                                       // PBWTAMD_ONEPASS_PROF=1: the last launch's stamps, per tile, relative to the first tile's entry (us)
+        std::vector<unsigned long long> hp((size_t)e->Wt * 8);
+        if (hipMemcpy(hp.data(), e->op_prof, hp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long t0 = ~0ULL; for (int w = 0; w < e->Wt; ++w) if (hp[(size_t)w * 8]) t0 = std::min(t0, hp[(size_t)w * 8]);
+            const char *nm[7] = {"entry", "row ready", "level 1 folded", "level 2 folded", "scattered", "sparse table built", "ranks, range maxima"};
+            for (int i : {0, 1, 5, 6, 2, 3, 4}) {
+                double mn = 1e30, mx = 0, sum = 0; int n = 0;
+                for (int w = 0; w < e->Wt; ++w) { const unsigned long long v = hp[(size_t)w * 8 + i]; if (!v || !hp[(size_t)w * 8]) continue; const double us = (double)(v - t0) * 0.01; mn = std::min(mn, us); mx = std::max(mx, us); sum += us; ++n; }
+                fprintf(stderr, "[onepass prof] W %d g1 %d %-16s min %.2f mean %.2f max %.2f us after the first tile's entry (%d tiles)\n", e->Wt, e->op_g1, nm[i], mn, n ? sum / n : 0.0, mx, n);
+            }
+        }
+    }
     shard_release(e);
     if (e->s2) (void)hipStreamDestroy(e->s2);
     for (int i = 0; i < 16; ++i) if (e->tev[i]) (void)hipEventDestroy(e->tev[i]);
@@ -291,6 +303,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (e->teamprof) (void)dev_free(e->teamprof);
     if (e->op_rows) (void)dev_free(e->op_rows);
     if (e->op_grows) (void)dev_free(e->op_grows);
+    if (e->op_prof) (void)dev_free(e->op_prof);
     if (e->h_used) (void)hipHostFree(e->h_used);
     if (e->h_nflag) (void)hipHostFree(e->h_nflag);
     if (e->evFlag) (void)hipEventDestroy(e->evFlag);
@@ -444,6 +457,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             ALLOC(e->op_grows, (size_t)ngrp * SKK * sizeof(unsigned long long));
             ECHK(hipMemsetAsync(e->op_rows, 0, (size_t)e->Wt * SKK * sizeof(unsigned long long), e->stream));        // tag 0: no launch has published yet (the first launch's tag is 1)
             ECHK(hipMemsetAsync(e->op_grows, 0, (size_t)ngrp * SKK * sizeof(unsigned long long), e->stream));
+            if (env_int("PBWTAMD_ONEPASS_PROF", 0)) { ALLOC(e->op_prof, (size_t)e->Wt * 8 * sizeof(unsigned long long)); ECHK(hipMemsetAsync(e->op_prof, 0, (size_t)e->Wt * 8 * sizeof(unsigned long long), e->stream)); }
         }
         ALLOC(e->k2agg, (size_t)64 * SKK * sizeof(unsigned long long));
         ALLOC(e->k2cnt, 64);

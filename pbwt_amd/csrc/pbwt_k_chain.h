@@ -82,6 +82,7 @@ struct SkArgs {
     // (round 5) the ONE-LAUNCH round (skel_onepass_kernel): rows[tile][key] / grows[group][key] = tagged {count, tail} granules published by the tiles / by the
     // last tile of every group of g1 consecutive tiles; tag = this launch's epoch (11 bits); total[] is precomputed (skel_totals_kernel)
     unsigned long long *rows = nullptr, *grows = nullptr; int g1 = 0; unsigned tag = 0; int *err = nullptr;
+    unsigned long long *prof = nullptr;                         // PBWTAMD_ONEPASS_PROF=1: [tile][8] wall-clock stamps of the launch (debugging aid)
 };
 // the global (keys before, carry) of a row from the aggregate of the scan workgroups before its own (L) and its prefix local to that workgroup (R):
 // skel_k2_kernel's combine, with the carry of "no earlier occurrence" = -1 on the way out
@@ -134,18 +135,16 @@ struct SkShardOut {
 // first half; the scan over the tiles then runs on half as many rows (the scan launch is what a wide panel pays most for beside
 // the consumers: 22.7 us per round at 1954 rows, 14 at 977), and the rank / fill workgroup of an odd tile folds the first half's
 // row into its pair's prefix (skel_k2_kernel's combine).  Waves 2, 3 hold the first half.
+// skel_hist_row: the row of tile w for key t = threadIdx.x — {count, tail} (and {c0, tl0} of the first half with HALF) — left in registers; skel_hist_body stores it
 template <int EPT, bool HALF, int MODE = SKM_LAUNCH>
-__device__ __forceinline__ void skel_hist_body(const SkArgs &g, int wsel = -1) {
+__device__ __forceinline__ void skel_hist_row(const SkArgs &g, int w, int &c_out, int &tl_out, int &c0_out, int &tl0_out) {
     static_assert(MODE == SKM_LAUNCH || EPT <= 2, "the persistent forms run 256- and 512-position tiles");
-#ifndef PBWT_NO_SETPRIO
-    __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
-#endif
     constexpr int T = BLOCK * EPT;
     __shared__ int h_cnt[SKK], h_last[SKK];
     __shared__ int s_suf[T];
     __shared__ int s_w[WAVES];
     __shared__ int h_cnt0[HALF ? SKK : 1], h_last0[HALF ? SKK : 1], s_suf0[HALF ? T / 2 : 1];
-    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = (wsel >= 0) ? wsel : g.w0 + ((g.xcd & 4) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x);
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
     const int rb = BLOCK - 1 - t;
     const int l0 = rb * EPT, i0 = w * T + l0;
     unsigned packed;
@@ -201,12 +200,20 @@ __device__ __forceinline__ void skel_hist_body(const SkArgs &g, int wsel = -1) {
     int tilemax = 0;
     for (int q = 0; q < WAVES; ++q) tilemax = max(tilemax, s_w[q]);
     lds_barrier();
-    const int c = h_cnt[t], tl = c ? s_suf[h_last[t]] : tilemax;
+    const int c = h_cnt[t];
+    c_out = c; tl_out = c ? s_suf[h_last[t]] : tilemax;
+    if (HALF) { const int c0 = h_cnt0[t]; c0_out = c0; tl0_out = c0 ? s_suf0[h_last0[t]] : max(s_w[2], s_w[3]); }
+}
+template <int EPT, bool HALF, int MODE = SKM_LAUNCH>
+__device__ __forceinline__ void skel_hist_body(const SkArgs &g, int wsel = -1) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);                          // the dependent chain shares SIMDs with the throughput kernels of the consumer stream: issue first
+#endif
+    const int t = threadIdx.x, w = (wsel >= 0) ? wsel : g.w0 + ((g.xcd & 4) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x);
+    int c = 0, tl = 0, c0 = 0, tl0 = 0;
+    skel_hist_row<EPT, HALF, MODE>(g, w, c, tl, c0, tl0);
     skm_st2<MODE>(g.tbl + (size_t)w * SKK + t, make_int2(c, tl));      // row-major: one coalesced 2 KB row per tile
-    if (HALF) {
-        const int c0 = h_cnt0[t], tl0 = c0 ? s_suf0[h_last0[t]] : max(s_w[2], s_w[3]);
-        g.tbl0[(size_t)w * SKK + t] = make_int2(c0, tl0);
-    }
+    if (HALF) g.tbl0[(size_t)w * SKK + t] = make_int2(c0, tl0);
 }
 template <int EPT, bool HALF = false>
 __global__ __launch_bounds__(BLOCK) void skel_hist_kernel(SkArgs g) { skel_hist_body<EPT, HALF>(g); }
@@ -831,6 +838,10 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     int *const s_gw = &s_tbl[NL - 1][0], *const s_lw = &s_tbl[NL - 1][WAVES];   // (eight words of the top level no query reads: skel_rank_body)
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = (g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
     const int S = w * T;
+#define SK1_STAMP(i) do { if (g.prof && t == 0) g.prof[(size_t)w * 8 + (i)] = wall_clock64(); } while (0)
+    SK1_STAMP(0);
+    // every address-known load of the launch is issued here: the tile in the rank's (striped) order, then — inside skel_hist_row — keys and d once more in
+    // the hist's (reverse-blocked) order: the same lines, 5 bytes per position more through the L1
     int av[EPT], dv[EPT], key[EPT];
     unsigned nk[EPT];
 #pragma unroll
@@ -838,6 +849,25 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     const int tq = g.total[t];                              // precomputed (skel_totals_kernel)
     if (t == 0) s_failed = 0;
     for (int x = t; x < NC * SKK / 2; x += BLOCK) { reinterpret_cast<int *>(&s_cnt[0][0])[x] = 0; reinterpret_cast<int *>(&s_lastp[0][0])[x] = -1; }
+    // (1) this tile's row first, the way skel_hist_kernel derives it (three LDS barriers), and out with it: everything a tile after this one waits for
+    int cnt_t = 0, tail_t = 0, c0u = 0, t0u = 0;
+    skel_hist_row<EPT, false>(g, w, cnt_t, tail_t, c0u, t0u);
+    SK1_STAMP(1);
+    __hip_atomic_store(g.rows + (size_t)w * SKK + t, sk1_enc(cnt_t, tail_t, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the launch's critical path runs through the LAST tile of every group: rows of its group -> the group's aggregate -> every later tile.  That tile folds its
+    // group and publishes the aggregate before anything else; the others build their tables first and find the rows waiting
+    const int grp = w / g.g1, first = grp * g.g1, lastw = min(first + g.g1, g.W) - 1;
+    int pc = 0, pt = 0;
+    bool ok = true;
+    if (w == lastw) {
+        ok = sk1_fold_rows<16>(g.rows + (size_t)first * SKK, w - first, g.tag, pc, pt, g.err, 11);
+        if (ok) {
+            const int ac = pc + cnt_t, at = cnt_t ? tail_t : max(pt, tail_t);
+            __hip_atomic_store(g.grows + (size_t)grp * SKK + t, sk1_enc(ac, at, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // (2) in the shadow of the hand-offs: the rank's tables — chunk tables, the sparse table of d, every element's rank inside the tile, its previous
+    // same-key position and the range maximum since then; none of it depends on another tile
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
         const int l = r * BLOCK + t;
@@ -863,13 +893,13 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
         }
     }
     lds_barrier();
-    int cnt_t = 0, last_t = -1;                             // thread = key: the key's count and last position in this tile
-    {
+    {   // thread = key: exclusive scan over the chunks
+        int base = 0, last = -1;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int cn = s_cnt[c][t], lp = s_lastp[c][t];
-            s_cnt[c][t] = (short)cnt_t; s_lastp[c][t] = (short)last_t;
-            cnt_t += cn; if (cn) last_t = lp;
+            s_cnt[c][t] = (short)base; s_lastp[c][t] = (short)last;
+            base += cn; if (cn) last = lp;
         }
     }
 #pragma unroll
@@ -887,31 +917,35 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
         }
     }
     lds_barrier();
-    auto range_max = [&](int p, int l) -> int {             // max of d over (p, l], p >= -1
-        const int len = l - p;
+    SK1_STAMP(5);
+    int rloc[EPT], pp[EPT], rmx[EPT];
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+        rloc[r] = 0; pp[r] = -1; rmx[r] = 0;
+        if (key[r] < 0) continue;
+        const int l = r * BLOCK + t, c = r * 4 + wv, ky = key[r];
+        rloc[r] = s_cnt[c][ky] + rk[r];
+        const int p = (pl[r] >= 0) ? pl[r] : s_lastp[c][ky];
+        pp[r] = p;
+        const int len = l - p;                              // range max of d over (p, l]
         const int lv = min((31 - __clz(len)) >> 1, NL - 1), wq = 1 << (2 * lv);
-        return max(max(s_tbl[lv][l], s_tbl[lv][p + wq]), max(s_tbl[lv][len > 2 * wq ? l - wq : l], s_tbl[lv][len > 3 * wq ? l - 2 * wq : l]));
-    };
-    // this tile's row: the key's count and the maximum of d after its last occurrence (the whole tile's for an absent key) — what skel_hist_kernel emits
-    const int tail_t = range_max(last_t, T - 1);
-    __hip_atomic_store(g.rows + (size_t)w * SKK + t, sk1_enc(cnt_t, tail_t, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // look-back, level 1: the tiles before this one in its group; the group's last tile publishes the group's aggregate
-    const int grp = w / g.g1, first = grp * g.g1, lastw = min(first + g.g1, g.W) - 1;
-    int pc = 0, pt = 0;
-    bool ok = sk1_fold_rows<16>(g.rows + (size_t)first * SKK, w - first, g.tag, pc, pt, g.err, 11);
-    if (ok && w == lastw) {
-        const int ac = pc + cnt_t, at = cnt_t ? tail_t : max(pt, tail_t);
-        __hip_atomic_store(g.grows + (size_t)grp * SKK + t, sk1_enc(ac, at, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rmx[r] = max(max(s_tbl[lv][l], s_tbl[lv][p + wq]), max(s_tbl[lv][len > 2 * wq ? l - wq : l], s_tbl[lv][len > 3 * wq ? l - 2 * wq : l]));
     }
+    const int ginc = wave_iscan_sum(tq), linc = wave_iscan_max(tq ? t + 1 : 0);
+    const int lexc = lane_shr1(linc, 0);
+    lds_barrier();                                          // every query of the sparse table is done: its top level's first words carry the cross-wave scan
+    if (lane == 63) { s_gw[wv] = ginc; s_lw[wv] = linc; }
+    SK1_STAMP(6);
+    // (3) look-back, level 1: the tiles before this one in its group (the group's last tile has done it above)
+    if (w != lastw) ok = sk1_fold_rows<16>(g.rows + (size_t)first * SKK, w - first, g.tag, pc, pt, g.err, 11);
+    SK1_STAMP(2);
     // level 2: the groups before this tile's
     int qc = 0, qt = 0;
     ok = ok && sk1_fold_rows<16>(g.grows, grp, g.tag, qc, qt, g.err, 11);
+    SK1_STAMP(3);
     if (!ok) s_failed = 1;
     const int bq = qc + pc, cq = pc ? pt : (qc ? max(qt, pt) : -1);      // keys before the tile, carry (-1: no earlier occurrence)
     g.scan[(size_t)w * SKK + t] = make_int2(bq, cq);       // kept for the fill
-    const int ginc = wave_iscan_sum(tq), linc = wave_iscan_max(tq ? t + 1 : 0);
-    if (lane == 63) { s_gw[wv] = ginc; s_lw[wv] = linc; }
-    const int lexc = lane_shr1(linc, 0);
     lds_barrier();
     if (s_failed) return;                                   // a bounded wait ran out: nothing is scattered from tables that are not there
     int Gq = ginc - tq, lq = lexc;
@@ -920,17 +954,15 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     s_base[t] = Gq + bq;
     s_ext[t] = (cq >= 0) ? (cq | SK_EFLAG) : (lq >= 0 ? g.k + 1 + (31 - __clz(t ^ lq)) : 0);
     lds_barrier();
+    // (4) what is left behind the look-back: one addition and one table word per element, and the scatter
 #pragma unroll
     for (int r = 0; r < EPT; ++r) {
         if (key[r] < 0) continue;
-        const int l = r * BLOCK + t, c = r * 4 + wv, ky = key[r];
-        const int rank = s_cnt[c][ky] + rk[r];
-        const int p = (pl[r] >= 0) ? pl[r] : s_lastp[c][ky];
-        const int rm = range_max(p, l);
+        const int ky = key[r];
         int dd;
-        if (p >= 0) dd = rm;
-        else { const int ex = s_ext[ky]; dd = (ex & SK_EFLAG) ? max(ex & ~SK_EFLAG, rm) : ex; }
-        const int pos = s_base[ky] + rank;
+        if (pp[r] >= 0) dd = rmx[r];
+        else { const int ex = s_ext[ky]; dd = (ex & SK_EFLAG) ? max(ex & ~SK_EFLAG, rmx[r]) : ex; }
+        const int pos = s_base[ky] + rloc[r];
         if (pos == 0) dd = g.k + SKB + 1;
         if (g.ycnext) {
             const unsigned tg = g.has_next ? (unsigned)((g.ycnext[pos >> 6] >> (pos & 63)) & 1ULL) : 0u;
@@ -943,6 +975,8 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
         }
     }
     if (w == g.Wtot - 1 && t == 0) g.d_out[g.M] = g.k + SKB + 1;
+    SK1_STAMP(4);
+#undef SK1_STAMP
 }
 template <int EPT>
 __global__ __launch_bounds__(BLOCK) void skel_onepass_kernel(SkArgs g) { skel_onepass_body<EPT>(g); }
