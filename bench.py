@@ -613,7 +613,8 @@ def main():
                    "haplotypes": M, "sites_per_step": S, "sites_timed": K * S, "device_batch_sites": args.batch,
                    "panel": "founder-mosaic" if args.kind == 0 else "iid", "within": not args.no_within,
                    "pack3": not args.no_pack3, "units_per_rank": "independent panel per rank", "panels_per_gpu": args.panels},
-        "roofline": {"bound": "hbm", "kernel": ("skeleton chain: skel_hist_kernel + skel_k2_kernel + skel_rank_kernel, 3 launches per 8 sites" if sites_per_launch > 2.5 else
+        "roofline": {"bound": "hbm", "kernel": ("one-launch round: skel_onepass_kernel, 1 launch per 8 sites (key totals per batch: skel_totals_kernel)" if sites_per_launch > 7.5 else
+                                "skeleton chain: skel_hist_kernel + skel_k2_kernel + skel_rank_kernel, 3 launches per 8 sites" if sites_per_launch > 2.5 else
                                 "step2_kernel<WITH_D> (two sites per launch)" if sites_per_launch > 1.5 else "step1_kernel<WITH_D,GATHER>"), "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "alg_bytes_per_launch": alg_bytes_per_launch, "us_per_launch": us_per_launch,

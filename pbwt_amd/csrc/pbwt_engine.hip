@@ -411,7 +411,10 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             static const bool pair_rows = !(tune_env("PBWTAMD_PAIR_ROWS") && !atoi(tune_env("PBWTAMD_PAIR_ROWS")));
             // the one-launch round (pbwt_k_chain.h, skel_onepass_kernel): every tile of a launch must be able to become resident (a tile waits for the rows of tiles
             // before it), so at most 1024 tiles and no more than the device holds at once; it needs neither pair rows nor the two-level scan
-            e->onepass = env_int("PBWTAMD_ONEPASS", 0) != 0 && e->skEPT <= 2 && e->Wt <= 1024;
+            // Measured (profiles/r05_onepass.txt, with the bench consumers): 1.02 against 1.39 us/site at 30 k haplotypes, 1.13 / 1.34 at 50 k, 1.37-1.43 / 1.56-1.68 at 100 k,
+            // 1.69 / 1.83 at 150 k; 2.04 / 1.96 at 200 k, 2.45 / 2.12 at 250 k, 5.05 / 3.04 at 500 k (more tiles: longer look-backs, five workgroups per CU): on up to
+            // 320 tiles (163 840 haplotypes).  PBWTAMD_ONEPASS=0: the three- / two-launch round; PBWTAMD_ONEPASS_MAXW=n: up to n <= 1024 tiles (tests)
+            e->onepass = env_int("PBWTAMD_ONEPASS", 1) != 0 && e->skEPT <= 2 && e->Wt <= std::min(1024, env_int("PBWTAMD_ONEPASS_MAXW", 320));
             if (e->onepass) {
                 int per_cu = 0, ncu = 0;
                 const hipError_t r1 = (e->skEPT == 1) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<1>, BLOCK, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<2>, BLOCK, 0);

@@ -371,7 +371,7 @@ def test_both_chains_every_site(amd, orc, skel, M, N, batch, kind, monkeypatch):
     if skel == "onepass" and M > 524288:
         pytest.skip("the one-launch round takes up to 1 024 tiles")
     monkeypatch.setenv("PBWTAMD_SKEL", "0" if skel == "0" else "1")
-    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if skel == "onepass" else "0")
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if skel == "onepass" else "0"); monkeypatch.setenv("PBWTAMD_ONEPASS_MAXW", "1024")
     eng = amd.Engine(M, batch_sites=batch)
     buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()               # the engine enqueues on its own stream: the fill must have landed
@@ -413,6 +413,7 @@ def test_team_chain_every_site(amd, orc, M, N, batch, kind, K, monkeypatch):
     fed from those states (histogram, .pbwt bytes), with one tile per member, several tiles per member (K = 7) and odd team sizes."""
     import torch
     monkeypatch.setenv("PBWTAMD_TEAM", "1")
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "0")             # (the team form replaces the three-launch round; the one-launch round is a form of its own)
     if K:
         monkeypatch.setenv("PBWTAMD_TEAM_K", str(K))
     eng = amd.Engine(M, batch_sites=batch)
@@ -458,7 +459,7 @@ def test_histogram_and_pack3_consumers_without_ids(amd, orc, packed, M, N, batch
         monkeypatch.setenv("PBWTAMD_NO_PACKED_FILL", "1")
     if packed == "onepass" and M > 524288:
         pytest.skip("the one-launch round takes up to 1 024 tiles")
-    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if packed == "onepass" else "0")     # the packed consumers behind the one-launch round (no pair rows at any width)
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if packed == "onepass" else "0"); monkeypatch.setenv("PBWTAMD_ONEPASS_MAXW", "1024")     # the packed consumers behind the one-launch round (no pair rows at any width)
     eng = amd.Engine(M, batch_sites=batch)
     buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()               # the engine enqueues on its own stream: the fill must have landed
@@ -495,7 +496,7 @@ def test_packed_fill_every_position(amd, orc, form, M, N, batch, kind, monkeypat
     # 32 767 sites or more does in production: here most positions take that path); seq32: the d | y << 31 slots (PBWTAMD_P16=0)
     if form.startswith("onepass") and M > 524288:
         pytest.skip("the one-launch round takes up to 1 024 tiles")
-    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if form.startswith("onepass") else "0")     # both fills behind the one-launch round's tables
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if form.startswith("onepass") else "0"); monkeypatch.setenv("PBWTAMD_ONEPASS_MAXW", "1024")     # both fills behind the one-launch round's tables
     monkeypatch.setenv("PBWTAMD_P16", "0" if form == "seq32" else "1")
     monkeypatch.setenv("PBWTAMD_P16_CLIP", "3" if form == "seq_esc" else "32767")
     monkeypatch.setenv("PBWTAMD_FILL_SEQ", "0" if form in ("table", "onepass_table") else "1")
@@ -640,7 +641,7 @@ def test_many_panels_per_launch(amd, orc, P, M, N, B, team, monkeypatch):
     if team == "1" and (M <= 12288 or M > 139000):
         pytest.skip("the team form takes the widths of the three-launch round without pair rows")
     monkeypatch.setenv("PBWTAMD_TEAM", "1" if team == "1" else "0")
-    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if team == "onepass" else "0")        # grid.y = panel on the one-launch round
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if team == "onepass" else "0"); monkeypatch.setenv("PBWTAMD_ONEPASS_MAXW", "1024")        # grid.y = panel on the one-launch round
     if team == "onepass" and M > 524288:
         pytest.skip("the one-launch round takes up to 1 024 tiles")
     st = torch.cuda.Stream()
@@ -697,7 +698,7 @@ def test_read_side_both_chains(amd, orc, skel_read, M, N, batch, kind, monkeypat
     if skel_read == "onepass" and M > 524288:
         pytest.skip("the one-launch round takes up to 1 024 tiles")
     monkeypatch.setenv("PBWTAMD_SKEL_READ", "0" if skel_read == "0" else "1")
-    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if skel_read == "onepass" else "0")    # the one-launch round on the read side: totals from the LF-mapped key rows
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if skel_read == "onepass" else "0"); monkeypatch.setenv("PBWTAMD_ONEPASS_MAXW", "1024")    # the one-launch round on the read side: totals from the LF-mapped key rows
     bits = orc.synth_bitcols(M, N, seed=3000 + M, kind=kind)
     yz = orc.build_bitcols(bits, M, with_d=False)["yz"]
     eng = amd.Engine(M, batch_sites=batch)

@@ -41,7 +41,7 @@ def bench_pass(amd, eng, buf, N, step=8192):
 def test_config2_bench_path_32768_sites(gpu_lib, orc, team, monkeypatch):
     amd = gpu_lib
     monkeypatch.setenv("PBWTAMD_TEAM", "1" if team == "1" else "0")           # "1": the team-persistent chain (one launch per batch, skel_team_kernel)
-    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if team == "onepass" else "0")  # the one-launch round (skel_onepass_kernel)
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if team == "onepass" else "0"); monkeypatch.setenv("PBWTAMD_ONEPASS_MAXW", "1024")  # the one-launch round (skel_onepass_kernel)
     M, N = 100000, 32768
     eng = amd.Engine(M, batch_sites=512)
     buf = device_panel(eng, N, seed=0x5EED0001)
