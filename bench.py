@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_SITEHAP = 16.125        # r a,d + w a,d (4 B each) + 1 allele bit
 HBM_PEAK_GBPS = 8000.0                # MI355X_MICROARCH.md: 8 TB/s HBM3E
+MANY_PANELS_P = 8                     # the `many_panels` object: a fixed number of panels (no best-of-tried)
 BOUNDARY_US = 1.54                    # measured cost of one dependent kernel boundary on MI355X, empty kernels (profiles/r01_probes.txt)
 
 
@@ -251,7 +252,7 @@ def many_panels(torch, pbwt_amd, dev, opts, kind, M, P=2, sites=32768, batch=512
         e.close()
     return {"panels": P, "haplotypes_per_panel": M, "sites_timed": sites, "value": P * M * sites / dt, "unit": "site*haps/s over all panels",
             "us_per_site_per_panel": 1e6 * dt / sites / P, "us_per_site_all_panels": 1e6 * dt / sites, "within_reports_hist_total": tot,
-            "note": "pbwtamd_pass_advance_many: every launch of the chain covers all panels (grid.y = panel); consumers per panel"}
+            "note": "pbwtamd_pass_advance_many: six panels or more — the team-persistent chain, one launch per batch, panel p on XCD p; fewer — every launch of the chain covers all panels (grid.y = panel); consumers per panel"}
 
 
 def match_dynamic(torch, pbwt_amd, dev, kind, M=1000000, Q=10000, sites=65536, batch=512):
@@ -627,10 +628,9 @@ def main():
     if hep:
         out["host_entry_points"] = hep
     if rank == 0 and world == 1 and not args.no_1m and args.panels == 1:
-        # two points of the P sweep (round 4, with the lighter consumers: P = 2 9.8e10, 3 8.5e10, 4 9.5e10, 6 1.08e11, 8 1.03e11 on one box); the better one is the object
-        tried = [many_panels(torch, pbwt_amd, dev, opts, args.kind, M, P=P) for P in (2, 6)]
-        out["many_panels"] = max(tried, key=lambda r: r["value"])
-        out["many_panels"]["tried"] = [{"panels": r["panels"], "value": r["value"]} for r in tried]
+        # ONE fixed point, P = 8 (eight chromosomes of a cohort side by side; from six panels on pbwtamd_pass_advance_many runs the team-persistent chain,
+        # panel p on XCD p — round 5).  Not a maximum over tried configurations.
+        out["many_panels"] = many_panels(torch, pbwt_amd, dev, opts, args.kind, M, P=MANY_PANELS_P)
         out["many_panels"]["speedup_vs_one_panel"] = out["many_panels"]["value"] / out["value"]
     if rank == 0 and world == 1 and not args.no_1m:
         del panel

@@ -630,7 +630,7 @@ def test_no_match_events_beyond_the_cap_keep_the_log_order(amd, orc):
     assert np.array_equal(ev[:, 0], idx % Mq) and np.all(ev[:, 1] == 1) and np.all(ev[:, 3] == 0)   # identical queries keep their original order in the query PBWT
 
 
-@pytest.mark.parametrize("team", ["0", "1", "onepass"])
+@pytest.mark.parametrize("team", ["0", "1", "onepass", "auto"])
 @pytest.mark.parametrize("P,M,N,B", [(3, 5000, 602, 256), (4, 30000, 520, 256), (2, 100000, 264, 128), (2, 600100, 24, 8), (8, 60000, 264, 128), (11, 20000, 136, 64)])
 def test_many_panels_per_launch(amd, orc, P, M, N, B, team, monkeypatch):
     """pbwtamd_pass_advance_many: P independent panels (chromosomes) of one width advance through fused chain launches (grid.y = panel;
@@ -640,8 +640,13 @@ def test_many_panels_per_launch(amd, orc, P, M, N, B, team, monkeypatch):
     # team = "1": panel p on XCD p, all rounds of a batch in one launch (skel_team_kernel), eight panels at a time (the 11-panel case: 8 + 3)
     if team == "1" and (M <= 12288 or M > 139000):
         pytest.skip("the team form takes the widths of the three-launch round without pair rows")
-    monkeypatch.setenv("PBWTAMD_TEAM", "1" if team == "1" else "0")
-    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if team == "onepass" else "0"); monkeypatch.setenv("PBWTAMD_ONEPASS_MAXW", "1024")        # grid.y = panel on the one-launch round
+    if team == "auto":                                      # the shipped choice: the one-launch round with grid.y = panel, the team form from six panels on
+        if P < 6:
+            pytest.skip("as the onepass case")
+        monkeypatch.delenv("PBWTAMD_TEAM", raising=False); monkeypatch.delenv("PBWTAMD_ONEPASS", raising=False); monkeypatch.delenv("PBWTAMD_ONEPASS_MAXW", raising=False)
+    else:
+        monkeypatch.setenv("PBWTAMD_TEAM", "1" if team == "1" else "0")
+        monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if team == "onepass" else "0"); monkeypatch.setenv("PBWTAMD_ONEPASS_MAXW", "1024")        # grid.y = panel on the one-launch round
     if team == "onepass" and M > 524288:
         pytest.skip("the one-launch round takes up to 1 024 tiles")
     st = torch.cuda.Stream()

@@ -40,9 +40,11 @@ def test_config1_full_size_build_AD(gpu_lib, orc):
     assert np.array_equal(ca, o["csum_a"]), "a[] differs at site %d" % int(np.argmax(ca != o["csum_a"]))
     assert np.array_equal(cd, o["csum_d"]), "d[] differs at site %d" % int(np.argmax(cd != o["csum_d"]))
     assert np.array_equal(a, o["aFend"]) and np.array_equal(d, o["d_final"])
-    # two sites per launch all the way; on the skeleton path TWO launches per 8 sites at this width (40 tiles of 256 positions:
+    # two sites per launch all the way; on the skeleton path ONE launch per 8 sites (PBWTAMD_ONEPASS=0: TWO at this width (40 tiles of 256 positions:
     # the rank kernel scans the tile table itself up to 48 tiles), three above
     per_round = 2 if (M + 255) // 256 <= int(os.environ.get("PBWTAMD_SKN_MAXW", "48")) and os.environ.get("PBWTAMD_SKN", "1") != "0" else 3
+    if os.environ.get("PBWTAMD_ONEPASS", "1") != "0":
+        per_round = 1                          # (round 5) the one-launch round: totals precomputed per batch, the tile prefixes fetched inside the launch
     assert eng.chain_timing()[1] == (per_round * (N // 8) if os.environ.get("PBWTAMD_SKEL", "1") != "0" else N // 2)
 
 
