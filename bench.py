@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--ps-timeout", type=float, default=900.0, help="seconds after which the attached position-sharded job is given up (the line is printed without it)")
     ap.add_argument("--no-posshard", action="store_true", help="N > 1: do not attach the position-sharded job")
     ap.add_argument("--stream-panel", action="store_true", help="run ONLY the north-star job with the panel generated per step into a column ring (configs[4] at its own length: --ns-sites 10000000); prints that object")
+    ap.add_argument("--with-queries", action="store_true", help="--stream-panel: configs[4] whole — build + maxWithin + pack3 + -matchDynamic of 10 000 queries in ONE streamed pass (pbwtamd_match_sweep_stream)")
     ap.add_argument("--ns-no-pack3", action="store_true", help="--stream-panel: build + maxWithin without the pack3 consumer (10 M sites of .pbwt bytes do not fit beside the job)")
     ap.add_argument("--own-stream", action="store_true", help="let the engine create its own (high-priority) chain stream instead of torch's current stream")
     ap.add_argument("--mode", default=os.environ.get("PBWT_BENCH_MODE", "replicas"), choices=["replicas", "siteblock", "posshard"],
@@ -166,6 +167,71 @@ def north_star_streamed(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=10000
             "panel": "generated per %d-site step into a two-slot column ring (%.1f GB instead of %.0f GB resident), one step ahead of the chain"
                      % (step, 2 * (step + look) * ((M + 31) // 32) * 4 / 1e9, n_total * ((M + 31) // 32) * 4 / 1e9),
             "pack3": bool(opts & pbwt_amd.OPT_PACK3)}
+
+
+def configs4_streamed_with_queries(torch, pbwt_amd, dev, kind, M=1000000, Q=10000, sites=10000000, batch=512, pack3=True):
+    """BASELINE configs[4] at its own length, ALL of it in one pass: 1 M haplotypes x `sites` sites build + -maxWithin (histogram) + pack3 + -matchDynamic of a
+    Q-haplotype query panel (matchSequencesSweep, pbwtMatch.c:363-443) through the STREAMED entry point pbwtamd_match_sweep_stream — the library asks for both
+    panels' bit columns a device batch at a time (generated here on a second stream, one batch ahead: panel and queries are the two parts of ONE (M + Q)-wide
+    synthetic panel, shared founders), hands the records over per batch (counted, not kept) and the pack3 bytes leave through pbwtamd_drain_packed into a
+    pinned buffer (counted).  Nothing of either panel ever exists beyond two batches of columns."""
+    assert M % 32 == 0
+    sites = (sites // batch) * batch
+    s_gen = torch.cuda.Stream(device=dev)
+    eng = pbwt_amd.Engine(M, batch_sites=batch, device=dev.index)
+    full = pbwt_amd.Engine(M + Q, batch_sites=8, device=dev.index, stream=s_gen.cuda_stream)      # only its generator and its stream are used
+    wq = pbwt_amd.wpc_for(Q)
+    look = 8
+    stage = [torch.empty((batch + look, full.wpc), dtype=torch.int32, device=dev) for _ in range(2)]
+    pcols = [torch.zeros((batch + look, eng.wpc), dtype=torch.int32, device=dev) for _ in range(2)]
+    qcols = [torch.zeros((batch + look, wq), dtype=torch.int32, device=dev) for _ in range(2)]
+    nqw = (Q + 31) // 32
+    ev = [torch.cuda.Event() for _ in range(2)]
+    state = {"next": 0, "records": 0, "bytes": 0, "calls": 0, "t_snap": None}
+    pinned = torch.empty(64 << 20, dtype=torch.uint8).pin_memory().numpy() if pack3 else None
+
+    def generate(slot, k0):
+        n = min(batch + look, sites - k0)
+        with torch.cuda.stream(s_gen):
+            full.synth_device(stage[slot].data_ptr(), k0, n, seed=0x3D, kind=kind)
+            pcols[slot][:n, : M // 32] = stage[slot][:n, : M // 32]
+            qcols[slot][:n, :nqw] = stage[slot][:n, M // 32: M // 32 + nqw]
+            if Q % 32:
+                qcols[slot][:n, nqw - 1] &= (1 << (Q % 32)) - 1
+            ev[slot].record(s_gen)
+
+    def cols(site0, ncols):
+        slot = (site0 // batch) % 2
+        if state["calls"] == 0:
+            generate(slot, site0)
+        ev[slot].synchronize()                              # this batch's columns are complete
+        if site0 + batch < sites:
+            generate(slot ^ 1, site0 + batch)               # the next batch's are generated while this one runs (its slot's last reader, two batches back, is done)
+        if pinned is not None and site0:
+            state["bytes"] += len(eng.drain_packed(pinned))
+        state["calls"] += 1
+        return pcols[slot].data_ptr(), qcols[slot].data_ptr()
+
+    def on_records(arr):
+        state["records"] += len(arr)
+
+    popts = pbwt_amd.OPT_WITHIN_HIST | (pbwt_amd.OPT_PACK3 if pack3 else 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, nom, tot = eng.match_sweep_stream(sites, Q, cols, on_records=on_records, panel_opts=popts)
+    if pinned is not None:
+        state["bytes"] += len(eng.drain_packed(pinned))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    hist = eng.get_hist(sites + 1)
+    eng.close(); full.close()
+    alg = (ALG_BYTES_PER_SITEHAP * (M + Q) * sites + 16.0 * state["records"]) / dt / 1e9
+    return {"haplotypes": M, "queries": Q, "sites": sites, "seconds": dt, "us_per_site": 1e6 * dt / sites, "value": M * sites / dt, "unit": "panel site*haps/s",
+            "records": int(state["records"]), "no_match_events": int(nom), "nTot": int(tot[0]), "totLen": int(tot[1]),
+            "within_reports_hist_total": int(hist.sum()), "pack3_bytes": int(state["bytes"]), "pack3": bool(pack3),
+            "achieved_GBps": alg, "frac_of_hbm_peak": alg / HBM_PEAK_GBPS,
+            "note": "ONE pass: build (ForwardsAD) + maxWithin histogram + pack3 + matchSequencesSweep; both panels generated per %d-site batch on a second stream "
+                    "(pbwtamd_match_sweep_stream), records and .pbwt bytes handed over per batch; set-up and the closing tails included" % batch}
 
 
 def north_star_width(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=1000000, batch=512, step=8192, want_hist=False):
@@ -512,6 +578,10 @@ def main():
         torch.cuda.set_device(dev)
         pdist.init(args.backend)
     import pbwt_amd
+    if args.stream_panel and args.with_queries:
+        out = configs4_streamed_with_queries(torch, pbwt_amd, dev, args.kind, sites=args.ns_sites, pack3=not args.ns_no_pack3)
+        print(json.dumps(out), flush=True)
+        return pdist.finish()
     if args.stream_panel:
         o = pbwt_amd.OPT_WITH_D | pbwt_amd.OPT_WITHIN_HIST | (0 if args.ns_no_pack3 else pbwt_amd.OPT_PACK3)
         out = north_star_streamed(torch, pbwt_amd, dev, o, args.kind, sites=args.ns_sites)

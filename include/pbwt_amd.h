@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PBWTAMD_ABI_VERSION 2   /* 2: pbwtamd_shard_* , pbwtamd_pass_advance_many, pbwtamd_get_nomatch_events (round 3-4) */
+#define PBWTAMD_ABI_VERSION 3   /* 2: pbwtamd_shard_* , pbwtamd_pass_advance_many, pbwtamd_get_nomatch_events (round 3-4); 3: pbwtamd_match_sweep_stream, pbwtamd_drain_packed (round 5) */
 
 typedef struct pbwtamd_engine pbwtamd_engine;
 
@@ -147,6 +147,23 @@ int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, int64_t pnz
                                pbwtamd_report5_fn report, pbwtamd_match5 **recs_out, int64_t *nrecs_out,
                                int64_t *n_nomatch, int64_t *tot);
 
+/* matchSequencesSweep (pbwtMatch.c:363-443) STREAMED: neither panel is ever materialised — the form configs[4] (10^6 haplotypes x 10^7 sites, 10^4
+ * queries) needs, where the packed panels alone would be O(100 GB) of host memory.  The library asks `cols` for the bit columns of both panels a batch at a
+ * time and hands every batch's records to `recs`:
+ *   cols(user, site0, ncols, &d_panel, &d_queries) -> 0: `ncols` consecutive columns of each panel from site0 on, DEVICE pointers on the engine's device,
+ *        original haplotype order (the layout of pbwtamd_pass_advance: rows of pbwtamd_engine_wpc(e) words for the panel, of the same formula for Mq
+ *        haplotypes — ((Mq + 31) / 32 rounded up to 4 — for the queries); contents complete when the callback returns; valid until the next call;
+ *   recs(user, records, n) -> 0: the next n records (ai = query, bi = panel haplotype, start, end, sparse = 0) in the reference's callback order
+ *        (k ascending, then the query panel's PBWT order, then i ascending; the tails at N last); valid during the call.
+ * pStart / qStart: start orders (NULL = identity).  panel_opts — PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_CHECKSUM — makes the SAME pass
+ * over the panel feed those consumers too (histogram: pbwtamd_get_hist; bytes: pbwtamd_drain_packed, e.g. from inside `cols`).  n_nomatch, tot_out as
+ * pbwtamd_match_sweep; the log lines' events through pbwtamd_get_nomatch_events. */
+typedef int (*pbwtamd_cols_fn)(void *user, int site0, int ncols, const void **d_panel_cols, const void **d_query_cols);
+typedef int (*pbwtamd_recs_fn)(void *user, const pbwtamd_match5 *records, int64_t n);
+int pbwtamd_match_sweep_stream(pbwtamd_engine *e, int N, const int32_t *pStart, int Mq, const int32_t *qStart,
+                               pbwtamd_cols_fn cols, pbwtamd_recs_fn recs, void *user, unsigned panel_opts,
+                               int64_t *n_nomatch, int64_t *tot_out);
+
 /* Query sharding across GPUs for matchSequencesSweep / -matchDynamic (queries are independent given the panel state:
  * pbwtMatch.c:376-414 touches f[jj], d[jj] of one query at a time).  After this call the query sweeps of `e` process the
  * queries lo <= jj < hi only (original indices in the query panel).  Every record's `sparse` field (and the isSparse column
@@ -232,6 +249,10 @@ int pbwtamd_get_checksums(pbwtamd_engine *e, int k_first, int n, uint64_t *csum_
 /* the pack3 bytes (PBWTAMD_OPT_PACK3) written since pass_begin = the p->yz array of pbwtCore.c:254-267; malloc'd, free with
  * pbwtamd_free */
 int pbwtamd_get_packed(pbwtamd_engine *e, uint8_t **yz_out, int64_t *nz_out);
+/* the same bytes handed over a piece at a time (what pbwtWrite fwrites, pbwtIO.c:33-57, for panels whose packed columns outgrow HBM): copies the bytes written
+ * since pass_begin or the previous drain into buf (cap bytes) and rewinds the engine's buffer; *n = their number; buf == NULL: size only.  Synchronises the
+ * consumer stream. */
+int pbwtamd_drain_packed(pbwtamd_engine *e, uint8_t *buf, int64_t cap, int64_t *n);
 
 /* timing of the chain kernel (the dominant kernel) over the last pass_advance calls since
  * pass_begin, measured with HIP events on the engine's stream: total ms and launches */

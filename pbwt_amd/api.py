@@ -229,6 +229,60 @@ class Engine:
             out = _take(self._L, rp, n.value, MATCH_DTYPE)
         return out, nom.value, (tot[0], tot[1])
 
+    def match_sweep_stream(self, N, Mq, cols, on_records=None, pStart=None, qStart=None, panel_opts=0):
+        """matchSequencesSweep with both panels STREAMED from the device (pbwtamd_match_sweep_stream): cols(site0, ncols) -> (panel_ptr, query_ptr), device
+        addresses of `ncols` original-order bit columns of each panel from site0 on (valid until the next call); on_records(array of MATCH5_DTYPE) is
+        called per batch (the array is valid during the call) — None collects the records.  panel_opts: OPT_WITHIN_HIST | OPT_PACK3 | OPT_CHECKSUM feed
+        those consumers from the same pass.  Returns (records or None, n_nomatch, (nTot, totLen))"""
+        pa, qa = _i32(pStart), _i32(qStart)
+        kept, err = [], []
+
+        def _cols(user, site0, ncols, pp, qq):
+            try:
+                a, b = cols(int(site0), int(ncols))
+                pp[0] = C.c_void_p(int(a)); qq[0] = C.c_void_p(int(b))
+                return 0
+            except Exception as ex:                         # (never let an exception cross the C frame)
+                err.append(ex)
+                return 1
+
+        def _recs(user, rp, n):
+            try:
+                arr = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_int32)), shape=(int(n) * 5,)).view(MATCH5_DTYPE)
+                if on_records is None:
+                    kept.append(arr.copy())
+                else:
+                    on_records(arr)
+                return 0
+            except Exception as ex:
+                err.append(ex)
+                return 1
+
+        COLS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
+        RECS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+        nom = C.c_int64(0)
+        tot = (C.c_int64 * 2)()
+        cf, rf = COLS_FN(_cols), RECS_FN(_recs)
+        rc = self._L.pbwtamd_match_sweep_stream(self._h, C.c_int(N), _p(pa, C.c_int32), C.c_int(Mq), _p(qa, C.c_int32), cf, rf, None, C.c_uint(panel_opts),
+                                                C.byref(nom), tot)
+        if err:
+            raise err[0]
+        self._chk(rc)
+        out = None
+        if on_records is None:
+            out = np.concatenate(kept) if kept else np.zeros(0, MATCH5_DTYPE)
+        return out, nom.value, (tot[0], tot[1])
+
+    def drain_packed(self, buf=None):
+        """the pack3 bytes written since pass_begin / the previous drain, out of the engine (pbwtamd_drain_packed): into `buf` (uint8 array, reused by the
+        caller) or a fresh array; returns the array view of the bytes"""
+        n = C.c_int64(0)
+        self._chk(self._L.pbwtamd_drain_packed(self._h, None, C.c_int64(0), C.byref(n)))
+        if buf is None or buf.size < n.value:
+            buf = np.empty(max(n.value, 1), np.uint8)
+        self._chk(self._L.pbwtamd_drain_packed(self._h, _p(buf, C.c_uint8), C.c_int64(buf.size), C.byref(n)))
+        return buf[: n.value]
+
     def set_query_range(self, lo, hi=0):
         """query sweeps process the queries lo <= jj < hi only and tag records with the query's PBWT rank (sparse >> 1); lo < 0: all"""
         self._chk(self._L.pbwtamd_set_query_range(self._h, C.c_int(lo), C.c_int(hi)))

@@ -231,6 +231,51 @@ def test_match_sweep_vs_oracle(amd, orc, Mp, Mq, N, kind, batch):
     assert got == [tuple(r) for r in want.tolist()]
 
 
+@pytest.mark.parametrize("Mp,Mq,N,kind,batch,popts", [(5, 3, 40, 1, 16, 0), (700, 90, 300, 0, 64, 0), (3000, 400, 501, 0, 128, 1), (20000, 64, 136, 1, 64, 1), (70001, 33, 96, 0, 32, 1),
+                                                      (150600, 20, 48, 0, 16, 0)])
+def test_match_sweep_stream_vs_oracle(amd, orc, Mp, Mq, N, kind, batch, popts):
+    """matchSequencesSweep STREAMED (pbwtamd_match_sweep_stream): neither panel is packed or uploaded — the library asks a callback for the original-order
+    bit columns of both panels a batch at a time (device pointers) and hands every batch's records to another.  Records, no-match count and totals equal
+    the oracle's; with panel_opts the SAME pass also feeds the -stats histogram and pack3 (drained piece by piece: the pieces concatenate to the .pbwt
+    payload), and a ragged last batch (N = 501) takes the fallback chains."""
+    import torch
+    bits = orc.synth_bitcols(Mp + Mq, N, seed=77 + Mp, kind=kind)
+    hap = orc.unpack_bitcols(bits, Mp + Mq)
+    pb = np.ascontiguousarray(orc.pack_bitcols(hap[:, :Mp])); qb = np.ascontiguousarray(orc.pack_bitcols(hap[:, Mp:]))
+    op = orc.build_bitcols(pb, Mp, with_d=True)
+    qz = orc.build_bitcols(qb, Mq, with_d=False)["yz"]
+    want, w_nomatch, w_tot = orc.match_sweep(op["yz"], Mp, qz, Mq, N)
+    eng = amd.Engine(Mp, batch_sites=batch)
+    dp = torch.from_numpy(pb.view(np.int32)).cuda(); dq = torch.from_numpy(qb.view(np.int32)).cuda()
+    torch.cuda.synchronize()
+    assert pb.shape[1] == eng.wpc and qb.shape[1] == amd.wpc_for(Mq)
+    asked, pieces = [], []
+    opts = (amd.OPT_WITHIN_HIST | amd.OPT_PACK3) if popts else 0
+
+    def cols(site0, ncols):
+        asked.append((site0, ncols))
+        assert site0 + ncols <= N
+        if popts and site0:
+            pieces.append(eng.drain_packed().copy())        # the bytes of the batches before this one leave the engine here
+        return dp.data_ptr() + site0 * eng.wpc * 4, dq.data_ptr() + site0 * qb.shape[1] * 4
+
+    recs, nomatch, tot = eng.match_sweep_stream(N, Mq, cols, panel_opts=opts)
+    assert [a for a, _ in asked] == list(range(0, N, batch))
+    got = np.zeros(len(recs), amd.MATCH_DTYPE)
+    for f in ("ai", "bi", "start", "end"):
+        got[f] = recs[f]
+    assert np.all(recs["sparse"] == 0)
+    assert np.array_equal(got, want)
+    assert nomatch == w_nomatch and tuple(tot) == tuple(w_tot)
+    if popts:
+        pieces.append(eng.drain_packed().copy())
+        assert np.array_equal(np.concatenate(pieces), op["yz"]), "the drained pieces are not the .pbwt payload"
+        assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(op["yz"], Mp, N)[: N + 1])
+    chunks = []
+    eng.match_sweep_stream(N, Mq, cols, on_records=lambda a: chunks.append(len(a)))     # records delivered batch by batch, nothing kept by the library
+    assert sum(chunks) == len(want)
+
+
 def test_haplotypes_and_y_dump(amd, orc):
     M, N = 1234, 77
     bits = orc.synth_bitcols(M, N, seed=8, kind=0)
