@@ -566,6 +566,10 @@ def run_posshard(args, torch, pdist, pbwt_amd, dev, rank, world):
 
 def main():
     args = parse()
+    # before torch initialises HIP: the launching thread and the runtime's helper threads on the physical cores of the GPU's NUMA node (pbwt_amd/pin.py; the
+    # "slow mode" — one fresh process in five 10 % slower — follows their placement).  PBWTAMD_PIN=0: off
+    from pbwt_amd.pin import pin_for_gpu
+    pinned_cpus = pin_for_gpu(int(os.environ.get("LOCAL_RANK", "0")))
     import torch
     from pbwt_amd import dist as pdist
     rank, local, world = pdist.env_world()
@@ -694,6 +698,8 @@ def main():
                      "latency_bound_frac": latency_bound(alg_bytes_per_launch, us_per_launch)["latency_bound_frac"],
                      "note": "one launch = sites_per_launch sites; duration = HIP-event time of the dependent launch chain / launches, i.e. including launch gaps"},
         "within_reports_hist_total": int(hist.sum()),
+        "launch_us_level_warmup": 1e3 * ms_w / max(n_w, 1),      # the chain's us per launch over the warm-up steps (the slow mode shows here first: 4.3 against 3.9 at three launches per round)
+        "pinned_cpus": (len(pinned_cpus) if pinned_cpus else 0),
     }
     if hep:
         out["host_entry_points"] = hep

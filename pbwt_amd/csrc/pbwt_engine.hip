@@ -171,6 +171,7 @@ struct ShardCtx {
 
 struct pbwtamd_engine {
     int device = 0, M = 0, Mpad = 0, wpc = 0, wpc64 = 0, W = 0, wpad = 0, E = 4, T = 1024, B = 0;
+    bool pinned = false;                    // this engine holds a count of pin_first_engine
     hipStream_t stream = nullptr; bool own_stream = false;   // the launch chain
     hipStream_t s2 = nullptr;                                 // batch consumers
     hipEvent_t evChain[2] = {nullptr, nullptr}, evCons[2] = {nullptr, nullptr}; bool consRecorded[2] = {false, false}, chainRecorded[2] = {false, false};
@@ -245,6 +246,67 @@ struct pbwtamd_engine {
     ShardCtx *sh = nullptr;          // position sharding across GPUs (pbwt_shard.inc): this engine is one rank of a panel
 };
 
+// ------------------------------------------------------------------------------------ CPU placement of the launching thread
+// About one fresh process in five ran the 100 k chain 10-11 % slower as a whole (every launch 4.3 instead of 3.9 us): it follows where the launching thread and
+// the HIP runtime's helper threads run (tools/slowmode.sh: 5 of 16 unpinned processes slow, 0 of 20 under taskset on the physical cores of one socket), and an
+// affinity set AFTER the runtime's threads exist does not confine them.  So the first pbwtamd_engine_create of a process — before its first HIP call — confines
+// the calling thread, and with it every thread the runtime creates, to the physical cores (one hardware thread per core) of the NUMA node the GPU hangs off; the
+// calling thread's own mask is restored when the process's last engine is destroyed.  PBWTAMD_PIN=0: off.  (A host that initialised HIP before — PyTorch — pins
+// itself first: pbwt_amd/pin.py, as bench.py does.)
+#include <sched.h>
+#include <dirent.h>
+static std::mutex g_pin_mu;
+static int g_pin_engines = 0; static bool g_pin_active = false; static cpu_set_t g_pin_old;
+static bool read_small(const char *path, char *buf, size_t n) { FILE *f = fopen(path, "r"); if (!f) return false; const bool ok = fgets(buf, (int)n, f) != nullptr; fclose(f); return ok; }
+static void cpulist_to_set(const char *txt, cpu_set_t *set) {
+    CPU_ZERO(set);
+    for (const char *p = txt; p && *p;) {
+        char *end; const long a = strtol(p, &end, 10); if (end == p) break;
+        long b = a; if (*end == '-') { p = end + 1; b = strtol(p, &end, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) CPU_SET((int)c, set);
+        p = (*end == ',') ? end + 1 : end; if (*end != ',') break;
+    }
+}
+static void pin_first_engine(int device) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (g_pin_engines++ > 0) return;
+    if (const char *s = getenv("PBWTAMD_PIN")) if (!atoi(s)) return;
+    int node = -1, seen = 0;
+    if (DIR *d = opendir("/sys/class/drm")) {               // the device-th AMD card (PCI vendor 0x1002), in name order as far as readdir gives it
+        std::vector<std::string> cards;
+        while (dirent *de = readdir(d)) if (!strncmp(de->d_name, "card", 4) && !strchr(de->d_name, '-')) cards.push_back(de->d_name);
+        closedir(d);
+        std::sort(cards.begin(), cards.end());
+        for (const std::string &c : cards) {
+            char buf[64];
+            if (!read_small(("/sys/class/drm/" + c + "/device/vendor").c_str(), buf, sizeof buf) || strncmp(buf, "0x1002", 6)) continue;
+            if (seen++ == device || node < 0) { if (read_small(("/sys/class/drm/" + c + "/device/numa_node").c_str(), buf, sizeof buf)) node = atoi(buf); }
+            if (seen > device) break;
+        }
+    }
+    cpu_set_t cand; char txt[4096];
+    bool have = false;
+    if (node >= 0) { char path[128]; snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node); if (read_small(path, txt, sizeof txt)) { cpulist_to_set(txt, &cand); have = CPU_COUNT(&cand) > 0; } }
+    if (!have && read_small("/sys/devices/system/cpu/online", txt, sizeof txt)) { cpulist_to_set(txt, &cand); have = CPU_COUNT(&cand) > 0; }
+    if (!have || sched_getaffinity(0, sizeof g_pin_old, &g_pin_old) != 0) return;
+    cpu_set_t want; CPU_ZERO(&want);
+    for (int c = 0; c < CPU_SETSIZE; ++c) {
+        if (!CPU_ISSET(c, &cand) || !CPU_ISSET(c, &g_pin_old)) continue;
+        char path[128]; snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+        cpu_set_t sib; bool first = true;
+        if (read_small(path, txt, sizeof txt)) { cpulist_to_set(txt, &sib); for (int q = 0; q < c; ++q) if (CPU_ISSET(q, &sib)) { first = false; break; } }
+        if (first) CPU_SET(c, &want);                       // one hardware thread per core
+    }
+    if (CPU_COUNT(&want) < 2) return;                       // (a narrow cpuset: leave it alone)
+    if (sched_setaffinity(0, sizeof want, &want) == 0) g_pin_active = true;
+}
+static void unpin_last_engine() {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (--g_pin_engines > 0) return;
+    g_pin_engines = 0;
+    if (g_pin_active) { (void)sched_setaffinity(0, sizeof g_pin_old, &g_pin_old); g_pin_active = false; }
+}
+
 extern "C" int pbwtamd_abi_version(void) { return PBWTAMD_ABI_VERSION; }
 #ifdef PBWTAMD_WALKSTAT
 extern "C" int pbwtamd_measure_walkstat(unsigned long long *out, int reset) {      // measurement builds: the sweep's walk counters (pbwt_k_sweep.h: g_walkstat)
@@ -314,12 +376,16 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
                     e->blockCount, e->scal, e->hist, e->hist_rep, e->csum, e->recs, e->yz};
     for (void *p : ptrs) if (p) (void)dev_free(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    const bool pinned = e->pinned;
     delete e;
+    if (pinned) unpin_last_engine();
 }
 
 extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, int batch_sites, void *stream) {
     *out = nullptr;
     if (M < 1) return fail("pbwtamd_engine_create: M=%d", M);
+    pin_first_engine(device);                               // (before the first HIP call of this library: the runtime's threads inherit the mask)
+    struct PinGuard { bool keep = false; ~PinGuard() { if (!keep) unpin_last_engine(); } } pinGuard;      // a create that fails gives its count back
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail("pbwtamd: no HIP device available (this library has no CPU path)");
@@ -491,6 +557,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     ECHK(hipMemsetAsync(e->zerocol, 0, (size_t)e->wpc * sizeof(uint32_t), e->stream));
     ECHK(hipStreamSynchronize(e->stream));
 #undef ECHK
+    e->pinned = true; pinGuard.keep = true;                 // from here on pbwtamd_engine_destroy gives the count back
     *out = e;
     return 0;
 }
