@@ -4,7 +4,7 @@ import csv, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join("gpurun_out", tag)
 line = json.load(open(os.path.join(src, "bench.json")))
-CHAIN = ("skel_hist_kernel", "skel_k2_kernel", "skel_k2_local_kernel", "skel_k2_wide_kernel", "skel_rank_kernel", "skel_team_kernel")
+CHAIN = ("skel_hist_kernel", "skel_k2_kernel", "skel_k2_local_kernel", "skel_k2_wide_kernel", "skel_rank_kernel", "skel_team_kernel", "skel_onepass_kernel")
 stats = {}
 p = os.path.join(src, "trace", "bench_kernel_stats.csv")
 for r in csv.DictReader(open(p)):

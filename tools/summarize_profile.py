@@ -52,8 +52,8 @@ for p, k, c, n, m in rows:
     if k.startswith("calib_copy4"):
         cal[c] = (256 << 20) * 4 / 1024.0 / m                      # known bytes (1 GiB copy, 4 B/lane) / reported KiB
 cf, cw = cal.get("FETCH_SIZE", 2.0), cal.get("WRITE_SIZE", 1.0)
-CHAIN = ("skel_hist_kernel", "skel_k2_kernel", "skel_k2_local_kernel", "skel_k2_wide_kernel", "skel_rank_kernel", "skel_team_kernel")
-CONS = ("skel_fill_kernel", "skel_fillseq_kernel", "skel_fillprep_kernel", "sweep_hist_kernel", "p3r_scan_kernel", "p3r_combine_kernel", "p3r_emit_kernel", "transpose32_kernel")
+CHAIN = ("skel_hist_kernel", "skel_k2_kernel", "skel_k2_local_kernel", "skel_k2_wide_kernel", "skel_rank_kernel", "skel_team_kernel", "skel_onepass_kernel")
+CONS = ("skel_totals_kernel", "skel_fill_kernel", "skel_fillseq_kernel", "skel_fillprep_kernel", "sweep_hist_kernel", "p3r_scan_kernel", "p3r_combine_kernel", "p3r_emit_kernel", "transpose32_kernel")
 
 
 def counters(passname, counter, names):
@@ -110,7 +110,7 @@ with open(os.path.join("profiles", tag + "_traffic.txt"), "w") as f:
                 % (tot / 1e6, sites, tot / 1e6 / sites, 16.125 * M / 1e6, tot / alg))
         if chain_launches:
             f.write("  chain: %.0f bytes per launch (%d launches)\n\n" % (chain_bytes / chain_launches, chain_launches))
-            result[str(M)] = {"with_d": True, "kernel": "skeleton chain (skel_hist/k2/rank), mean over the launches of a round",
+            result[str(M)] = {"with_d": True, "kernel": "the chain's launches, mean (one-launch round: skel_onepass_kernel; wider panels: skel_hist / k2 / rank)",
                               "bytes_per_launch": int(chain_bytes / chain_launches),
                               "source": "profiles/%s_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x%.1f per the calibration kernel tools/pmc_calib.hip)" % (tag, cf)}
     if result:
