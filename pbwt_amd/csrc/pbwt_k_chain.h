@@ -797,24 +797,37 @@ __device__ __forceinline__ bool sk1_fold_rows(const unsigned long long *base, in
 }
 
 // totals of every round of a batch: tot[r * strideT + key] = number of entries of src[r * strideSrc + 0 .. M) equal to key.  src = the byte planes of the
-// transposed panel (keys by haplotype, build side) or the rounds' key rows (by position, read side).  grid (chunks of 65536 entries, rounds); more than one
+// transposed panel (keys by haplotype, build side) or the rounds' key rows (by position, read side).  grid (chunks of SKTOT_CHUNK entries, rounds); more than one
 // chunk per round: atomics onto totals zeroed by skel_totals_zero_kernel.
 __global__ __launch_bounds__(BLOCK) void skel_totals_zero_kernel(int *tot, size_t strideT) { tot[(size_t)blockIdx.x * strideT + threadIdx.x] = 0; }
+constexpr int SKTOT_CHUNK = 16384;                          // entries per workgroup: 64 bytes per thread, all four 16-byte loads in flight
 __global__ __launch_bounds__(BLOCK) void skel_totals_kernel(const unsigned char *src, size_t strideSrc, int M, int *tot, size_t strideT) {
     __shared__ int h[WAVES][SKK];                           // a private histogram per wave: LDS atomics of different waves do not collide
     const int t = threadIdx.x, wv = wave_id(), r = blockIdx.y;
     const unsigned char *p = src + (size_t)r * strideSrc;
     for (int x = t; x < WAVES * SKK; x += BLOCK) (&h[0][0])[x] = 0;
+    const int lo = blockIdx.x * SKTOT_CHUNK, hi = min(M, lo + SKTOT_CHUNK);
+    uint4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int i0 = lo + (q * BLOCK + t) * 16; v[q] = (i0 < hi) ? *reinterpret_cast<const uint4 *>(p + i0) : make_uint4(0, 0, 0, 0); }   // rows are padded to 4096 entries: whole 16-byte pieces
     lds_barrier();
-    const int lo = blockIdx.x * 65536, hi = min(M, lo + 65536);
-    for (int i0 = lo + t * 16; i0 < hi; i0 += BLOCK * 16) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(p + i0);                      // rows are padded to 4096 entries: whole 16-byte pieces
-        const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+    // the all-zero key (most positions of a real panel: a site's minor allele is rare) is counted in a register — same-address LDS atomics serialise; only the
+    // other keys go through the LDS histogram
+    int zeros = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 4; ++q) {
+        const int i0 = lo + (q * BLOCK + t) * 16;
+        const unsigned wd[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
-            for (int b = 0; b < 4; ++b) if (i0 + 4 * q + b < hi) atomicAdd(&h[wv][(wd[q] >> (8 * b)) & 0xffu], 1);
+        for (int j = 0; j < 4; ++j) {
+            const int n = min(max(hi - (i0 + 4 * j), 0), 4);  // entries of this word inside the panel
+            if (wd[j] == 0u) { zeros += n; continue; }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { if (b >= n) break; const unsigned ky = (wd[j] >> (8 * b)) & 0xffu; if (ky) atomicAdd(&h[wv][ky], 1); else ++zeros; }
+        }
     }
+    const int wz = wave_sum(zeros);
+    if (lane_id() == 0 && wz) atomicAdd(&h[wv][0], wz);
     lds_barrier();
     const int c = h[0][t] + h[1][t] + h[2][t] + h[3][t];
     if (gridDim.x == 1) tot[(size_t)r * strideT + t] = c;
