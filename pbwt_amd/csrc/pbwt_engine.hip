@@ -162,7 +162,7 @@ struct ShardCtx {
     bool connected = false;
     int *SA = nullptr, *SD = nullptr; size_t nslot = 0;       // the skeleton ring: 2 rings of B/8+1 slots, a and d of the states 0, 8, 16, ... of a batch
     int2 *tbl = nullptr, *scan = nullptr; int *total = nullptr;              // chain scratch, rows indexed by global tile
-    unsigned long long *agg = nullptr; unsigned *cnt = nullptr; unsigned cntEpoch = 0;
+    unsigned long long *agg = nullptr; unsigned *cnt = nullptr; unsigned cntEpoch = 0; int2 *aggx = nullptr;   // two-level tile scan of the rank's tiles; aggx: one exclusive row per scan workgroup (skel_k2s_local_kernel)
     unsigned e1 = 0, e2 = 0, e3 = 0;                          // epochs of f1 / f2 / f3
     int2 *ctbl = nullptr; unsigned long long *cagg = nullptr; unsigned *ccnt = nullptr; unsigned cEpoch = 0;   // consumer stream: hist rows + two-level scan state
     std::vector<long long> blkSite0, blkSites; unsigned long long *blkEnd = nullptr; size_t blkCap = 0;          // pack3 blocks this rank wrote

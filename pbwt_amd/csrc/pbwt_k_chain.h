@@ -536,6 +536,82 @@ __global__ __launch_bounds__(SKK) void skel_k2s_kernel(Sk2SArgs g, ShardPeers P)
     if (j == 0) g.total[t] = tot;
 }
 
+// The same scan WITHOUT waiting workgroups (round 5; the form skel_k2_local_kernel gave the plain engine in round 4): every workgroup writes the prefixes LOCAL to
+// itself in its one pass over its rows, publishes its aggregate and arrives; only the LAST arriver goes on — it folds the workgroups' aggregates into the RANK's row,
+// publishes that to every rank and raises f1, waits (bounded) for the other ranks' rows, and leaves one exclusive row per workgroup in aggx — the fold of the
+// rows of the ranks before this one and of this rank's workgroups before it — plus the totals over ALL ranks.  The rank launch folds aggx[(tile - w0) / TPW] in
+// front of its row (sk_fold_aggx).  One workgroup of the launch waits for the peers instead of all of them (22 us -> 8 us per round with one rank at 1 M).
+template <int TPW, int CH = 16>
+__global__ __launch_bounds__(SKK) void skel_k2s_local_kernel(Sk2SArgs g, ShardPeers P, int2 *aggx) {
+#ifndef PBWT_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    __shared__ int s_last;
+    const int t = threadIdx.x, j = blockIdx.x, r0 = j * TPW;
+    int lc = 0, lt = 0;                                      // running local prefix for key t
+#pragma unroll 1
+    for (int x0 = 0; x0 < TPW; x0 += CH) {
+        int2 v[CH];
+#pragma unroll
+        for (int x = 0; x < CH; ++x) v[x] = (r0 + x0 + x < g.Wl) ? g.tbl[(size_t)(g.w0 + r0 + x0 + x) * SKK + t] : make_int2(0, 0);
+#pragma unroll
+        for (int x = 0; x < CH; ++x) {
+            if (r0 + x0 + x < g.Wl) g.scan[(size_t)(g.w0 + r0 + x0 + x) * SKK + t] = make_int2(lc, lt);
+            lt = v[x].x ? v[x].y : max(lt, v[x].y); lc += v[x].x;
+        }
+    }
+    __hip_atomic_store(g.agg + (size_t)j * SKK + t, ((unsigned long long)(unsigned)lt << 32) | (unsigned)lc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) s_last = (__hip_atomic_fetch_add(g.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == g.target) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    const int nwg = (int)gridDim.x;                          // <= 64
+    int rc = 0, rt = 0;                                      // this rank's row: the fold of its workgroups' aggregates
+#pragma unroll 1
+    for (int i0 = 0; i0 < nwg; i0 += 16) {
+        unsigned long long pv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[i] = (i0 + i < nwg) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32); rt = vc ? vt : max(rt, vt); rc += vc; }
+    }
+    const unsigned long long row = ((unsigned long long)(unsigned)rt << 32) | (unsigned)rc;
+    for (int p = 0; p < P.n; ++p) __hip_atomic_store(&P.x[p]->ragg[P.me][t], row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __atomic_thread_fence(__ATOMIC_RELEASE);                // system scope: the row is out before the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t < P.n) __hip_atomic_store(&P.x[t]->f1[P.me], g.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    shard_wait_flags(P.x[P.me]->f1, P.x[P.me]->perr, P.n, g.epoch, g.err, 7);      // every rank's row of this round (bounded; this rank's own among them)
+    __syncthreads();
+    if (__hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // incomplete rows: no aggregates (the rank launch sees the error word and scatters nothing)
+    int ec = 0, et = 0, tot = 0;
+    {
+        unsigned long long rv[SHARD_MAX];
+#pragma unroll
+        for (int r = 0; r < SHARD_MAX; ++r) rv[r] = (r < P.n) ? __hip_atomic_load(&P.x[P.me]->ragg[r][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ULL;
+#pragma unroll
+        for (int r = 0; r < SHARD_MAX; ++r) {
+            const int vc = (int)(unsigned)rv[r], vt = (int)(rv[r] >> 32);
+            tot += vc;
+            if (r < P.me) { et = vc ? vt : max(et, vt); ec += vc; }
+        }
+    }
+#pragma unroll 1
+    for (int i0 = 0; i0 < nwg; i0 += 16) {                   // (the aggregates again: L2)
+        unsigned long long pv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pv[i] = (i0 + i < nwg) ? __hip_atomic_load(g.agg + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (i0 + i < nwg) aggx[(size_t)(i0 + i) * SKK + t] = make_int2(ec, et);
+            const int vc = (int)(unsigned)pv[i], vt = (int)(pv[i] >> 32);
+            et = vc ? vt : max(et, vt); ec += vc;
+        }
+    }
+    g.total[t] = tot;
+}
+
 // PULL: the consumer of rounds s0 .. s0+ns-1 of a batch copies those skeleton states (a, d, keys) out of every rank's skeleton
 // ring — the range each rank owns — into slots slot_step * s of its own full ring.  grid (chunks, ns, ranks); 16 bytes per
 // thread and array.  slot_step == 0 (with ns == 1): skeleton slot s0 into slot 0.
@@ -613,7 +689,7 @@ __device__ __forceinline__ void skel_rank_body(const SkArgs &g, const SkShardOut
     } else {
         const int srow = g.pair ? (w >> 1) : w;
         int2 sv = skm_ld2<MODE>(g.scan + (size_t)srow * SKK + t);
-        if (g.aggx) sv = sk_fold_aggx(skm_ld2<MODE>(g.aggx + (size_t)(srow / g.aggx_tpw) * SKK + t), sv);      // (both loads in flight together)
+        if (g.aggx) sv = sk_fold_aggx(skm_ld2<MODE>(g.aggx + (size_t)((srow - g.w0) / g.aggx_tpw) * SKK + t), sv);      // (both loads in flight together; w0 = 0 outside the sharded chain, which has no pair rows)
         if (g.pair && (w & 1)) {                            // second tile of its pair: fold the first one's row in
             const int2 r0 = skm_ld2<MODE>(g.tbl0 + (size_t)(w >> 1) * SKK + t);
             sv.y = r0.x ? r0.y : (sv.x ? max(sv.y, r0.y) : -1);

@@ -161,23 +161,25 @@ def test_position_sharded_step_on_device_tensors_over_rccl(tmp_path):
     assert res["ok"] and res["ok8"]
 
 
-@pytest.mark.parametrize("world,M,N,B,kind,step,csum", [
-    (2, 30000, 1024, 256, 0, 8192, 1),        # 256-position tiles (M <= 56 k), four batches: both rings reused
-    (3, 5000, 520, 128, 1, 200, 1),           # iid panel, ragged advance calls: replicated (non-multiple-of-8) batches between sharded ones
-    (2, 100000, 1024, 512, 0, 8192, 0),       # configs[2]'s width on the bench option set (packed fill: no checksums)
-    (3, 70000, 776, 512, 0, 8192, 1),         # N not a multiple of 8: the tail runs replicated
-    (2, 1000000, 1024, 512, 0, 8192, 0),      # BASELINE configs[3]'s width (1 M haplotypes), bench option set, two ranks, two batches
-    (3, 1000000, 264, 128, 0, 8192, 1),       # the same width on three ranks with every site's checksum
-    (4, 70000, 264, 128, 0, 8192, 1),         # world 4: 137 tiles of 512 positions -> 34-35 tiles per rank, four ranks' rows folded in front of the last
-    (8, 70000, 136, 64, 0, 8192, 1),          # world 8 = SHARD_MAX: all eight entries of pb[] / tb[], the 7-compare owner search, 8 exchange rows, one round per rank and batch
-    (8, 300000, 72, 64, 1, 8192, 0),          # world 8, iid panel on the bench option set (packed fill), 586 tiles: 73-74 per rank
+@pytest.mark.parametrize("world,M,N,B,kind,step,csum,k2s_local", [
+    (3, 70000, 776, 512, 0, 8192, 1, "0"),    # PBWTAMD_K2S_LOCAL=0: the two-pass tile scan with waiting workgroups (the form before round 5)
+    (2, 100000, 1024, 512, 0, 8192, 0, "0"),
+    (2, 30000, 1024, 256, 0, 8192, 1, "1"),        # 256-position tiles (M <= 56 k), four batches: both rings reused
+    (3, 5000, 520, 128, 1, 200, 1, "1"),           # iid panel, ragged advance calls: replicated (non-multiple-of-8) batches between sharded ones
+    (2, 100000, 1024, 512, 0, 8192, 0, "1"),       # configs[2]'s width on the bench option set (packed fill: no checksums)
+    (3, 70000, 776, 512, 0, 8192, 1, "1"),         # N not a multiple of 8: the tail runs replicated
+    (2, 1000000, 1024, 512, 0, 8192, 0, "1"),      # BASELINE configs[3]'s width (1 M haplotypes), bench option set, two ranks, two batches
+    (3, 1000000, 264, 128, 0, 8192, 1, "1"),       # the same width on three ranks with every site's checksum
+    (4, 70000, 264, 128, 0, 8192, 1, "1"),         # world 4: 137 tiles of 512 positions -> 34-35 tiles per rank, four ranks' rows folded in front of the last
+    (8, 70000, 136, 64, 0, 8192, 1, "1"),          # world 8 = SHARD_MAX: all eight entries of pb[] / tb[], the 7-compare owner search, 8 exchange rows, one round per rank and batch
+    (8, 300000, 72, 64, 1, 8192, 0, "1"),          # world 8, iid panel on the bench option set (packed fill), 586 tiles: 73-74 per rank
 ])
-def test_position_sharded_chain_ranks_one_gpu(world, M, N, B, kind, step, csum, tmp_path):
+def test_position_sharded_chain_ranks_one_gpu(world, M, N, B, kind, step, csum, k2s_local, tmp_path):
     """BASELINE configs[3]'s device path at small widths: `world` processes on one GPU, each owning a range of positions of the
     sorted order (hipIpc peer stores for the scatter, flag barriers per round), consumers sharded by site inside every batch;
     every site's a/d checksum, the summed histogram, the interleaved pack3 bytes and the final state equal the oracle's"""
     env = dict(os.environ, OUT_DIR=str(tmp_path), PS_M=str(M), PS_N=str(N), PS_B=str(B), PS_KIND=str(kind), PS_STEP=str(step), PS_CSUM=str(csum),
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", PBWTAMD_K2S_LOCAL=k2s_local)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "posshard_worker.py")],
                        capture_output=True, text=True, env=env, timeout=900)
