@@ -318,7 +318,7 @@ def many_panels(torch, pbwt_amd, dev, opts, kind, M, P=2, sites=32768, batch=512
         e.close()
     return {"panels": P, "haplotypes_per_panel": M, "sites_timed": sites, "value": P * M * sites / dt, "unit": "site*haps/s over all panels",
             "us_per_site_per_panel": 1e6 * dt / sites / P, "us_per_site_all_panels": 1e6 * dt / sites, "within_reports_hist_total": tot,
-            "note": "pbwtamd_pass_advance_many: six panels or more — the team-persistent chain, one launch per batch, panel p on XCD p; fewer — every launch of the chain covers all panels (grid.y = panel); consumers per panel"}
+            "note": "pbwtamd_pass_advance_many: whole sets of eight panels — the team-persistent chain, one launch per batch, panel p on XCD p; otherwise — every launch of the chain covers all panels (grid.y = panel); consumers per panel"}
 
 
 def match_dynamic(torch, pbwt_amd, dev, kind, M=1000000, Q=10000, sites=65536, batch=512):

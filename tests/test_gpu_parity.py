@@ -685,8 +685,8 @@ def test_many_panels_per_launch(amd, orc, P, M, N, B, team, monkeypatch):
     # team = "1": panel p on XCD p, all rounds of a batch in one launch (skel_team_kernel), eight panels at a time (the 11-panel case: 8 + 3)
     if team == "1" and (M <= 12288 or M > 139000):
         pytest.skip("the team form takes the widths of the three-launch round without pair rows")
-    if team == "auto":                                      # the shipped choice: the one-launch round with grid.y = panel, the team form from six panels on
-        if P < 6:
+    if team == "auto":                                      # the shipped choice: the one-launch round with grid.y = panel, the team form for whole sets of eight panels
+        if P % 8:
             pytest.skip("as the onepass case")
         monkeypatch.delenv("PBWTAMD_TEAM", raising=False); monkeypatch.delenv("PBWTAMD_ONEPASS", raising=False); monkeypatch.delenv("PBWTAMD_ONEPASS_MAXW", raising=False)
     else:
