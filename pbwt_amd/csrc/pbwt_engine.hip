@@ -179,6 +179,7 @@ struct pbwtamd_engine {
     int qs_bsum_sites[2] = {0, 0};          // ... and how many leading sites of the ring's batch they have summarised so far
     SkArgs *margs = nullptr, *margs_host = nullptr; size_t margs_cap = 0; int margs_half = 0; hipEvent_t evMargs[2] = {nullptr, nullptr};   // pbwtamd_pass_advance_many (panel 0 owns them)
     // the one-launch round (skel_onepass_kernel; PBWTAMD_ONEPASS): tagged row / group-row granules, tiles per group, launches so far (the tag)
+    bool op_ordered = false;               // one-launch round with tile = workgroup index (no XCD-contiguous dealing): see skel_round_args
     bool onepass = false; unsigned long long *op_rows = nullptr, *op_grows = nullptr; int op_g1 = 0; unsigned op_epoch = 0; unsigned long long *op_prof = nullptr;
     unsigned long long *teamprof = nullptr;                 // PBWTAMD_TEAM_PROF=1: member 0's wall-clock stamps per round and phase
     unsigned *teamctl = nullptr; unsigned team_round = 0; int team_cap = 0;   // team-persistent chain (skel_team_kernel): tickets + flag words per XCD, barriers passed so far (the first engine of a group owns them)
@@ -491,6 +492,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
                 if (r1 != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
                 if ((long long)std::min(per_cu, 6) * ncu < e->Wt) e->onepass = false;      // (6: what the hardware admits of a kernel with ~100 SGPRs whatever the API says)
             }
+            e->op_ordered = env_int("PBWTAMD_ONEPASS_ORDERED", 0) != 0;
             if (e->onepass) { e->op_g1 = 1; while (e->op_g1 * e->op_g1 < e->Wt) ++e->op_g1; }     // groups of ceil(sqrt(W)) tiles: as many groups as tiles per group
             e->W2 = (e->Wt + 1) / 2;
             static const int prow_min = tune_env("PBWTAMD_PROW_MIN") ? atoi(tune_env("PBWTAMD_PROW_MIN")) : 136;
