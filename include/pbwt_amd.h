@@ -274,7 +274,7 @@ int pbwtamd_get_chain_sites(pbwtamd_engine *e, int64_t *sites);   /* sites those
  * Afterwards every rank holds the complete final state (pbwtamd_get_state); the histogram and the per-site checksums of a
  * rank cover the sites it consumed — sum them over the ranks; the pack3 bytes of a rank are the blocks of sites
  * pbwtamd_shard_blocks lists, which concatenate in site order into PBWT.yz.  Several ranks may share one device (tests). */
-#define PBWTAMD_SHARD_HANDLE_BYTES 320
+#define PBWTAMD_SHARD_HANDLE_BYTES 576
 int pbwtamd_shard_init(pbwtamd_engine *e, int rank, int world, void *handles_out);
 int pbwtamd_shard_connect(pbwtamd_engine *e, const void *all_handles);
 /* positions [*pos_lo, *pos_hi) of the sorted order that `rank` owns */

@@ -11,7 +11,7 @@ MATCH_DTYPE = np.dtype([("ai", "<i4"), ("bi", "<i4"), ("start", "<i4"), ("end", 
 MATCH5_DTYPE = np.dtype([("ai", "<i4"), ("bi", "<i4"), ("start", "<i4"), ("end", "<i4"), ("sparse", "<i4")])
 REPORT5_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)
 REPORT_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_int, C.c_int)
-SHARD_HANDLE_BYTES = 320              # PBWTAMD_SHARD_HANDLE_BYTES
+SHARD_HANDLE_BYTES = 576              # PBWTAMD_SHARD_HANDLE_BYTES
 
 
 class PbwtAmdError(RuntimeError):

@@ -137,7 +137,7 @@ constexpr unsigned OPT_INTERNAL_KEEP_STATES = 0x100u;
 constexpr unsigned OPT_INTERNAL_D_ONLY = 0x200u;
 
 struct GraphKey { int with_d, sorted, ring, pair; hipGraphExec_t exec; };
-struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; bool skel = false; bool sharded = false; bool early = false; int flushed = 0; /* leading sites whose consumers are enqueued already */ const uint32_t *cols = nullptr; /* the batch's bit columns */ };
+struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; bool skel = false; bool sharded = false; bool shard_tables = false; /* sharded batch whose tile tables were pulled from the chain (rows per tile, no pair rows) */ bool early = false; int flushed = 0; /* leading sites whose consumers are enqueued already */ const uint32_t *cols = nullptr; /* the batch's bit columns */ };
 
 // skeleton batches whose consumers need (d, y) of every site but not the haplotype ids (histogram sweep, pack3 through the
 // sweep's bit columns): the fill writes d | y << 31 and no a — half the consumer stream's bytes (they are what slows the chain)
@@ -158,6 +158,8 @@ struct ShardCtx {
     ShardXch *xch = nullptr; bool xch_ext = false;            // own exchange block
     volatile int *h_err = nullptr;                            // pinned host mirror of the engine's device error word (refreshed behind every throttle event)
     ShardPeers peers = {};                                    // every rank's exchange block as mapped here (own = xch)
+    int2 *aggxR[2] = {nullptr, nullptr};                     // per ring and round: the scan workgroups' exclusive rows (kept for the consumers)
+    int2 *peerS[2][SHARD_MAX] = {}, *peerX[2][SHARD_MAX] = {};   // every rank's saveR blocks and aggxR rows as mapped here
     int *peerA[SHARD_MAX] = {}, *peerD[SHARD_MAX] = {}; unsigned char *peerK[2][SHARD_MAX] = {};   // skeleton rings and key rows of every rank (own = this rank's)
     bool connected = false;
     int *SA = nullptr, *SD = nullptr; size_t nslot = 0;       // the skeleton ring: 2 rings of B/8+1 slots, a and d of the states 0, 8, 16, ... of a batch

@@ -4,5 +4,5 @@
 tag=${1:-r5s}; out=gpurun_out/$tag; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 2400 python -m pytest tests/test_gpu_multi.py -x -q -m gpu -k "position_sharded_chain" > $out/pytest.log 2>&1; tail -3 $out/pytest.log
-{ for L in 1 0; do echo "== PBWTAMD_K2S_LOCAL=$L"; PBWTAMD_K2S_LOCAL=$L bash tools/run_posshard_bench.sh 1 1000000 4; done
+{ for L in 1 0; do echo "== PBWTAMD_K2S_LOCAL=$L"; PBWTAMD_K2S_LOCAL=$L bash tools/run_posshard_bench.sh 1 1000000 4; done; echo "== tile tables recomputed by the consumers (PBWTAMD_SHARD_TABLES=0)"; PBWTAMD_SHARD_TABLES=0 bash tools/run_posshard_bench.sh 1 1000000 4
   echo "== plain engine, same width"; timeout 200 python tools/wide_bench.py 1000000 32768 hp 2>&1 | tail -1; } > $out/onerank.txt 2>&1; cat $out/onerank.txt
