@@ -427,7 +427,9 @@ __device__ __forceinline__ void shard_wait_flags(const unsigned *mine, const uns
     if (t < n) {
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
         long spins = 0;
-        while ((int)(__hip_atomic_load(mine + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+        // (relaxed polls: an acquire per poll is a buffer_inv per poll; what is read behind the wait is either read with system-scope atomics — the rows — or by the
+        // next kernel, whose start is the acquire)
+        while ((int)(__hip_atomic_load(mine + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
             __builtin_amdgcn_s_sleep(2);
             ++spins;
             if ((spins & 1023) == 0 && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
@@ -443,7 +445,9 @@ __global__ __launch_bounds__(64) void shard_xbar_kernel(ShardPeers P, int which,
         __hip_atomic_store(&P.x[t]->perr[P.me], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if ((mode & 1) && t < P.n) {
         unsigned *f = which == 0 ? P.x[t]->f1 : which == 1 ? P.x[t]->f2 : P.x[t]->f3;
-        __hip_atomic_store(f + P.me, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (relaxed: what the flag announces — the scatter of a round, the consumers' reads of a ring — was done by kernels that ENDED before this one started; a
+        // release here is a write-back of the whole L2 per flag kernel: 5.4 us per round with one rank at 1 M)
+        __hip_atomic_store(f + P.me, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (mode & 2) {
         const unsigned *f = which == 0 ? P.x[P.me]->f1 : which == 1 ? P.x[P.me]->f2 : P.x[P.me]->f3;
@@ -578,10 +582,11 @@ __global__ __launch_bounds__(SKK) void skel_k2s_local_kernel(Sk2SArgs g, ShardPe
     }
     const unsigned long long row = ((unsigned long long)(unsigned)rt << 32) | (unsigned)rc;
     for (int p = 0; p < P.n; ++p) __hip_atomic_store(&P.x[p]->ragg[P.me][t], row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __atomic_thread_fence(__ATOMIC_RELEASE);                // system scope: the row is out before the flag
+    // the row goes out as write-through system-scope stores; every storing wave drains them, then ONE relaxed flag store per peer (MI355X_MICROARCH.md, the
+    // drained-flag form) — no release fence: a system-scope release writes the whole L2 back, and nothing but the row has to be visible with the flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t < P.n) __hip_atomic_store(&P.x[t]->f1[P.me], g.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t < P.n) __hip_atomic_store(&P.x[t]->f1[P.me], g.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     shard_wait_flags(P.x[P.me]->f1, P.x[P.me]->perr, P.n, g.epoch, g.err, 7);      // every rank's row of this round (bounded; this rank's own among them)
     __syncthreads();
     if (__hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;      // incomplete rows: no aggregates (the rank launch sees the error word and scatters nothing)
