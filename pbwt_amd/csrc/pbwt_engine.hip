@@ -384,6 +384,9 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (pinned) unpin_last_engine();
 }
 
+// set by a caller inside the library around pbwtamd_engine_create: the engine will run the persistent small-panel chain (skel_persist_kernel: the query cursor
+// of the query sweeps), not the one-launch round — its tile geometry follows the two-launch round's rule
+static thread_local bool g_create_persist = false;
 extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, int batch_sites, void *stream) {
     *out = nullptr;
     if (M < 1) return fail("pbwtamd_engine_create: M=%d", M);
@@ -456,7 +459,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         if (M > 8192 && M <= 12288) e->skEPT = 2;
         // under the one-launch round (below) 256-position tiles stay ahead up to ~72 k haplotypes (with the bench consumers: 0.95 against 1.07 us/site at 10-12 k,
         // 1.13 / 1.21 at 60 k, 1.19 / 1.22 at 70 k; 1.42 / 1.25 at 80 k — profiles/r05_onepass.txt), and the 8 193-12 288 exception of the two-launch round goes
-        const bool want_onepass = env_int("PBWTAMD_ONEPASS", 1) != 0;
+        const bool want_onepass = env_int("PBWTAMD_ONEPASS", 1) != 0 && !g_create_persist;
         if (want_onepass && (M + 255) / 256 <= std::min(1024, env_int("PBWTAMD_ONEPASS_MAXW", 320))) e->skEPT = (M <= 72000) ? 1 : 2;
         if (const char *sv = tune_env("PBWTAMD_SKT")) e->skEPT = (atoi(sv) == 256) ? 1 : (atoi(sv) == 512) ? 2 : 4;
 
@@ -487,7 +490,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             // Measured (profiles/r05_onepass.txt, with the bench consumers): 1.02 against 1.39 us/site at 30 k haplotypes, 1.13 / 1.34 at 50 k, 1.37-1.43 / 1.56-1.68 at 100 k,
             // 1.69 / 1.83 at 150 k; 2.04 / 1.96 at 200 k, 2.45 / 2.12 at 250 k, 5.05 / 3.04 at 500 k (more tiles: longer look-backs, five workgroups per CU): on up to
             // 320 tiles (163 840 haplotypes).  PBWTAMD_ONEPASS=0: the three- / two-launch round; PBWTAMD_ONEPASS_MAXW=n: up to n <= 1024 tiles (tests)
-            e->onepass = env_int("PBWTAMD_ONEPASS", 1) != 0 && e->skEPT <= 2 && e->Wt <= std::min(1024, env_int("PBWTAMD_ONEPASS_MAXW", 320));
+            e->onepass = want_onepass && e->skEPT <= 2 && e->Wt <= std::min(1024, env_int("PBWTAMD_ONEPASS_MAXW", 320));
             if (e->onepass) {
                 int per_cu = 0, ncu = 0;
                 const hipError_t r1 = (e->skEPT == 1) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<1>, BLOCK, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<2>, BLOCK, 0);
