@@ -137,7 +137,13 @@ constexpr unsigned OPT_INTERNAL_KEEP_STATES = 0x100u;
 constexpr unsigned OPT_INTERNAL_D_ONLY = 0x200u;
 
 struct GraphKey { int with_d, sorted, ring, pair; hipGraphExec_t exec; };
-struct Pending { bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; bool skel = false; bool sharded = false; bool shard_tables = false; /* sharded batch whose tile tables were pulled from the chain (rows per tile, no pair rows) */ bool early = false; int flushed = 0; /* leading sites whose consumers are enqueued already */ const uint32_t *cols = nullptr; /* the batch's bit columns */ };
+struct Pending {
+    bool valid = false; int ring = 0, kbase = 0, nb = 0; unsigned opts = 0; bool skel = false; bool sharded = false;
+    bool shard_tables = false;              // sharded batch whose tile tables were pulled from the chain (rows per tile, no pair rows)
+    bool early = false;
+    int flushed = 0;                        // leading sites whose consumers are enqueued already
+    const uint32_t *cols = nullptr;         // the batch's bit columns
+};
 
 // skeleton batches whose consumers need (d, y) of every site but not the haplotype ids (histogram sweep, pack3 through the
 // sweep's bit columns): the fill writes d | y << 31 and no a — half the consumer stream's bytes (they are what slows the chain)
@@ -375,7 +381,9 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     for (int i = 0; i < 2; ++i) { if (e->evChain[i]) (void)hipEventDestroy(e->evChain[i]); if (e->evCons[i]) (void)hipEventDestroy(e->evCons[i]); if (e->evRounds[i]) (void)hipEventDestroy(e->evRounds[i]); }
     for (auto &g : e->graphs) (void)hipGraphExecDestroy(g.exec);
     for (auto &p : e->ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1], (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->fillGB[0], (void *)e->fillGB[1], (void *)e->p16r, (void *)e->wflags, (void *)e->nflag, (void *)e->rankdirS, (void *)e->skT, (void *)e->k2agg, (void *)e->k2cnt, e->cols_stage, e->ycols, e->colBytes, (void *)e->p3regs,
+    void *ptrs[] = {e->A, e->D, e->summ, e->ctl, (void *)e->ctlblk, (void *)e->prof, (void *)e->zerocol, (void *)e->ystale, (void *)e->xTr[0], (void *)e->xTr[1],
+                    (void *)e->keysR[0], (void *)e->keysR[1], (void *)e->saveR[0], (void *)e->saveR[1], (void *)e->fillGB[0], (void *)e->fillGB[1], (void *)e->p16r,
+                    (void *)e->wflags, (void *)e->nflag, (void *)e->rankdirS, (void *)e->skT, (void *)e->k2agg, (void *)e->k2cnt, e->cols_stage, e->ycols, e->colBytes, (void *)e->p3regs,
                     e->blockCount, e->scal, e->hist, e->hist_rep, e->csum, e->recs, e->yz};
     for (void *p : ptrs) if (p) (void)dev_free(p);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -514,7 +522,9 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
                 // Below 513 rows the one-level scan (skel_k2_kernel) stays ahead: 2.88 against 3.15 us/site at 500 k, 2.48 / 2.74 at 350 k, 1.90 / 2.28 at 200 k
                 // (PBWTAMD_K2_LOCAL_MIN=n, A/B and parity runs only: the local form from n + 1 rows on).
                 e->k2local = !e->onepass && rows > env_int("PBWTAMD_K2_LOCAL_MIN", 512) && rows <= env_int("PBWTAMD_K2_LOCAL_MAX", 1024) && env_int("PBWTAMD_K2_LOCAL", 1) != 0;
-                e->k2tpw = rows > 1024 ? 64 : 32;           // (16 rows per scan workgroup, twice the arrivals: 4.70 against 4.57 us/site at 1 M, 3.60 / 3.53 at 600 k; PBWTAMD_K2_LOCAL_MAX=2048, A/B: 64-row workgroups there — 6.34 against 6.36 us/site at 1.5 M, 8.20 against 8.04 at 2 M: not taken)
+                // (16 rows per scan workgroup, twice the arrivals: 4.70 against 4.57 us/site at 1 M, 3.60 / 3.53 at 600 k; PBWTAMD_K2_LOCAL_MAX=2048, A/B: 64-row
+                // workgroups there — 6.34 against 6.36 us/site at 1.5 M, 8.20 against 8.04 at 2 M: not taken)
+                e->k2tpw = rows > 1024 ? 64 : 32;
                 // the local form's capacity: aggx and k2agg hold 64 rows (one per scan workgroup), so rows <= 64 * k2tpw — odd PBWTAMD_K2_LOCAL_MIN / _MAX
                 // combinations fall back to the other scans instead of writing past them
                 if ((rows + e->k2tpw - 1) / e->k2tpw > 64) e->k2local = false;
@@ -582,7 +592,9 @@ extern "C" int pbwtamd_sync(pbwtamd_engine *e) {
     HIPCHK(hipStreamSynchronize(e->s2));
     int err = 0;
     HIPCHK(hipMemcpy(&err, e->ctl + 2, sizeof(int), hipMemcpyDeviceToHost));
-    if (err) return fail("pbwtamd: device-side error flag %d (1=histogram range, 2/3=malformed packed column, 4=yz buffer overflow, 5=tile scan of a wide panel timed out waiting for its workgroups, 6/7=a position-sharded rank timed out waiting for its peers, 9=a peer reported its own failure)", err);
+    if (err) return fail("pbwtamd: device-side error flag %d (1=histogram range, 2/3=malformed packed column, 4=yz buffer overflow, 5=tile scan of a wide panel timed out "
+                         "waiting for its workgroups, 6/7=a position-sharded rank timed out waiting for its peers, 9=a peer reported its own failure, 10=a team of the "
+                         "team-persistent chain did not fill, 11=a tile of the one-launch round timed out waiting for the tiles before it)", err);
     return 0;
 }
 
