@@ -188,7 +188,7 @@ struct pbwtamd_engine {
     SkArgs *margs = nullptr, *margs_host = nullptr; size_t margs_cap = 0; int margs_half = 0; hipEvent_t evMargs[2] = {nullptr, nullptr};   // pbwtamd_pass_advance_many (panel 0 owns them)
     // the one-launch round (skel_onepass_kernel; PBWTAMD_ONEPASS): tagged row / group-row granules, tiles per group, launches so far (the tag)
     bool op_ordered = false;               // one-launch round with tile = workgroup index (no XCD-contiguous dealing): see skel_round_args
-    bool op_lb = false;                     // ... with look-back waves (skel_onepass_lb_kernel: eight waves per tile; PBWTAMD_ONEPASS_LB)
+    bool op_folders = false;                // one-launch round: a folder workgroup per group publishes the group's aggregate (PBWTAMD_ONEPASS_FOLDERS=0: the group's last tile does)
     bool onepass = false; unsigned long long *op_rows = nullptr, *op_grows = nullptr; int op_g1 = 0; unsigned op_epoch = 0; unsigned long long *op_prof = nullptr;
     unsigned long long *teamprof = nullptr;                 // PBWTAMD_TEAM_PROF=1: member 0's wall-clock stamps per round and phase
     unsigned *teamctl = nullptr; unsigned team_round = 0; int team_cap = 0;   // team-persistent chain (skel_team_kernel): tickets + flag words per XCD, barriers passed so far (the first engine of a group owns them)
@@ -361,8 +361,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
                 for (int w = 0; w < e->Wt; ++w) {
                     fprintf(stderr, "[onepass tile] %4d", w);
                     for (int i : {0, 1, 5, 6, 2, 3, 4}) fprintf(stderr, " %6.2f", hp[(size_t)w * 8 + i] ? (double)(hp[(size_t)w * 8 + i] - t0) * 0.01 : -1.0);
-                    const unsigned long long x = hp[(size_t)w * 8 + 7];
-                    fprintf(stderr, "  | barriers with loads in flight %d, polls %d, failed %d + %d\n", (int)(x & 0xffff), (int)(x >> 48), (int)((x >> 16) & 0xffff), (int)((x >> 32) & 0xffff));
+                    fprintf(stderr, "\n");
                 }
         }
     }
@@ -511,15 +510,11 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
                 int per_cu = 0, ncu = 0;
                 const hipError_t r1 = (e->skEPT == 1) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<1>, BLOCK, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<2>, BLOCK, 0);
                 if (r1 != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
-                if ((long long)std::min(per_cu, 6) * ncu < e->Wt) e->onepass = false;      // (6: what the hardware admits of a kernel with ~100 SGPRs whatever the API says)
-            }
-            if (e->onepass && env_int("PBWTAMD_ONEPASS_LB", 0) != 0) {      // the form with look-back waves: every tile (eight waves) resident at once
-                int per_cu = 0, ncu = 0;
-                const hipError_t r1 = (e->skEPT == 1) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_lb_kernel<1>, 2 * BLOCK, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_lb_kernel<2>, 2 * BLOCK, 0);
-                if (r1 != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
-                e->op_lb = (long long)std::min(per_cu, 3) * ncu >= e->Wt;
+                int gg = 1; while (gg * gg < e->Wt) ++gg;                                   // (+ one folder workgroup per group of ceil(sqrt(W)) tiles)
+                if ((long long)std::min(per_cu, 6) * ncu < e->Wt + gg) e->onepass = false;      // (6: what the hardware admits of a kernel with ~100 SGPRs whatever the API says)
             }
             e->op_ordered = env_int("PBWTAMD_ONEPASS_ORDERED", 0) != 0;
+            e->op_folders = e->onepass && env_int("PBWTAMD_ONEPASS_FOLDERS", 1) != 0 && e->Wt <= env_int("PBWTAMD_ONEPASS_FOLDERS_MAXW", 256);
             if (e->onepass) { e->op_g1 = 1; while (e->op_g1 * e->op_g1 < e->Wt) ++e->op_g1; }     // groups of ceil(sqrt(W)) tiles: as many groups as tiles per group
             e->W2 = (e->Wt + 1) / 2;
             static const int prow_min = tune_env("PBWTAMD_PROW_MIN") ? atoi(tune_env("PBWTAMD_PROW_MIN")) : 136;

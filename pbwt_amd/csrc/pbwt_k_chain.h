@@ -82,6 +82,7 @@ struct SkArgs {
     // (round 5) the ONE-LAUNCH round (skel_onepass_kernel): rows[tile][key] / grows[group][key] = tagged {count, tail} granules published by the tiles / by the
     // last tile of every group of g1 consecutive tiles; tag = this launch's epoch (11 bits); total[] is precomputed (skel_totals_kernel)
     unsigned long long *rows = nullptr, *grows = nullptr; int g1 = 0; unsigned tag = 0; int *err = nullptr;
+    int nfold = 0;                                              // > 0: the launch carries one FOLDER workgroup per group behind its W tiles (it folds the group's rows into the aggregate); 0: the group's last tile does
     unsigned long long *prof = nullptr;                         // PBWTAMD_ONEPASS_PROF=1: [tile][8] wall-clock stamps of the launch (debugging aid)
 };
 // the global (keys before, carry) of a row from the aggregate of the scan workgroups before its own (L) and its prefix local to that workgroup (R):
@@ -136,7 +137,6 @@ struct SkShardOut {
 // the consumers: 22.7 us per round at 1954 rows, 14 at 977), and the rank / fill workgroup of an odd tile folds the first half's
 // row into its pair's prefix (skel_k2_kernel's combine).  Waves 2, 3 hold the first half.
 // skel_hist_row: the row of tile w for key t = threadIdx.x — {count, tail} (and {c0, tl0} of the first half with HALF) — left in registers; skel_hist_body stores it
-constexpr int SK_HIST_ROW_BARRIERS = 3;                     // (skel_onepass_lb_body's look-back waves pass one s_barrier per barrier of the other waves)
 template <int EPT, bool HALF, int MODE = SKM_LAUNCH>
 __device__ __forceinline__ void skel_hist_row(const SkArgs &g, int w, int &c_out, int &tl_out, int &c0_out, int &tl0_out) {
     static_assert(MODE == SKM_LAUNCH || EPT <= 2, "the persistent forms run 256- and 512-position tiles");
@@ -931,7 +931,19 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     __shared__ int s_failed;
     constexpr int SK_EFLAG = 0x40000000;
     int *const s_gw = &s_tbl[NL - 1][0], *const s_lw = &s_tbl[NL - 1][WAVES];   // (eight words of the top level no query reads: skel_rank_body)
-    const int t = threadIdx.x, lane = lane_id(), wv = wave_id(), w = (g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
+    const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
+    if (g.nfold && (int)blockIdx.x >= g.W) {
+        // a FOLDER: the rows of one group -> the group's aggregate, and nothing else.  With the group's last tile doing this in front of its own tables that tile
+        // was the launch's last to scatter (profiles/r05_onepass.txt, r5t: it waits here for the rows of an XCD that entered late, 8.2 against 7.45 us).
+        // Measured on top, not kept (r5g): the folder also folding the aggregates before its group into a BASE row, so that a tile's look-back is one fold — the
+        // base arrives a hop later than the tiles can fold the aggregates themselves: 1.20-1.23 against 1.155 us/site at 100 k.
+        const int fg = (int)blockIdx.x - g.W, f0 = fg * g.g1;
+        int fc = 0, ft = 0;
+        if (sk1_fold_rows<16>(g.rows + (size_t)f0 * SKK, min(g.g1, g.W - f0), g.tag, fc, ft, g.err, 11))
+            __hip_atomic_store(g.grows + (size_t)fg * SKK + t, sk1_enc(fc, ft, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int w = (g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
     const int S = w * T;
 #define SK1_STAMP(i) do { if (g.prof && t == 0) g.prof[(size_t)w * 8 + (i)] = wall_clock64(); } while (0)
     SK1_STAMP(0);
@@ -954,7 +966,8 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     const int grp = w / g.g1, first = grp * g.g1, lastw = min(first + g.g1, g.W) - 1;
     int pc = 0, pt = 0;
     bool ok = true;
-    if (w == lastw) {
+    const bool selffold = (w == lastw) && g.nfold == 0;
+    if (selffold) {
         ok = sk1_fold_rows<16>(g.rows + (size_t)first * SKK, w - first, g.tag, pc, pt, g.err, 11);
         if (ok) {
             const int ac = pc + cnt_t, at = cnt_t ? tail_t : max(pt, tail_t);
@@ -1032,7 +1045,7 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     if (lane == 63) { s_gw[wv] = ginc; s_lw[wv] = linc; }
     SK1_STAMP(6);
     // (3) look-back, level 1: the tiles before this one in its group (the group's last tile has done it above)
-    if (w != lastw) ok = sk1_fold_rows<16>(g.rows + (size_t)first * SKK, w - first, g.tag, pc, pt, g.err, 11);
+    if (!selffold) ok = sk1_fold_rows<16>(g.rows + (size_t)first * SKK, w - first, g.tag, pc, pt, g.err, 11);
     SK1_STAMP(2);
     // level 2: the groups before this tile's
     int qc = 0, qt = 0;
@@ -1077,239 +1090,6 @@ template <int EPT>
 __global__ __launch_bounds__(BLOCK) void skel_onepass_kernel(SkArgs g) { skel_onepass_body<EPT>(g); }
 template <int EPT>
 __global__ __launch_bounds__(BLOCK) void skel_onepass_many_kernel(const SkArgs *args) { const SkArgs g = args[blockIdx.y]; skel_onepass_body<EPT>(g); }
-
-// THE ONE-LAUNCH ROUND WITH LOOK-BACK WAVES (round 5, second form).  Per-tile stamps of skel_onepass_kernel (profiles/r05_onepass.txt, r5t) show every tile
-// paying its two look-back round trips (0.95 us each, sc1 loads of rows that have been waiting since the tile's row went out) AFTER its tables: entry ->
-// +1.2 row -> +3.4 tables and ranks -> +4.35 level 1 -> +5.3 level 2 -> +5.95 scattered.  Nothing in the look-back depends on the tables.  Here a workgroup
-// carries eight waves: waves 0-3 (thread = position pair, as before) load, derive the row, publish it and build the tables; waves 4-7 (thread = key) do
-// nothing but the look-back: poll the rows of the group, publish the group's aggregate (last tile of a group), poll the
-// aggregates of the groups before, and leave bucket base and the "no predecessor" extension per key in LDS.  The two sets of waves meet at ONE barrier
-// in front of the scatter.  gfx950 has no named barriers: every s_barrier of the table phase counts all eight waves, so the look-back waves pass one
-// s_barrier per barrier of the other four — without waiting for memory: between two barriers they look at their own VM_CNT (HW_REG_IB_STS) and touch
-// the polled registers only when the loads have returned; once the table phase is over they poll in the blocking form.
-__device__ __forceinline__ int wave_vmcnt() { const unsigned x = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 7); return (int)((x & 15u) | (((x >> 22) & 3u) << 4)); }   // HW_REG_IB_STS: VM_CNT[3:0], VM_CNT_HI[23:22]
-
-template <int EPT>
-__device__ __forceinline__ void skel_onepass_lb_body(const SkArgs &g) {
-    constexpr int T = BLOCK * EPT, NC = EPT * WAVES;
-    constexpr int NL = (EPT == 1) ? 4 : 5;
-    constexpr int CH = 16;                                  // granules of one poll (per thread)
-    static_assert(EPT <= 2, "the one-launch round runs 256- and 512-position tiles");
-    __shared__ short s_cnt[NC][SKK];
-    __shared__ short s_lastp[NC][SKK];
-    __shared__ int s_tbl[NL][T];
-    __shared__ int s_base[SKK], s_ext[SKK];                 // first the tile's own row (count, tail: waves 0-3 -> 4-7), at the end bucket base and extension (4-7 -> 0-3)
-    __shared__ int s_gw[WAVES], s_lw[WAVES];
-    __shared__ int s_failed;
-    // barriers of waves 0-3 in front of (F): skel_hist_row's three, two in front of the chunk scan, one per level of the sparse table, one behind it.  The
-    // look-back waves pass exactly as many; the tile's own row is in LDS behind the fourth (LB_ROW)
-    constexpr int NT = SK_HIST_ROW_BARRIERS + 2 + (NL - 1) + 1, LB_ROW = SK_HIST_ROW_BARRIERS + 1;
-#ifndef SK1_LB_T0
-#define SK1_LB_T0 4                                         // first poll behind this many barriers (the rows of an on-time XCD leave at ~1.25 us, three barriers in)
-#endif
-    constexpr int SK_EFLAG = 0x40000000;
-    const int tt = threadIdx.x, lane = lane_id(), w = (g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
-    const int grp = w / g.g1, first = grp * g.g1, lastw = min(first + g.g1, g.W) - 1;
-#define SK1_STAMP(i) do { if (g.prof && (tt & (BLOCK - 1)) == 0) g.prof[(size_t)w * 8 + (i)] = wall_clock64(); } while (0)
-    if (tt == 0) s_failed = 0;
-    if (tt >= BLOCK) {
-        // ---- the look-back waves: thread = key
-        const int kt = tt - BLOCK, bw = wave_id() - WAVES;
-        const int tq = g.total[kt];                         // precomputed (skel_totals_kernel)
-        const int ginc = wave_iscan_sum(tq), linc = wave_iscan_max(tq ? kt + 1 : 0);
-        const int lexc = lane_shr1(linc, 0);
-        if (lane == 63) { s_gw[bw] = ginc; s_lw[bw] = linc; }
-        const unsigned long long want = (unsigned long long)(g.tag & 2047u);
-        const int n1 = w - first, n2 = grp;
-        const bool islast = (w == lastw);
-        int pc = 0, pt = 0, qc = 0, qt = 0;
-        int lvl = 0, i0 = 0, tick = 0, nvm = 0, nf1 = 0, nf2 = 0, ncheck = 0, age = 0;
-        bool inflight = false, failed = false;
-        unsigned long long v[CH];
-        unsigned long long t0 = 0; int spins = 0;
-        // one step of the look-back; block = false: never waits for memory
-        auto issue = [&](const unsigned long long *base, int n) {
-#pragma unroll
-            for (int i = 0; i < CH; ++i) v[i] = (i0 + i < n) ? __hip_atomic_load(base + (size_t)(i0 + i) * SKK + kt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (want << 53);
-            inflight = true; age = 0;
-        };
-        auto step = [&](bool block) {
-            if (inflight) {
-#if defined(SK1_LB_AGE) && SK1_LB_AGE > 0
-                if (!block && ++age < SK1_LB_AGE) { ++nvm; return; }
-#else
-                if (!block && wave_vmcnt() != 0) { ++nvm; return; }
-#endif
-                bool ok = true;
-#pragma unroll
-                for (int i = 0; i < CH; ++i) ok &= (v[i] >> 53) == want;
-                ++ncheck;
-                if (!__all(ok)) {                           // not all there yet: the same rows again
-                    if (lvl == 0) ++nf1; else ++nf2;
-                    if (block) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if ((++spins & 63) == 0) {          // bounded (2 s of wall clock, 100 MHz): a predecessor that never ran must not hang the GPU
-                            const unsigned long long now = wall_clock64();
-                            if (t0 == 0) t0 = now;
-                            if (now - t0 > 200000000ULL || __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicCAS(g.err, 0, 11); failed = true; lvl = 3; inflight = false; return; }
-                        }
-                    }
-                    if (lvl == 0) issue(g.rows + (size_t)first * SKK, n1); else issue(g.grows, n2);
-                    return;
-                }
-#pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    const int vc = (int)(v[i] & 0x3fffffu), vt = (int)((v[i] >> 22) & 0x7fffffffu);     // beyond n: (0, 0), the identity
-                    if (lvl == 0) { pt = vc ? vt : max(pt, vt); pc += vc; } else { qt = vc ? vt : max(qt, vt); qc += vc; }
-                }
-                i0 += CH; inflight = false;
-            }
-            if (lvl == 0) {
-                if (i0 < n1) { issue(g.rows + (size_t)first * SKK, n1); return; }
-                lvl = 1;
-                if (g.prof && kt == 0) g.prof[(size_t)w * 8 + 2] = wall_clock64();
-            }
-            if (lvl == 1) {
-                if (islast) {                               // the group's aggregate: the rows before this tile's and its own (LDS, from waves 0-3)
-                    if (tick < LB_ROW) return;
-                    const int cnt_t = s_base[kt], tail_t = s_ext[kt];
-                    const int ac = pc + cnt_t, at = cnt_t ? tail_t : max(pt, tail_t);
-                    __hip_atomic_store(g.grows + (size_t)grp * SKK + kt, sk1_enc(ac, at, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                lvl = 2; i0 = 0;
-            }
-            if (lvl == 2) {
-                if (i0 < n2) { issue(g.grows, n2); return; }
-                lvl = 3;
-                if (g.prof && kt == 0) g.prof[(size_t)w * 8 + 3] = wall_clock64();
-            }
-        };
-        // the table phase of waves 0-3: one s_barrier of ours per barrier of theirs
-        for (; tick < NT; ++tick) {                          // (tick = barriers passed)
-            if (tick >= SK1_LB_T0) step(false);
-            lds_barrier();
-        }
-        while (lvl < 3) step(true);
-        if (g.prof && kt == 0) g.prof[(size_t)w * 8 + 7] = (unsigned long long)nvm | ((unsigned long long)nf1 << 16) | ((unsigned long long)nf2 << 32) | ((unsigned long long)ncheck << 48);
-        const int bq = qc + pc, cq = pc ? pt : (qc ? max(qt, pt) : -1);      // keys before the tile, carry (-1: no earlier occurrence)
-        g.scan[(size_t)w * SKK + kt] = make_int2(bq, cq);  // kept for the fill
-        int Gq = ginc - tq, lq = lexc;
-        for (int x = 0; x < bw; ++x) { Gq += s_gw[x]; lq = max(lq, s_lw[x]); }
-        lq -= 1;
-        s_base[kt] = Gq + bq;
-        s_ext[kt] = (cq >= 0) ? (cq | SK_EFLAG) : (lq >= 0 ? g.k + 1 + (31 - __clz(kt ^ lq)) : 0);
-        if (failed) s_failed = 1;
-        lds_barrier();                                      // (F) bases and extensions are in LDS
-        return;
-    }
-    // ---- waves 0-3: the tile
-#ifndef PBWT_NO_SETPRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
-    const int t = tt, wv = wave_id();
-    const int S = w * T;
-    SK1_STAMP(0);
-    int av[EPT], dv[EPT], key[EPT];
-    unsigned nk[EPT];
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) { const int i = S + r * BLOCK + t; av[r] = g.a[i]; dv[r] = g.d[i]; key[r] = (int)g.keys[i]; }
-    for (int x = t; x < NC * SKK / 2; x += BLOCK) { reinterpret_cast<int *>(&s_cnt[0][0])[x] = 0; reinterpret_cast<int *>(&s_lastp[0][0])[x] = -1; }
-    int cnt_t = 0, tail_t = 0, c0u = 0, t0u = 0;
-    skel_hist_row<EPT, false>(g, w, cnt_t, tail_t, c0u, t0u);
-    SK1_STAMP(1);
-    __hip_atomic_store(g.rows + (size_t)w * SKK + t, sk1_enc(cnt_t, tail_t, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_base[t] = cnt_t; s_ext[t] = tail_t;
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-        const int l = r * BLOCK + t;
-        const bool valid = S + l < g.M;
-        av[r] &= AMASK; if (!valid) { dv[r] = 0; key[r] = -1; }
-        s_tbl[0][l] = dv[r];
-        nk[r] = (g.has_next && valid && !g.ycnext) ? (unsigned)g.kbnext[av[r]] : 0u;
-    }
-    int rk[EPT], pl[EPT];
-    const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-    lds_barrier();
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-        unsigned long long same = __ballot(key[r] >= 0);
-#pragma unroll
-        for (int b = 0; b < SKB; ++b) { const unsigned long long bal = __ballot((key[r] >> b) & 1); same &= ((key[r] >> b) & 1) ? bal : ~bal; }
-        const unsigned long long before = same & lt;
-        rk[r] = __popcll(before);
-        pl[r] = before ? (r * 4 + wv) * 64 + (63 - __clzll(before)) : -1;
-        if (key[r] >= 0 && !before) {
-            s_cnt[r * 4 + wv][key[r]] = (short)__popcll(same);
-            s_lastp[r * 4 + wv][key[r]] = (short)((r * 4 + wv) * 64 + (63 - __clzll(same)));
-        }
-    }
-    lds_barrier();
-    {   // thread = key: exclusive scan over the chunks
-        int base = 0, last = -1;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int cn = s_cnt[c][t], lp = s_lastp[c][t];
-            s_cnt[c][t] = (short)base; s_lastp[c][t] = (short)last;
-            base += cn; if (cn) last = lp;
-        }
-    }
-#pragma unroll
-    for (int l = 1; l < NL; ++l) {
-        lds_barrier();
-#pragma unroll
-        for (int r = 0; r < EPT; ++r) {
-            const int i = r * BLOCK + t;
-            const int wq = 1 << (2 * (l - 1));
-            int m = s_tbl[l - 1][i];
-            if (i - wq >= 0) m = max(m, s_tbl[l - 1][i - wq]);
-            if (i - 2 * wq >= 0) m = max(m, s_tbl[l - 1][i - 2 * wq]);
-            if (i - 3 * wq >= 0) m = max(m, s_tbl[l - 1][i - 3 * wq]);
-            s_tbl[l][i] = m;
-        }
-    }
-    lds_barrier();
-    SK1_STAMP(5);
-    int rloc[EPT], pp[EPT], rmx[EPT];
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-        rloc[r] = 0; pp[r] = -1; rmx[r] = 0;
-        if (key[r] < 0) continue;
-        const int l = r * BLOCK + t, c = r * 4 + wv, ky = key[r];
-        rloc[r] = s_cnt[c][ky] + rk[r];
-        const int p = (pl[r] >= 0) ? pl[r] : s_lastp[c][ky];
-        pp[r] = p;
-        const int len = l - p;                              // range max of d over (p, l]
-        const int lv = min((31 - __clz(len)) >> 1, NL - 1), wq = 1 << (2 * lv);
-        rmx[r] = max(max(s_tbl[lv][l], s_tbl[lv][p + wq]), max(s_tbl[lv][len > 2 * wq ? l - wq : l], s_tbl[lv][len > 3 * wq ? l - 2 * wq : l]));
-    }
-    SK1_STAMP(6);
-    lds_barrier();                                          // (F) bases and extensions are in LDS
-    if (s_failed) return;                                   // a bounded wait ran out: nothing is scattered from tables that are not there
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-        if (key[r] < 0) continue;
-        const int ky = key[r];
-        int dd;
-        if (pp[r] >= 0) dd = rmx[r];
-        else { const int ex = s_ext[ky]; dd = (ex & SK_EFLAG) ? max(ex & ~SK_EFLAG, rmx[r]) : ex; }
-        const int pos = s_base[ky] + rloc[r];
-        if (pos == 0) dd = g.k + SKB + 1;
-        if (g.ycnext) {
-            const unsigned tg = g.has_next ? (unsigned)((g.ycnext[pos >> 6] >> (pos & 63)) & 1ULL) : 0u;
-            g.a_out[pos] = av[r] | (int)(tg << 31);
-            g.d_out[pos] = dd;
-        } else {
-            g.a_out[pos] = av[r] | (int)((nk[r] & 1u) << 31);
-            g.d_out[pos] = dd;
-            g.keys_out[pos] = (unsigned char)nk[r];
-        }
-    }
-    if (w == g.Wtot - 1 && t == 0) g.d_out[g.M] = g.k + SKB + 1;
-    SK1_STAMP(4);
-#undef SK1_STAMP
-}
-template <int EPT>
-__global__ __launch_bounds__(2 * BLOCK) void skel_onepass_lb_kernel(SkArgs g) { skel_onepass_lb_body<EPT>(g); }
 
 // PERSISTENT chain of a small panel (<= TR tiles: the two-launch regime): ALL rounds of a batch in ONE launch, hist and rank of every
 // round separated by barriers over the launch's <= 128 co-resident workgroups instead of by kernel boundaries.  Such a barrier costs MORE
