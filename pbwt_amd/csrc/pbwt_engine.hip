@@ -510,11 +510,14 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
                 int per_cu = 0, ncu = 0;
                 const hipError_t r1 = (e->skEPT == 1) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<1>, BLOCK, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<2>, BLOCK, 0);
                 if (r1 != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
-                int gg = 1; while (gg * gg < e->Wt) ++gg;                                   // (+ one folder workgroup per group of ceil(sqrt(W)) tiles)
-                if ((long long)std::min(per_cu, 6) * ncu < e->Wt + gg) e->onepass = false;      // (6: what the hardware admits of a kernel with ~100 SGPRs whatever the API says)
+                const long long cap = (long long)std::min(per_cu, 6) * ncu;                  // (6: what the hardware admits of a kernel with ~100 SGPRs whatever the API says)
+                if (cap < e->Wt) e->onepass = false;
+                // a folder workgroup per group of ceil(sqrt(W)) tiles behind the tiles, where they too fit: -5 % alone / -2.6 % beside the consumers at 100 k, -6 / -4 % at
+                // 50 k, -3 / -2 % at 130 k (254 tiles); +3.5 % beside the consumers at 150 k (294 tiles): up to 256 tiles (profiles/r05_onepass.txt, r5i)
+                int gg = 1; while (gg * gg < e->Wt) ++gg;
+                e->op_folders = e->onepass && env_int("PBWTAMD_ONEPASS_FOLDERS", 1) != 0 && e->Wt <= env_int("PBWTAMD_ONEPASS_FOLDERS_MAXW", 256) && cap >= e->Wt + gg;
             }
             e->op_ordered = env_int("PBWTAMD_ONEPASS_ORDERED", 0) != 0;
-            e->op_folders = e->onepass && env_int("PBWTAMD_ONEPASS_FOLDERS", 1) != 0 && e->Wt <= env_int("PBWTAMD_ONEPASS_FOLDERS_MAXW", 256);
             if (e->onepass) { e->op_g1 = 1; while (e->op_g1 * e->op_g1 < e->Wt) ++e->op_g1; }     // groups of ceil(sqrt(W)) tiles: as many groups as tiles per group
             e->W2 = (e->Wt + 1) / 2;
             static const int prow_min = tune_env("PBWTAMD_PROW_MIN") ? atoi(tune_env("PBWTAMD_PROW_MIN")) : 136;
