@@ -188,6 +188,7 @@ struct pbwtamd_engine {
     SkArgs *margs = nullptr, *margs_host = nullptr; size_t margs_cap = 0; int margs_half = 0; hipEvent_t evMargs[2] = {nullptr, nullptr};   // pbwtamd_pass_advance_many (panel 0 owns them)
     // the one-launch round (skel_onepass_kernel; PBWTAMD_ONEPASS): tagged row / group-row granules, tiles per group, launches so far (the tag)
     bool op_ordered = false;               // one-launch round with tile = workgroup index (no XCD-contiguous dealing): see skel_round_args
+    bool op_both = false;                   // ... and a tile polls both look-back levels in one round trip (512-position tiles; PBWTAMD_ONEPASS_BOTH)
     bool op_folders = false;                // one-launch round: a folder workgroup per group publishes the group's aggregate (PBWTAMD_ONEPASS_FOLDERS=0: the group's last tile does)
     bool onepass = false; unsigned long long *op_rows = nullptr, *op_grows = nullptr; int op_g1 = 0; unsigned op_epoch = 0; unsigned long long *op_prof = nullptr;
     unsigned long long *teamprof = nullptr;                 // PBWTAMD_TEAM_PROF=1: member 0's wall-clock stamps per round and phase
@@ -517,6 +518,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
                 int gg = 1; while (gg * gg < e->Wt) ++gg;
                 e->op_folders = e->onepass && env_int("PBWTAMD_ONEPASS_FOLDERS", 1) != 0 && e->Wt <= env_int("PBWTAMD_ONEPASS_FOLDERS_MAXW", 256) && cap >= e->Wt + gg;
             }
+            e->op_both = e->op_folders && env_int("PBWTAMD_ONEPASS_BOTH", e->skEPT == 2 ? 1 : 0) != 0;
             e->op_ordered = env_int("PBWTAMD_ONEPASS_ORDERED", 0) != 0;
             if (e->onepass) { e->op_g1 = 1; while (e->op_g1 * e->op_g1 < e->Wt) ++e->op_g1; }     // groups of ceil(sqrt(W)) tiles: as many groups as tiles per group
             e->W2 = (e->Wt + 1) / 2;

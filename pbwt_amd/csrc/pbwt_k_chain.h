@@ -878,6 +878,35 @@ __device__ __forceinline__ bool sk1_fold_rows(const unsigned long long *base, in
     return true;
 }
 
+// both levels of a tile's look-back in ONE round trip (n1, n2 <= CH): the rows before the tile in its group onto (pc, pt), the aggregates of the groups before
+// onto (qc, qt).  A level whose granules are not all there is polled again on its own (sk1_fold_rows).
+template <int CH>
+__device__ __forceinline__ bool sk1_fold_both(const unsigned long long *b1, int n1, const unsigned long long *b2, int n2, unsigned tag, int &pc, int &pt, int &qc, int &qt, int *err, int code) {
+    const int t = threadIdx.x;
+    const unsigned long long want = (unsigned long long)(tag & 2047u);
+    unsigned long long v1[CH], v2[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) v1[i] = (i < n1) ? __hip_atomic_load(b1 + (size_t)i * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (want << 53);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) v2[i] = (i < n2) ? __hip_atomic_load(b2 + (size_t)i * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (want << 53);
+    bool ok1 = true, ok2 = true;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) { ok1 &= (v1[i] >> 53) == want; ok2 &= (v2[i] >> 53) == want; }
+    const bool a1 = __all(ok1), a2 = __all(ok2);
+    if (a1) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) { const int vc = (int)(v1[i] & 0x3fffffu), vt = (int)((v1[i] >> 22) & 0x7fffffffu); pt = vc ? vt : max(pt, vt); pc += vc; }
+    }
+    if (a2) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) { const int vc = (int)(v2[i] & 0x3fffffu), vt = (int)((v2[i] >> 22) & 0x7fffffffu); qt = vc ? vt : max(qt, vt); qc += vc; }
+    }
+    bool ok = true;
+    if (!a1) ok = sk1_fold_rows<CH>(b1, n1, tag, pc, pt, err, code);
+    if (!a2) ok = ok && sk1_fold_rows<CH>(b2, n2, tag, qc, qt, err, code);
+    return ok;
+}
+
 // totals of every round of a batch: tot[r * strideT + key] = number of entries of src[r * strideSrc + 0 .. M) equal to key.  src = the byte planes of the
 // transposed panel (keys by haplotype, build side) or the rounds' key rows (by position, read side).  grid (chunks of SKTOT_CHUNK entries, rounds); more than one
 // chunk per round: atomics onto totals zeroed by skel_totals_zero_kernel.
@@ -916,7 +945,7 @@ __global__ __launch_bounds__(BLOCK) void skel_totals_kernel(const unsigned char 
     else if (c) atomicAdd(tot + (size_t)r * strideT + t, c);
 }
 
-template <int EPT>
+template <int EPT, bool BOTH = false>
 __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
@@ -1045,12 +1074,19 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     if (lane == 63) { s_gw[wv] = ginc; s_lw[wv] = linc; }
     SK1_STAMP(6);
     // (3) look-back, level 1: the tiles before this one in its group (the group's last tile has done it above)
-    if (!selffold) ok = sk1_fold_rows<16>(g.rows + (size_t)first * SKK, w - first, g.tag, pc, pt, g.err, 11);
-    SK1_STAMP(2);
-    // level 2: the groups before this tile's
     int qc = 0, qt = 0;
-    ok = ok && sk1_fold_rows<16>(g.grows, grp, g.tag, qc, qt, g.err, 11);
-    SK1_STAMP(3);
+    if (BOTH && g.nfold && w - first <= 16 && grp <= 16) {
+        // with folders the aggregates are out by the time a 512-position tile has its tables: both levels in ONE round trip (100 k: 1.10 against 1.155 us/site alone,
+        // 1.26 against 1.33 beside the consumers; 256-position tiles are behind their tables too early for it: 50 k 1.04 against 0.995 — profiles/r05_onepass.txt, r5j)
+        ok = sk1_fold_both<16>(g.rows + (size_t)first * SKK, w - first, g.grows, grp, g.tag, pc, pt, qc, qt, g.err, 11);
+        SK1_STAMP(2); SK1_STAMP(3);
+    } else {
+        if (!selffold) ok = sk1_fold_rows<16>(g.rows + (size_t)first * SKK, w - first, g.tag, pc, pt, g.err, 11);
+        SK1_STAMP(2);
+        // level 2: the groups before this tile's
+        ok = ok && sk1_fold_rows<16>(g.grows, grp, g.tag, qc, qt, g.err, 11);
+        SK1_STAMP(3);
+    }
     if (!ok) s_failed = 1;
     const int bq = qc + pc, cq = pc ? pt : (qc ? max(qt, pt) : -1);      // keys before the tile, carry (-1: no earlier occurrence)
     g.scan[(size_t)w * SKK + t] = make_int2(bq, cq);       // kept for the fill
@@ -1086,8 +1122,9 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     SK1_STAMP(4);
 #undef SK1_STAMP
 }
-template <int EPT>
-__global__ __launch_bounds__(BLOCK) void skel_onepass_kernel(SkArgs g) { skel_onepass_body<EPT>(g); }
+// BOTH (with folders): a tile polls the two levels of its look-back together
+template <int EPT, bool BOTH = false>
+__global__ __launch_bounds__(BLOCK) void skel_onepass_kernel(SkArgs g) { skel_onepass_body<EPT, BOTH>(g); }
 template <int EPT>
 __global__ __launch_bounds__(BLOCK) void skel_onepass_many_kernel(const SkArgs *args) { const SkArgs g = args[blockIdx.y]; skel_onepass_body<EPT>(g); }
 
