@@ -844,24 +844,41 @@ __global__ __launch_bounds__(BLOCK) void skel_rank_shard_kernel(SkArgs g, SkShar
 // tail as a range maximum from the sparse table) and the look-back in front of the bucket bases.  Waits are bounded by the wall clock (error 11); every
 // workgroup of the launch must be able to become resident (W <= 1024 and the occupancy check in pbwtamd_engine_create): a tile waits for tiles
 // before it, which the xcd_tile dealing does not dispatch in tile order.
-// Granule: count [0, 22) | tail [22, 53) | tag [53, 64).
-__device__ __forceinline__ unsigned long long sk1_enc(int c, int tl, unsigned tag) { return (unsigned long long)(unsigned)c | ((unsigned long long)(unsigned)tl << 22) | ((unsigned long long)(tag & 2047u) << 53); }
-// fold the n rows base[i * SKK + t], i = 0 .. n - 1 (in that order) onto (c, tl) with the scan's combine; false: the bounded wait ran out
+// Granule: tail [0, 31) | count [32, 53) | tag [53, 64): the tail is the low word as it stands, count and tag share the high word.
+__device__ __forceinline__ unsigned long long sk1_enc(int c, int tl, unsigned tag) { return (unsigned long long)(unsigned)tl | ((unsigned long long)((unsigned)c | ((tag & 2047u) << 21)) << 32); }
+__device__ __forceinline__ int sk1_cnt(unsigned long long v) { return (int)((unsigned)(v >> 32) & 0x1fffffu); }
+__device__ __forceinline__ int sk1_tail(unsigned long long v) { return (int)(unsigned)v; }
+// bits that differ from the wanted tag, accumulated over granules: all tags right <=> the accumulated word is below 2^21
+__device__ __forceinline__ unsigned sk1_tagdiff(unsigned long long v, unsigned want21) { return (unsigned)(v >> 32) ^ want21; }
+__device__ __forceinline__ void sk1_fold1(unsigned long long v, int &c, int &tl) { const int vc = sk1_cnt(v), vt = sk1_tail(v); tl = vc ? vt : max(tl, vt); c += vc; }
+// fold the n rows base[i * SKK + t], i = 0 .. n - 1 (in that order) onto (c, tl) with the scan's combine; false: the bounded wait ran out.  Loads, tag checks
+// and folds run in blocks of four rows behind wave-uniform guards: nothing is spent on rows beyond n
 template <int CH>
 __device__ __forceinline__ bool sk1_fold_rows(const unsigned long long *base, int n, unsigned tag, int &c, int &tl, int *err, int code) {
+    static_assert(CH % 4 == 0, "blocks of four rows");
     const int t = threadIdx.x;
-    const unsigned long long want = (unsigned long long)(tag & 2047u);
+    const unsigned want21 = (tag & 2047u) << 21;
 #pragma unroll 1
     for (int i0 = 0; i0 < n; i0 += CH) {
         unsigned long long v[CH];
         int spins = 0; unsigned long long t0 = 0;
         for (;;) {
-            bool ok = true;
 #pragma unroll
-            for (int i = 0; i < CH; ++i) v[i] = (i0 + i < n) ? __hip_atomic_load(base + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (want << 53);
+            for (int b = 0; b < CH; b += 4) {
+                if (i0 + b < n) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i) ok &= (v[i] >> 53) == want;
-            if (__all(ok)) break;
+                    for (int i = b; i < b + 4; ++i) v[i] = (i0 + i < n) ? __hip_atomic_load(base + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)want21 << 32);
+                }
+            }
+            unsigned diff = 0;
+#pragma unroll
+            for (int b = 0; b < CH; b += 4) {
+                if (i0 + b < n) {
+#pragma unroll
+                    for (int i = b; i < b + 4; ++i) diff |= sk1_tagdiff(v[i], want21);
+                }
+            }
+            if (__all(diff < (1u << 21))) break;
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 63) == 0) {                      // bounded (2 s of wall clock, 100 MHz): a predecessor that never ran must not hang the GPU
                 const unsigned long long now = wall_clock64();
@@ -870,36 +887,68 @@ __device__ __forceinline__ bool sk1_fold_rows(const unsigned long long *base, in
             }
         }
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int vc = (int)(v[i] & 0x3fffffu), vt = (int)((v[i] >> 22) & 0x7fffffffu);     // beyond n: (0, 0), the identity
-            tl = vc ? vt : max(tl, vt); c += vc;
+        for (int b = 0; b < CH; b += 4) {
+            if (i0 + b < n) {
+#pragma unroll
+                for (int i = b; i < b + 4; ++i) sk1_fold1(v[i], c, tl);     // beyond n: (0, 0), the identity
+            }
         }
     }
     return true;
 }
-
 // both levels of a tile's look-back in ONE round trip (n1, n2 <= CH): the rows before the tile in its group onto (pc, pt), the aggregates of the groups before
 // onto (qc, qt).  A level whose granules are not all there is polled again on its own (sk1_fold_rows).
 template <int CH>
 __device__ __forceinline__ bool sk1_fold_both(const unsigned long long *b1, int n1, const unsigned long long *b2, int n2, unsigned tag, int &pc, int &pt, int &qc, int &qt, int *err, int code) {
+    static_assert(CH % 4 == 0, "blocks of four rows");
     const int t = threadIdx.x;
-    const unsigned long long want = (unsigned long long)(tag & 2047u);
+    const unsigned want21 = (tag & 2047u) << 21;
+    const unsigned long long idv = (unsigned long long)want21 << 32;
     unsigned long long v1[CH], v2[CH];
 #pragma unroll
-    for (int i = 0; i < CH; ++i) v1[i] = (i < n1) ? __hip_atomic_load(b1 + (size_t)i * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (want << 53);
+    for (int b = 0; b < CH; b += 4) {
+        if (b < n1) {
 #pragma unroll
-    for (int i = 0; i < CH; ++i) v2[i] = (i < n2) ? __hip_atomic_load(b2 + (size_t)i * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (want << 53);
-    bool ok1 = true, ok2 = true;
+            for (int i = b; i < b + 4; ++i) v1[i] = (i < n1) ? __hip_atomic_load(b1 + (size_t)i * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : idv;
+        }
+    }
 #pragma unroll
-    for (int i = 0; i < CH; ++i) { ok1 &= (v1[i] >> 53) == want; ok2 &= (v2[i] >> 53) == want; }
-    const bool a1 = __all(ok1), a2 = __all(ok2);
+    for (int b = 0; b < CH; b += 4) {
+        if (b < n2) {
+#pragma unroll
+            for (int i = b; i < b + 4; ++i) v2[i] = (i < n2) ? __hip_atomic_load(b2 + (size_t)i * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : idv;
+        }
+    }
+    unsigned d1 = 0, d2 = 0;
+#pragma unroll
+    for (int b = 0; b < CH; b += 4) {
+        if (b < n1) {
+#pragma unroll
+            for (int i = b; i < b + 4; ++i) d1 |= sk1_tagdiff(v1[i], want21);
+        }
+        if (b < n2) {
+#pragma unroll
+            for (int i = b; i < b + 4; ++i) d2 |= sk1_tagdiff(v2[i], want21);
+        }
+    }
+    const bool a1 = __all(d1 < (1u << 21)), a2 = __all(d2 < (1u << 21));
     if (a1) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) { const int vc = (int)(v1[i] & 0x3fffffu), vt = (int)((v1[i] >> 22) & 0x7fffffffu); pt = vc ? vt : max(pt, vt); pc += vc; }
+        for (int b = 0; b < CH; b += 4) {
+            if (b < n1) {
+#pragma unroll
+                for (int i = b; i < b + 4; ++i) sk1_fold1(v1[i], pc, pt);
+            }
+        }
     }
     if (a2) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) { const int vc = (int)(v2[i] & 0x3fffffu), vt = (int)((v2[i] >> 22) & 0x7fffffffu); qt = vc ? vt : max(qt, vt); qc += vc; }
+        for (int b = 0; b < CH; b += 4) {
+            if (b < n2) {
+#pragma unroll
+                for (int i = b; i < b + 4; ++i) sk1_fold1(v2[i], qc, qt);
+            }
+        }
     }
     bool ok = true;
     if (!a1) ok = sk1_fold_rows<CH>(b1, n1, tag, pc, pt, err, code);

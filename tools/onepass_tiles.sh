@@ -5,4 +5,4 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for M in ${WIDTHS:-100000}; do for W in none hp; do for i in 1 2; do
   PBWTAMD_ONEPASS=1 PBWTAMD_ONEPASS_PROF=2 timeout 200 python tools/wide_bench.py $M 4096 $W > $out/tiles_${M}_${W}_$i.txt 2>&1
 done; done; done
-tail -3 $out/tiles_*_1.txt
+for f in $out/tiles_*_1.txt; do grep "us/site\|onepass prof" $f; done
