@@ -342,6 +342,7 @@ static int wpc_for(int M) { return ((M + 31) / 32 + 3) / 4 * 4; }
 static inline int p3_regions(int M) { return ((M + 63) / 64 + 63) / 64; }   // regions of 64 words per column (region-parallel pack3 encoder)
 
 static void shard_release(pbwtamd_engine *e);
+static inline int onepass_folders(const pbwtamd_engine *e);
 
 extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (!e) return;
@@ -349,7 +350,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->s2) (void)hipStreamSynchronize(e->s2);
     if (e->op_prof) {                                       // PBWTAMD_ONEPASS_PROF=1: the last launch's stamps, per tile, relative to the first tile's entry (us)
-        std::vector<unsigned long long> hp((size_t)e->Wt * 8);
+        std::vector<unsigned long long> hp((size_t)(e->Wt + 64) * 8);    // [tile][8], then [folder][8]
         if (hipMemcpy(hp.data(), e->op_prof, hp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
             unsigned long long t0 = ~0ULL; for (int w = 0; w < e->Wt; ++w) if (hp[(size_t)w * 8]) t0 = std::min(t0, hp[(size_t)w * 8]);
             const char *nm[7] = {"entry", "row ready", "level 1 folded", "level 2 folded", "scattered", "sparse table built", "ranks, range maxima"};
@@ -358,7 +359,10 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
                 for (int w = 0; w < e->Wt; ++w) { const unsigned long long v = hp[(size_t)w * 8 + i]; if (!v || !hp[(size_t)w * 8]) continue; const double us = (double)(v - t0) * 0.01; mn = std::min(mn, us); mx = std::max(mx, us); sum += us; ++n; }
                 fprintf(stderr, "[onepass prof] W %d g1 %d %-16s min %.2f mean %.2f max %.2f us after the first tile's entry (%d tiles)\n", e->Wt, e->op_g1, nm[i], mn, n ? sum / n : 0.0, mx, n);
             }
-            if (env_int("PBWTAMD_ONEPASS_PROF", 0) > 1)         // = 2: every tile's line (entry, row, sparse table, ranks, level 1, level 2, scattered)
+            if (env_int("PBWTAMD_ONEPASS_PROF", 0) > 1)         // = 2: every folder's line (entry, aggregate out) ...
+                for (int f = 0; f < 64 && f < onepass_folders(e); ++f)
+                    fprintf(stderr, "[onepass folder] %3d %6.2f %6.2f\n", f, (double)(hp[(size_t)(e->Wt + f) * 8] - t0) * 0.01, (double)(hp[(size_t)(e->Wt + f) * 8 + 1] - t0) * 0.01);
+            if (env_int("PBWTAMD_ONEPASS_PROF", 0) > 1)         // ... and every tile's (entry, row, sparse table, ranks, level 1, level 2, scattered)
                 for (int w = 0; w < e->Wt; ++w) {
                     fprintf(stderr, "[onepass tile] %4d", w);
                     for (int i : {0, 1, 5, 6, 2, 3, 4}) fprintf(stderr, " %6.2f", hp[(size_t)w * 8 + i] ? (double)(hp[(size_t)w * 8 + i] - t0) * 0.01 : -1.0);
@@ -561,7 +565,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             ALLOC(e->op_grows, (size_t)ngrp * SKK * sizeof(unsigned long long));
             ECHK(hipMemsetAsync(e->op_rows, 0, (size_t)e->Wt * SKK * sizeof(unsigned long long), e->stream));        // tag 0: no launch has published yet (the first launch's tag is 1)
             ECHK(hipMemsetAsync(e->op_grows, 0, (size_t)ngrp * SKK * sizeof(unsigned long long), e->stream));
-            if (env_int("PBWTAMD_ONEPASS_PROF", 0)) { ALLOC(e->op_prof, (size_t)e->Wt * 8 * sizeof(unsigned long long)); ECHK(hipMemsetAsync(e->op_prof, 0, (size_t)e->Wt * 8 * sizeof(unsigned long long), e->stream)); }
+            if (env_int("PBWTAMD_ONEPASS_PROF", 0)) { ALLOC(e->op_prof, (size_t)(e->Wt + 64) * 8 * sizeof(unsigned long long)); ECHK(hipMemsetAsync(e->op_prof, 0, (size_t)(e->Wt + 64) * 8 * sizeof(unsigned long long), e->stream)); }
         }
         ALLOC(e->k2agg, (size_t)64 * SKK * sizeof(unsigned long long));
         ALLOC(e->k2cnt, 64);
