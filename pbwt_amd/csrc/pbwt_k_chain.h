@@ -1174,8 +1174,8 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
 // BOTH (with folders): a tile polls the two levels of its look-back together
 template <int EPT, bool BOTH = false>
 __global__ __launch_bounds__(BLOCK) void skel_onepass_kernel(SkArgs g) { skel_onepass_body<EPT, BOTH>(g); }
-template <int EPT>
-__global__ __launch_bounds__(BLOCK) void skel_onepass_many_kernel(const SkArgs *args) { const SkArgs g = args[blockIdx.y]; skel_onepass_body<EPT>(g); }
+template <int EPT, bool BOTH = false>
+__global__ __launch_bounds__(BLOCK) void skel_onepass_many_kernel(const SkArgs *args) { const SkArgs g = args[blockIdx.y]; skel_onepass_body<EPT, BOTH>(g); }
 
 // PERSISTENT chain of a small panel (<= TR tiles: the two-launch regime): ALL rounds of a batch in ONE launch, hist and rank of every
 // round separated by barriers over the launch's <= 128 co-resident workgroups instead of by kernel boundaries.  Such a barrier costs MORE
