@@ -511,6 +511,30 @@ def test_onepass_round_in_dispatch_order(amd, orc, M, N, batch, kind, monkeypatc
     assert np.array_equal(eng.get_packed(), o["yz"])
 
 
+@pytest.mark.parametrize("folders,both", [("0", "0"), ("1", "0"), ("1", "1")])
+@pytest.mark.parametrize("M,N,batch,kind", [(100000, 72, 24, 1), (40000, 136, 64, 0), (131072, 24, 8, 0), (3000, 40, 40, 1)])
+def test_onepass_look_back_forms(amd, orc, M, N, batch, kind, folders, both, monkeypatch):
+    """the one-launch round's look-back in its three forms — the group's last tile folding the group (PBWTAMD_ONEPASS_FOLDERS=0), a folder workgroup per group
+    with the tiles polling level 1 then level 2 (FOLDERS=1, BOTH=0), and both levels in one round trip (BOTH=1) — on 256- and 512-position tiles, one tile
+    and 256 tiles included: every site's a / d, histogram and .pbwt bytes against the oracle"""
+    import torch
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "1"); monkeypatch.setenv("PBWTAMD_ONEPASS_FOLDERS", folders); monkeypatch.setenv("PBWTAMD_ONEPASS_BOTH", both)
+    eng = amd.Engine(M, batch_sites=batch)
+    buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    eng.synth_device(buf.data_ptr(), 0, N, seed=5200 + M, kind=kind)
+    eng.sync()
+    bits = buf.cpu().numpy().view(np.uint32)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    opts = amd.OPT_WITH_D | amd.OPT_CHECKSUM | amd.OPT_WITHIN_HIST | amd.OPT_PACK3
+    eng.pass_begin(N); eng.pass_advance(buf.data_ptr(), N, N, opts); eng.pass_end(opts)
+    ca, cd, _ = eng.get_checksums(0, N + 1)
+    assert np.array_equal(ca, o["csum_a"]) and np.array_equal(cd, o["csum_d"])
+    assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
+    assert np.array_equal(eng.get_packed(), o["yz"])
+    assert eng.chain_timing()[1] <= N // 8 + 2 * (N % batch) + 2, "the one-launch round did not take the batches"
+
+
 @pytest.mark.parametrize("packed", ["1", "0", "onepass"])
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1025, 96, 24, 0), (70001, 80, 40, 1), (2, 40, 8, 1), (300000, 24, 8, 0),
                                             (600100, 24, 8, 1), (150600, 32, 16, 1), (139300, 24, 8, 0),      # 600 100: pair rows with an odd number of tiles (1173); 150 600 / 139 300: pair rows, one-level scan (the narrowest: 137 rows)
