@@ -535,6 +535,27 @@ def test_onepass_look_back_forms(amd, orc, M, N, batch, kind, folders, both, mon
     assert eng.chain_timing()[1] <= N // 8 + 2 * (N % batch) + 2, "the one-launch round did not take the batches"
 
 
+@pytest.mark.parametrize("alone", ["0", "1"])
+@pytest.mark.parametrize("M,N,batch,kind", [(100000, 72, 24, 1), (9000, 136, 64, 0), (600100, 24, 8, 0), (1, 16, 8, 0)])
+def test_pack3_without_the_histogram(amd, orc, M, N, batch, kind, alone, monkeypatch):
+    """OPT_PACK3 without OPT_WITHIN_HIST (a plain build + write of the .pbwt columns): by default such a pass takes the packed fill and the sweep's sorted
+    columns (the histogram comes along unasked), PBWTAMD_PACK3_ALONE=1 the table fill — the .pbwt bytes and the final state against the oracle either way"""
+    import torch
+    monkeypatch.setenv("PBWTAMD_PACK3_ALONE", alone)
+    eng = amd.Engine(M, batch_sites=batch)
+    buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    eng.synth_device(buf.data_ptr(), 0, N, seed=6300 + M, kind=kind)
+    eng.sync()
+    bits = buf.cpu().numpy().view(np.uint32)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    opts = amd.OPT_WITH_D | amd.OPT_PACK3
+    eng.pass_begin(N); eng.pass_advance(buf.data_ptr(), N, N, opts); eng.pass_end(opts)
+    assert np.array_equal(eng.get_packed(), o["yz"])
+    a, d = eng.get_state()
+    assert np.array_equal(a, o["aFend"]) and np.array_equal(d, o["d_final"])
+
+
 @pytest.mark.parametrize("packed", ["1", "0", "onepass"])
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1025, 96, 24, 0), (70001, 80, 40, 1), (2, 40, 8, 1), (300000, 24, 8, 0),
                                             (600100, 24, 8, 1), (150600, 32, 16, 1), (139300, 24, 8, 0),      # 600 100: pair rows with an odd number of tiles (1173); 150 600 / 139 300: pair rows, one-level scan (the narrowest: 137 rows)
