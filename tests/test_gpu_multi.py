@@ -205,14 +205,25 @@ def test_position_sharded_across_devices(M, N, B, kind, csum, tmp_path):
     mappings of another GPU's rings, the flag barriers and the per-round row exchange over xGMI.  What one shared GPU cannot show — a peer store that
     is late or stale in the owner's L2 — fails here as a checksum mismatch at the first site it touches."""
     world = min(_device_count(), 8)
+    # first the platform probe across the same devices (tools/ipcprobe.hip, memory kind 0 = the plain hipMalloc rings the sharded chain exports): peer scatter,
+    # flag barrier, read-back — its "mismatches" are words a peer wrote that the owner did not see.  Printed (pytest -s / the failure text below), so that a
+    # visibility failure of the platform is told apart from a defect of the chain at the first multi-GPU run.
+    probe = os.path.join(ROOT, "tools", "ipcprobe")
+    probe_report = "ipcprobe not built"
+    if os.path.exists(probe):
+        pr = subprocess.run([probe, str(world), "200", "0"], capture_output=True, text=True, timeout=300, env=dict(os.environ, IPCPROBE_SPREAD="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        lines = [ln for ln in pr.stdout.splitlines() if "mismatches" in ln or "staggered barrier" in ln or ln.startswith("ipcprobe:")]
+        stale = sum(int(ln.split("mismatches")[1].split(",")[0]) for ln in lines if "mismatches" in ln)
+        probe_report = "ipcprobe across %d devices: rc %d, %d stale words\n%s" % (world, pr.returncode, stale, "\n".join(lines))
+    print(probe_report)
     env = dict(os.environ, OUT_DIR=str(tmp_path), PS_M=str(M), PS_N=str(N), PS_B=str(B), PS_KIND=str(kind), PS_STEP="8192", PS_CSUM=str(csum), PS_SPREAD="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "posshard_worker.py")],
                        capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.returncode == 0, probe_report + "\n" + r.stdout[-2000:] + r.stderr[-4000:]
     outs = [json.load(open(tmp_path / ("ps%d.json" % rk))) for rk in range(world)]
-    assert all(o["ok"] for o in outs), outs
+    assert all(o["ok"] for o in outs), (probe_report, outs)
     assert sorted(o["device"] for o in outs) == list(range(world))
 
 

@@ -3,7 +3,8 @@
 //   2. do kernels of different processes run CONCURRENTLY (a kernel spinning on a flag another process's kernel sets)?
 //   3. latency of a cross-process flag barrier done by one tiny kernel per rank (signal all peers, wait for all peers)
 //   4. peer stores into a neighbour's coarse-grained buffer + barrier kernel + read-back in the next kernel: is the data there?
-// build: hipcc --offload-arch=gfx950 -O2 -o tools/ipcprobe tools/ipcprobe.hip ; run: tools/ipcprobe [G=2] [iters=2000]
+// build: hipcc --offload-arch=gfx950 -O2 -o tools/ipcprobe tools/ipcprobe.hip ; run: tools/ipcprobe [G=2] [iters=2000] [only: memory kind 0..2, 3 = VMM]
+// IPCPROBE_SPREAD=1 puts rank r on device r (tests/test_gpu_multi.py runs `ipcprobe <world> 200 0` that way before the position-sharded check)
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
@@ -55,11 +56,18 @@ __global__ void check_kernel(const int *mine, int from, int n, int it, int *bad)
     if (i < n && mine[(int)(((unsigned)i * 7919u) % (unsigned)n)] != it * 1000003 + i + from) atomicAdd(bad, 1);
 }
 
+// IPCPROBE_SPREAD=1: rank r on device r mod device count (a multi-GPU node: the peer stores, flags and read-backs of run_rank cross xGMI); default: one GPU
+static int probe_device(int rank) {
+    const char *s = getenv("IPCPROBE_SPREAD");
+    int n = 1;
+    if (!s || !atoi(s) || hipGetDeviceCount(&n) != hipSuccess || n < 1) return 0;
+    return rank % n;
+}
 static int run_rank(Shared *sh, int rank, int G, int iters, int kind) {
     g_rank = rank;
     setvbuf(stdout, nullptr, _IONBF, 0);
     int phase = kind * 16;
-    CK(hipSetDevice(0));
+    CK(hipSetDevice(probe_device(rank)));
     const int n = 1 << 20;
     unsigned *flags = nullptr; int *data = nullptr, *err = nullptr, *bad = nullptr;
     if (kind == 0) CK(hipMalloc((void **)&flags, 4096));
