@@ -477,11 +477,12 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         // 33-48 of 256 — half the rows in front of every rank workgroup: 1.30 -> 1.21 us/site at 10 k, 1.31 -> 1.22 at 12 k; equal at 5-8 k,
         // worse at 2 k (0.98 -> 1.05) and from 13 k on, where three launches on 256-position tiles take over (1.20)
         if (M > 8192 && M <= 12288) e->skEPT = 2;
+        // (r5r3, with the 256-position tile's row taken from its own chunk tables: 1.004 / 1.040 at 50 k, 1.054 / 1.065 at 60 k, 1.120 / 1.089 at 70 k: up to 256 tiles)
         // under the one-launch round (below) 256-position tiles stay ahead up to ~55 k haplotypes (with the bench consumers and folder workgroups: 0.935 against 0.976
         // us/site at 20 k, 0.987 / 1.026 at 40 k, 1.042 / 1.044 at 50 k; 1.089 / 1.068 at 60 k, 1.193 / 1.106 at 70 k, where 512-position tiles poll both look-back
         // levels at once — profiles/r05_onepass.txt, r5r2), and the 8 193-12 288 exception of the two-launch round goes
         const bool want_onepass = env_int("PBWTAMD_ONEPASS", 1) != 0 && !g_create_persist;
-        if (want_onepass && (M + 255) / 256 <= std::min(1024, env_int("PBWTAMD_ONEPASS_MAXW", 320))) e->skEPT = (M <= 55000) ? 1 : 2;
+        if (want_onepass && (M + 255) / 256 <= std::min(1024, env_int("PBWTAMD_ONEPASS_MAXW", 320))) e->skEPT = (M <= 65536) ? 1 : 2;
         if (const char *sv = tune_env("PBWTAMD_SKT")) e->skEPT = (atoi(sv) == 256) ? 1 : (atoi(sv) == 512) ? 2 : 4;
 
         // pair rows carry 512-position tiles up to 4096 rows of pairs = 2^22 haplotypes, every width the skeleton takes (the wide scan: <= 64

@@ -994,7 +994,7 @@ __global__ __launch_bounds__(BLOCK) void skel_totals_kernel(const unsigned char 
     else if (c) atomicAdd(tot + (size_t)r * strideT + t, c);
 }
 
-template <int EPT, bool BOTH = false>
+template <int EPT, bool BOTH = false, bool MERGED = (EPT == 1)>
 __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
@@ -1006,7 +1006,7 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     __shared__ short s_lastp[NC][SKK];
     __shared__ int s_tbl[NL][T];
     __shared__ int s_base[SKK], s_ext[SKK];
-    __shared__ int s_failed;
+    __shared__ int s_failed, s_cmax[NC];
     constexpr int SK_EFLAG = 0x40000000;
     int *const s_gw = &s_tbl[NL - 1][0], *const s_lw = &s_tbl[NL - 1][WAVES];   // (eight words of the top level no query reads: skel_rank_body)
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
@@ -1024,70 +1024,144 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     const int w = (g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
     const int S = w * T;
 #define SK1_STAMP(i) do { if (g.prof && t == 0) g.prof[(size_t)w * 8 + (i)] = wall_clock64(); } while (0)
-    SK1_STAMP(0);
-    // every address-known load of the launch is issued here: the tile in the rank's (striped) order, then — inside skel_hist_row — keys and d once more in
-    // the hist's (reverse-blocked) order: the same lines, 5 bytes per position more through the L1
-    int av[EPT], dv[EPT], key[EPT];
+    // MERGED (256-position tiles): the tile's row out of the rank's own chunk tables; otherwise the separate histogram phase (skel_hist_row) in front of them.
+    // Measured (profiles/r05_onepass.txt, r5v2 / r5v3): merged 0.93 against 0.975 us/site at 50 k (1.01 / 1.046 beside the consumers); on 512-position tiles the
+    // tiles then reach their look-back 0.7 us EARLIER than the folders' aggregates and pay a failed poll: 1.10-1.13 against 1.046 at 100 k (1.24-1.27 / 1.20)
+    const int tp = MERGED ? ((t & ~63) | (63 - lane)) : t;  // the position (inside the tile's 256-position row r) this thread holds
+    int av[EPT], dv[EPT], key[EPT], rk[EPT], pl[EPT];
     unsigned nk[EPT];
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) { const int i = S + r * BLOCK + t; av[r] = g.a[i]; dv[r] = g.d[i]; key[r] = (int)g.keys[i]; }
-    const int tq = g.total[t];                              // precomputed (skel_totals_kernel)
-    if (t == 0) s_failed = 0;
-    for (int x = t; x < NC * SKK / 2; x += BLOCK) { reinterpret_cast<int *>(&s_cnt[0][0])[x] = 0; reinterpret_cast<int *>(&s_lastp[0][0])[x] = -1; }
-    // (1) this tile's row first, the way skel_hist_kernel derives it (three LDS barriers), and out with it: everything a tile after this one waits for
-    int cnt_t = 0, tail_t = 0, c0u = 0, t0u = 0;
-    skel_hist_row<EPT, false>(g, w, cnt_t, tail_t, c0u, t0u);
-    SK1_STAMP(1);
-    __hip_atomic_store(g.rows + (size_t)w * SKK + t, sk1_enc(cnt_t, tail_t, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // the launch's critical path runs through the LAST tile of every group: rows of its group -> the group's aggregate -> every later tile.  That tile folds its
-    // group and publishes the aggregate before anything else; the others build their tables first and find the rows waiting
+    int tq = 0, cnt_t = 0, tail_t = 0;
     const int grp = w / g.g1, first = grp * g.g1, lastw = min(first + g.g1, g.W) - 1;
     int pc = 0, pt = 0;
     bool ok = true;
     const bool selffold = (w == lastw) && g.nfold == 0;
-    if (selffold) {
-        ok = sk1_fold_rows<16>(g.rows + (size_t)first * SKK, w - first, g.tag, pc, pt, g.err, 11);
-        if (ok) {
-            const int ac = pc + cnt_t, at = cnt_t ? tail_t : max(pt, tail_t);
-            __hip_atomic_store(g.grows + (size_t)grp * SKK + t, sk1_enc(ac, at, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (MERGED) {
+        SK1_STAMP(0);
+        // every address-known load of the launch is issued here.  A wave holds its 64-position chunks in REVERSE lane order (lane i = position 63 - i of the chunk):
+        // a prefix scan over the lanes is then a suffix scan over the positions, which is what the row's "max of d after the key's last occurrence" needs — the
+        // row comes out of the SAME ballots and the SAME per-key scan over the chunks that the rank's tables are built from (one LDS barrier behind the loads),
+        // not from a separate histogram phase with its own loads, ballots and atomics (skel_hist_row: three barriers; -0.6 us of a tile's 5 us)
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) { const int i = S + r * BLOCK + tp; av[r] = g.a[i]; dv[r] = g.d[i]; key[r] = (int)g.keys[i]; }
+        tq = g.total[t];                                        // precomputed (skel_totals_kernel)
+        if (t == 0) s_failed = 0;
+        for (int x = t; x < NC * SKK / 2; x += BLOCK) { reinterpret_cast<int *>(&s_cnt[0][0])[x] = 0; reinterpret_cast<int *>(&s_lastp[0][0])[x] = -1; }
+        int *const s_sfx = &s_tbl[NL - 1][0];                   // [T] max of d over the LATER positions of the element's chunk (the top level is written three barriers on)
+        lds_barrier();                                          // zeroed tables visible (the loads are still in flight)
+        // (1) chunk tables: every element's rank among the same keys of its chunk, its previous same-key position; per (chunk, key) count and last position
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const int l = r * BLOCK + tp;
+            const bool valid = S + l < g.M;
+            av[r] &= AMASK; if (!valid) { dv[r] = 0; key[r] = -1; }
+            s_tbl[0][l] = dv[r];
+            nk[r] = (g.has_next && valid && !g.ycnext) ? (unsigned)g.kbnext[av[r]] : 0u;
+        }
+        const unsigned long long gt = (lane == 63) ? 0ULL : (~0ULL << (lane + 1));     // the lanes above mine = the positions before mine
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const int cb = (r * 4 + wv) * 64;
+            unsigned long long same = __ballot(key[r] >= 0);
+#pragma unroll
+            for (int b = 0; b < SKB; ++b) { const unsigned long long bal = __ballot((key[r] >> b) & 1); same &= ((key[r] >> b) & 1) ? bal : ~bal; }
+            const unsigned long long before = same & gt;
+            rk[r] = __popcll(before);
+            pl[r] = before ? cb + 63 - (__ffsll((long long)before) - 1) : -1;
+            if (key[r] >= 0 && !before) {                       // first of its key in this chunk
+                s_cnt[r * 4 + wv][key[r]] = (short)__popcll(same);
+                s_lastp[r * 4 + wv][key[r]] = (short)(cb + 63 - (__ffsll((long long)same) - 1));
+            }
+            const int inc = wave_iscan_max(dv[r]);             // lanes 0 .. mine = my position and the later ones of the chunk
+            s_sfx[r * BLOCK + tp] = lane_shr1(inc, 0);
+            if (lane == 63) s_cmax[r * 4 + wv] = inc;
+        }
+        lds_barrier();
+        // (2) thread = key: exclusive scan over the chunks (count before the chunk, last position before it) — and with it this tile's ROW: the key's count and
+        // the max of d behind its last occurrence (the whole tile's for an absent key), out at once: everything a tile after this one waits for
+        {
+            int base = 0, last = -1, lastc = -1;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int cn = s_cnt[c][t], lp = s_lastp[c][t];
+                s_cnt[c][t] = (short)base; s_lastp[c][t] = (short)last;
+                base += cn; if (cn) { last = lp; lastc = c; }
+            }
+            int later = (last >= 0) ? s_sfx[last] : 0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) if (c > lastc) later = max(later, s_cmax[c]);
+            cnt_t = base; tail_t = later;
+        }
+        SK1_STAMP(1);
+        __hip_atomic_store(g.rows + (size_t)w * SKK + t, sk1_enc(cnt_t, tail_t, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // without folders the launch's critical path runs through the LAST tile of every group: rows of its group -> the group's aggregate -> every later tile.
+        // That tile folds its group and publishes the aggregate before anything else
+        if (selffold) {
+            ok = sk1_fold_rows<16>(g.rows + (size_t)first * SKK, w - first, g.tag, pc, pt, g.err, 11);
+            if (ok) {
+                const int ac = pc + cnt_t, at = cnt_t ? tail_t : max(pt, tail_t);
+                __hip_atomic_store(g.grows + (size_t)grp * SKK + t, sk1_enc(ac, at, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    } else {
+        SK1_STAMP(0);
+        // every address-known load of the launch is issued here: the tile in the rank's (striped) order, then — inside skel_hist_row — keys and d once more in
+        // the hist's (reverse-blocked) order: the same lines, 5 bytes per position more through the L1
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) { const int i = S + r * BLOCK + t; av[r] = g.a[i]; dv[r] = g.d[i]; key[r] = (int)g.keys[i]; }
+        tq = g.total[t];                                        // precomputed (skel_totals_kernel)
+        if (t == 0) s_failed = 0;
+        for (int x = t; x < NC * SKK / 2; x += BLOCK) { reinterpret_cast<int *>(&s_cnt[0][0])[x] = 0; reinterpret_cast<int *>(&s_lastp[0][0])[x] = -1; }
+        // (1) this tile's row first, the way skel_hist_kernel derives it (three LDS barriers), and out with it: everything a tile after this one waits for
+        int c0u = 0, t0u = 0;
+        skel_hist_row<EPT, false>(g, w, cnt_t, tail_t, c0u, t0u);
+        SK1_STAMP(1);
+        __hip_atomic_store(g.rows + (size_t)w * SKK + t, sk1_enc(cnt_t, tail_t, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the launch's critical path runs through the LAST tile of every group: rows of its group -> the group's aggregate -> every later tile.  That tile folds its
+        // group and publishes the aggregate before anything else; the others build their tables first and find the rows waiting
+        if (selffold) {
+            ok = sk1_fold_rows<16>(g.rows + (size_t)first * SKK, w - first, g.tag, pc, pt, g.err, 11);
+            if (ok) {
+                const int ac = pc + cnt_t, at = cnt_t ? tail_t : max(pt, tail_t);
+                __hip_atomic_store(g.grows + (size_t)grp * SKK + t, sk1_enc(ac, at, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // (2) in the shadow of the hand-offs: the rank's tables — chunk tables, the sparse table of d, every element's rank inside the tile, its previous
+        // same-key position and the range maximum since then; none of it depends on another tile
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            const int l = r * BLOCK + t;
+            const bool valid = S + l < g.M;
+            av[r] &= AMASK; if (!valid) { dv[r] = 0; key[r] = -1; }
+            s_tbl[0][l] = dv[r];
+            nk[r] = (g.has_next && valid && !g.ycnext) ? (unsigned)g.kbnext[av[r]] : 0u;
+        }
+        const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < EPT; ++r) {
+            unsigned long long same = __ballot(key[r] >= 0);
+#pragma unroll
+            for (int b = 0; b < SKB; ++b) { const unsigned long long bal = __ballot((key[r] >> b) & 1); same &= ((key[r] >> b) & 1) ? bal : ~bal; }
+            const unsigned long long before = same & lt;
+            rk[r] = __popcll(before);
+            pl[r] = before ? (r * 4 + wv) * 64 + (63 - __clzll(before)) : -1;
+            if (key[r] >= 0 && !before) {
+                s_cnt[r * 4 + wv][key[r]] = (short)__popcll(same);
+                s_lastp[r * 4 + wv][key[r]] = (short)((r * 4 + wv) * 64 + (63 - __clzll(same)));
+            }
+        }
+        lds_barrier();
+        {   // thread = key: exclusive scan over the chunks
+            int base = 0, last = -1;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int cn = s_cnt[c][t], lp = s_lastp[c][t];
+                s_cnt[c][t] = (short)base; s_lastp[c][t] = (short)last;
+                base += cn; if (cn) last = lp;
+            }
         }
     }
-    // (2) in the shadow of the hand-offs: the rank's tables — chunk tables, the sparse table of d, every element's rank inside the tile, its previous
-    // same-key position and the range maximum since then; none of it depends on another tile
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-        const int l = r * BLOCK + t;
-        const bool valid = S + l < g.M;
-        av[r] &= AMASK; if (!valid) { dv[r] = 0; key[r] = -1; }
-        s_tbl[0][l] = dv[r];
-        nk[r] = (g.has_next && valid && !g.ycnext) ? (unsigned)g.kbnext[av[r]] : 0u;
-    }
-    int rk[EPT], pl[EPT];
-    const unsigned long long lt = (lane == 0) ? 0ULL : (~0ULL >> (64 - lane));
-    lds_barrier();
-#pragma unroll
-    for (int r = 0; r < EPT; ++r) {
-        unsigned long long same = __ballot(key[r] >= 0);
-#pragma unroll
-        for (int b = 0; b < SKB; ++b) { const unsigned long long bal = __ballot((key[r] >> b) & 1); same &= ((key[r] >> b) & 1) ? bal : ~bal; }
-        const unsigned long long before = same & lt;
-        rk[r] = __popcll(before);
-        pl[r] = before ? (r * 4 + wv) * 64 + (63 - __clzll(before)) : -1;
-        if (key[r] >= 0 && !before) {
-            s_cnt[r * 4 + wv][key[r]] = (short)__popcll(same);
-            s_lastp[r * 4 + wv][key[r]] = (short)((r * 4 + wv) * 64 + (63 - __clzll(same)));
-        }
-    }
-    lds_barrier();
-    {   // thread = key: exclusive scan over the chunks
-        int base = 0, last = -1;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int cn = s_cnt[c][t], lp = s_lastp[c][t];
-            s_cnt[c][t] = (short)base; s_lastp[c][t] = (short)last;
-            base += cn; if (cn) last = lp;
-        }
-    }
+    // (3) in the shadow of the hand-offs: the sparse table of d, every element's rank inside the tile and the range maximum since its previous same-key position
 #pragma unroll
     for (int l = 1; l < NL; ++l) {
         lds_barrier();
@@ -1109,7 +1183,7 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     for (int r = 0; r < EPT; ++r) {
         rloc[r] = 0; pp[r] = -1; rmx[r] = 0;
         if (key[r] < 0) continue;
-        const int l = r * BLOCK + t, c = r * 4 + wv, ky = key[r];
+        const int l = r * BLOCK + tp, c = r * 4 + wv, ky = key[r];
         rloc[r] = s_cnt[c][ky] + rk[r];
         const int p = (pl[r] >= 0) ? pl[r] : s_lastp[c][ky];
         pp[r] = p;
