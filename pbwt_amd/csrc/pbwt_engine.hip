@@ -188,6 +188,7 @@ struct pbwtamd_engine {
     SkArgs *margs = nullptr, *margs_host = nullptr; size_t margs_cap = 0; int margs_half = 0; hipEvent_t evMargs[2] = {nullptr, nullptr};   // pbwtamd_pass_advance_many (panel 0 owns them)
     // the one-launch round (skel_onepass_kernel; PBWTAMD_ONEPASS): tagged row / group-row granules, tiles per group, launches so far (the tag)
     bool op_ordered = false;               // one-launch round with tile = workgroup index (no XCD-contiguous dealing): see skel_round_args
+    bool op_merged = false; int op_fk = 1;  // the row out of the rank's chunk tables (256-position tiles; PBWTAMD_ONEPASS_MERGED); folder copies per group (PBWTAMD_ONEPASS_FOLDERS_K)
     bool op_both = false;                   // ... and a tile polls both look-back levels in one round trip (512-position tiles; PBWTAMD_ONEPASS_BOTH)
     bool op_folders = false;                // one-launch round: a folder workgroup per group publishes the group's aggregate (PBWTAMD_ONEPASS_FOLDERS=0: the group's last tile does)
     bool onepass = false; unsigned long long *op_rows = nullptr, *op_grows = nullptr; int op_g1 = 0; unsigned op_epoch = 0; unsigned long long *op_prof = nullptr;
@@ -522,7 +523,9 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
                 // a folder workgroup per group of ceil(sqrt(W)) tiles behind the tiles, where they too fit: -5 % alone / -2.6 % beside the consumers at 100 k, -6 / -4 % at
                 // 50 k, -3 / -2 % at 130 k (254 tiles); +3.5 % beside the consumers at 150 k (294 tiles): up to 256 tiles (profiles/r05_onepass.txt, r5i)
                 int gg = 1; while (gg * gg < e->Wt) ++gg;
-                e->op_folders = e->onepass && env_int("PBWTAMD_ONEPASS_FOLDERS", 1) != 0 && e->Wt <= env_int("PBWTAMD_ONEPASS_FOLDERS_MAXW", 256) && cap >= e->Wt + gg;
+                e->op_fk = std::max(1, std::min(4, env_int("PBWTAMD_ONEPASS_FOLDERS_K", 1)));
+                e->op_folders = e->onepass && env_int("PBWTAMD_ONEPASS_FOLDERS", 1) != 0 && e->Wt <= env_int("PBWTAMD_ONEPASS_FOLDERS_MAXW", 256) && cap >= e->Wt + e->op_fk * gg;
+                e->op_merged = env_int("PBWTAMD_ONEPASS_MERGED", e->skEPT == 1 ? 1 : 0) != 0;
             }
             e->op_both = e->op_folders && env_int("PBWTAMD_ONEPASS_BOTH", e->skEPT == 2 ? 1 : 0) != 0;
             e->op_ordered = env_int("PBWTAMD_ONEPASS_ORDERED", 0) != 0;

@@ -1015,7 +1015,9 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
         // was the launch's last to scatter (profiles/r05_onepass.txt, r5t: it waits here for the rows of an XCD that entered late, 8.2 against 7.45 us).
         // Measured on top, not kept (r5g): the folder also folding the aggregates before its group into a BASE row, so that a tile's look-back is one fold — the
         // base arrives a hop later than the tiles can fold the aggregates themselves: 1.20-1.23 against 1.155 us/site at 100 k.
-        const int fg = (int)blockIdx.x - g.W, f0 = fg * g.g1;
+        // (nfold may be a multiple of the number of groups: the copies of a group's folder start their polls a third of a round trip apart and publish the same words)
+        const int ngrp = (g.W + g.g1 - 1) / g.g1, fq = (int)blockIdx.x - g.W, fg = fq % ngrp, f0 = fg * g.g1;
+        for (int z = fq / ngrp; z > 0; --z) __builtin_amdgcn_s_sleep(12);
         int fc = 0, ft = 0;
         if (sk1_fold_rows<16>(g.rows + (size_t)f0 * SKK, min(g.g1, g.W - f0), g.tag, fc, ft, g.err, 11))
             __hip_atomic_store(g.grows + (size_t)fg * SKK + t, sk1_enc(fc, ft, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1246,8 +1248,8 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
 #undef SK1_STAMP
 }
 // BOTH (with folders): a tile polls the two levels of its look-back together
-template <int EPT, bool BOTH = false>
-__global__ __launch_bounds__(BLOCK) void skel_onepass_kernel(SkArgs g) { skel_onepass_body<EPT, BOTH>(g); }
+template <int EPT, bool BOTH = false, bool MERGED = (EPT == 1)>
+__global__ __launch_bounds__(BLOCK) void skel_onepass_kernel(SkArgs g) { skel_onepass_body<EPT, BOTH, MERGED>(g); }
 template <int EPT, bool BOTH = false>
 __global__ __launch_bounds__(BLOCK) void skel_onepass_many_kernel(const SkArgs *args) { const SkArgs g = args[blockIdx.y]; skel_onepass_body<EPT, BOTH>(g); }
 
