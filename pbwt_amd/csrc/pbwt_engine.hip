@@ -529,7 +529,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             }
             e->op_both = e->op_folders && env_int("PBWTAMD_ONEPASS_BOTH", e->skEPT == 2 ? 1 : 0) != 0;
             e->op_ordered = env_int("PBWTAMD_ONEPASS_ORDERED", 0) != 0;
-            if (e->onepass) { e->op_g1 = 1; while (e->op_g1 * e->op_g1 < e->Wt) ++e->op_g1; }     // groups of ceil(sqrt(W)) tiles: as many groups as tiles per group
+            if (e->onepass) { e->op_g1 = 1; while (e->op_g1 * e->op_g1 < e->Wt) ++e->op_g1; if (const char *sg = tune_env("PBWTAMD_ONEPASS_G1")) e->op_g1 = std::max(2, std::min(atoi(sg), 64)); }     // groups of ceil(sqrt(W)) tiles: as many groups as tiles per group
             e->W2 = (e->Wt + 1) / 2;
             static const int prow_min = tune_env("PBWTAMD_PROW_MIN") ? atoi(tune_env("PBWTAMD_PROW_MIN")) : 136;
             static const bool prow_ept1 = tune_env("PBWTAMD_PROW_EPT1") && atoi(tune_env("PBWTAMD_PROW_EPT1"));   // measurement builds: pairs of 256-position tiles
