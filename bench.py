@@ -706,16 +706,25 @@ def main():
     if rank == 0 and world == 1 and not args.no_1m and args.panels == 1:
         # ONE fixed point, P = 8 (eight chromosomes of a cohort side by side; from six panels on pbwtamd_pass_advance_many runs the team-persistent chain,
         # panel p on XCD p — round 5).  Not a maximum over tried configurations.
-        out["many_panels"] = many_panels(torch, pbwt_amd, dev, opts, args.kind, M, P=MANY_PANELS_P)
-        out["many_panels"]["speedup_vs_one_panel"] = out["many_panels"]["value"] / out["value"]
+        try:                                                # (a secondary object must not take the line with it)
+            out["many_panels"] = many_panels(torch, pbwt_amd, dev, opts, args.kind, M, P=MANY_PANELS_P)
+            out["many_panels"]["speedup_vs_one_panel"] = out["many_panels"]["value"] / out["value"]
+        except Exception as ex:
+            out["many_panels"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     if rank == 0 and world == 1 and not args.no_1m:
         del panel
         torch.cuda.empty_cache()
         free_b = torch.cuda.mem_get_info(dev)[0]
         ns_sites = min(args.ns_sites, int((free_b - 24e9) // 125000) // 512 * 512)     # leave room for the engine's rings (~10 GB) and the query sweep
-        out["north_star_width"] = north_star_width(torch, pbwt_amd, dev, opts, args.kind, sites=max(ns_sites, 4096))
+        try:
+            out["north_star_width"] = north_star_width(torch, pbwt_amd, dev, opts, args.kind, sites=max(ns_sites, 4096))
+        except Exception as ex:
+            out["north_star_width"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         torch.cuda.empty_cache()
-        out["match_dynamic"] = match_dynamic(torch, pbwt_amd, dev, args.kind)
+        try:
+            out["match_dynamic"] = match_dynamic(torch, pbwt_amd, dev, args.kind)
+        except Exception as ex:
+            out["match_dynamic"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args, first)
     if world > 1 and not args.no_posshard and args.panels == 1:

@@ -188,6 +188,7 @@ struct pbwtamd_engine {
     SkArgs *margs = nullptr, *margs_host = nullptr; size_t margs_cap = 0; int margs_half = 0; hipEvent_t evMargs[2] = {nullptr, nullptr};   // pbwtamd_pass_advance_many (panel 0 owns them)
     // the one-launch round (skel_onepass_kernel; PBWTAMD_ONEPASS): tagged row / group-row granules, tiles per group, launches so far (the tag)
     bool op_ordered = false;               // one-launch round with tile = workgroup index (no XCD-contiguous dealing): see skel_round_args
+    hipStream_t s2_single = nullptr; bool s2_many = false;      // pass_advance_many: the consumer stream confined to more CUs (many_consumer_stream); the first one kept for destroy
     bool op_merged = false; int op_fk = 1;  // the row out of the rank's chunk tables (256-position tiles; PBWTAMD_ONEPASS_MERGED); folder copies per group (PBWTAMD_ONEPASS_FOLDERS_K)
     bool op_both = false;                   // ... and a tile polls both look-back levels in one round trip (512-position tiles; PBWTAMD_ONEPASS_BOTH)
     bool op_folders = false;                // one-launch round: a folder workgroup per group publishes the group's aggregate (PBWTAMD_ONEPASS_FOLDERS=0: the group's last tile does)
@@ -373,6 +374,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     }
     shard_release(e);
     if (e->s2) (void)hipStreamDestroy(e->s2);
+    if (e->s2_single) (void)hipStreamDestroy(e->s2_single);
     for (int i = 0; i < 16; ++i) if (e->tev[i]) (void)hipEventDestroy(e->tev[i]);
     for (int i = 0; i < 8; ++i) if (e->evUsed[i]) (void)hipEventDestroy(e->evUsed[i]);
     for (int i = 0; i < 8; ++i) if (e->evSub[i]) (void)hipEventDestroy(e->evSub[i]);
