@@ -5,12 +5,15 @@ kernel's achieved algorithmic HBM GB/s against the gfx950 roofline, beside a CPU
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2]): synthetic founder-mosaic panel, M = 100,000 haplotypes; one
-"step" = one batch of S = 8192 consecutive sites pushed through the hot path with the panel's bit
-columns already resident in HBM: per site pbwtCursorForwardsAD (a[], d[]) + the matchMaximalWithin
-sweep (histogram sink, the reference's -stats mode) + pack3 encoding of the PBWT column.  The
-default K = 122 steps is the whole 1M-site panel of configs[2].  Steps continue one forward pass,
-so every step works on a realistic cursor state.
+Workload (BASELINE.json configs[2] ITSELF): synthetic founder-mosaic panel, M = 100,000 haplotypes x N = K*S sites; one
+"step" = S = 50,000 consecutive sites pushed through the hot path with the panel's bit columns already
+resident in HBM: per site pbwtCursorForwardsAD (a[], d[]) + the matchMaximalWithin sweep (histogram
+sink, the reference's -stats mode) + pack3 encoding of the PBWT column.  The timed region is ONE pass
+from site 0 to site N (the k == N sweep included): with the default (and the driver's) K = 20 steps that
+is the 100,000 x 1,000,000 panel of configs[2], whole; the W warm-up steps run a separate, untimed pass over
+the first W*S sites of the same panel.  tests/test_gpu_z_c3_full.py runs this very pass (same seed, same
+calls) under the oracle, block by block from the device's own checkpoints, and pins its histogram total
+(tests/golden/c3_full.json), which this script compares its own total with.
 
 Multi-GPU (⑤), two modes:
   --mode replicas (default): ranks process independent panels (different chromosomes = seeds) with no data-path
@@ -56,11 +59,11 @@ def latency_bound(alg_bytes_per_launch, us_per_launch):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=122)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--haps", type=int, default=None, help="M, haplotypes in the panel (default 100000; 1000000 in --mode posshard)")
     ap.add_argument("--backend", default=os.environ.get("PBWT_BENCH_BACKEND", "nccl"), help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share ONE GPU)")
-    ap.add_argument("--sites-per-step", type=int, default=8192)
+    ap.add_argument("--sites-per-step", type=int, default=50000, help="S, sites per step (a multiple of 8); K*S = the panel's sites: 20 x 50 000 = configs[2]")
     ap.add_argument("--batch", type=int, default=512, help="sites per device batch (graph length)")
     ap.add_argument("--kind", type=int, default=0, help="0 founder mosaic, 1 iid")
     ap.add_argument("--no-within", action="store_true")
@@ -104,9 +107,35 @@ def cpu_baseline(args, first_cols):
             oracle.max_within_hist(b["yz"], M, n)
         tb, tw = t1 - t0, time.perf_counter() - t1
         kind, what = "port", "oracle C restatement"
-    return {"value": M * n / (tb + tw), "unit": "site*haps/s", "cores": 1, "kind": kind,
+    model, ncpu = host_cpu()
+    return {"value": M * n / (tb + tw), "unit": "site*haps/s", "cores": 1, "kind": kind, "host_cpu": model, "host_logical_cpus": ncpu,
             "sample": "first %d sites of the same %d-haplotype panel, %s: build(WriteForwardsAD + pack3) %.2fs + -stats maxWithin %.2fs"
                       % (n, M, what, tb, tw)}
+
+
+def verified_total(M, N, args, unit, got):
+    """tests/golden/c3_full.json: the histogram total of THIS pass (same seed, same pbwt_amd calls) as tests/test_gpu_z_c3_full.py got it with every
+    block of sites checked against the oracle from the device's own checkpoints.  None when the run is not that configuration."""
+    try:
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", "c3_full.json")))
+    except Exception:
+        return None
+    if (M, N, args.kind, unit) != (g["haplotypes"], g["sites"], g["kind"], 0) or args.no_within or args.panels != 1:
+        return None
+    return {"expected": g["within_reports_hist_total"], "matches": got == g["within_reports_hist_total"], "source": "tests/golden/c3_full.json (tests/test_gpu_z_c3_full.py)"}
+
+
+def host_cpu():
+    """model string and logical CPUs of the host the cpu_baseline ran on (BASELINE.md section 4 asks for both)"""
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return model, os.cpu_count()
 
 
 def north_star_streamed(torch, pbwt_amd, dev, opts, kind, M=1000000, sites=10000000, batch=512, step=8192, snapshot_at=1000000):
@@ -597,7 +626,9 @@ def main():
         return run_posshard(args, torch, pdist, pbwt_amd, dev, rank, world)
 
     M, S, K, Wm = args.haps, args.sites_per_step, args.steps, args.warmup
-    n_total = (K + Wm) * S
+    if S % 8:
+        raise SystemExit("--sites-per-step must be a multiple of 8 (the chain's radix step spans 8 sites)")
+    n_total = K * S                                         # the panel: the timed pass covers ALL of it, site 0 to site N
     stream = torch.cuda.current_stream().cuda_stream
     if args.panels > 1:                                     # the fused launches need every panel's engine on ONE (non-null) stream
         shared = torch.cuda.Stream(device=dev)
@@ -635,14 +666,21 @@ def main():
         else:
             eng.pass_advance(panel.data_ptr() + k * row_bytes, S, avail, opts)
 
-    eng.pass_begin(n_total)
-    for e2, _ in extra:
-        e2.pass_begin(n_total)
-    for i in range(Wm):
-        step(i)
+    # warm-up: W untimed steps as a pass of their own over the panel's first sites (allocations, code objects, clocks)
+    ms_w, n_w, w_left = 0.0, 0, Wm
+    while w_left > 0:
+        nw = min(w_left, K)
+        for e in engines:
+            e.pass_begin(n_total)
+        for i in range(nw):
+            step(i)
+        for e in engines:
+            e.pass_stop()
+        m_, n_ = eng.chain_timing(); ms_w += m_; n_w += n_
+        w_left -= nw
+    for e in engines:                      # the timed pass: cursor creation (pbwtCursorCreate, pbwtCore.c:420-445) is set-up, outside the timed region
+        e.pass_begin(n_total)
     eng.sync()
-    ms_w, n_w = eng.chain_timing()
-    sites_w = eng.chain_sites()
 
     def barrier():
         pdist.barrier()
@@ -650,7 +688,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for i in range(Wm, Wm + K):
+    for i in range(K):
         step(i)
     eng.pass_end(opts)                     # includes the k == N sweep; synchronises the stream
     for e2, _ in extra:
@@ -660,8 +698,8 @@ def main():
     ms_all, n_all = eng.chain_timing()
     dt = pdist.max_over_ranks(dt, device=dev)
 
-    chain_ms, chain_n = ms_all - ms_w, n_all - n_w
-    chain_sites = eng.chain_sites() - sites_w
+    chain_ms, chain_n = ms_all, n_all
+    chain_sites = eng.chain_sites()
     sites_per_launch = chain_sites / max(chain_n, 1)
     us_per_launch = 1e3 * chain_ms / max(chain_n, 1)
     alg_bytes_per_launch = ALG_BYTES_PER_SITEHAP * M * sites_per_launch
@@ -683,8 +721,8 @@ def main():
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": 1e3 * dt / K,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "configs[2]: %d haplotypes x %d sites build (ForwardsAD + pack3) + maxWithin (hist sink)"
-                               % (M, K * S),
+        "config": {"workload": "configs[2]%s: %d haplotypes x %d sites, ONE pass from site 0 to site N: build (ForwardsAD + pack3) + maxWithin (hist sink, k == N sweep included)"
+                               % (" itself" if (M == 100000 and K * S == 1000000) else " width", M, K * S),
                    "haplotypes": M, "sites_per_step": S, "sites_timed": K * S, "device_batch_sites": args.batch,
                    "panel": "founder-mosaic" if args.kind == 0 else "iid", "within": not args.no_within,
                    "pack3": not args.no_pack3, "units_per_rank": "independent panel per rank", "panels_per_gpu": args.panels},
@@ -698,6 +736,7 @@ def main():
                      "latency_bound_frac": latency_bound(alg_bytes_per_launch, us_per_launch)["latency_bound_frac"],
                      "note": "one launch = sites_per_launch sites; duration = HIP-event time of the dependent launch chain / launches, i.e. including launch gaps"},
         "within_reports_hist_total": int(hist.sum()),
+        "verified_hist_total": verified_total(M, K * S, args, unit, int(hist.sum())),
         "launch_us_level_warmup": 1e3 * ms_w / max(n_w, 1),      # the chain's us per launch over the warm-up steps (the slow mode shows here first: 4.3 against 3.9 at three launches per round)
         "pinned_cpus": (len(pinned_cpus) if pinned_cpus else 0),
     }

@@ -160,6 +160,25 @@ def build_bitcols(bits, M, with_d=True, k0=0, a0=None, d0=None, dump_sites=(), w
                 a_dump=a_dump, d_dump=d_dump, a_final=a_io, d_final=d_io)
 
 
+def segment(bits, M, k0, n_total, a0, d0, want_yz=True, want_hist=True, yz_cap=None):
+    """a block of sites of build + -stats maxWithin continued from the cursor (a0, d0) at site k0 (orc_segment): returns
+    dict(a, d: the cursor after the block; yz: the block's pack3 bytes; hist: int64[n_total + 2], the block's reports).
+    Releases the GIL for the duration (ctypes): blocks can be checked from several threads at once."""
+    bits = np.ascontiguousarray(bits, dtype=np.uint32)
+    ncols, wpc = bits.shape
+    a = np.ascontiguousarray(a0, dtype=np.int32).copy()
+    d = np.ascontiguousarray(d0, dtype=np.int32).copy()
+    assert a.size == M and d.size == M + 1
+    yz = np.zeros((ncols * M + 16) if yz_cap is None else int(yz_cap), dtype=np.uint8) if want_yz else None   # (yz_cap: the bytes expected + M of slack)
+    hist = np.zeros(n_total + 2, dtype=np.int64) if want_hist else None
+    nz = C.c_size_t(0)
+    rc = lib().orc_segment(C.c_int(M), C.c_int(ncols), C.c_int(k0), C.c_int(n_total), _p(bits, C.c_uint32), C.c_int(wpc),
+                           _p(a, C.c_int32), _p(d, C.c_int32), _p(yz, C.c_uint8), C.c_size_t(0 if yz is None else yz.size), C.byref(nz),
+                           _p(hist, C.c_int64), C.c_int(0 if hist is None else hist.size))
+    assert rc == 0, rc
+    return dict(a=a, d=d, yz=None if yz is None else yz[:nz.value].copy(), hist=hist)
+
+
 def sweep_AD(yz, M, N, aFstart=None, dump_sites=()):
     yz = np.ascontiguousarray(yz, dtype=np.uint8)
     a0 = np.arange(M, dtype=np.int32) if aFstart is None else np.ascontiguousarray(aFstart, dtype=np.int32)

@@ -330,6 +330,30 @@ static void mv_push(orc_matchvec *mv, int ai, int bi, int start, int end)
 /* pbwtMatch.c:115-142.  The two scans walk away from i while the divergence stays within the
  * best-match block; finding an equal allele there (and not being at the final site) means the
  * match extends, so i is skipped. */
+/* one site of the sweep (the body of the loop over i, pbwtMatch.c:120-137): `live` = k < N.  hist mode (the -stats sink,
+ * pbwtMatch.c:46-49 counts by length) or record mode (the report callback's arguments in callback order). */
+static inline int within_site(int M, int k, int live, const uint8_t *y, const int32_t *a, const int32_t *d,
+                              int mode, orc_matchvec *out, int64_t *hist, int histlen)
+{
+    for (int i = 0; i < M; ++i) {
+        int m = i - 1, n = i + 1, skip = 0;
+        if (d[i] <= d[i + 1])
+            while (d[m + 1] <= d[i]) { if (y[m--] == y[i] && live) { skip = 1; break; } }
+        if (!skip && d[i] >= d[i + 1])
+            while (d[n] <= d[i + 1]) { if (y[n++] == y[i] && live) { skip = 1; break; } }
+        if (skip) continue;
+        if (mode == 1) {
+            int len = (d[i] < d[i + 1]) ? k - d[i] : k - d[i + 1];
+            if (len < 0 || len >= histlen) return -2;
+            ++hist[len];
+        } else {
+            for (int j = m + 1; j < i; ++j) mv_push(out, a[i], a[j], d[i], k);
+            for (int j = i + 1; j < n; ++j) mv_push(out, a[i], a[j], d[i + 1], k);
+        }
+    }
+    return 0;
+}
+
 static int max_within_range(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aFstart,
                             int mode, orc_matchvec *out, int64_t *hist, int histlen, int k_lo, int k_hi)
 {
@@ -338,29 +362,51 @@ static int max_within_range(int M, int N, const uint8_t *yz, size_t nz, const in
     if (M < 2) return -3;
     oc_open(&u, M, yz, nz, aFstart);
     for (int k = 0; k <= N; ++k) {
-        const int32_t *d = u.d, *a = u.a;
-        const uint8_t *y = u.y;
-        int live = k < N;
-        for (int i = 0; i < M && k >= k_lo && k < k_hi; ++i) {
-            int m = i - 1, n = i + 1, skip = 0;
-            if (d[i] <= d[i + 1])
-                while (d[m + 1] <= d[i]) { if (y[m--] == y[i] && live) { skip = 1; break; } }
-            if (!skip && d[i] >= d[i + 1])
-                while (d[n] <= d[i + 1]) { if (y[n++] == y[i] && live) { skip = 1; break; } }
-            if (skip) continue;
-            if (mode == 1) {
-                int len = (d[i] < d[i + 1]) ? k - d[i] : k - d[i + 1];
-                if (len < 0 || len >= histlen) { rc = -2; goto done; }
-                ++hist[len];
-            } else {
-                for (int j = m + 1; j < i; ++j) mv_push(out, a[i], a[j], d[i], k);
-                for (int j = i + 1; j < n; ++j) mv_push(out, a[i], a[j], d[i + 1], k);
-            }
+        if (k >= k_lo && k < k_hi) {
+            rc = within_site(M, k, k < N, u.y, u.a, u.d, mode, out, hist, histlen);
+            if (rc) break;
         }
         oc_forwards_read_AD(&u, k);
     }
-done:
     oc_close(&u);
+    return rc;
+}
+
+/* A BLOCK of sites of the build + -stats maxWithin job, continued from a checkpointed cursor (a_k0, d_k0): per site the
+ * build loop's gather and pack3 (pbwtIO.c:477-483, pbwtCore.c:269-277), the sweep of matchMaximalWithin at that site
+ * (pbwtMatch.c:120-137, histogram sink) and WriteForwardsAD (pbwtCore.c:580-585); when the block reaches the panel's end
+ * (k0 + ncols == n_total) the closing sweep at k == N (pbwtMatch.c:118 runs k <= N; `live` is false there so the stale
+ * column is never consulted).  Lets a full-length run be checked block by block from the device's own checkpoints: block i
+ * starts from checkpoint i and must arrive at checkpoint i+1.  No global state: callable from several threads at once. */
+int orc_segment(int M, int ncols, int k0, int n_total, const uint32_t *bits, int wpc,
+                int32_t *a_io, int32_t *d_io, uint8_t *yz, size_t yzcap, size_t *nz, int64_t *hist, int histlen)
+{
+    int32_t *a = a_io, *d = d_io;
+    int32_t *b = malloc(sizeof(int32_t) * (size_t)M);
+    int32_t *e = malloc(sizeof(int32_t) * (size_t)(M + 1));
+    uint8_t *y = malloc((size_t)M + 1);
+    size_t n = 0;
+    int rc = 0;
+    if (M < 2 || d[0] != k0 + 1 || d[M] != k0 + 1) { rc = -3; goto done; }
+    y[M] = 2;                                   /* Y_SENTINEL (pbwt.h:143) */
+    for (int j = 0; j < ncols; ++j) {
+        const int k = k0 + j;
+        const uint32_t *col = bits + (size_t)j * (size_t)wpc;
+        for (int i = 0; i < M; ++i) {
+            int32_t h = a[i];
+            y[i] = (uint8_t)((col[h >> 5] >> (h & 31)) & 1u);
+        }
+        if (hist && (rc = within_site(M, k, 1, y, a, d, 1, NULL, hist, histlen))) goto done;
+        if (yz) {
+            if (n + (size_t)M > yzcap) { rc = -1; goto done; }
+            n += orc_pack3(y, M, yz + n);
+        }
+        orc_step_AD(M, k, y, a, d, b, e);
+    }
+    if (hist && k0 + ncols == n_total) rc = within_site(M, n_total, 0, y, a, d, 1, NULL, hist, histlen);
+done:
+    if (nz) *nz = n;
+    free(b); free(e); free(y);
     return rc;
 }
 

@@ -79,6 +79,10 @@ int orc_max_within(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aF
 /* the same, reports filtered to the sites k_lo <= k < k_hi (mode 0 only) */
 int orc_max_within_range(int M, int N, const uint8_t *yz, size_t nz, const int32_t *aFstart,
                          int k_lo, int k_hi, orc_matchvec *out);
+/* a block of sites of build + -stats maxWithin continued from a checkpointed cursor (a_io/d_io in: state at k0, out: state at
+ * k0+ncols); hist accumulates the block's reports (and the k == N sweep when the block ends the panel) */
+int orc_segment(int M, int ncols, int k0, int n_total, const uint32_t *bits, int wpc,
+                int32_t *a_io, int32_t *d_io, uint8_t *yz, size_t yzcap, size_t *nz, int64_t *hist, int histlen);
 
 /* ---- matchLongWithin2 (pbwtMatch.c:85-113), the -longWithin L command: records in callback order */
 int orc_long_within(int M, int N, int L, const uint8_t *yz, size_t nz, const int32_t *aFstart, orc_matchvec *out);

@@ -129,3 +129,34 @@ def test_sparse_sweep_matches_reference_goldens(orc):
     s1 = orc.match_sweep_sparse(g["nomatch_pz"], Mp, g["nomatch_qz"], Mq, N, 1)[0]
     assert np.array_equal(dense, g["nomatch_dense"].view(dense.dtype).reshape(-1))
     assert len(s1) == len(dense) and all(np.array_equal(s1[f], dense[f]) for f in ("ai", "bi", "start", "end")) and not s1["sparse"].any()
+
+
+def test_segment_blocks_compose_to_the_whole_panel(orc):
+    """orc_segment (build + -stats maxWithin over a block of sites from a checkpointed cursor — how the full-length configs[2]
+    run is checked block by block, tests/test_gpu_z_c3_full.py): blocks chained through their (a, d) give the whole panel's
+    bytes, final state and histogram (= the golden-pinned build_bitcols / max_within paths, and the reference where built),
+    also from several threads at once"""
+    from concurrent.futures import ThreadPoolExecutor
+    for (M, N, kind, seed, cuts) in [(300, 400, 0, 9, (0, 1, 130, 399, 400)), (70, 150, 1, 4, (0, 64, 150)), (2, 9, 1, 3, (0, 4, 9)), (1500, 96, 0, 5, (0, 40, 96))]:
+        bits = orc.synth_bitcols(M, N, seed=seed, kind=kind)
+        o = orc.build_bitcols(bits, M, with_d=True, dump_sites=cuts)
+        want_hist = orc.max_within_hist(o["yz"], M, N)
+        if orc.ref() is not None:
+            r = orc.ref_build_bitcols(bits, M, with_d=True)
+            assert np.array_equal(o["yz"], r["yz"])
+        jobs = [(cuts[i], cuts[i + 1], o["a_dump"][i], o["d_dump"][i]) for i in range(len(cuts) - 1)]       # every block from the whole run's own checkpoint
+        with ThreadPoolExecutor(4) as ex:
+            segs = list(ex.map(lambda j: orc.segment(bits[j[0]:j[1]], M, j[0], N, j[2], j[3]), jobs))
+        for i, s in enumerate(segs):
+            assert np.array_equal(s["a"], o["a_dump"][i + 1]) and np.array_equal(s["d"], o["d_dump"][i + 1])
+        assert np.array_equal(np.concatenate([s["yz"] for s in segs]), o["yz"])
+        assert np.array_equal(sum(s["hist"] for s in segs), want_hist)
+        # a wrong start state is refused (sentinels), and a chained run (each block from the previous block's OUTPUT) agrees too
+        a, d = np.arange(M, dtype=np.int32), np.zeros(M + 1, np.int32); d[0] = d[M] = 1
+        tot = np.zeros(N + 2, np.int64)
+        for (k0, k1, _, _) in jobs:
+            s = orc.segment(bits[k0:k1], M, k0, N, a, d, yz_cap=len(o["yz"]) + M + 16)
+            a, d = s["a"], s["d"]; tot += s["hist"]
+        assert np.array_equal(a, o["aFend"]) and np.array_equal(d, o["d_final"]) and np.array_equal(tot, want_hist)
+        with pytest.raises(AssertionError):
+            orc.segment(bits[:1], M, 5, N, a, np.zeros(M + 1, np.int32))
