@@ -192,6 +192,8 @@ struct pbwtamd_engine {
     bool op_merged = false; int op_fk = 1;  // the row out of the rank's chunk tables (256-position tiles; PBWTAMD_ONEPASS_MERGED); folder copies per group (PBWTAMD_ONEPASS_FOLDERS_K)
     bool op_both = false;                   // ... and a tile polls both look-back levels in one round trip (512-position tiles; PBWTAMD_ONEPASS_BOTH)
     bool op_folders = false;                // one-launch round: a folder workgroup per group publishes the group's aggregate (PBWTAMD_ONEPASS_FOLDERS=0: the group's last tile does)
+    // (round 6) the scanner form of the one-launch round (wide panels): op_nscan scanner workgroups in front of the tiles, op_scanl[tile][key] their local prefixes
+    bool op_scan = false; int op_nscan = 0; unsigned long long *op_scanl = nullptr;
     bool onepass = false; unsigned long long *op_rows = nullptr, *op_grows = nullptr; int op_g1 = 0; unsigned op_epoch = 0; unsigned long long *op_prof = nullptr;
     unsigned long long *teamprof = nullptr;                 // PBWTAMD_TEAM_PROF=1: member 0's wall-clock stamps per round and phase
     unsigned *teamctl = nullptr; unsigned team_round = 0; int team_cap = 0;   // team-persistent chain (skel_team_kernel): tickets + flag words per XCD, barriers passed so far (the first engine of a group owns them)
@@ -389,6 +391,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (e->teamprof) (void)dev_free(e->teamprof);
     if (e->op_rows) (void)dev_free(e->op_rows);
     if (e->op_grows) (void)dev_free(e->op_grows);
+    if (e->op_scanl) (void)dev_free(e->op_scanl);
     if (e->op_prof) (void)dev_free(e->op_prof);
     if (e->h_used) (void)hipHostFree(e->h_used);
     if (e->h_nflag) (void)hipHostFree(e->h_nflag);
@@ -516,6 +519,21 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             // 1.69 / 1.83 at 150 k; 2.04 / 1.96 at 200 k, 2.45 / 2.12 at 250 k, 5.05 / 3.04 at 500 k (more tiles: longer look-backs, five workgroups per CU): on up to
             // 320 tiles (163 840 haplotypes).  PBWTAMD_ONEPASS=0: the three- / two-launch round; PBWTAMD_ONEPASS_MAXW=n: up to n <= 1024 tiles (tests)
             e->onepass = want_onepass && e->skEPT <= 2 && e->Wt <= std::min(1024, env_int("PBWTAMD_ONEPASS_MAXW", 320));
+            // (round 6) wider panels: the SCANNER form (pbwt_k_chain.h) — the scan over the tiles by scanner workgroups inside the launch, tiles in dispatch order: nothing
+            // has to be co-resident but the scanners and one group, and a tile polls two granules per key whatever the width.  Counts are 21-bit fields: below 2^21
+            // haplotypes.  PBWTAMD_ONEPASS_SCAN=0: off (three launches per round as before); PBWTAMD_ONEPASS_SCAN_MIN=n: from n + 1 tiles on (tests: 0)
+            const int scan_min = env_int("PBWTAMD_ONEPASS_SCAN_MIN", std::min(1024, env_int("PBWTAMD_ONEPASS_MAXW", 320)));
+            e->op_scan = want_onepass && e->skEPT <= 2 && M < (1 << 21) && e->Wt > scan_min && env_int("PBWTAMD_ONEPASS_SCAN", 1) != 0;
+            if (e->op_scan) {
+                e->op_g1 = std::max(4, std::min(64, env_int("PBWTAMD_ONEPASS_SCAN_G", 32)));
+                e->op_nscan = (e->Wt + e->op_g1 - 1) / e->op_g1;
+                int per_cu = 0, ncu = 0;
+                const hipError_t r1 = (e->skEPT == 1) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<1, false, true, true>, BLOCK, 0)
+                                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<2, false, true, true>, BLOCK, 0);
+                if (r1 != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+                if ((long long)std::min(per_cu, 6) * ncu < (long long)e->op_nscan + 2 * e->op_g1) e->op_scan = false;      // the scanners and two groups of tiles must fit beside each other
+                e->onepass = e->op_scan;
+            } else
             if (e->onepass) {
                 int per_cu = 0, ncu = 0;
                 const hipError_t r1 = (e->skEPT == 1) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<1>, BLOCK, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<2>, BLOCK, 0);
@@ -531,7 +549,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             }
             e->op_both = e->op_folders && env_int("PBWTAMD_ONEPASS_BOTH", e->skEPT == 2 ? 1 : 0) != 0;
             e->op_ordered = env_int("PBWTAMD_ONEPASS_ORDERED", 0) != 0;
-            if (e->onepass) { e->op_g1 = 1; while (e->op_g1 * e->op_g1 < e->Wt) ++e->op_g1; if (const char *sg = tune_env("PBWTAMD_ONEPASS_G1")) e->op_g1 = std::max(2, std::min(atoi(sg), 64)); }     // groups of ceil(sqrt(W)) tiles: as many groups as tiles per group
+            if (e->onepass && !e->op_scan) { e->op_g1 = 1; while (e->op_g1 * e->op_g1 < e->Wt) ++e->op_g1; if (const char *sg = tune_env("PBWTAMD_ONEPASS_G1")) e->op_g1 = std::max(2, std::min(atoi(sg), 64)); }     // groups of ceil(sqrt(W)) tiles: as many groups as tiles per group
             e->W2 = (e->Wt + 1) / 2;
             static const int prow_min = tune_env("PBWTAMD_PROW_MIN") ? atoi(tune_env("PBWTAMD_PROW_MIN")) : 136;
             static const bool prow_ept1 = tune_env("PBWTAMD_PROW_EPT1") && atoi(tune_env("PBWTAMD_PROW_EPT1"));   // measurement builds: pairs of 256-position tiles
@@ -567,11 +585,15 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         }
         ALLOC(e->skT, (size_t)(e->Wt + 1) * SKK * sizeof(int2));
         if (e->onepass) {
-            const int ngrp = (e->Wt + e->op_g1 - 1) / e->op_g1;
+            const int ngrp = (e->op_scan ? 2 : 1) * ((e->Wt + e->op_g1 - 1) / e->op_g1);        // (scanner form: the groups' aggregates, then their exclusive folds)
             ALLOC(e->op_rows, (size_t)e->Wt * SKK * sizeof(unsigned long long));
             ALLOC(e->op_grows, (size_t)ngrp * SKK * sizeof(unsigned long long));
             ECHK(hipMemsetAsync(e->op_rows, 0, (size_t)e->Wt * SKK * sizeof(unsigned long long), e->stream));        // tag 0: no launch has published yet (the first launch's tag is 1)
             ECHK(hipMemsetAsync(e->op_grows, 0, (size_t)ngrp * SKK * sizeof(unsigned long long), e->stream));
+            if (e->op_scan) {
+                ALLOC(e->op_scanl, (size_t)e->Wt * SKK * sizeof(unsigned long long));
+                ECHK(hipMemsetAsync(e->op_scanl, 0, (size_t)e->Wt * SKK * sizeof(unsigned long long), e->stream));
+            }
             if (env_int("PBWTAMD_ONEPASS_PROF", 0)) { ALLOC(e->op_prof, (size_t)(e->Wt + 64) * 8 * sizeof(unsigned long long)); ECHK(hipMemsetAsync(e->op_prof, 0, (size_t)(e->Wt + 64) * 8 * sizeof(unsigned long long), e->stream)); }
         }
         ALLOC(e->k2agg, (size_t)64 * SKK * sizeof(unsigned long long));

@@ -84,6 +84,9 @@ struct SkArgs {
     unsigned long long *rows = nullptr, *grows = nullptr; int g1 = 0; unsigned tag = 0; int *err = nullptr;
     int nfold = 0;                                              // > 0: the launch carries one FOLDER workgroup per group behind its W tiles (it folds the group's rows into the aggregate); 0: the group's last tile does
     unsigned long long *prof = nullptr;                         // PBWTAMD_ONEPASS_PROF=1: [tile][8] wall-clock stamps of the launch (debugging aid)
+    // (round 6) the one-launch round's SCANNER form (wide panels): nscan scanner workgroups IN FRONT of the W tiles; scanner s turns the rows of tiles
+    // s * g1 .. into scanl[tile][key] (the prefix local to the group) and grows[s] (the group's aggregate), then grows[nscan + s] (the fold of the groups before)
+    unsigned long long *scanl = nullptr; int nscan = 0;
 };
 // the global (keys before, carry) of a row from the aggregate of the scan workgroups before its own (L) and its prefix local to that workgroup (R):
 // skel_k2_kernel's combine, with the carry of "no earlier occurrence" = -1 on the way out
@@ -956,6 +959,94 @@ __device__ __forceinline__ bool sk1_fold_both(const unsigned long long *b1, int 
     return ok;
 }
 
+// THE SCANNER FORM (round 6; wide panels).  A tile's look-back reads O(sqrt(W)) rows of 2 KB: at 1 954 tiles that is 344 MB of polls per round against 129 MB of
+// algorithmic traffic, and the tiles cannot all be resident (which the look-back's XCD-contiguous dealing needs).  Here the per-key scan over the tiles is done
+// INSIDE the launch by nscan = ceil(W / G) scanner workgroups dispatched in FRONT of the tiles (thread = key, as skel_k2_local_kernel): scanner s polls the G rows
+// of its group as the tiles publish them, writes every tile's prefix LOCAL to the group (scanl[tile]) and the group's aggregate (grows[s]), then folds the aggregates
+// of the groups before its own into grows[nscan + s].  A tile polls exactly TWO granules per key — its scanl row and its group's exclusive aggregate — in one round
+// trip behind its tables.  Tile = workgroup index - nscan: a tile waits for scanners (dispatched first, always resident) which wait for rows of tiles dispatched
+// before the group's last tile — dispatch order, deadlock-free whatever is resident (the device must hold nscan + G + 1 workgroups).  Hand-offs: row -> scanner ->
+// (aggregate -> scanner ->) tile, three hops of ~1 us instead of two kernel boundaries, a 2 x 4 MB table pass and the separate histogram launch's loads.
+// Polls are gated: a scanner watches ONE row (the batch's last: rows arrive in dispatch order) until that is there, and only then loads the batch.
+template <int CH>
+__device__ __forceinline__ bool sk1_wait_row(const unsigned long long *p, unsigned want21, int *err, int code) {
+    int spins = 0; unsigned long long t0 = 0;
+    for (;;) {
+        const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(sk1_tagdiff(v, want21) < (1u << 21))) return true;
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 63) == 0) {
+            const unsigned long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            if (now - t0 > 200000000ULL || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicCAS(err, 0, code); return false; }
+        }
+    }
+}
+// rows[i][t], i = 0 .. n - 1 in order: out[i][t] = the fold of the rows before i (tagged), (c, tl) = the fold of all n on the way out
+template <int CH>
+__device__ __forceinline__ bool sk1_scan_rows(const unsigned long long *rows, unsigned long long *out, int n, unsigned tag, int &c, int &tl, int *err, int code) {
+    static_assert(CH % 4 == 0, "blocks of four rows");
+    const int t = threadIdx.x;
+    const unsigned want21 = (tag & 2047u) << 21;
+#pragma unroll 1
+    for (int i0 = 0; i0 < n; i0 += CH) {
+        const int m = min(CH, n - i0);
+        if (!sk1_wait_row<CH>(rows + (size_t)(i0 + m - 1) * SKK + t, want21, err, code)) return false;
+        unsigned long long v[CH];
+        int spins = 0; unsigned long long t0 = 0;
+        for (;;) {
+#pragma unroll
+            for (int b = 0; b < CH; b += 4) {
+                if (b < m) {
+#pragma unroll
+                    for (int i = b; i < b + 4; ++i) v[i] = (i < m) ? __hip_atomic_load(rows + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)want21 << 32);
+                }
+            }
+            unsigned diff = 0;
+#pragma unroll
+            for (int b = 0; b < CH; b += 4) {
+                if (b < m) {
+#pragma unroll
+                    for (int i = b; i < b + 4; ++i) diff |= sk1_tagdiff(v[i], want21);
+                }
+            }
+            if (__all(diff < (1u << 21))) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 63) == 0) {
+                const unsigned long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                if (now - t0 > 200000000ULL || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicCAS(err, 0, code); return false; }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < CH; b += 4) {
+            if (b < m) {
+#pragma unroll
+                for (int i = b; i < b + 4; ++i) {
+                    if (i < m) __hip_atomic_store(out + (size_t)(i0 + i) * SKK + t, sk1_enc(c, tl, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sk1_fold1(v[i], c, tl);                   // beyond m: (0, 0), the identity
+                }
+            }
+        }
+    }
+    return true;
+}
+// a tile's two granules: its prefix local to the group (p1) and the fold of the groups before (p2), one round trip when both are there
+__device__ __forceinline__ bool sk1_poll2(const unsigned long long *p1, const unsigned long long *p2, unsigned tag, int &pc, int &pt, int &qc, int &qt, int *err, int code) {
+    const unsigned want21 = (tag & 2047u) << 21;
+    int spins = 0; unsigned long long t0 = 0;
+    for (;;) {
+        const unsigned long long v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v2 = __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((sk1_tagdiff(v1, want21) | sk1_tagdiff(v2, want21)) < (1u << 21))) { pc = sk1_cnt(v1); pt = sk1_tail(v1); qc = sk1_cnt(v2); qt = sk1_tail(v2); return true; }
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63) == 0) {
+            const unsigned long long now = wall_clock64();
+            if (t0 == 0) t0 = now;
+            if (now - t0 > 200000000ULL || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicCAS(err, 0, code); return false; }
+        }
+    }
+}
+
 // totals of every round of a batch: tot[r * strideT + key] = number of entries of src[r * strideSrc + 0 .. M) equal to key.  src = the byte planes of the
 // transposed panel (keys by haplotype, build side) or the rounds' key rows (by position, read side).  grid (chunks of SKTOT_CHUNK entries, rounds); more than one
 // chunk per round: atomics onto totals zeroed by skel_totals_zero_kernel.
@@ -994,7 +1085,7 @@ __global__ __launch_bounds__(BLOCK) void skel_totals_kernel(const unsigned char 
     else if (c) atomicAdd(tot + (size_t)r * strideT + t, c);
 }
 
-template <int EPT, bool BOTH = false, bool MERGED = (EPT == 1)>
+template <int EPT, bool BOTH = false, bool MERGED = (EPT == 1), bool SCAN = false>
 __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
 #ifndef PBWT_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
@@ -1005,12 +1096,32 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     __shared__ short s_cnt[NC][SKK];
     __shared__ short s_lastp[NC][SKK];
     __shared__ int s_tbl[NL][T];
-    __shared__ int s_base[SKK], s_ext[SKK];
-    __shared__ int s_failed, s_cmax[NC];
+    // SCAN (wide panels): 20 480 bytes exactly, so that EIGHT workgroups fit a CU's 160 KB (skel_rank_body's rule) — the failure word and the chunk maxima live in
+    // words nothing else holds at the time: the top level of the sparse table is read from index 4^(NL-1) - 1 on only (its first 16 words are not written
+    // there), and s_base is written behind the look-back
+    static_assert(!SCAN || (MERGED && !BOTH), "the scanner form takes its row from the chunk tables");
+    __shared__ int s_base[SKK + (SCAN ? 0 : 1 + NC)], s_ext[SKK];
+    int &s_failed = SCAN ? s_tbl[NL - 1][2 * WAVES] : s_base[SKK];
+    int *const s_cmax = SCAN ? &s_base[0] : &s_base[SKK + 1];
+    constexpr int TOPFREE = SCAN ? 16 : 2 * WAVES;
     constexpr int SK_EFLAG = 0x40000000;
     int *const s_gw = &s_tbl[NL - 1][0], *const s_lw = &s_tbl[NL - 1][WAVES];   // (eight words of the top level no query reads: skel_rank_body)
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
-    if (g.nfold && (int)blockIdx.x >= g.W) {
+    if constexpr (SCAN) {
+        if ((int)blockIdx.x < g.nscan) {
+            // a SCANNER: the rows of one group of g1 tiles -> every tile's prefix local to the group and the group's aggregate; then the fold of the groups before
+            const int sg = (int)blockIdx.x, f0 = sg * g.g1, n = min(g.g1, g.W - f0);
+            int lc = 0, lt = 0;
+            if (!sk1_scan_rows<16>(g.rows + (size_t)f0 * SKK, g.scanl + (size_t)f0 * SKK, n, g.tag, lc, lt, g.err, 11)) return;
+            __hip_atomic_store(g.grows + (size_t)sg * SKK + t, sk1_enc(lc, lt, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int ec = 0, et = 0;
+            if (sg > 0 && !sk1_wait_row<16>(g.grows + (size_t)(sg - 1) * SKK + t, (g.tag & 2047u) << 21, g.err, 11)) return;
+            if (!sk1_fold_rows<16>(g.grows, sg, g.tag, ec, et, g.err, 11)) return;
+            __hip_atomic_store(g.grows + (size_t)(g.nscan + sg) * SKK + t, sk1_enc(ec, et, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
+    if (!SCAN && g.nfold && (int)blockIdx.x >= g.W) {
         // a FOLDER: the rows of one group -> the group's aggregate, and nothing else.  With the group's last tile doing this in front of its own tables that tile
         // was the launch's last to scatter (profiles/r05_onepass.txt, r5t: it waits here for the rows of an XCD that entered late, 8.2 against 7.45 us).
         // Measured on top, not kept (r5g): the folder also folding the aggregates before its group into a BASE row, so that a tile's look-back is one fold — the
@@ -1023,7 +1134,7 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
             __hip_atomic_store(g.grows + (size_t)fg * SKK + t, sk1_enc(fc, ft, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    const int w = (g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
+    const int w = SCAN ? (int)blockIdx.x - g.nscan : (g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
     const int S = w * T;
 #define SK1_STAMP(i) do { if (g.prof && t == 0) g.prof[(size_t)w * 8 + (i)] = wall_clock64(); } while (0)
     // MERGED (256-position tiles): the tile's row out of the rank's own chunk tables; otherwise the separate histogram phase (skel_hist_row) in front of them.
@@ -1036,7 +1147,7 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     const int grp = w / g.g1, first = grp * g.g1, lastw = min(first + g.g1, g.W) - 1;
     int pc = 0, pt = 0;
     bool ok = true;
-    const bool selffold = (w == lastw) && g.nfold == 0;
+    const bool selffold = !SCAN && (w == lastw) && g.nfold == 0;
     if constexpr (MERGED) {
         SK1_STAMP(0);
         // every address-known load of the launch is issued here.  A wave holds its 64-position chunks in REVERSE lane order (lane i = position 63 - i of the chunk):
@@ -1046,7 +1157,7 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
 #pragma unroll
         for (int r = 0; r < EPT; ++r) { const int i = S + r * BLOCK + tp; av[r] = g.a[i]; dv[r] = g.d[i]; key[r] = (int)g.keys[i]; }
         tq = g.total[t];                                        // precomputed (skel_totals_kernel)
-        if (t == 0) s_failed = 0;
+        if (!SCAN && t == 0) s_failed = 0;
         for (int x = t; x < NC * SKK / 2; x += BLOCK) { reinterpret_cast<int *>(&s_cnt[0][0])[x] = 0; reinterpret_cast<int *>(&s_lastp[0][0])[x] = -1; }
         int *const s_sfx = &s_tbl[NL - 1][0];                   // [T] max of d over the LATER positions of the element's chunk (the top level is written three barriers on)
         lds_barrier();                                          // zeroed tables visible (the loads are still in flight)
@@ -1167,6 +1278,7 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
 #pragma unroll
     for (int l = 1; l < NL; ++l) {
         lds_barrier();
+        if (SCAN && l == 1 && t == 0) s_failed = 0;         // (the top level's words are free from here on: the suffix maxima it carried have been read)
 #pragma unroll
         for (int r = 0; r < EPT; ++r) {
             const int i = r * BLOCK + t;
@@ -1175,7 +1287,7 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
             if (i - wq >= 0) m = max(m, s_tbl[l - 1][i - wq]);
             if (i - 2 * wq >= 0) m = max(m, s_tbl[l - 1][i - 2 * wq]);
             if (i - 3 * wq >= 0) m = max(m, s_tbl[l - 1][i - 3 * wq]);
-            if (l < NL - 1 || i >= 2 * WAVES) s_tbl[l][i] = m;
+            if (l < NL - 1 || i >= TOPFREE) s_tbl[l][i] = m;
         }
     }
     lds_barrier();
@@ -1200,6 +1312,10 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     SK1_STAMP(6);
     // (3) look-back, level 1: the tiles before this one in its group (the group's last tile has done it above)
     int qc = 0, qt = 0;
+    if constexpr (SCAN) {
+        ok = sk1_poll2(g.scanl + (size_t)w * SKK + t, g.grows + (size_t)(g.nscan + grp) * SKK + t, g.tag, pc, pt, qc, qt, g.err, 11);
+        SK1_STAMP(2); SK1_STAMP(3);
+    } else
     if (BOTH && g.nfold && w - first <= 16 && grp <= 16) {
         // with folders the aggregates are out by the time a 512-position tile has its tables: both levels in ONE round trip (100 k: 1.10 against 1.155 us/site alone,
         // 1.26 against 1.33 beside the consumers; 256-position tiles are behind their tables too early for it: 50 k 1.04 against 0.995 — profiles/r05_onepass.txt, r5j)
@@ -1248,8 +1364,8 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
 #undef SK1_STAMP
 }
 // BOTH (with folders): a tile polls the two levels of its look-back together
-template <int EPT, bool BOTH = false, bool MERGED = (EPT == 1)>
-__global__ __launch_bounds__(BLOCK) void skel_onepass_kernel(SkArgs g) { skel_onepass_body<EPT, BOTH, MERGED>(g); }
+template <int EPT, bool BOTH = false, bool MERGED = (EPT == 1), bool SCAN = false>
+__global__ __launch_bounds__(BLOCK) void skel_onepass_kernel(SkArgs g) { skel_onepass_body<EPT, BOTH, MERGED, SCAN>(g); }
 template <int EPT, bool BOTH = false>
 __global__ __launch_bounds__(BLOCK) void skel_onepass_many_kernel(const SkArgs *args) { const SkArgs g = args[blockIdx.y]; skel_onepass_body<EPT, BOTH>(g); }
 

@@ -400,7 +400,7 @@ def test_malformed_packed_panel_is_rejected(amd, orc):
     assert np.array_equal(eng.max_within(yz, N, mode="hist"), orc.max_within_hist(yz, M, N)[: N + 1])   # the engine is still usable
 
 
-@pytest.mark.parametrize("skel", ["1", "0", "onepass"])
+@pytest.mark.parametrize("skel", ["1", "0", "onepass", "scan"])
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 264, 64, 0), (1024, 130, 32, 1), (1025, 96, 24, 0), (70001, 80, 40, 0),
                                             (300000, 40, 16, 0), (600100, 24, 8, 0), (1500, 41, 8, 1), (5, 64, 16, 1), (1, 16, 8, 0),
                                             (150600, 40, 16, 0), (524288, 24, 8, 1),    # pair rows with the one-level scan: 148 rows (odd tile count), 512 rows
@@ -413,10 +413,12 @@ def test_both_chains_every_site(amd, orc, skel, M, N, batch, kind, monkeypatch):
     import torch
     # "onepass": the skeleton with ONE launch per round of 8 sites (skel_onepass_kernel: totals precomputed, two-level look-back inside the launch) instead of
     # three (two below 12 289 haplotypes); it takes every width up to 1 024 tiles of 512 positions
-    if skel == "onepass" and M > 524288:
-        pytest.skip("the one-launch round takes up to 1 024 tiles")
+    # (its look-back form up to 1 024 tiles here — PBWTAMD_ONEPASS_MAXW — and its SCANNER form above: scanner workgroups in front of the tiles do the scan over the
+    # tiles inside the launch, tiles in dispatch order); "scan": the scanner form at every width (PBWTAMD_ONEPASS_SCAN_MIN=0)
     monkeypatch.setenv("PBWTAMD_SKEL", "0" if skel == "0" else "1")
-    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if skel == "onepass" else "0"); monkeypatch.setenv("PBWTAMD_ONEPASS_MAXW", "1024")
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if skel in ("onepass", "scan") else "0"); monkeypatch.setenv("PBWTAMD_ONEPASS_MAXW", "1024")
+    if skel == "scan":
+        monkeypatch.setenv("PBWTAMD_ONEPASS_SCAN_MIN", "0")
     eng = amd.Engine(M, batch_sites=batch)
     buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()               # the engine enqueues on its own stream: the fill must have landed
@@ -442,7 +444,7 @@ def test_both_chains_every_site(amd, orc, skel, M, N, batch, kind, monkeypatch):
     n = eng.chain_timing()[1]
     if skel == "1" and N >= batch and batch % 8 == 0:
         assert n < (N + 1) // 2                # at least one batch went through the skeleton (3 launches per 8 sites)
-    if skel == "onepass" and batch % 8 == 0:
+    if skel in ("onepass", "scan") and batch % 8 == 0:
         assert n <= N // 8 + 2 * (N % batch) + 2, "the one-launch round did not take the batches (%d chain launches for %d sites)" % (n, N)
     b = eng.build(bits, with_d=True)           # host entry point: pack3 stream + records sink
     assert np.array_equal(b["yz"], o["yz"]) and np.array_equal(b["dFend"], o["d_final"])
