@@ -366,6 +366,11 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
             if (env_int("PBWTAMD_ONEPASS_PROF", 0) > 1)         // = 2: every folder's line (entry, aggregate out) ...
                 for (int f = 0; f < 64 && f < onepass_folders(e); ++f)
                     fprintf(stderr, "[onepass folder] %3d %6.2f %6.2f\n", f, (double)(hp[(size_t)(e->Wt + f) * 8] - t0) * 0.01, (double)(hp[(size_t)(e->Wt + f) * 8 + 1] - t0) * 0.01);
+            if (env_int("PBWTAMD_ONEPASS_PROF", 0) > 1)         // the scanner form: every scanner's line (entry, local prefixes + aggregate out, exclusive aggregate out)
+                for (int f = 0; f < 64 && f < e->op_nscan; ++f)
+                    { const unsigned long long *q = &hp[(size_t)(e->Wt + f) * 8];
+                      fprintf(stderr, "[onepass scanner] %3d entry %6.2f first watch %6.2f passes done %6.2f aggregate out %6.2f (wave 3 %6.2f) repasses (all launches) %llu | aggregator wave %d done %6.2f\n", f, (double)(q[0] - t0) * 0.01, (double)(q[2] - t0) * 0.01,
+                              (double)(q[6] - t0) * 0.01, (double)(q[1] - t0) * 0.01, (double)(q[4] - t0) * 0.01, q[3], f, (double)(q[7] - t0) * 0.01); }
             if (env_int("PBWTAMD_ONEPASS_PROF", 0) > 1)         // ... and every tile's (entry, row, sparse table, ranks, level 1, level 2, scattered)
                 for (int w = 0; w < e->Wt; ++w) {
                     fprintf(stderr, "[onepass tile] %4d", w);
@@ -519,19 +524,21 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             // 1.69 / 1.83 at 150 k; 2.04 / 1.96 at 200 k, 2.45 / 2.12 at 250 k, 5.05 / 3.04 at 500 k (more tiles: longer look-backs, five workgroups per CU): on up to
             // 320 tiles (163 840 haplotypes).  PBWTAMD_ONEPASS=0: the three- / two-launch round; PBWTAMD_ONEPASS_MAXW=n: up to n <= 1024 tiles (tests)
             e->onepass = want_onepass && e->skEPT <= 2 && e->Wt <= std::min(1024, env_int("PBWTAMD_ONEPASS_MAXW", 320));
-            // (round 6) wider panels: the SCANNER form (pbwt_k_chain.h) — the scan over the tiles by scanner workgroups inside the launch, tiles in dispatch order: nothing
-            // has to be co-resident but the scanners and one group, and a tile polls two granules per key whatever the width.  Counts are 21-bit fields: below 2^21
-            // haplotypes.  PBWTAMD_ONEPASS_SCAN=0: off (three launches per round as before); PBWTAMD_ONEPASS_SCAN_MIN=n: from n + 1 tiles on (tests: 0)
+            // (round 6) wider panels: the SCANNER form (pbwt_k_chain.h) — the scan over the tiles by scanner / aggregator workgroups inside the launch, XCD-local groups,
+            // tiles in dispatch order.  Bit-exact at every width (the parity tests run it), and MEASURED SLOWER than three launches per round at every width above 320 tiles
+            // (us per round alone: 300 k 18.6 against 16.6, 1 M 38.0 against 26.1; with the bench consumers 2.85 / 2.53 and 6.5 / 4.7 us/site — profiles/r06_onepass.txt has
+            // the timeline and the five forms tried): OFF unless PBWTAMD_ONEPASS_SCAN=1.  Counts are 21-bit fields: below 2^21 haplotypes.  PBWTAMD_ONEPASS_SCAN_MIN=n: from
+            // n + 1 tiles on (tests: 0)
             const int scan_min = env_int("PBWTAMD_ONEPASS_SCAN_MIN", std::min(1024, env_int("PBWTAMD_ONEPASS_MAXW", 320)));
-            e->op_scan = want_onepass && e->skEPT <= 2 && M < (1 << 21) && e->Wt > scan_min && env_int("PBWTAMD_ONEPASS_SCAN", 1) != 0;
+            e->op_scan = want_onepass && e->skEPT <= 2 && M < (1 << 21) && e->Wt > scan_min && env_int("PBWTAMD_ONEPASS_SCAN", 0) != 0;
             if (e->op_scan) {
-                e->op_g1 = std::max(4, std::min(64, env_int("PBWTAMD_ONEPASS_SCAN_G", 32)));
+                e->op_g1 = std::max(4, std::min(32, env_int("PBWTAMD_ONEPASS_SCAN_G", 32)));
                 e->op_nscan = (e->Wt + e->op_g1 - 1) / e->op_g1;
                 int per_cu = 0, ncu = 0;
-                const hipError_t r1 = (e->skEPT == 1) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<1, false, true, true>, BLOCK, 0)
-                                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<2, false, true, true>, BLOCK, 0);
+                const hipError_t r1 = (e->skEPT == 1) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_scan_kernel<1>, BLOCK, 0)
+                                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_scan_kernel<2>, BLOCK, 0);
                 if (r1 != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
-                if ((long long)std::min(per_cu, 6) * ncu < (long long)e->op_nscan + 2 * e->op_g1) e->op_scan = false;      // the scanners and two groups of tiles must fit beside each other
+                if ((long long)std::min(per_cu, 6) * ncu < (long long)sk1_front(e->op_nscan) + 2 * 8 * e->op_g1 || e->op_nscan > 128) e->op_scan = false;      // the front and two runs of tiles must fit beside each other      // the scanners and two groups of tiles must fit beside each other
                 e->onepass = e->op_scan;
             } else
             if (e->onepass) {
@@ -586,7 +593,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
         ALLOC(e->skT, (size_t)(e->Wt + 1) * SKK * sizeof(int2));
         if (e->onepass) {
             const int ngrp = (e->op_scan ? 2 : 1) * ((e->Wt + e->op_g1 - 1) / e->op_g1);        // (scanner form: the groups' aggregates, then their exclusive folds)
-            ALLOC(e->op_rows, (size_t)e->Wt * SKK * sizeof(unsigned long long));
+            ALLOC(e->op_rows, (size_t)(e->Wt + 64) * SKK * sizeof(unsigned long long));       // (+ 64 rows: the scanner form's windows read ahead of a group's last row)
             ALLOC(e->op_grows, (size_t)ngrp * SKK * sizeof(unsigned long long));
             ECHK(hipMemsetAsync(e->op_rows, 0, (size_t)e->Wt * SKK * sizeof(unsigned long long), e->stream));        // tag 0: no launch has published yet (the first launch's tag is 1)
             ECHK(hipMemsetAsync(e->op_grows, 0, (size_t)ngrp * SKK * sizeof(unsigned long long), e->stream));

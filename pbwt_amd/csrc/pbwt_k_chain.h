@@ -961,19 +961,28 @@ __device__ __forceinline__ bool sk1_fold_both(const unsigned long long *b1, int 
 
 // THE SCANNER FORM (round 6; wide panels).  A tile's look-back reads O(sqrt(W)) rows of 2 KB: at 1 954 tiles that is 344 MB of polls per round against 129 MB of
 // algorithmic traffic, and the tiles cannot all be resident (which the look-back's XCD-contiguous dealing needs).  Here the per-key scan over the tiles is done
-// INSIDE the launch by nscan = ceil(W / G) scanner workgroups dispatched in FRONT of the tiles (thread = key, as skel_k2_local_kernel): scanner s polls the G rows
-// of its group as the tiles publish them, writes every tile's prefix LOCAL to the group (scanl[tile]) and the group's aggregate (grows[s]), then folds the aggregates
-// of the groups before its own into grows[nscan + s].  A tile polls exactly TWO granules per key — its scanl row and its group's exclusive aggregate — in one round
-// trip behind its tables.  Tile = workgroup index - nscan: a tile waits for scanners (dispatched first, always resident) which wait for rows of tiles dispatched
-// before the group's last tile — dispatch order, deadlock-free whatever is resident (the device must hold nscan + G + 1 workgroups).  Hand-offs: row -> scanner ->
-// (aggregate -> scanner ->) tile, three hops of ~1 us instead of two kernel boundaries, a 2 x 4 MB table pass and the separate histogram launch's loads.
-// Polls are gated: a scanner watches ONE row (the batch's last: rows arrive in dispatch order) until that is there, and only then loads the batch.
-template <int CH>
-__device__ __forceinline__ bool sk1_wait_row(const unsigned long long *p, unsigned want21, int *err, int code) {
+// INSIDE the launch by workgroups dispatched in FRONT of the tiles, laid out the way the chip is: a GROUP of g1 <= 32 consecutive tiles and its SCANNER workgroup
+// sit on ONE XCD (workgroups go to the XCDs round robin: inside every run of 8 * g1 tile workgroups XCD x takes one group), and everything a tile touches of the
+// scan stays inside that XCD's L2 — plain stores, L1-bypassing (nt) loads, the hand-off of skel_team_kernel (0.4 us).  Only 2 KB per group cross the XCDs, twice:
+//   tile    : row[tile] (plain)                                       -> scanner of its group
+//   scanner : pass 1 over the group's rows: the group's aggregate     -> aggregators           (sc1, laid out per aggregator workgroup)
+//   aggregators (SK1_NAGG workgroups, lanes = groups): exclusive fold  -> scanner               (sc1; one poller per line)
+//   scanner : pass 2 over the rows (its L2): the FINAL {keys before the tile, carry} of every tile, scanl[tile] (plain) -> tile: ONE granule per key, one hop
+// What was measured on the way (profiles/r06_onepass.txt): 2 000 tiles polling cross-XCD granules with every lane are the fabric's whole request rate (every hand-off
+// 3-5x slower); a line polled from several XCDs, or by 128 waves, before it is written takes the write 5-15 us instead of ~1; a branch per row in the scanner drains
+// the load queue at every row (32 dependent round trips); a register spilled to scratch is a round trip.  Tile = dispatch order inside its XCD: a tile waits for its
+// scanner, which waits for rows of its own group (the same run of workgroups) and for the aggregates of groups before it — deadlock-free whatever is resident
+// (the device must hold the front and two runs of tiles: checked at pbwtamd_engine_create).
+constexpr int SK1_NAGG = 8;                                 // aggregator workgroups in front of the scanners: SKK / (8 * WAVES) = 8 keys per wave
+__host__ __device__ constexpr int sk1_front(int nscan) { return SK1_NAGG + (nscan + 7) / 8 * 8; }      // workgroups in front of the tiles (aggregators, scanners, padding to a multiple of 8: XCD of a tile = its index % 8)
+__host__ __device__ constexpr int sk1_grid(int nscan, int W, int g1) { return sk1_front(nscan) + (W + 8 * g1 - 1) / (8 * g1) * (8 * g1); }
+// wait until every lane's granule *p carries the tag; LOCAL: the writer is on this XCD (plain store, nt load), otherwise an agent-scope (sc1) load
+template <bool LOCAL>
+__device__ __forceinline__ bool sk1_wait_row(const unsigned long long *p, unsigned want21, int *err, int code, unsigned long long *val = nullptr) {
     int spins = 0; unsigned long long t0 = 0;
     for (;;) {
-        const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all(sk1_tagdiff(v, want21) < (1u << 21))) return true;
+        const unsigned long long v = LOCAL ? __builtin_nontemporal_load(p) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(sk1_tagdiff(v, want21) < (1u << 21))) { if (val) *val = v; return true; }
         __builtin_amdgcn_s_sleep(2);
         if ((++spins & 63) == 0) {
             const unsigned long long now = wall_clock64();
@@ -982,71 +991,161 @@ __device__ __forceinline__ bool sk1_wait_row(const unsigned long long *p, unsign
         }
     }
 }
-// rows[i][t], i = 0 .. n - 1 in order: out[i][t] = the fold of the rows before i (tagged), (c, tl) = the fold of all n on the way out
-template <int CH>
-__device__ __forceinline__ bool sk1_scan_rows(const unsigned long long *rows, unsigned long long *out, int n, unsigned tag, int &c, int &tl, int *err, int code) {
-    static_assert(CH % 4 == 0, "blocks of four rows");
+// A SCANNER (thread = key).  Rows stream through a window of WIN buffer loads in flight: a load costs its two data registers and nothing for its address, rows
+// beyond the group are out of range (zeros), and the pass is STRAIGHT-LINE code, so that the compiler counts the loads in flight exactly.  Pass 1 folds; a granule
+// that had not landed when it was read stops the fold, and the pass restarts there behind a watch on exactly that row (each wave for its own 64 keys).
+template <int WIN, int GMAX>
+__device__ __forceinline__ bool sk1_scanner(const SkArgs &g, int sg) {
     const int t = threadIdx.x;
-    const unsigned want21 = (tag & 2047u) << 21;
+    const int f0 = sg * g.g1, n = min(min(g.g1, GMAX), g.W - f0);
+    const unsigned want21 = (g.tag & 2047u) << 21;
+    const unsigned long long idv = (unsigned long long)want21 << 32;
+    const unsigned long long *rows = g.rows + (size_t)f0 * SKK;
+    unsigned long long *out = g.scanl + (size_t)f0 * SKK;
+    // (loads: the row's offset rides in the scalar offset and nothing is out of range — rows beyond the group are other groups' rows, or the 64 rows of slack behind
+    // the table; pass 1 ends at the group's last row by count, pass 2's stores beyond it are out of range)
+    const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long *>(rows), 0, (GMAX + WIN + 1) * SKK * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out, 0, n * SKK * 8, 0x00020000);
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define SKS_STAMP(i) do { if (g.prof && t == 0 && sg < 64) g.prof[(size_t)(g.W + sg) * 8 + (i)] = wall_clock64(); } while (0)
+    int c = 0, tl = 0, done = 0, stuck = 0;
 #pragma unroll 1
-    for (int i0 = 0; i0 < n; i0 += CH) {
-        const int m = min(CH, n - i0);
-        if (!sk1_wait_row<CH>(rows + (size_t)(i0 + m - 1) * SKK + t, want21, err, code)) return false;
-        unsigned long long v[CH];
-        int spins = 0; unsigned long long t0 = 0;
-        for (;;) {
+    for (int watch = n - 1; done < n; watch = done) {
+        if (!sk1_wait_row<true>(rows + (size_t)watch * SKK + t, want21, g.err, 11)) return false;
+        if (done == 0) SKS_STAMP(2);
+        asm volatile("" ::: "memory");
+        const int voff = t * 8, soff = done * SKK * 8, left = n - done;
+        u32x2 v[WIN];
 #pragma unroll
-            for (int b = 0; b < CH; b += 4) {
-                if (b < m) {
+        for (int i = 0; i < WIN; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b64(rl, voff, soff + i * SKK * 8, 2 /* nt: this XCD's L2 */);
+        int good = 1, adv = 0;
+#pragma unroll 1
+        for (int i0 = 0; i0 < GMAX; i0 += WIN) {            // (a real loop: unrolled over all GMAX rows the compiler hoisted every load to the top and spilled them)
 #pragma unroll
-                    for (int i = b; i < b + 4; ++i) v[i] = (i < m) ? __hip_atomic_load(rows + (size_t)(i0 + i) * SKK + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)want21 << 32);
-                }
-            }
-            unsigned diff = 0;
-#pragma unroll
-            for (int b = 0; b < CH; b += 4) {
-                if (b < m) {
-#pragma unroll
-                    for (int i = b; i < b + 4; ++i) diff |= sk1_tagdiff(v[i], want21);
-                }
-            }
-            if (__all(diff < (1u << 21))) break;
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 63) == 0) {
-                const unsigned long long now = wall_clock64();
-                if (t0 == 0) t0 = now;
-                if (now - t0 > 200000000ULL || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicCAS(err, 0, code); return false; }
+            for (int j = 0; j < WIN; ++j) {
+                const unsigned long long x = ((unsigned long long)v[j].y << 32) | v[j].x;
+                v[j] = __builtin_amdgcn_raw_buffer_load_b64(rl, voff, soff + (i0 + j + WIN) * SKK * 8, 2);
+                good &= (int)(__ballot(sk1_tagdiff(x, want21) >= (1u << 21)) == 0ULL) & (int)(i0 + j < left);      // (no &&: a branch per row makes the compiler drain the load queue at every row)
+                int nc = c, nt = tl;
+                sk1_fold1(x, nc, nt);
+                c = good ? nc : c; tl = good ? nt : tl; adv += good;
+                __builtin_amdgcn_sched_barrier(0);          // (row by row: the scheduler otherwise pulls every row's unpacking to the top, waits for the whole window at once and spills)
             }
         }
+        if (g.prof && t == 0 && sg < 64 && adv < left) g.prof[(size_t)(g.W + sg) * 8 + 3] += 1;
+        if (adv == 0 && ++stuck > 64) { atomicCAS(g.err, 0, 11); return false; }      // (the watched row was there and the pass did not take it: cannot happen; never spin on it)
+        done += adv;
+    }
+    // the group's aggregate, laid out per AGGREGATOR workgroup (a = key / 32): [a][group][32 keys] — every line of it is polled by one workgroup, on one XCD
+    __hip_atomic_store(g.grows + ((size_t)(t >> 5) * g.nscan + sg) * 32 + (t & 31), sk1_enc(c, tl, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SKS_STAMP(1);
+    // the fold of the groups before this one: one poller per line
+    unsigned long long ex = idv;
+    if (sg > 0 && !sk1_wait_row<false>(g.grows + (size_t)(g.nscan + sg) * SKK + t, want21, g.err, 11, &ex)) return false;
+    SKS_STAMP(6);
+    asm volatile("" ::: "memory");
+    // pass 2: the rows again (they are all there), the running GLOBAL prefix in front of each — scanl[tile][key] = {keys before the tile, max d since the key's last
+    // occurrence before the tile (all tiles' maximum so far if there is none)}: the tile reads (count, count ? tail : -1)
+    c = sk1_cnt(ex); tl = sk1_tail(ex);
+    {
+        const int voff = t * 8;
+        u32x2 v[WIN];
 #pragma unroll
-        for (int b = 0; b < CH; b += 4) {
-            if (b < m) {
+        for (int i = 0; i < WIN; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b64(rl, voff, i * SKK * 8, 2);
+#pragma unroll 1
+        for (int i0 = 0; i0 < GMAX; i0 += WIN) {
 #pragma unroll
-                for (int i = b; i < b + 4; ++i) {
-                    if (i < m) __hip_atomic_store(out + (size_t)(i0 + i) * SKK + t, sk1_enc(c, tl, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    sk1_fold1(v[i], c, tl);                   // beyond m: (0, 0), the identity
-                }
+            for (int j = 0; j < WIN; ++j) {
+                const unsigned long long x = ((unsigned long long)v[j].y << 32) | v[j].x;      // (beyond n: zeros, the identity; the store is out of range too)
+                v[j] = __builtin_amdgcn_raw_buffer_load_b64(rl, voff, (i0 + j + WIN) * SKK * 8, 2);
+                const unsigned long long e = sk1_enc(c, tl, g.tag);
+                u32x2 ev; ev.x = (unsigned)e; ev.y = (unsigned)(e >> 32);
+                __builtin_amdgcn_raw_buffer_store_b64(ev, rs, voff + (i0 + j) * SKK * 8, 0, 0);
+                sk1_fold1(x, c, tl);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
+    SKS_STAMP(4);
+#undef SKS_STAMP
     return true;
 }
-// a tile's two granules: its prefix local to the group (p1) and the fold of the groups before (p2), one round trip when both are there
-__device__ __forceinline__ bool sk1_poll2(const unsigned long long *p1, const unsigned long long *p2, unsigned tag, int &pc, int &pt, int &qc, int &qt, int *err, int code) {
-    const unsigned want21 = (tag & 2047u) << 21;
+// AN AGGREGATOR: the groups' aggregates grows[0 .. nscan) -> their exclusive folds grows[nscan + s].  A wave owns KPV keys, its LANES are the scanners (TPL <= 2
+// consecutive ones per lane: up to 128 groups): one load per (key, scanner) in flight at once, a DPP scan across the lanes with the scan's (non-commutative)
+// combine on the pair, one round trip behind the last aggregate — where a scanner folding the aggregates before its own (thread = key) walks up to 61 rows in batches.
+// PROGRESSIVE: the exclusive row of group s goes out as soon as the aggregates of the groups before it are there — a tile waits for nothing dispatched after
+// its own group (dispatch order, deadlock-free whatever is resident)
+__device__ __forceinline__ void sk1_pair_scan(int &c, int &tl) {      // inclusive scan over the 64 lanes of (count, tail) under fold(L, R) = (L.c + R.c, R.c ? R.tl : max(L.tl, R.tl)); (0, 0) is the identity
+#define SK1_STAGE(CTRL, MASK) { const int c2 = dpp_mov<CTRL, MASK>(0, c), t2 = dpp_mov<CTRL, MASK>(0, tl); tl = c ? tl : max(t2, tl); c += c2; }
+    SK1_STAGE(0x111, 0xf) SK1_STAGE(0x112, 0xf) SK1_STAGE(0x114, 0xf) SK1_STAGE(0x118, 0xf) SK1_STAGE(0x142, 0xa) SK1_STAGE(0x143, 0xc)
+#undef SK1_STAGE
+}
+template <int KPV>
+__device__ __forceinline__ bool sk1_aggregator(const SkArgs &g, int gw) {
+    static_assert(KPV % 2 == 0, "16-byte pieces of two keys");
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = lane_id(), k0 = gw * KPV, ag = gw / (32 / KPV), kk0 = (gw % (32 / KPV)) * KPV;      // aggregator workgroup, first key inside its 32
+    const unsigned want21 = (g.tag & 2047u) << 21;
+    const int tpl = (g.nscan + 63) >> 6, s0 = lane * tpl;
+    unsigned long long *dst = g.grows + (size_t)(g.nscan + s0) * SKK + k0;
+    const int nl = (g.nscan + tpl - 1) / tpl;               // lanes that hold scanners
+    // the aggregates through a descriptor over grows[0 .. nscan) ([aggregator][group][32 keys]): 16-byte loads (two keys); scanners beyond nscan are read OUT OF RANGE —
+    // zeros, the identity of the fold — so that nothing has to be selected afterwards (registers: the kernel is held to 64, a spill to scratch costs a round trip)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g.grows, 0, g.nscan * SKK * 8, 0x00020000);
+    constexpr int OOB = 0x40000000;
+    const bool in0 = s0 < g.nscan, in1 = tpl > 1 && s0 + 1 < g.nscan;
+    const int vo0 = in0 ? ((ag * g.nscan + s0) * 32 + kk0) * 8 : OOB, vo1 = in1 ? ((ag * g.nscan + s0 + 1) * 32 + kk0) * 8 : OOB;
+    int pub = -1;                                           // lanes 0 .. pub have published their exclusive rows
     int spins = 0; unsigned long long t0 = 0;
-    for (;;) {
-        const unsigned long long v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), v2 = __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all((sk1_tagdiff(v1, want21) | sk1_tagdiff(v2, want21)) < (1u << 21))) { pc = sk1_cnt(v1); pt = sk1_tail(v1); qc = sk1_cnt(v2); qt = sk1_tail(v2); return true; }
-        __builtin_amdgcn_s_sleep(1);
+    while (pub < nl - 1) {
+        asm volatile("" ::: "memory");
+        // the watch: the first two keys of every scanner of this lane; the rest follow when those say that more groups are complete than have been published
+        u32x4 q0[KPV / 2], q1[KPV / 2];
+        q0[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo0, 0, 16 /* sc1 */);
+        q1[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo1, 0, 16);
+        const bool g0 = !in0 || ((q0[0].y ^ want21) | (q0[0].w ^ want21)) < (1u << 21), g1 = !in1 || ((q1[0].y ^ want21) | (q1[0].w ^ want21)) < (1u << 21);
+        const unsigned long long gbad = ~__ballot(g0 && g1);
+        const int glc = gbad ? (__ffsll((long long)gbad) - 1) : 64;
+        if (min(glc, nl - 1) > pub) {
+#pragma unroll
+            for (int h = 1; h < KPV / 2; ++h) { q0[h] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo0 + h * 16, 0, 16); q1[h] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo1 + h * 16, 0, 16); }
+            unsigned d0 = 0, d1 = 0;
+#pragma unroll
+            for (int h = 0; h < KPV / 2; ++h) { d0 |= (q0[h].y ^ want21) | (q0[h].w ^ want21); d1 |= (q1[h].y ^ want21) | (q1[h].w ^ want21); }
+            const bool ok0 = !in0 || d0 < (1u << 21), ok1 = !in1 || d1 < (1u << 21);
+            const unsigned long long bad = ~__ballot(ok0 && ok1);
+            const int lc = bad ? (__ffsll((long long)bad) - 1) : 64;       // lanes 0 .. lc-1 hold complete aggregates: lanes <= lc have everything before them
+            const int upto = min(lc, nl - 1);
+            if (upto > pub) {
+                const bool mine = lane > pub && lane <= upto && in0, mine1 = mine && in1 && (lane < lc || ok0);
+#pragma unroll
+                for (int k = 0; k < KPV; ++k) {
+                    const unsigned a_lo = (k & 1) ? q0[k / 2].z : q0[k / 2].x, a_hi = (k & 1) ? q0[k / 2].w : q0[k / 2].y;
+                    const unsigned b_lo = (k & 1) ? q1[k / 2].z : q1[k / 2].x, b_hi = (k & 1) ? q1[k / 2].w : q1[k / 2].y;
+                    const int ac = (int)(a_hi & 0x1fffffu), at = (int)a_lo, bc = (int)(b_hi & 0x1fffffu), bt = (int)b_lo;
+                    // this lane's scanners, in order (incomplete lanes: the identity — nothing behind them is published)
+                    int c = (lane < lc) ? ac + bc : 0, tl = (lane < lc) ? (bc ? bt : max(at, bt)) : 0;
+                    sk1_pair_scan(c, tl);
+                    int ec = lane_shr1(c, 0), et = lane_shr1(tl, 0);
+                    if (mine) __hip_atomic_store(dst + k, sk1_enc(ec, et, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (mine1) { et = ac ? at : max(et, at); ec += ac; __hip_atomic_store(dst + SKK + k, sk1_enc(ec, et, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                }
+                // (tpl == 2: lane lc's second scanner needs the lane's own first aggregate; if that was missing it goes out with the next pass — the lane is not counted as published)
+                pub = (tpl > 1 && upto == lc && lc < 64 && !__builtin_amdgcn_readlane((int)ok0, min(lc, 63))) ? upto - 1 : upto;
+                if (pub >= nl - 1) break;
+                continue;                                   // more may have landed meanwhile: look again at once
+            }
+        }
+        __builtin_amdgcn_s_sleep(2);
         if ((++spins & 63) == 0) {
             const unsigned long long now = wall_clock64();
             if (t0 == 0) t0 = now;
-            if (now - t0 > 200000000ULL || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicCAS(err, 0, code); return false; }
+            if (now - t0 > 200000000ULL || __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicCAS(g.err, 0, 11); return false; }
         }
     }
+    if (g.prof && lane == 0 && gw < 32) g.prof[(size_t)(g.W + gw) * 8 + 7] = wall_clock64();
+    return true;
 }
-
 // totals of every round of a batch: tot[r * strideT + key] = number of entries of src[r * strideSrc + 0 .. M) equal to key.  src = the byte planes of the
 // transposed panel (keys by haplotype, build side) or the rounds' key rows (by position, read side).  grid (chunks of SKTOT_CHUNK entries, rounds); more than one
 // chunk per round: atomics onto totals zeroed by skel_totals_zero_kernel.
@@ -1108,16 +1207,13 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     int *const s_gw = &s_tbl[NL - 1][0], *const s_lw = &s_tbl[NL - 1][WAVES];   // (eight words of the top level no query reads: skel_rank_body)
     const int t = threadIdx.x, lane = lane_id(), wv = wave_id();
     if constexpr (SCAN) {
-        if ((int)blockIdx.x < g.nscan) {
-            // a SCANNER: the rows of one group of g1 tiles -> every tile's prefix local to the group and the group's aggregate; then the fold of the groups before
-            const int sg = (int)blockIdx.x, f0 = sg * g.g1, n = min(g.g1, g.W - f0);
-            int lc = 0, lt = 0;
-            if (!sk1_scan_rows<16>(g.rows + (size_t)f0 * SKK, g.scanl + (size_t)f0 * SKK, n, g.tag, lc, lt, g.err, 11)) return;
-            __hip_atomic_store(g.grows + (size_t)sg * SKK + t, sk1_enc(lc, lt, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int ec = 0, et = 0;
-            if (sg > 0 && !sk1_wait_row<16>(g.grows + (size_t)(sg - 1) * SKK + t, (g.tag & 2047u) << 21, g.err, 11)) return;
-            if (!sk1_fold_rows<16>(g.grows, sg, g.tag, ec, et, g.err, 11)) return;
-            __hip_atomic_store(g.grows + (size_t)(g.nscan + sg) * SKK + t, sk1_enc(ec, et, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int bi = (int)blockIdx.x;
+        if (bi < SK1_NAGG) { sk1_aggregator<SKK / (SK1_NAGG * WAVES)>(g, bi * WAVES + wv); return; }
+        if (bi < sk1_front(g.nscan)) {
+            const int sg = bi - SK1_NAGG;
+            if (sg >= g.nscan) return;                      // (padding: the tiles start at a multiple of 8)
+            if (g.prof && t == 0 && sg < 64) g.prof[(size_t)(g.W + sg) * 8] = wall_clock64();
+            sk1_scanner<16, 32>(g, sg);
             return;
         }
     }
@@ -1134,7 +1230,15 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
             __hip_atomic_store(g.grows + (size_t)fg * SKK + t, sk1_enc(fc, ft, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    const int w = SCAN ? (int)blockIdx.x - g.nscan : (g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
+    // scanner form: workgroups go to the XCDs round robin; inside every run of 8 * g1 of them XCD x takes the g1 tiles of ONE group (and that group's scanner sits on
+    // the same XCD): a group's exclusive aggregate is polled from one XCD only, and neighbouring tiles complete their destination lines in one L2 (xcd_tile's point)
+    int wsc = 0;
+    if constexpr (SCAN) {
+        const int i = (int)blockIdx.x - sk1_front(g.nscan), run = 8 * g.g1, r = i % run;
+        wsc = (i / run) * run + (r & 7) * g.g1 + (r >> 3);
+        if (wsc >= g.W) return;                             // (the launch's last run is padded)
+    }
+    const int w = SCAN ? wsc : (g.xcd & 2) ? xcd_tile(blockIdx.x, g.W) : blockIdx.x;
     const int S = w * T;
 #define SK1_STAMP(i) do { if (g.prof && t == 0) g.prof[(size_t)w * 8 + (i)] = wall_clock64(); } while (0)
     // MERGED (256-position tiles): the tile's row out of the rank's own chunk tables; otherwise the separate histogram phase (skel_hist_row) in front of them.
@@ -1205,7 +1309,8 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
             cnt_t = base; tail_t = later;
         }
         SK1_STAMP(1);
-        __hip_atomic_store(g.rows + (size_t)w * SKK + t, sk1_enc(cnt_t, tail_t, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (SCAN) g.rows[(size_t)w * SKK + t] = sk1_enc(cnt_t, tail_t, g.tag);      // (its scanner is on this XCD: a plain store, read there past the L1)
+        else __hip_atomic_store(g.rows + (size_t)w * SKK + t, sk1_enc(cnt_t, tail_t, g.tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // without folders the launch's critical path runs through the LAST tile of every group: rows of its group -> the group's aggregate -> every later tile.
         // That tile folds its group and publishes the aggregate before anything else
         if (selffold) {
@@ -1313,7 +1418,32 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
     // (3) look-back, level 1: the tiles before this one in its group (the group's last tile has done it above)
     int qc = 0, qt = 0;
     if constexpr (SCAN) {
-        ok = sk1_poll2(g.scanl + (size_t)w * SKK + t, g.grows + (size_t)(g.nscan + grp) * SKK + t, g.tag, pc, pt, qc, qt, g.err, 11);
+        // the scanner of this tile's group (same XCD) delivers the final prefix: one lane per wave watches, then the wave's 64 granules
+        const unsigned long long *ps = g.scanl + (size_t)w * SKK + t;
+        const unsigned want21 = (g.tag & 2047u) << 21;
+        unsigned long long fv = 0;
+        int spins = 0; unsigned long long t0w = 0;
+#ifndef PBWT_NO_SETPRIO
+        __builtin_amdgcn_s_setprio(0);                      // a waiting tile yields the SIMD to the scanners and aggregators it waits for (and to the tiles still at their tables)
+#endif
+        for (;;) {
+            unsigned long long gv = 0;
+            if (lane == 0) gv = __builtin_nontemporal_load(ps);
+            if (sk1_tagdiff((unsigned long long)__builtin_amdgcn_readfirstlane((int)(gv >> 32)) << 32, want21) < (1u << 21)) {
+                fv = __builtin_nontemporal_load(ps);
+                if (__all(sk1_tagdiff(fv, want21) < (1u << 21))) break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 63) == 0) {
+                const unsigned long long now = wall_clock64();
+                if (t0w == 0) t0w = now;
+                if (now - t0w > 200000000ULL || __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { atomicCAS(g.err, 0, 11); ok = false; break; }
+            }
+        }
+#ifndef PBWT_NO_SETPRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        qc = sk1_cnt(fv); qt = sk1_tail(fv);                // (pc, pt stay the identity: the fold below gives {count, count ? tail : -1})
         SK1_STAMP(2); SK1_STAMP(3);
     } else
     if (BOTH && g.nfold && w - first <= 16 && grp <= 16) {
@@ -1366,6 +1496,9 @@ __device__ __forceinline__ void skel_onepass_body(const SkArgs &g) {
 // BOTH (with folders): a tile polls the two levels of its look-back together
 template <int EPT, bool BOTH = false, bool MERGED = (EPT == 1), bool SCAN = false>
 __global__ __launch_bounds__(BLOCK) void skel_onepass_kernel(SkArgs g) { skel_onepass_body<EPT, BOTH, MERGED, SCAN>(g); }
+// the scanner form: eight workgroups per CU (64 VGPRs), so that a 1 M-haplotype launch (1 954 tiles + 70 in front) is resident at once on an idle chip
+template <int EPT>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void skel_onepass_scan_kernel(SkArgs g) { skel_onepass_body<EPT, false, true, true>(g); }
 template <int EPT, bool BOTH = false>
 __global__ __launch_bounds__(BLOCK) void skel_onepass_many_kernel(const SkArgs *args) { const SkArgs g = args[blockIdx.y]; skel_onepass_body<EPT, BOTH>(g); }
 
