@@ -500,6 +500,60 @@ def host_entry_points(torch, pbwt_amd, panel, M, sites=16384, batch=512):
             "note": "caller buffers in ordinary host memory (the build pins its input for the call), transfers included, first call at this size"}
 
 
+def match_records(torch, pbwt_amd, dev, kind, with_ref=True):
+    """The reference's DEFAULT -maxWithin sink: every maximal match as a record / a MATCH text line (pbwtMatch.c:46-49,133-134), not the -stats histogram the
+    headline uses.  configs[0] (2 000 x 20 000) and configs[1] (10 000 x 100 000), BASELINE.md section 4's last bullet: R, seconds and
+    (16.125 M N + 16 R) / t for (a) pbwtamd_max_within with the record sink (packed panel in host memory in, records out), (b) the CLI
+    `pbwt -read f -maxWithin > /dev/null` (file read, device pass, text formatting), beside (c) the reference's own pbwtLongMatches writing the same text
+    to /dev/null on one host core (oracle/_ref; skipped when it did not travel).  The text itself is pinned by tests/test_cli.py::test_config0_full_size..."""
+    import subprocess
+    import tempfile
+    out = {}
+    cli = os.path.join(ROOT, "pbwt_amd", "pbwt")
+    for name, M, N in (("configs[0]", 2000, 20000), ("configs[1]", 10000, 100000)):
+        eng = pbwt_amd.Engine(M, batch_sites=512)
+        buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        eng.synth_device(buf.data_ptr(), 0, N, seed=0x5EED + M, kind=kind)
+        eng.sync()
+        bits = buf.cpu().numpy().view(np.uint32)
+        yz = eng.build(bits, with_d=False)["yz"]
+        eng.max_within(yz, N, mode="hist")                               # warm-up (allocations of the read side)
+        t0 = time.perf_counter(); rec = eng.max_within(yz, N, mode="records"); t1 = time.perf_counter()
+        R = int(len(rec))
+        alg = ALG_BYTES_PER_SITEHAP * M * N + 16.0 * R
+        o = {"haplotypes": M, "sites": N, "records": R, "record_sink_seconds": t1 - t0, "record_sink_GBps": alg / (t1 - t0) / 1e9,
+             "record_sink_site_haps_per_s": M * N / (t1 - t0)}
+        del rec
+        eng.close()
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "p.pbwt")
+            ident = np.arange(M, dtype="<i4").tobytes()
+            open(f, "wb").write(b"PBW3" + np.array([M, N], "<i4").tobytes() + ident + ident + np.array([len(yz)], "<i8").tobytes() + b"    " + np.asarray(yz, np.uint8).tobytes())
+            if os.path.exists(cli):
+                t0 = time.perf_counter()
+                r = subprocess.run([cli, "-read", f, "-maxWithin"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+                t1 = time.perf_counter()
+                if r.returncode == 0:
+                    o["cli_text_to_devnull_seconds"] = t1 - t0
+                    o["cli_text_GBps"] = alg / (t1 - t0) / 1e9
+                else:
+                    o["cli_error"] = r.stderr.decode(errors="replace")[-200:]
+            if with_ref:
+                try:
+                    import oracle
+                    if oracle.ref() is not None:
+                        t0 = time.perf_counter(); oracle.ref_max_within_file(yz, M, N, "/dev/null"); t1 = time.perf_counter()
+                        o["reference_text_to_devnull_seconds_1core"] = t1 - t0
+                        o["speedup_record_sink_vs_reference"] = (t1 - t0) / o["record_sink_seconds"]
+                except Exception as ex:
+                    o["reference_error"] = "%s: %s" % (type(ex).__name__, ex)
+        out[name] = o
+    out["note"] = ("-maxWithin with the RECORD sink (the reference's default: one MATCH line per maximal match), host-buffer entry point, transfers and set-up included; "
+                   "GBps = (16.125 B x M x N + 16 B x R) / seconds (SURVEY 8(d)); the CLI line also reads the .pbwt file, starts a process and formats the text")
+    return out
+
+
 def run_siteblock(args, torch, pdist, pbwt_amd, dev, rank, world):
     """--mode siteblock: one panel, sharded by site blocks across the ranks (strong scaling)"""
     from pbwt_amd import siteblock as sb
@@ -764,6 +818,11 @@ def main():
             out["match_dynamic"] = match_dynamic(torch, pbwt_amd, dev, args.kind)
         except Exception as ex:
             out["match_dynamic"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    if rank == 0 and world == 1 and not args.no_1m:
+        try:
+            out["match_records"] = match_records(torch, pbwt_amd, dev, args.kind, with_ref=not args.no_cpu)
+        except Exception as ex:
+            out["match_records"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args, first)
     if world > 1 and not args.no_posshard and args.panels == 1:

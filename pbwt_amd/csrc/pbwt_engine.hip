@@ -194,6 +194,10 @@ struct pbwtamd_engine {
     bool op_folders = false;                // one-launch round: a folder workgroup per group publishes the group's aggregate (PBWTAMD_ONEPASS_FOLDERS=0: the group's last tile does)
     // (round 6) the scanner form of the one-launch round (wide panels): op_nscan scanner workgroups in front of the tiles, op_scanl[tile][key] their local prefixes
     bool op_scan = false; int op_nscan = 0; unsigned long long *op_scanl = nullptr;
+    // where this stream's workgroups land (xcd_probe_kernel, read once at creation): bit x = XCD x takes workgroups; xcd_rr: workgroup b runs on XCD b mod 8 of eight
+    unsigned xcd_mask = 0; bool xcd_rr = false;
+    long long op_cap = 0;                   // workgroups of the one-launch kernel the device holds at once (occupancy x CUs; 0: not a one-launch engine)
+    bool team_broken = false;               // a team of the team-persistent chain did not fill once: three launches per round from then on
     bool onepass = false; unsigned long long *op_rows = nullptr, *op_grows = nullptr; int op_g1 = 0; unsigned op_epoch = 0; unsigned long long *op_prof = nullptr;
     unsigned long long *teamprof = nullptr;                 // PBWTAMD_TEAM_PROF=1: member 0's wall-clock stamps per round and phase
     unsigned *teamctl = nullptr; unsigned team_round = 0; int team_cap = 0;   // team-persistent chain (skel_team_kernel): tickets + flag words per XCD, barriers passed so far (the first engine of a group owns them)
@@ -463,6 +467,21 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
     else { if (hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prHigh) != hipSuccess) { delete e; return fail("hipStreamCreate failed"); } e->own_stream = true; }
     e->strideA = (size_t)e->Mpad;
     e->strideD = (size_t)e->Mpad + 64;
+    if (e->skel) {                                          // one tiny launch on the chain's stream (a caller's stream may carry a CU mask)
+        unsigned *pr = nullptr, hp[65];
+        if (dev_alloc((void **)&pr, sizeof hp) == hipSuccess && hipMemsetAsync(pr, 0, sizeof hp, e->stream) == hipSuccess) {
+            hipLaunchKernelGGL(xcd_probe_kernel, dim3(64), dim3(64), 0, e->stream, pr);
+            if (hipStreamSynchronize(e->stream) == hipSuccess && hipMemcpy(hp, pr, sizeof hp, hipMemcpyDeviceToHost) == hipSuccess) {
+                e->xcd_mask = hp[0];
+                bool rr = __builtin_popcount(hp[0]) == 8;
+                for (int b = 0; rr && b < 64; ++b) rr = hp[1 + b] == hp[1 + (b & 7)];
+                for (int b = 0; rr && b < 8; ++b) for (int c = 0; c < b; ++c) if (hp[1 + b] == hp[1 + c]) rr = false;
+                e->xcd_rr = rr;
+            }
+        }
+        (void)hipGetLastError();
+        if (pr) (void)dev_free(pr);
+    }
     const size_t slots = (size_t)e->B + 2;
 #define ALLOC(ptr, bytes) do { hipError_t _e = dev_alloc((void **)&(ptr), (bytes)); if (_e != hipSuccess) { int r = fail("hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(_e)); pbwtamd_engine_destroy(e); return r; } } while (0)
     ALLOC(e->A, 2 * slots * e->strideA * sizeof(int));
@@ -530,7 +549,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
             // the timeline and the five forms tried): OFF unless PBWTAMD_ONEPASS_SCAN=1.  Counts are 21-bit fields: below 2^21 haplotypes.  PBWTAMD_ONEPASS_SCAN_MIN=n: from
             // n + 1 tiles on (tests: 0)
             const int scan_min = env_int("PBWTAMD_ONEPASS_SCAN_MIN", std::min(1024, env_int("PBWTAMD_ONEPASS_MAXW", 320)));
-            e->op_scan = want_onepass && e->skEPT <= 2 && M < (1 << 21) && e->Wt > scan_min && env_int("PBWTAMD_ONEPASS_SCAN", 0) != 0;
+            e->op_scan = want_onepass && e->skEPT <= 2 && M < (1 << 21) && e->Wt > scan_min && env_int("PBWTAMD_ONEPASS_SCAN", 0) != 0 && e->xcd_rr;
             if (e->op_scan) {
                 e->op_g1 = std::max(4, std::min(32, env_int("PBWTAMD_ONEPASS_SCAN_G", 32)));
                 e->op_nscan = (e->Wt + e->op_g1 - 1) / e->op_g1;
@@ -546,6 +565,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
                 const hipError_t r1 = (e->skEPT == 1) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<1>, BLOCK, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, skel_onepass_kernel<2>, BLOCK, 0);
                 if (r1 != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
                 const long long cap = (long long)std::min(per_cu, 6) * ncu;                  // (6: what the hardware admits of a kernel with ~100 SGPRs whatever the API says)
+                e->op_cap = cap;
                 if (cap < e->Wt) e->onepass = false;
                 // a folder workgroup per group of ceil(sqrt(W)) tiles behind the tiles, where they too fit: -5 % alone / -2.6 % beside the consumers at 100 k, -6 / -4 % at
                 // 50 k, -3 / -2 % at 130 k (254 tiles); +3.5 % beside the consumers at 150 k (294 tiles): up to 256 tiles (profiles/r05_onepass.txt, r5i)

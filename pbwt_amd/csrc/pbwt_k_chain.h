@@ -1547,6 +1547,12 @@ __global__ __launch_bounds__(BLOCK) void skel_persist_kernel(const SkArgs *round
 constexpr int TEAM_MAXK = 256;                              // members per team (flag words per XCD)
 constexpr int TEAM_TICKETS = 64;                            // words in front of the flags: [x] = tickets taken on XCD x in this launch (zeroed before every launch)
 __device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15; }     // HW_REG_XCC_ID[3:0]
+// where the workgroups of a launch on this stream land: out[0] |= 1 << XCD of every workgroup, out[1 + b] = XCD of workgroup b (64 workgroups).  The engine
+// reads it once at creation: the team-persistent chain needs XCD x0 + p to exist for every panel p, the scanner form of the one-launch round needs "workgroup b
+// runs on XCD b mod 8" (its groups hand off through one XCD's L2 with plain stores)
+__global__ __launch_bounds__(64) void xcd_probe_kernel(unsigned *out) {
+    if (threadIdx.x == 0) { const unsigned x = (unsigned)xcc_id(); atomicOr(out, 1u << x); out[1 + (blockIdx.x & 63)] = x; }
+}
 
 __device__ __forceinline__ bool team_barrier(unsigned *flags, int m, int K, unsigned round, int *err, int *s_abort) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every wave's stores acknowledged by the L2 ...

@@ -494,6 +494,31 @@ def test_team_chain_every_site(amd, orc, M, N, batch, kind, K, monkeypatch):
     assert np.array_equal(eng.get_packed(), o["yz"])
 
 
+@pytest.mark.parametrize("M,N,batch,kind", [(70001, 80, 40, 0), (100000, 72, 24, 1)])
+def test_team_that_does_not_fill_falls_back(amd, orc, M, N, batch, kind, monkeypatch, capfd):
+    """a team of the team-persistent chain that does not fill (a device or partition with fewer XCDs than panels, no room beside other kernels) must not
+    fail the pass or, worse, leave a panel unadvanced without a word: team_batch reads the tickets taken per XCD behind every launch; PBWTAMD_TEAM_FAIL_ONCE=1 makes
+    that check fail once — the batch is run again with three launches per round, the rest of the pass stays there, the states equal the oracle's at every site"""
+    import torch
+    monkeypatch.setenv("PBWTAMD_TEAM", "1"); monkeypatch.setenv("PBWTAMD_ONEPASS", "0"); monkeypatch.setenv("PBWTAMD_TEAM_FAIL_ONCE", "1")
+    eng = amd.Engine(M, batch_sites=batch)
+    buf = torch.zeros((N, eng.wpc), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    eng.synth_device(buf.data_ptr(), 0, N, seed=1800 + M, kind=kind)
+    eng.sync()
+    bits = buf.cpu().numpy().view(np.uint32)
+    o = orc.build_bitcols(bits, M, with_d=True)
+    opts = amd.OPT_WITH_D | amd.OPT_CHECKSUM | amd.OPT_WITHIN_HIST
+    eng.pass_begin(N)
+    eng.pass_advance(buf.data_ptr(), N, N, opts)
+    eng.pass_end(opts)
+    ca, cd, _ = eng.get_checksums(0, N + 1)
+    assert np.array_equal(ca, o["csum_a"]) and np.array_equal(cd, o["csum_d"])
+    assert np.array_equal(eng.get_hist(N + 1), orc.max_within_hist(o["yz"], M, N)[: N + 1])
+    ms, n = eng.chain_timing()
+    assert n >= 3 * ((N // batch) * (batch // 8) - batch // 8), "the batches after the failed one did not take three launches per round (%d chain launches)" % n
+
+
 @pytest.mark.parametrize("M,N,batch,kind", [(100000, 72, 24, 1), (30000, 136, 64, 0), (300000, 24, 8, 0)])
 def test_onepass_round_in_dispatch_order(amd, orc, M, N, batch, kind, monkeypatch):
     """PBWTAMD_ONEPASS_ORDERED=1: the one-launch round with tile = workgroup index (what the library uses where several chains run at once: a tile then waits only for
