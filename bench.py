@@ -406,7 +406,7 @@ def position_sharded_selfcheck(torch, pdist, pbwt_amd, dev, rank, world, backend
     plain engine on rank 0 (histogram, .pbwt bytes, final a/d).  On a multi-GPU node this is the first thing that exercises the peer stores and
     flag barriers over xGMI; a mismatch is reported and the big job is skipped."""
     from pbwt_amd import posshard as ps
-    opts = pbwt_amd.OPT_WITH_D | pbwt_amd.OPT_WITHIN_HIST | pbwt_amd.OPT_PACK3
+    opts = pbwt_amd.OPT_WITH_D | pbwt_amd.OPT_WITHIN_HIST | pbwt_amd.OPT_PACK3 | pbwt_amd.OPT_CHECKSUM
     eng = pbwt_amd.Engine(M, batch_sites=batch, device=dev.index)
     ps.setup(eng, rank, world)
     panel = torch.empty((N, eng.wpc), dtype=torch.int32, device=dev)
@@ -414,17 +414,28 @@ def position_sharded_selfcheck(torch, pdist, pbwt_amd, dev, rank, world, backend
     eng.sync()
     ps.run(eng, lambda k: panel.data_ptr() + k * eng.wpc * 4, N, opts)
     hist = ps.reduce_hist(eng.get_hist(N + 1), device=dev if backend == "nccl" else None)
+    cs = ps.gather_checksums(eng, 0, N + 1)
     yz = ps.gather_packed(eng)
     a, d = eng.get_state()
     eng.close()
-    ok = True
+    ok, detail = True, None
     if rank == 0:
         ref = pbwt_amd.Engine(M, batch_sites=batch, device=dev.index)
         ref.pass_begin(N); ref.pass_advance(panel.data_ptr(), N, N, opts); ref.pass_end(opts)
         a0, d0 = ref.get_state()
-        ok = bool(np.array_equal(hist, ref.get_hist(N + 1)) and np.array_equal(yz, ref.get_packed()) and np.array_equal(a, a0) and np.array_equal(d, d0))
+        ra, rd, _ = ref.get_checksums(0, N + 1)
+        same = {"hist": bool(np.array_equal(hist, ref.get_hist(N + 1))), "pack3_bytes": bool(np.array_equal(yz, ref.get_packed())),
+                "final_a": bool(np.array_equal(a, a0)), "final_d": bool(np.array_equal(d, d0))}
+        if cs is not None:                                   # every site's order-sensitive checksum of (a, d): WHERE the sharded chain first leaves the plain one
+            bad = np.nonzero((np.asarray(cs[0]) != ra) | (np.asarray(cs[1]) != rd))[0]
+            same["every_site_checksums"] = bool(bad.size == 0)
+            if bad.size:
+                same["first_differing_site"] = int(bad[0])
+        ok = all(v for k, v in same.items() if k != "first_differing_site")
+        detail = same
         ref.close()
-    return bool(pdist.max_over_ranks(0.0 if ok else 1.0, device=dev if backend == "nccl" else None) == 0.0)
+    ok = bool(pdist.max_over_ranks(0.0 if ok else 1.0, device=dev if backend == "nccl" else None) == 0.0)
+    return {"ok": ok, "haplotypes": M, "sites": N, "equal_to_the_plain_engine": detail}
 
 
 def position_sharded_job(torch, pdist, pbwt_amd, dev, rank, world, backend, opts, kind, M=1000000, sites=1000000, batch=512, step=8192):
@@ -461,6 +472,8 @@ def position_sharded_job(torch, pdist, pbwt_amd, dev, rank, world, backend, opts
     lo, hi = eng.shard_range(rank)
     ach = ALG_BYTES_PER_SITEHAP * (hi - lo) * spl / (us * 1e-6) / 1e9
     ndev = len({int(x) for x in _gather_ints(pdist, torch, dev.index if dev.index is not None else 0, red)})
+    st = eng.shard_stats()                                      # what rank 0's chain spent waiting for its peers (rows of a round, flag barriers), whole engine life (warm-up batch included)
+    rounds = max(st["row_waits"], 1)
     eng.close()
     del panel
     return {"haplotypes": M, "sites_timed": sites, "n_ranks": world, "devices": ndev, "backend": backend, "seconds": dt, "value": M * sites / dt, "unit": "site*haps/s",
@@ -472,7 +485,29 @@ def position_sharded_job(torch, pdist, pbwt_amd, dev, rank, world, backend, opts
                          "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None, "us_per_launch": us, "sites_per_launch": spl,
                          "positions_of_rank0": [lo, hi], "note": "rank 0's chain over its own range of positions (launch gaps and peer waits included)"},
             "exchange": "per round of 8 sites: one row of 256 (count, carry) per rank + the scatter as peer stores (hipIpc / xGMI), 2 flag barriers; consumers sharded "
-                        "by site inside every batch (bulk pulls); one all-reduce of the histogram at the end"}
+                        "by site inside every batch (bulk pulls); one all-reduce of the histogram at the end",
+            "exchange_wait_rank0": {"row_wait_us_per_round": st["row_wait_us"] / rounds, "barrier_wait_us_per_round": st["barrier_us"] / rounds, "rounds": st["row_waits"], "barriers": st["barriers"],
+                                    "chain_us_per_round": us * (8.0 / max(spl, 1e-9)),
+                                    "note": "time rank 0's chain kernels spent waiting for the peers' rows and inside the flag barriers (device wall clock, pbwtamd_shard_stats), "
+                                            "beside the chain's launch-to-launch time per round: the exchange's share of a round"}}
+
+
+def ipcprobe_report(world, spread):
+    """tools/ipcprobe (hipIpc peer scatter + flag barrier + read-back between `world` processes, the sharded chain's own traffic pattern on plain hipMalloc rings) across
+    the same devices, BEFORE the sharded engine runs: its "mismatches" are words a peer wrote that the owner did not see — a platform visibility failure told apart from a
+    defect of the chain.  Best effort: None when the probe is not built or does not come back."""
+    import subprocess
+    probe = os.path.join(ROOT, "tools", "ipcprobe")
+    if not os.path.exists(probe):
+        return {"error": "tools/ipcprobe not built"}
+    try:
+        pr = subprocess.run([probe, str(world), "200", "0"], capture_output=True, text=True, timeout=120,
+                            env=dict(os.environ, IPCPROBE_SPREAD="1" if spread else "0", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        lines = [ln for ln in pr.stdout.splitlines() if "mismatches" in ln or "staggered barrier" in ln or ln.startswith("ipcprobe:")]
+        stale = sum(int(ln.split("mismatches")[1].split(",")[0]) for ln in lines if "mismatches" in ln)
+        return {"rc": pr.returncode, "stale_words": stale, "processes": world, "one_process_per_device": bool(spread), "lines": lines[:8]}
+    except Exception as ex:
+        return {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
 
 
 def _gather_ints(pdist, torch, value, device):
@@ -856,14 +891,17 @@ def main():
             ps_sites = min(ps_sites, int((free_b - 24e9 / rpd) // 125000) // 512 * 512)
             red = dev if args.backend == "nccl" else None
             ps_sites = int(-pdist.max_over_ranks(-float(ps_sites), device=red))         # the same job on every rank: the smallest
+            probe = ipcprobe_report(world, spread=torch.cuda.device_count() >= world) if rank == 0 else None
+            pdist.barrier()
             check = position_sharded_selfcheck(torch, pdist, pbwt_amd, dev, rank, world, args.backend, args.kind)
-            if not check:
-                out["position_sharded"] = {"error": "self-check failed: the sharded engine's histogram / bytes / final state differ from the plain engine's on a 70 000 x 264 panel", "selfcheck": False}
+            if not check["ok"]:
+                out["position_sharded"] = {"error": "self-check failed: the sharded engine differs from the plain engine on a 70 000 x 264 panel (equal_to_the_plain_engine says where)", "selfcheck": check}
             elif ps_sites < 512:
-                out["position_sharded"] = {"error": "not enough free device memory for the replicated panel", "selfcheck": True}
+                out["position_sharded"] = {"error": "not enough free device memory for the replicated panel", "selfcheck": check}
             else:
                 out["position_sharded"] = position_sharded_job(torch, pdist, pbwt_amd, dev, rank, world, args.backend, opts, args.kind, sites=ps_sites)
-                out["position_sharded"]["selfcheck"] = True
+                out["position_sharded"]["selfcheck"] = check
+            out["position_sharded"]["ipcprobe"] = probe
         except Exception as ex:                              # the secondary object must not cost the line
             out["position_sharded"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:500])}
         done.set()

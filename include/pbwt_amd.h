@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PBWTAMD_ABI_VERSION 3   /* 2: pbwtamd_shard_* , pbwtamd_pass_advance_many, pbwtamd_get_nomatch_events (round 3-4); 3: pbwtamd_match_sweep_stream, pbwtamd_drain_packed (round 5) */
+#define PBWTAMD_ABI_VERSION 4   /* 2: pbwtamd_shard_* , pbwtamd_pass_advance_many, pbwtamd_get_nomatch_events (round 3-4); 3: pbwtamd_match_sweep_stream, pbwtamd_drain_packed (round 5); 4: pbwtamd_shard_stats (round 6; nothing removed or re-typed) */
 
 typedef struct pbwtamd_engine pbwtamd_engine;
 
@@ -44,7 +44,13 @@ int         pbwtamd_device_count(void);            /* usable HIP devices (0 if n
 
 /* ---- engine: device state for one panel of M haplotypes (the role of a PbwtCursor,
  * pbwt.h:74-87, plus its scratch, held in HBM).  batch_sites = sites processed per device
- * batch (0 = default).  stream = a hipStream_t to enqueue on, or NULL for the engine's own. */
+ * batch (0 = default).  stream = a hipStream_t to enqueue on, or NULL for the engine's own.
+ * PROCESS-WIDE SIDE EFFECT: the first engine a process creates narrows the CALLING thread's CPU affinity — and with it that of every thread created while an engine
+ * is alive, the HIP runtime's helpers included, which is the point — to one hardware thread per physical core of the GPU's NUMA node (the launching thread's
+ * placement decides whether the chain runs 10 % slower as a whole).  The mask of that thread is restored when the process's last engine is
+ * destroyed; threads the host created meanwhile keep what they inherited.  PBWTAMD_PIN=0 in the environment switches it off (a host with its own placement policy,
+ * OpenMP teams, I/O threads: set it, and pin the launching thread yourself as pbwt_amd/pin.py does).  The card is found through HIP_VISIBLE_DEVICES /
+ * ROCR_VISIBLE_DEVICES when they are index lists; anything else (UUIDs): no pinning. */
 int  pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, int batch_sites, void *stream);
 void pbwtamd_engine_destroy(pbwtamd_engine *e);
 int  pbwtamd_engine_M(const pbwtamd_engine *e);
@@ -152,7 +158,7 @@ int pbwtamd_match_sweep_sparse(pbwtamd_engine *e, const uint8_t *pz, int64_t pnz
  * time and hands every batch's records to `recs`:
  *   cols(user, site0, ncols, &d_panel, &d_queries) -> 0: `ncols` consecutive columns of each panel from site0 on, DEVICE pointers on the engine's device,
  *        original haplotype order (the layout of pbwtamd_pass_advance: rows of pbwtamd_engine_wpc(e) words for the panel, of the same formula for Mq
- *        haplotypes — ((Mq + 31) / 32 rounded up to 4 — for the queries); contents complete when the callback returns; valid until the next call;
+ *        haplotypes — ((Mq + 31) / 32 rounded up to 4 — for the queries); contents complete when the callback returns; they must stay valid until the SECOND call after this one (two buffers, used alternately: the library prepares batch b + 1 beside batch b's sweep);
  *   recs(user, records, n) -> 0: the next n records (ai = query, bi = panel haplotype, start, end, sparse = 0) in the reference's callback order
  *        (k ascending, then the query panel's PBWT order, then i ascending; the tails at N last); valid during the call.
  * pStart / qStart: start orders (NULL = identity).  panel_opts — PBWTAMD_OPT_WITHIN_HIST | PBWTAMD_OPT_PACK3 | PBWTAMD_OPT_CHECKSUM — makes the SAME pass
@@ -276,6 +282,11 @@ int pbwtamd_get_chain_sites(pbwtamd_engine *e, int64_t *sites);   /* sites those
  * pbwtamd_shard_blocks lists, which concatenate in site order into PBWT.yz.  Several ranks may share one device (tests). */
 #define PBWTAMD_SHARD_HANDLE_BYTES 576
 int pbwtamd_shard_init(pbwtamd_engine *e, int rank, int world, void *handles_out);
+
+/* What this rank's chain has spent waiting for its peers since the engine was created (position sharding; SURVEY 8e(1), the exchange step of pbwtCore.c:485-508 split
+ * over ranks): out = {10 ns ticks waiting for the peers' rows of a round, number of such waits, ticks inside flag barriers, number of barriers}.  Synchronises the
+ * engine's chain stream. */
+int pbwtamd_shard_stats(pbwtamd_engine *e, uint64_t out[4]);
 int pbwtamd_shard_connect(pbwtamd_engine *e, const void *all_handles);
 /* positions [*pos_lo, *pos_hi) of the sorted order that `rank` owns */
 int pbwtamd_shard_range(const pbwtamd_engine *e, int rank, int *pos_lo, int *pos_hi);

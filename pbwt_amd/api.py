@@ -431,6 +431,12 @@ class Engine:
         self._chk(self._L.pbwtamd_shard_range(self._h, C.c_int(rank), C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
 
+    def shard_stats(self):
+        """{row_wait_us, row_waits, barrier_us, barriers}: what this rank's sharded chain spent waiting for its peers (pbwtamd_shard_stats)"""
+        out = (C.c_uint64 * 4)()
+        self._chk(self._L.pbwtamd_shard_stats(self._h, out))
+        return {"row_wait_us": out[0] * 0.01, "row_waits": int(out[1]), "barrier_us": out[2] * 0.01, "barriers": int(out[3])}
+
     def shard_blocks(self):
         """(site0[], nsites[], byte_end[]) of the pack3 blocks this rank wrote since pass_begin"""
         n = C.c_int(0)

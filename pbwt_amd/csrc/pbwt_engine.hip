@@ -274,8 +274,23 @@ struct pbwtamd_engine {
 // itself first: pbwt_amd/pin.py, as bench.py does.)
 #include <sched.h>
 #include <dirent.h>
+#include <unistd.h>
+#include <sys/syscall.h>
 static std::mutex g_pin_mu;
-static int g_pin_engines = 0; static bool g_pin_active = false; static cpu_set_t g_pin_old;
+static int g_pin_engines = 0; static bool g_pin_active = false; static cpu_set_t g_pin_old; static pid_t g_pin_tid = 0;      // (the mask goes back to the THREAD that was narrowed, whoever destroys the last engine)
+// the physical card behind HIP device `device`: HIP_VISIBLE_DEVICES, then ROCR_VISIBLE_DEVICES, when they are plain index lists (anything else: -1, no pinning by card)
+static int visible_to_physical(int device) {
+    int idx = device;
+    for (const char *name : {"HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"}) {
+        const char *v = getenv(name);
+        if (!v || !*v) continue;
+        std::vector<int> list;
+        for (const char *p = v; *p;) { char *end; const long x = strtol(p, &end, 10); if (end == p || (*end && *end != ',')) return -1; list.push_back((int)x); p = *end ? end + 1 : end; }
+        if (idx < 0 || idx >= (int)list.size()) return -1;
+        idx = list[idx];
+    }
+    return idx;
+}
 static bool read_small(const char *path, char *buf, size_t n) { FILE *f = fopen(path, "r"); if (!f) return false; const bool ok = fgets(buf, (int)n, f) != nullptr; fclose(f); return ok; }
 static void cpulist_to_set(const char *txt, cpu_set_t *set) {
     CPU_ZERO(set);
@@ -291,6 +306,8 @@ static void pin_first_engine(int device) {
     if (g_pin_engines++ > 0) return;
     if (const char *s = getenv("PBWTAMD_PIN")) if (!atoi(s)) return;
     int node = -1, seen = 0;
+    device = visible_to_physical(device);
+    if (device < 0) return;
     if (DIR *d = opendir("/sys/class/drm")) {               // the device-th AMD card (PCI vendor 0x1002), in name order as far as readdir gives it
         std::vector<std::string> cards;
         while (dirent *de = readdir(d)) if (!strncmp(de->d_name, "card", 4) && !strchr(de->d_name, '-')) cards.push_back(de->d_name);
@@ -317,13 +334,13 @@ static void pin_first_engine(int device) {
         if (first) CPU_SET(c, &want);                       // one hardware thread per core
     }
     if (CPU_COUNT(&want) < 2) return;                       // (a narrow cpuset: leave it alone)
-    if (sched_setaffinity(0, sizeof want, &want) == 0) g_pin_active = true;
+    if (sched_setaffinity(0, sizeof want, &want) == 0) { g_pin_active = true; g_pin_tid = (pid_t)syscall(SYS_gettid); }
 }
 static void unpin_last_engine() {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     if (--g_pin_engines > 0) return;
     g_pin_engines = 0;
-    if (g_pin_active) { (void)sched_setaffinity(0, sizeof g_pin_old, &g_pin_old); g_pin_active = false; }
+    if (g_pin_active) { (void)sched_setaffinity(g_pin_tid, sizeof g_pin_old, &g_pin_old); g_pin_active = false; }      // (ESRCH if that thread is gone: nothing to restore)
 }
 
 extern "C" int pbwtamd_abi_version(void) { return PBWTAMD_ABI_VERSION; }

@@ -426,8 +426,11 @@ struct ShardPeers { ShardXch *x[SHARD_MAX]; int n, me; };
 // Bounded (seconds): a rank that died must not hang the others' GPUs.  The error is STICKY: once the engine's error word is set (here, by
 // another workgroup, by an earlier launch) or a peer has flagged itself failed, nobody waits again — the rest of the pass falls through its
 // waits, the kernels skip their stores (skel_k2s_kernel, skel_rank_shard_kernel), and the host fails the pass at its next event poll.
+// What the waits cost is kept for the host (pbwtamd_shard_stats; err = the engine's ctl + 2, the counters are ctl + 8 ..): code 7 — a round's rows of the peers —
+// in words 0 / 1 (ticks of 10 ns, waits), code 6 — the flag barriers — in words 2 / 3.  The first multi-GPU run reads them to tell exchange time from chain time.
 __device__ __forceinline__ void shard_wait_flags(const unsigned *mine, const unsigned *perr, int n, unsigned epoch, int *err, int code) {
     const int t = threadIdx.x;
+    const unsigned long long tw0 = wall_clock64();
     if (t < n) {
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
         long spins = 0;
@@ -440,6 +443,10 @@ __device__ __forceinline__ void shard_wait_flags(const unsigned *mine, const uns
                                          __hip_atomic_load(perr + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) { atomicCAS(err, 0, 9); break; }
             if (spins > (1L << 24)) { atomicCAS(err, 0, code); break; }
         }
+    }
+    if (t == 0) {                                           // (reconverged: the longest of the n waits)
+        unsigned long long *st = reinterpret_cast<unsigned long long *>(err + 6) + (code == 7 ? 0 : 2);
+        atomicAdd(st, wall_clock64() - tw0); atomicAdd(st + 1, 1ULL);
     }
 }
 // which: 0 = f1, 1 = f2, 2 = f3.  mode bit 0: signal every rank (this one included), bit 1: wait for every rank

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 20
     for s in syms:
         assert hasattr(L, s), "libpbwtgpu.so does not export %s" % s
-    assert L.pbwtamd_abi_version() == 3
+    assert L.pbwtamd_abi_version() == 4
 
 
 def test_no_cpu_fallback():
