@@ -13,6 +13,7 @@
 #include <ctime>
 #include <string>
 #include <vector>
+#include <chrono>
 #include <unordered_map>
 #include <mutex>
 
@@ -197,6 +198,8 @@ struct pbwtamd_engine {
     // where this stream's workgroups land (xcd_probe_kernel, read once at creation): bit x = XCD x takes workgroups; xcd_rr: workgroup b runs on XCD b mod 8 of eight
     unsigned xcd_mask = 0; bool xcd_rr = false;
     long long op_cap = 0;                   // workgroups of the one-launch kernel the device holds at once (occupancy x CUs; 0: not a one-launch engine)
+    hipStream_t h2d_stream = nullptr; hipEvent_t evCopy[2] = {nullptr, nullptr};     // ... and the stream their copies to the device ride, one batch ahead of the chain
+    void *h_stage[2] = {nullptr, nullptr};  // pinned host staging of pbwtamd_build (two batches of columns), allocated by the first call that copies from pageable memory
     bool team_broken = false;               // a team of the team-persistent chain did not fill once: three launches per round from then on
     bool onepass = false; unsigned long long *op_rows = nullptr, *op_grows = nullptr; int op_g1 = 0; unsigned op_epoch = 0; unsigned long long *op_prof = nullptr;
     unsigned long long *teamprof = nullptr;                 // PBWTAMD_TEAM_PROF=1: member 0's wall-clock stamps per round and phase
@@ -418,6 +421,9 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (e->op_rows) (void)dev_free(e->op_rows);
     if (e->op_grows) (void)dev_free(e->op_grows);
     if (e->op_scanl) (void)dev_free(e->op_scanl);
+    for (int i = 0; i < 2; ++i) if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]);
+    if (e->h2d_stream) { (void)hipStreamSynchronize(e->h2d_stream); (void)hipStreamDestroy(e->h2d_stream); }
+    for (int i = 0; i < 2; ++i) if (e->evCopy[i]) (void)hipEventDestroy(e->evCopy[i]);
     if (e->op_prof) (void)dev_free(e->op_prof);
     if (e->h_used) (void)hipHostFree(e->h_used);
     if (e->h_nflag) (void)hipHostFree(e->h_nflag);
