@@ -178,6 +178,22 @@ struct ShardCtx {
     bool full_state = true;                                   // slot 0 of the current ring is complete on this rank (pass start, after a replicated batch)
 };
 
+// the records of a sweep on the host: ONE malloc'ed buffer that grows geometrically (realloc: no value-initialisation pass over gigabytes, as std::vector::resize
+// makes) and is handed to the caller as it is (pbwtamd_free) — 10^8 records of configs[1] are 1.6 GB, every extra pass over them a third of a second
+struct RecBuf {
+    pbwtamd_match *p = nullptr; size_t n = 0, cap = 0;
+    ~RecBuf() { free(p); }
+    pbwtamd_match *grow(size_t add) {                       // room for `add` more records behind the n there are; nullptr: out of memory
+        if (n + add > cap) {
+            const size_t want = std::max(n + add, cap + cap / 2 + 1024);
+            pbwtamd_match *q = (pbwtamd_match *)realloc(p, want * sizeof(pbwtamd_match));
+            if (!q) return nullptr;
+            p = q; cap = want;
+        }
+        return p + n;
+    }
+    pbwtamd_match *release() { pbwtamd_match *q = p ? p : (pbwtamd_match *)malloc(sizeof(pbwtamd_match)); p = nullptr; n = cap = 0; return q; }
+};
 struct pbwtamd_engine {
     int device = 0, M = 0, Mpad = 0, wpc = 0, wpc64 = 0, W = 0, wpad = 0, E = 4, T = 1024, B = 0;
     bool pinned = false;                    // this engine holds a count of pin_first_engine
@@ -261,7 +277,7 @@ struct pbwtamd_engine {
     uint32_t *zerocol = nullptr; long long sites_done = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; size_t ev_used = 0; long long launches = 0;
     // record sink for pass_advance (host-buffer entry points)
-    std::vector<pbwtamd_match> *rec_sink = nullptr; pbwtamd_report_fn rec_cb = nullptr;
+    RecBuf *rec_sink = nullptr; pbwtamd_report_fn rec_cb = nullptr;
     int longL = 0;                          // L of the -longWithin consumer (PBWTAMD_OPT_LONG_RECS)
     int *ystale = nullptr;                  // copy of the previous state's tagged a, for the k == N quirk of -longWithin
     std::vector<int32_t> nomatch_events;    // (jj, x, k[, isSparse]) of the last query sweep, in the reference's log order

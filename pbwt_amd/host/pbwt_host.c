@@ -311,7 +311,19 @@ static uint8_t *checkA, *checkB ; static int checkMA, checkMB, checkN ;
 static void reportMatch (int ai, int bi, int start, int end)
 {
   if (start == end) return ;
-  printf ("MATCH\t%d\t%d\t%d\t%d\t%d\n", ai, bi, start, end, end - start) ;
+  /* the text of printf ("MATCH\t%d\t%d\t%d\t%d\t%d\n", ...) (pbwtMatch.c:48), digits by hand: configs[1] prints 10^8 of these lines, and the format parser was
+     most of what `pbwt -read f -maxWithin` spent on the host */
+  { char buf[72] ; char *q = buf + sizeof buf ; int v[5] = { ai, bi, start, end, end - start } ;
+    *--q = '\n' ;
+    for (int f = 4 ; f >= 0 ; --f)
+      { unsigned u = v[f] < 0 ? 0u - (unsigned) v[f] : (unsigned) v[f] ;
+	do { *--q = (char) ('0' + u % 10) ; u /= 10 ; } while (u) ;
+	if (v[f] < 0) *--q = '-' ;
+	*--q = '\t' ;
+      }
+    q -= 5 ; memcpy (q, "MATCH", 5) ;
+    fwrite (q, 1, (size_t) (buf + sizeof buf - q), stdout) ;
+  }
   if (isCheck)
     { (void) checkMA ; (void) checkMB ;
 #define HA(k) checkA[(size_t)(k) * checkMA + ai]
