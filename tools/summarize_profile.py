@@ -137,4 +137,33 @@ with open(os.path.join("profiles", tag + "_sq.txt"), "w") as f:
             f.write("%-64s waves %9.0f; per wave: VALU %6.0f SALU %6.0f LDS %5.0f; wave-cycles %8.0f, waiting %8.0f (%.0f%%), issuing %7.0f\n"
                     % (k[:64], w, sq.get("SQ_INSTS_VALU", 0) / w, sq.get("SQ_INSTS_SALU", 0) / w, sq.get("SQ_INSTS_LDS", 0) / w, sq.get("SQ_WAVE_CYCLES", 0) / w,
                        sq.get("SQ_WAIT_ANY", 0) / w, 100.0 * sq.get("SQ_WAIT_ANY", 0) / max(sq.get("SQ_WAVE_CYCLES", 1), 1), sq.get("SQ_ACTIVE_INST_ANY", 0) / w))
+# the VALU / SALU issue bound of every kernel against its measured duration: a wave64 VALU instruction occupies its SIMD for 2 cycles (SIMD-32),
+# a SALU instruction the scalar unit of its CU for 1 (one scalar unit per SIMD: 4 per CU, 1 024 per chip); 1 024 SIMDs at CLOCK_GHZ.  "issue bound" = the time the
+# chip would need if nothing but those instructions were issued, perfectly spread; a kernel at 50 % of it can only get faster by executing FEWER instructions.
+CLOCK_GHZ, NSIMD = 2.4, 1024
+with open(os.path.join("profiles", tag + "_sq.txt"), "a") as f:
+    f.write("\nissue bound per dispatch = waves x (2 x VALU + SALU) cycles / (%d SIMDs x %.1f GHz), against the kernel's average duration in the kernel-trace pass of the same command\n" % (NSIMD, CLOCK_GHZ))
+    for label, pn, stats_sub, stem in (("configs[2] width (M = 100000)", "pmc_sq", "trace", "bench"), ("north-star width (M = 1000000)", "wide_sq", "wide_trace", "wide")):
+        d = collections.defaultdict(dict)
+        for pp, k, c, n, m in rows:
+            if pp == pn:
+                d[k][c] = m
+        dur = {}
+        sp = os.path.join(src, stats_sub, stem + "_kernel_stats.csv")
+        if os.path.exists(sp):
+            for r in csv.DictReader(open(sp)):
+                dur[r["Name"]] = float(r["AverageNs"]) / 1e3
+        if not d or not dur:
+            continue
+        f.write("\n" + label + "\n")
+        for k in sorted(d):
+            if not any(("::" + nm) in k for nm in CHAIN + CONS):
+                continue
+            sq = d[k]; w = sq.get("SQ_WAVES", 0)
+            if not w or k not in dur:
+                continue
+            valu_us = sq.get("SQ_INSTS_VALU", 0) * 2 / (NSIMD * CLOCK_GHZ * 1e3)
+            salu_us = sq.get("SQ_INSTS_SALU", 0) * 1 / (NSIMD * CLOCK_GHZ * 1e3)
+            f.write("%-64s measured %8.1f us; VALU issue %7.1f us, SALU issue %7.1f us, together %7.1f us = %3.0f%% of measured\n"
+                    % (k[:64], dur[k], valu_us, salu_us, valu_us + salu_us, 100.0 * (valu_us + salu_us) / dur[k]))
 print(open(os.path.join("profiles", tag + "_sq.txt")).read())
