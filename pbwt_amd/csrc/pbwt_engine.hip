@@ -214,6 +214,9 @@ struct pbwtamd_engine {
     // where this stream's workgroups land (xcd_probe_kernel, read once at creation): bit x = XCD x takes workgroups; xcd_rr: workgroup b runs on XCD b mod 8 of eight
     unsigned xcd_mask = 0; bool xcd_rr = false;
     long long op_cap = 0;                   // workgroups of the one-launch kernel the device holds at once (occupancy x CUs; 0: not a one-launch engine)
+    // (round 6) the NEXT batch's preparation — transposed panel, key totals — on the consumers' stream beside this batch's chain (skel_prepare_ahead): what it was found for
+    hipEvent_t evPrep[2] = {nullptr, nullptr}; bool prep_valid[2] = {false, false}; const uint32_t *prep_cols[2] = {nullptr, nullptr};
+    int prep_nb[2] = {0, 0}, prep_k[2] = {0, 0}, prep_navail[2] = {0, 0};
     hipStream_t h2d_stream = nullptr; hipEvent_t evCopy[2] = {nullptr, nullptr};     // ... and the stream their copies to the device ride, one batch ahead of the chain
     void *h_stage[2] = {nullptr, nullptr};  // pinned host staging of pbwtamd_build (two batches of columns), allocated by the first call that copies from pageable memory
     bool team_broken = false;               // a team of the team-persistent chain did not fill once: three launches per round from then on
@@ -439,6 +442,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (e->op_scanl) (void)dev_free(e->op_scanl);
     for (int i = 0; i < 2; ++i) if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]);
     if (e->h2d_stream) { (void)hipStreamSynchronize(e->h2d_stream); (void)hipStreamDestroy(e->h2d_stream); }
+    for (int i = 0; i < 2; ++i) if (e->evPrep[i]) (void)hipEventDestroy(e->evPrep[i]);
     for (int i = 0; i < 2; ++i) if (e->evCopy[i]) (void)hipEventDestroy(e->evCopy[i]);
     if (e->op_prof) (void)dev_free(e->op_prof);
     if (e->h_used) (void)hipHostFree(e->h_used);
