@@ -834,7 +834,7 @@ def test_match_sweep_sparse_golden_and_no_match_branch(amd, orc):
         amd.Engine(M - Mq, batch_sites=4).match_sweep_sparse(m["pz"], N, m["qz"], Mq, 9)
 
 
-@pytest.mark.parametrize("skel_read", ["1", "0", "onepass"])
+@pytest.mark.parametrize("skel_read", ["1", "0", "onepass", "scan"])
 @pytest.mark.parametrize("M,N,batch,kind", [(3000, 200, 64, 0), (1025, 96, 24, 1), (70001, 80, 40, 0), (2, 33, 8, 1), (300000, 24, 8, 0), (600100, 16, 8, 0)])
 def test_read_side_both_chains(amd, orc, skel_read, M, N, batch, kind, monkeypatch):
     """the read side (ForwardsReadAD over a packed panel, the reference's -read ... -maxWithin path): the skeleton chain
@@ -843,7 +843,9 @@ def test_read_side_both_chains(amd, orc, skel_read, M, N, batch, kind, monkeypat
     if skel_read == "onepass" and M > 524288:
         pytest.skip("the one-launch round takes up to 1 024 tiles")
     monkeypatch.setenv("PBWTAMD_SKEL_READ", "0" if skel_read == "0" else "1")
-    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if skel_read == "onepass" else "0"); monkeypatch.setenv("PBWTAMD_ONEPASS_MAXW", "1024")    # the one-launch round on the read side: totals from the LF-mapped key rows
+    monkeypatch.setenv("PBWTAMD_ONEPASS", "1" if skel_read in ("onepass", "scan") else "0"); monkeypatch.setenv("PBWTAMD_ONEPASS_MAXW", "1024")    # the one-launch round on the read side: totals from the LF-mapped key rows
+    if skel_read == "scan":                                # ... and its scanner form (round 6) at every width
+        monkeypatch.setenv("PBWTAMD_ONEPASS_SCAN", "1"); monkeypatch.setenv("PBWTAMD_ONEPASS_SCAN_MIN", "0")
     bits = orc.synth_bitcols(M, N, seed=3000 + M, kind=kind)
     yz = orc.build_bitcols(bits, M, with_d=False)["yz"]
     eng = amd.Engine(M, batch_sites=batch)
