@@ -219,6 +219,7 @@ struct pbwtamd_engine {
     int prep_nb[2] = {0, 0}, prep_k[2] = {0, 0}, prep_navail[2] = {0, 0};
     hipStream_t h2d_stream = nullptr; hipEvent_t evCopy[2] = {nullptr, nullptr};     // ... and the stream their copies to the device ride, one batch ahead of the chain
     void *h_stage[2] = {nullptr, nullptr};  // pinned host staging of pbwtamd_build (two batches of columns), allocated by the first call that copies from pageable memory
+    unsigned *team_host = nullptr;          // pinned: the tickets and the error word behind the last team launch
     bool team_broken = false;               // a team of the team-persistent chain did not fill once: three launches per round from then on
     bool onepass = false; unsigned long long *op_rows = nullptr, *op_grows = nullptr; int op_g1 = 0; unsigned op_epoch = 0; unsigned long long *op_prof = nullptr;
     unsigned long long *teamprof = nullptr;                 // PBWTAMD_TEAM_PROF=1: member 0's wall-clock stamps per round and phase
@@ -441,6 +442,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (e->op_grows) (void)dev_free(e->op_grows);
     if (e->op_scanl) (void)dev_free(e->op_scanl);
     for (int i = 0; i < 2; ++i) if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]);
+    if (e->team_host) (void)hipHostFree(e->team_host);
     if (e->h2d_stream) { (void)hipStreamSynchronize(e->h2d_stream); (void)hipStreamDestroy(e->h2d_stream); }
     for (int i = 0; i < 2; ++i) if (e->evPrep[i]) (void)hipEventDestroy(e->evPrep[i]);
     for (int i = 0; i < 2; ++i) if (e->evCopy[i]) (void)hipEventDestroy(e->evCopy[i]);
