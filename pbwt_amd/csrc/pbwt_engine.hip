@@ -218,6 +218,7 @@ struct pbwtamd_engine {
     hipEvent_t evPrep[2] = {nullptr, nullptr}; bool prep_valid[2] = {false, false}; const uint32_t *prep_cols[2] = {nullptr, nullptr};
     int prep_nb[2] = {0, 0}, prep_k[2] = {0, 0}, prep_navail[2] = {0, 0};
     hipStream_t h2d_stream = nullptr; hipEvent_t evCopy[2] = {nullptr, nullptr};     // ... and the stream their copies to the device ride, one batch ahead of the chain
+    hipEvent_t evD2H[2] = {nullptr, nullptr};   // d2h_staged: a piece has landed in its pinned buffer
     void *h_stage[2] = {nullptr, nullptr};  // pinned host staging of pbwtamd_build (two batches of columns), allocated by the first call that copies from pageable memory
     unsigned *team_host = nullptr;          // pinned: the tickets and the error word behind the last team launch
     bool team_broken = false;               // a team of the team-persistent chain did not fill once: three launches per round from then on
@@ -443,6 +444,7 @@ extern "C" void pbwtamd_engine_destroy(pbwtamd_engine *e) {
     if (e->op_scanl) (void)dev_free(e->op_scanl);
     for (int i = 0; i < 2; ++i) if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]);
     if (e->team_host) (void)hipHostFree(e->team_host);
+    for (int i = 0; i < 2; ++i) if (e->evD2H[i]) (void)hipEventDestroy(e->evD2H[i]);
     if (e->h2d_stream) { (void)hipStreamSynchronize(e->h2d_stream); (void)hipStreamDestroy(e->h2d_stream); }
     for (int i = 0; i < 2; ++i) if (e->evPrep[i]) (void)hipEventDestroy(e->evPrep[i]);
     for (int i = 0; i < 2; ++i) if (e->evCopy[i]) (void)hipEventDestroy(e->evCopy[i]);
@@ -703,6 +705,7 @@ extern "C" int pbwtamd_engine_create(pbwtamd_engine **out, int device, int M, in
 }
 
 static int flush_pending(pbwtamd_engine *e);
+static int d2h_staged(pbwtamd_engine *e, void *dst, const void *src, size_t bytes, hipStream_t st);
 
 extern "C" int pbwtamd_sync(pbwtamd_engine *e) {
     HIPCHK(hipSetDevice(e->device));
