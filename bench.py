@@ -532,7 +532,7 @@ def host_entry_points(torch, pbwt_amd, panel, M, sites=16384, batch=512):
     eng.max_within(b["yz"], sites, mode="hist"); t3 = time.perf_counter()
     eng.close()
     return {"sites": sites, "build_site_haps_per_s": M * sites / (t1 - t0), "read_maxwithin_stats_site_haps_per_s": M * sites / (t3 - t2),
-            "note": "caller buffers in ordinary host memory (the build pins its input for the call), transfers included, first call at this size"}
+            "note": "caller buffers in ordinary host memory (columns in and .pbwt bytes out through the engine's pinned staging buffers), transfers included, first call at this size"}
 
 
 def match_records(torch, pbwt_amd, dev, kind, with_ref=True):
