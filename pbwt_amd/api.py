@@ -141,8 +141,7 @@ class Engine:
                                         _p(aFend, C.c_int32), _p(dFend, C.c_int32)))
         yz = None
         if want_yz:
-            yz = np.ctypeslib.as_array(yzp, shape=(max(nz.value, 1),))[:nz.value].copy()
-            self._L.pbwtamd_free(yzp)
+            yz = _take(self._L, C.cast(yzp, C.c_void_p), nz.value, np.dtype(np.uint8))     # (no copy: the library's buffer, freed with the last view)
         return dict(yz=yz, aFend=aFend, dFend=dFend if with_d else None)
 
     def sweep_AD(self, yz, N, aFstart=None, dump_sites=(), checksums=True):
